@@ -1,0 +1,353 @@
+"""ctypes binding of the CPU oracle (oracle/liblocus_oracle.so).
+
+TEST INFRASTRUCTURE ONLY -- imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg; never by the product package (locus_amd).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "liblocus_oracle.so")
+LO_MAX_TRACE = 256
+
+
+class LoParams(C.Structure):
+    _fields_ = [
+        ("max_iterations", C.c_int),
+        ("max_inner_iterations", C.c_int),
+        ("corr_dist", C.c_double),
+        ("transformation_epsilon", C.c_double),
+        ("rotation_epsilon", C.c_double),
+        ("gicp_epsilon", C.c_double),
+        ("k_correspondences", C.c_int),
+        ("recompute_source_cov", C.c_int),
+        ("recompute_target_cov", C.c_int),
+        ("num_threads", C.c_int),
+        ("parallel_cost", C.c_int),
+    ]
+
+
+class LoTrace(C.Structure):
+    _fields_ = [
+        ("n_iters", C.c_int),
+        ("T", (C.c_float * 16) * LO_MAX_TRACE),
+        ("n_corr", C.c_int * LO_MAX_TRACE),
+        ("n_passes", C.c_int * LO_MAX_TRACE),
+        ("n_inner", C.c_int * LO_MAX_TRACE),
+        ("f_end", C.c_double * LO_MAX_TRACE),
+        ("delta", C.c_double * LO_MAX_TRACE),
+    ]
+
+
+class LoResult(C.Structure):
+    _fields_ = [
+        ("T", C.c_float * 16),
+        ("converged", C.c_int),
+        ("iterations", C.c_int),
+        ("n_corr_last", C.c_int),
+        ("status", C.c_int),
+        ("total_passes", C.c_long),
+        ("t_index", C.c_double),
+        ("t_cov", C.c_double),
+        ("t_nn", C.c_double),
+        ("t_opt", C.c_double),
+        ("t_total", C.c_double),
+    ]
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "locus_oracle.c")
+    if force or not os.path.exists(_LIB) or (
+        os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(_LIB)
+    ):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB)
+        L = _lib
+        L.lo_tree_build.restype = C.c_void_p
+        L.lo_tree_build.argtypes = [C.c_void_p, C.c_int]
+        L.lo_tree_free.argtypes = [C.c_void_p]
+        L.lo_fitness.restype = C.c_double
+        L.lo_fitness.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        L.lo_nn1.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        L.lo_nn1_brute.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.lo_knn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        L.lo_knn_brute.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.lo_transform.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.lo_cov_from_normals.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_void_p]
+        L.lo_cov_knn.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_int]
+        L.lo_nn_mahalanobis.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_int]
+        L.lo_cost_fdf.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.lo_apply_state.argtypes = [C.c_void_p, C.c_void_p]
+        L.lo_gicp_align.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                    C.POINTER(LoParams), C.c_void_p, C.POINTER(LoResult), C.POINTER(LoTrace),
+                                    C.c_void_p]
+        L.lo_normalize_cloud.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.lo_p2plane_Ap.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.lo_icp_covariance.argtypes = [C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]
+        L.lo_eig_sym.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.lo_voxel_grid.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_int]
+        L.lo_normals_knn.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.lo_read_pcd_xyzi.argtypes = [C.c_char_p, C.c_void_p, C.c_int]
+        L.lo_default_params.argtypes = [C.POINTER(LoParams)]
+    return _lib
+
+
+def _f4(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    assert a.ndim == 2 and a.shape[1] == 4, a.shape
+    return a
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def xyz4(xyz):
+    """(n,3|4) -> float32 (n,4) with w = 1 (pcl PointXYZ data[3] = 1)."""
+    xyz = np.asarray(xyz, dtype=np.float32)
+    out = np.ones((xyz.shape[0], 4), dtype=np.float32)
+    out[:, :3] = xyz[:, :3]
+    return out
+
+
+def nrm4(nrm):
+    nrm = np.asarray(nrm, dtype=np.float32)
+    out = np.zeros((nrm.shape[0], 4), dtype=np.float32)
+    out[:, : nrm.shape[1]] = nrm
+    return out
+
+
+def default_params(**kw):
+    p = LoParams()
+    lib().lo_default_params(C.byref(p))
+    for k, v in kw.items():
+        assert hasattr(p, k), k
+        setattr(p, k, v)
+    return p
+
+
+class Tree:
+    def __init__(self, pts4):
+        self.pts = _f4(pts4)
+        self.h = lib().lo_tree_build(_p(self.pts), self.pts.shape[0])
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().lo_tree_free(self.h)
+            self.h = None
+
+    def nn1(self, q4, threads=1):
+        q4 = _f4(q4)
+        idx = np.empty(q4.shape[0], np.int32)
+        d2 = np.empty(q4.shape[0], np.float32)
+        lib().lo_nn1(self.h, _p(q4), q4.shape[0], _p(idx), _p(d2), threads)
+        return idx, d2
+
+    def knn(self, q4, k, threads=1):
+        q4 = _f4(q4)
+        idx = np.empty((q4.shape[0], k), np.int32)
+        d2 = np.empty((q4.shape[0], k), np.float32)
+        lib().lo_knn(self.h, _p(q4), q4.shape[0], k, _p(idx), _p(d2), threads)
+        return idx, d2
+
+
+def nn1_brute(pts4, q4):
+    pts4, q4 = _f4(pts4), _f4(q4)
+    idx = np.empty(q4.shape[0], np.int32)
+    d2 = np.empty(q4.shape[0], np.float32)
+    lib().lo_nn1_brute(_p(pts4), pts4.shape[0], _p(q4), q4.shape[0], _p(idx), _p(d2))
+    return idx, d2
+
+
+def knn_brute(pts4, q4, k):
+    pts4, q4 = _f4(pts4), _f4(q4)
+    idx = np.empty((q4.shape[0], k), np.int32)
+    d2 = np.empty((q4.shape[0], k), np.float32)
+    lib().lo_knn_brute(_p(pts4), pts4.shape[0], _p(q4), q4.shape[0], k, _p(idx), _p(d2))
+    return idx, d2
+
+
+def transform(pts4, T_colmajor16, nrm=None):
+    pts4 = _f4(pts4)
+    T = np.ascontiguousarray(T_colmajor16, np.float32).reshape(16)
+    out = np.empty_like(pts4)
+    if nrm is not None:
+        nrm = _f4(nrm)
+        on = np.empty_like(nrm)
+        lib().lo_transform(_p(pts4), _p(nrm), pts4.shape[0], _p(T), _p(out), _p(on))
+        return out, on
+    lib().lo_transform(_p(pts4), None, pts4.shape[0], _p(T), _p(out), None)
+    return out
+
+
+def cov_from_normals(nrm, eps=1e-3):
+    nrm = _f4(nrm)
+    cov = np.empty((nrm.shape[0], 3, 3), np.float64)
+    lib().lo_cov_from_normals(_p(nrm), nrm.shape[0], eps, _p(cov))
+    return cov
+
+
+def cov_knn(pts4, k=20, eps=1e-3, threads=1, tree=None):
+    pts4 = _f4(pts4)
+    tree = tree or Tree(pts4)
+    cov = np.empty((pts4.shape[0], 3, 3), np.float64)
+    rc = lib().lo_cov_knn(_p(pts4), pts4.shape[0], tree.h, k, eps, _p(cov), threads)
+    assert rc == 0, rc
+    return cov
+
+
+def nn_mahalanobis(out4, tree, cov_src, cov_tgt, T16, R9, corr_dist, threads=1):
+    out4 = _f4(out4)
+    n = out4.shape[0]
+    cov_src = np.ascontiguousarray(cov_src, np.float64)
+    cov_tgt = np.ascontiguousarray(cov_tgt, np.float64)
+    T16 = np.ascontiguousarray(T16, np.float32).reshape(16)
+    R9 = np.ascontiguousarray(R9, np.float64).reshape(9)
+    idx = np.empty(n, np.int32)
+    maha = np.zeros((n, 3, 3), np.float64)
+    lib().lo_nn_mahalanobis(_p(out4), n, tree.h, _p(cov_src), _p(cov_tgt), _p(T16), _p(R9), corr_dist,
+                            _p(idx), _p(maha), threads)
+    return idx, maha
+
+
+def cost_fdf(out4, tgt4, src_idx, tgt_idx, maha, x6):
+    out4, tgt4 = _f4(out4), _f4(tgt4)
+    src_idx = np.ascontiguousarray(src_idx, np.int32)
+    tgt_idx = np.ascontiguousarray(tgt_idx, np.int32)
+    maha = np.ascontiguousarray(maha, np.float64)
+    x6 = np.ascontiguousarray(x6, np.float64)
+    f = C.c_double()
+    g = np.empty(6, np.float64)
+    sums = np.empty(13, np.float64)
+    lib().lo_cost_fdf(_p(out4), _p(tgt4), _p(src_idx), _p(tgt_idx), src_idx.shape[0], _p(maha), _p(x6),
+                      C.byref(f), _p(g), _p(sums))
+    return f.value, g, sums
+
+
+def apply_state(x6):
+    x6 = np.ascontiguousarray(x6, np.float64)
+    T = np.empty(16, np.float32)
+    lib().lo_apply_state(_p(x6), _p(T))
+    return T
+
+
+def T_to_mat(T16):
+    """column-major 16 floats -> (4,4) matrix"""
+    return np.asarray(T16, dtype=np.float64).reshape(4, 4).T.copy()
+
+
+def mat_to_T(M):
+    return np.ascontiguousarray(np.asarray(M, np.float32).T).reshape(16)
+
+
+def gicp_align(src4, src_n, tgt4, tgt_n, params, guess=None, want_trace=True, want_aligned=False):
+    src4, tgt4 = _f4(src4), _f4(tgt4)
+    src_n = _f4(src_n) if src_n is not None else None
+    tgt_n = _f4(tgt_n) if tgt_n is not None else None
+    res = LoResult()
+    trace = LoTrace() if want_trace else None
+    g = np.ascontiguousarray(guess, np.float32).reshape(16) if guess is not None else None
+    aligned = np.empty_like(src4) if want_aligned else None
+    lib().lo_gicp_align(_p(src4), _p(src_n), src4.shape[0], _p(tgt4), _p(tgt_n), tgt4.shape[0], C.byref(params),
+                        _p(g), C.byref(res), C.byref(trace) if trace is not None else None, _p(aligned))
+    out = {
+        "T": np.array(res.T[:], np.float32),
+        "converged": res.converged,
+        "iterations": res.iterations,
+        "n_corr_last": res.n_corr_last,
+        "status": res.status,
+        "total_passes": res.total_passes,
+        "t_index": res.t_index, "t_cov": res.t_cov, "t_nn": res.t_nn, "t_opt": res.t_opt, "t_total": res.t_total,
+    }
+    if trace is not None:
+        k = trace.n_iters
+        out["trace"] = {
+            "T": np.array([trace.T[i][:] for i in range(k)], np.float32).reshape(k, 16),
+            "n_corr": np.array(trace.n_corr[:k]),
+            "n_passes": np.array(trace.n_passes[:k]),
+            "n_inner": np.array(trace.n_inner[:k]),
+            "f_end": np.array(trace.f_end[:k]),
+            "delta": np.array(trace.delta[:k]),
+        }
+    if aligned is not None:
+        out["aligned"] = aligned
+    return out
+
+
+def fitness(src4, T16, tree, threads=1):
+    src4 = _f4(src4)
+    T16 = np.ascontiguousarray(T16, np.float32).reshape(16)
+    return lib().lo_fitness(_p(src4), src4.shape[0], _p(T16), tree.h, threads)
+
+
+def normalize_cloud(pts4):
+    pts4 = _f4(pts4)
+    out = np.empty_like(pts4)
+    lib().lo_normalize_cloud(_p(pts4), pts4.shape[0], _p(out))
+    return out
+
+
+def p2plane_Ap(qnorm4, ref_nrm4, corr):
+    qnorm4, ref_nrm4 = _f4(qnorm4), _f4(ref_nrm4)
+    corr = np.ascontiguousarray(corr, np.int64)
+    Ap = np.empty((6, 6), np.float64)
+    lib().lo_p2plane_Ap(_p(qnorm4), qnorm4.shape[0], _p(ref_nrm4), _p(corr), _p(Ap))
+    return Ap
+
+
+def icp_covariance(Ap, upper_bound=0.01):
+    Ap = np.ascontiguousarray(Ap, np.float64)
+    cov = np.empty((6, 6), np.float64)
+    cond = C.c_double()
+    ok = lib().lo_icp_covariance(_p(Ap), upper_bound, _p(cov), C.byref(cond))
+    return bool(ok), cov, cond.value
+
+
+def eig_sym(A):
+    A = np.ascontiguousarray(A, np.float64)
+    n = A.shape[0]
+    ev = np.empty(n, np.float64)
+    V = np.empty((n, n), np.float64)
+    lib().lo_eig_sym(_p(A), n, _p(ev), _p(V))
+    return ev, V
+
+
+def voxel_grid(xyzi, leaf, limit_axis=-1, lo=-np.inf, hi=np.inf):
+    xyzi = _f4(xyzi)
+    out = np.empty_like(xyzi)
+    n = lib().lo_voxel_grid(_p(xyzi), xyzi.shape[0], leaf, limit_axis, float(max(lo, -3.0e38)), float(min(hi, 3.0e38)),
+                            _p(out), xyzi.shape[0])
+    if n < 0:
+        return None
+    return out[:n].copy()
+
+
+def normals_knn(pts4, k=20, threads=1, tree=None):
+    pts4 = _f4(pts4)
+    tree = tree or Tree(pts4)
+    out = np.empty_like(pts4)
+    lib().lo_normals_knn(_p(pts4), pts4.shape[0], tree.h, k, _p(out), threads)
+    return out
+
+
+def read_pcd_xyzi(path, cap=1 << 22):
+    buf = np.empty((cap, 4), np.float32)
+    n = lib().lo_read_pcd_xyzi(path.encode(), _p(buf), cap)
+    if n < 0:
+        raise IOError("cannot read %s (%d)" % (path, n))
+    return buf[:n].copy()
