@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""bench.py -- GICP scan-pairs/s on MI355X (BASELINE.json metric), one process per GPU.
+
+A "step" = one pass of the hot path (lh_gicp_align_batch: NN-index build + covariances-from-normals + 20 outer
+GICP iterations with BFGS) over one batch of `--pairs` independent synthetic 100k-point scan pairs per GPU
+(BASELINE configs[1] replicated as a queued stream, like configs[3]).  Inputs (xyz + k=20 normals) are resident
+in HBM before the timed region.  value = pairs aligned by all ranks / max-over-ranks time.
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from locus_amd import capi, synth  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def make_pairs(ctx, n_pairs, rank, rings, az, scale):
+    """Synthetic consecutive-scan pairs: distinct seeds per rank and pair.  Normals are
+    computed on the GPU with the K3 kernel (k=20), like the NormalComputation nodelet upstream of GICP."""
+    S, T, host = [], [], []
+    for p in range(n_pairs):
+        seed = 1000 * rank + 10 + 2 * p
+        src, tgt, delta = synth.scan_pair(n_rings=rings, n_az=az, scale=scale, noise=0.02, seed=seed)
+        cs, ct = capi.Cloud(ctx, src), capi.Cloud(ctx, tgt)
+        cs.normals_knn(20)
+        ct.normals_knn(20)
+        ct.drop_index()
+        S.append(cs)
+        T.append(ct)
+        host.append((src, tgt, delta))
+    return S, T, host
+
+
+def cpu_baseline(S, T, host, P, budget_s=20.0):
+    """Reference-algorithm restatement (oracle) timed on the host cores: OMP on the two loops the reference
+    parallelises (k-NN/NN), serial cost functor (gicp.hpp:291-402).  Bounded sample of the same workload."""
+    from oracle import oracle as O
+    ncores = os.cpu_count() or 1
+    po = O.default_params(max_iterations=P.max_iterations, max_inner_iterations=P.max_inner_iterations, corr_dist=P.corr_dist,
+                          transformation_epsilon=P.transformation_epsilon, rotation_epsilon=P.rotation_epsilon,
+                          gicp_epsilon=P.gicp_epsilon, num_threads=ncores)
+    done, t_used, poses = 0, 0.0, []
+    for p in range(len(S)):
+        a, b = S[p].download(), T[p].download()
+        src4 = O.xyz4(np.stack([a["x"], a["y"], a["z"]], 1))
+        tgt4 = O.xyz4(np.stack([b["x"], b["y"], b["z"]], 1))
+        ns = O.nrm4(np.stack([a["normal_x"], a["normal_y"], a["normal_z"]], 1))
+        nt = O.nrm4(np.stack([b["normal_x"], b["normal_y"], b["normal_z"]], 1))
+        t0 = time.perf_counter()
+        r = O.gicp_align(src4, ns, tgt4, nt, po, want_trace=False)
+        t_used += time.perf_counter() - t0
+        poses.append(r["T"])
+        done += 1
+        if t_used > budget_s:
+            break
+    return {"value": done / t_used, "unit": "scan-pairs/s", "cores": ncores, "kind": "port",
+            "sample": "%d of the step's %d-pt pairs, 20 outer iterations, OMP on NN loops + serial cost functor (%.1f s)"
+                      % (done, len(S[0]), t_used)}, poses
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--pairs", type=int, default=16, help="scan pairs per GPU per step")
+    ap.add_argument("--in-flight", type=int, default=16)
+    ap.add_argument("--rings", type=int, default=64)
+    ap.add_argument("--azimuths", type=int, default=1563)  # 64 x 1563 = 100 032 points / scan
+    ap.add_argument("--scale", type=float, default=2.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--single-latency", action="store_true", help="also time one-pair-at-a-time lh_gicp_align")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus or world == 1, (world, args.gpus)
+
+    ctx = capi.Context(local_rank)
+    # forced 20 outer iterations: eps = 0 would divide by zero in the ratio, use a vanishing eps instead
+    P = capi.default_params(max_iterations=20, max_inner_iterations=20, corr_dist=1.0, transformation_epsilon=1e-12,
+                            rotation_epsilon=1e-12)
+    S, T, host = make_pairs(ctx, args.pairs, rank, args.rings, args.azimuths, args.scale)
+    n_pts = len(S[0])
+
+    def step():
+        for t in T:
+            t.drop_index()  # align() rebuilds the target index every scan, like pcl::Registration::initCompute
+        out = capi.align_batch(ctx, P, S, T, max_in_flight=args.in_flight)
+        if world > 1:  # result gather over RCCL/xGMI: 16 floats per pair
+            poses = torch.tensor(np.stack([o["T"] for o in out]), device="cuda")
+            gathered = torch.empty((world,) + tuple(poses.shape), device="cuda", dtype=poses.dtype)
+            dist.all_gather_into_tensor(gathered, poses)
+        return out
+
+    def barrier():
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    total_pairs = args.pairs * args.steps * world
+    value = total_pairs / elapsed
+    ok = all(o["status"] == 0 and o["iterations"] == 20 for o in out)
+    passes = float(np.mean([o["cost_passes"] for o in out]))
+
+    # accuracy of the timed work vs the simulated motion (sanity, not the parity test)
+    errs = []
+    for o, (_, _, delta) in zip(out, host):
+        Tm = np.asarray(o["T"], np.float64).reshape(4, 4).T
+        errs.append(np.abs(Tm[:3, 3] - delta[:3, 3]).max())
+
+    result = None
+    if rank == 0:
+        # ---- roofline leg: the same steps again with HIP-event timing of every launch on the library's stream ----
+        ctx.profile(True)
+        ctx.profile_reset()
+        for _ in range(max(1, min(args.steps, 2))):
+            step()
+        stats = ctx.profile_get()
+        ctx.profile(False)
+        dom = max(stats.items(), key=lambda kv: kv[1]["ms"])
+        name, st = dom
+        achieved = st["bytes"] / 1e9 / (st["ms"] / 1e3) if st["ms"] > 0 else 0.0
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        if os.path.exists(pmc_path):
+            try:
+                traffic = json.load(open(pmc_path)).get(name, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                    "avg_launch_us": round(1e3 * st["ms"] / max(1, st["launches"]), 2), "launches": st["launches"],
+                    "algorithmic_bytes_per_launch": round(st["bytes"] / max(1, st["launches"]), 1),
+                    "kernels_ms": {k: round(v["ms"], 3) for k, v in sorted(stats.items(), key=lambda kv: -kv[1]["ms"])}}
+        result = {
+            "metric": "GICP scan-pairs/s (100k-pt clouds, 20 iters)", "value": round(value, 3), "unit": "scan-pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 geometry / f64 cost",
+            "data": "synthetic",
+            "config": {"workload": "configs[1]: 100k-pt Velodyne-style scan-to-scan GICP, 20 outer iterations, odometry params "
+                                   "(corr_dist 1.0, inner 20), covariances from k=20 normals; %d independent pairs per GPU per step, "
+                                   "%d in flight" % (args.pairs, args.in_flight),
+                       "points_per_scan": n_pts, "pairs_per_gpu_per_step": args.pairs, "parallelism": "pairs sharded over %d GPU(s)" % world},
+            "all_ok": bool(ok), "mean_cost_passes_per_pair": passes, "max_translation_err_vs_truth_m": float(np.max(errs)),
+            "roofline": roofline,
+        }
+        if args.single_latency:
+            g = capi.Gicp(ctx, P)
+            g.set_source(S[0])
+            g.set_target(T[0])
+            T[0].drop_index()
+            g.align(want_trace=False)
+            t1 = time.perf_counter()
+            for _ in range(5):
+                T[0].drop_index()
+                g.align(want_trace=False)
+            result["single_pair_latency_ms"] = round(1e3 * (time.perf_counter() - t1) / 5, 3)
+        if world == 1 and not args.no_cpu_baseline:
+            cb, poses = cpu_baseline(S, T, host, P)
+            # parity of the timed GPU work against the CPU path on the sampled pairs (reported, asserted in tests/)
+            d = 0.0
+            for k, To in enumerate(poses):
+                d = max(d, float(np.abs(np.asarray(out[k]["T"]) - np.asarray(To)).max()))
+            cb["max_abs_pose_diff_vs_gpu"] = d
+            result["cpu_baseline"] = cb
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,191 @@
+/*
+ * locus_hip.h -- C ABI of the MI355X-native GICP registration hot path for LOCUS.
+ *
+ * This is the drop-in boundary: thin C++ adapters that keep the reference's class surfaces
+ * (pcl::Registration<PointF,PointF> selected by `registration_method`, the pcl_ros::Filter nodelets,
+ * PointCloudOdometry / PointCloudLocalization) call these entry points; see INTEGRATION.md for the
+ * adapter a LOCUS maintainer would add.  Plain pointers and sizes only; no C++/torch types.
+ * All `file:line` citations are relative to the LOCUS repository.
+ *
+ * Conventions
+ *   - 4x4 transforms are 16 floats, COLUMN-major (= Eigen::Matrix4f memory order).
+ *   - host clouds are described by lh_cloud_view (base, count, stride, field offsets) so both
+ *     pcl::PointXYZI (32 B) and pcl::PointXYZINormal (48 B = PointF) arrays can be passed as is.
+ *   - error convention: 0 = OK, < 0 = LH_E*; no C++ exception crosses the boundary.
+ *   - a handle is NOT re-entrant (one lidar callback at a time, Locus.cc:64-68); distinct handles may be
+ *     used from distinct threads.
+ *   - every entry point requires a HIP device; there is no CPU fallback (LH_EDEVICE when none).
+ */
+#ifndef LOCUS_HIP_H_
+#define LOCUS_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LH_ABI_VERSION 1
+
+typedef int lh_status;
+enum {
+  LH_OK = 0,
+  LH_EINVAL = -1,       /* bad argument / empty cloud / k_correspondences > cloud size (gicp.hpp:72-79) */
+  LH_ENOMEM = -2,
+  LH_EDEVICE = -3,      /* HIP error or no device */
+  LH_ETOO_FEW_CORR = -4,/* < 4 correspondences: NotEnoughPointsException (gicp.hpp:225-232) */
+  LH_ESOLVER = -5,      /* SolverDidntConvergeException (gicp.hpp:280-285) */
+  LH_ENO_NN = -6        /* no nearest neighbour found (gicp.hpp:471-478) */
+};
+
+typedef struct lh_ctx lh_ctx;     /* one per GPU / process rank */
+typedef struct lh_cloud lh_cloud; /* device-resident cloud (+ lazily built NN index) */
+typedef struct lh_gicp lh_gicp;   /* one registration object = one `icp_` member (PointCloudOdometry.h:154) */
+
+/* caller-owned, read-only host memory describing a pcl::PointCloud<PointT>::points array */
+typedef struct {
+  const void* base;
+  uint32_t count;
+  uint32_t stride;        /* bytes per point: 32 (PointXYZI) or 48 (PointXYZINormal) or 16 (xyz1) */
+  uint32_t off_xyz;       /* byte offset of float x,y,z */
+  uint32_t off_normal;    /* byte offset of float normal_x,y,z ; UINT32_MAX if the type has none */
+  uint32_t off_intensity; /* byte offset of float intensity   ; UINT32_MAX if none */
+  uint32_t off_curvature; /* byte offset of float curvature   ; UINT32_MAX if none */
+} lh_cloud_view;
+
+/* knobs of MultithreadedGeneralizedIterativeClosestPoint (gicp.h:111-132 defaults in comments) */
+typedef struct {
+  int max_iterations;            /* 200  ; LOCUS yaml 20 (point_cloud_odometry/config/parameters.yaml:12) */
+  int max_inner_iterations;      /* 20   ; localization 50 (PointCloudLocalization.cc:238) */
+  double corr_dist;              /* 5.0  ; 1.0 odom / 0.2 loc */
+  double transformation_epsilon; /* 5e-4 ; 1e-3 / 1e-5 */
+  double rotation_epsilon;       /* 2e-3 */
+  double gicp_epsilon;           /* 1e-3 */
+  int k_correspondences;         /* 20 */
+  int recompute_source_cov;      /* 0 = covariances from stored normals (production), 1 = k-NN + SVD */
+  int recompute_target_cov;
+  int num_threads;               /* accepted for surface compatibility (setNumThreads, gicp.h:134-141); ignored */
+  int enable_timing;             /* enableTimingOutput (gicp.h:143): collect per-kernel HIP-event times */
+} lh_gicp_params;
+
+typedef struct {
+  float T[16];                   /* final_transformation_ (gicp.hpp:583) */
+  int converged;                 /* hasConverged() */
+  int iterations;                /* nr_iterations_ */
+  int n_correspondences_last;
+  int status;                    /* LH_OK, or the exception the reference would have caught (gicp.hpp:542-547) */
+  double fitness;                /* getFitnessScore(); NaN unless requested via lh_gicp_fitness */
+  int cost_passes;               /* device passes over the correspondences (fused f+df evaluations) */
+  int reserved;
+} lh_gicp_result;
+
+/* per-outer-iteration trace (parity tests compare it with the oracle's) */
+#define LH_MAX_TRACE 256
+typedef struct {
+  int n_iters;
+  float T[LH_MAX_TRACE][16];
+  int n_corr[LH_MAX_TRACE];
+  int n_passes[LH_MAX_TRACE];
+  int n_inner[LH_MAX_TRACE];
+  double f_end[LH_MAX_TRACE];
+  double delta[LH_MAX_TRACE];
+} lh_gicp_trace;
+
+/* ---- context -------------------------------------------------------------------------------- */
+int lh_abi_version(void);
+const char* lh_status_string(lh_status s);
+lh_status lh_create(lh_ctx** out, int device_id);
+void lh_destroy(lh_ctx* ctx);
+lh_status lh_synchronize(lh_ctx* ctx);
+void lh_default_gicp_params(lh_gicp_params* p);          /* gicp.h:111-132 */
+
+/* ---- device-resident clouds ------------------------------------------------------------------ */
+/* copies xyz (+normals, intensity when present) to HBM.  Replaces holding a PointCloudF::Ptr
+   (PointCloudOdometry.h:125-131). */
+lh_status lh_cloud_create(lh_ctx* ctx, const lh_cloud_view* view, lh_cloud** out);
+void lh_cloud_destroy(lh_cloud* c);
+uint32_t lh_cloud_size(const lh_cloud* c);
+/* build / drop the NN index = tree_->setInputCloud() inside pcl::Registration::initCompute (K2) */
+lh_status lh_cloud_build_index(lh_cloud* c);
+lh_status lh_cloud_drop_index(lh_cloud* c);
+/* download into a caller array of `stride`-byte points (writes xyz, normals, intensity where offsets given) */
+lh_status lh_cloud_download(const lh_cloud* c, void* out_base, uint32_t stride, uint32_t off_xyz,
+                            uint32_t off_normal, uint32_t off_intensity, uint32_t off_curvature);
+/* y = T*x (pcl::transformPointCloud, gicp.hpp:440,586; PointCloudOdometry.cc:255,260) ;
+   with_normals != 0 also rotates normals (transformPointCloudWithNormals, PointCloudLocalization.cc:197,218,325).
+   out may alias in. */
+lh_status lh_cloud_transform(const lh_cloud* in, const float T[16], int with_normals, lh_cloud** out);
+
+/* ---- registration object (MultithreadedGeneralizedIterativeClosestPoint) ---------------------- */
+lh_status lh_gicp_create(lh_ctx* ctx, const lh_gicp_params* p, lh_gicp** out);
+void lh_gicp_destroy(lh_gicp* g);
+lh_status lh_gicp_set_params(lh_gicp* g, const lh_gicp_params* p);
+/* setInputSource (gicp.h:162-179): copies to device, invalidates source covariances */
+lh_status lh_gicp_set_source(lh_gicp* g, const lh_cloud_view* v);
+/* setInputTarget (gicp.h:196-200): copies to device, invalidates target covariances + index */
+lh_status lh_gicp_set_target(lh_gicp* g, const lh_cloud_view* v);
+/* device-resident variants (the handle borrows the cloud; caller keeps ownership) */
+lh_status lh_gicp_set_source_cloud(lh_gicp* g, lh_cloud* c);
+lh_status lh_gicp_set_target_cloud(lh_gicp* g, lh_cloud* c);
+/* odometry fast path for copyPointCloud(*query_, *reference_) (PointCloudOdometry.cc:243-244): the
+   current source becomes the target without leaving HBM; results identical to set_target of the same data */
+lh_status lh_gicp_promote_source_to_target(lh_gicp* g);
+/* pcl::Registration::align + computeTransformation (gicp.hpp:406-617).  guess NULL = identity.
+   aligned_out (nullable): count*stride bytes, receives final_T * input xyz at off_xyz (gicp.hpp:586). */
+lh_status lh_gicp_align(lh_gicp* g, const float guess[16], lh_gicp_result* out, lh_gicp_trace* trace,
+                        void* aligned_out, uint32_t stride, uint32_t off_xyz);
+/* getFitnessScore(max_range = DBL_MAX) of the last alignment (K7) */
+lh_status lh_gicp_fitness(lh_gicp* g, double* fitness);
+/* getSearchMethodTarget()->nearestKSearch(pt, 1, ...) for every point of q (PointCloudLocalization.cc:327-336) */
+lh_status lh_nn1(lh_gicp* g, const lh_cloud_view* q, int32_t* idx, float* d2);
+lh_status lh_nn1_cloud(lh_cloud* target, const lh_cloud* q, int32_t* idx, float* d2);
+/* k-NN on a cloud's own index (pcl::search::KdTree::nearestKSearch with k > 1; gicp.hpp:108-109) */
+lh_status lh_knn_cloud(lh_cloud* target, const lh_cloud* q, int k, int32_t* idx, float* d2);
+
+/* batched alignment of independent scan pairs on this context's GPU (BASELINE configs 4/5): pair p aligns
+   src[p] -> tgt[p].  The NN index of every target is (re)built inside the call, like align() does. */
+lh_status lh_gicp_align_batch(lh_ctx* ctx, const lh_gicp_params* p, int n_pairs, lh_cloud* const* src,
+                              lh_cloud* const* tgt, const float* guesses /* n_pairs*16 or NULL */,
+                              lh_gicp_result* out, int max_in_flight /* 0 = default */);
+
+/* ---- building blocks exported for parity tests and for the localization wrapper ---------------- */
+/* K3: computeCovariances k-NN branch (gicp.hpp:85-154) -> row-major 3x3 doubles [n][9] on the host */
+lh_status lh_cov_knn(lh_cloud* c, int k, double gicp_epsilon, double* cov9_out);
+/* K4: one NN + Mahalanobis sweep (gicp.hpp:464-498) with explicit transformation_ (col-major float) and guess.
+   tgt_idx[n] (-1 unmatched), maha9 [n][9] row-major (entries of unmatched points are unspecified). */
+lh_status lh_gicp_debug_sweep(lh_gicp* g, const float T[16], const float guess[16], int32_t* tgt_idx, double* maha9);
+/* K5: one cost-functor pass fdf(x) (gicp.hpp:362-402) on the correspondences of the last sweep */
+lh_status lh_gicp_debug_cost(lh_gicp* g, const double x[6], double* f, double g6[6], double sums13[13], int* m);
+
+/* K8: normalizePCloud + ComputeAp_ForPoint2PlaneICP (utils.cc:106-128, PointCloudLocalization.cc:723-750);
+   corr[i] indexes `reference` normals; Ap row-major 6x6 */
+lh_status lh_p2plane_information(lh_ctx* ctx, const lh_cloud* query, const lh_cloud* reference, const int64_t* corr,
+                                 double Ap[36]);
+/* H2: ComputePoint2PlaneICPCovariance conditioning (PointCloudLocalization.cc:487-538); host-side, 6x6 */
+lh_status lh_icp_covariance(const double Ap[36], double icp_max_covariance, double cov[36], double* condition_number);
+
+/* K1: CustomVoxelGrid::filter (custom_voxel_grid.cc:76-87): voxel centroid of x,y,z,intensity, pass-through
+   limits on one axis (limit_axis -1 none / 0,1,2), output in ascending voxel index.  out = xyzi float[cap][4].
+   *out_count is the number of voxels (may exceed cap: then only cap are written).  LH_EINVAL on int32 index overflow. */
+lh_status lh_voxel_grid(lh_ctx* ctx, const lh_cloud_view* in, float leaf, int limit_axis, double lo, double hi,
+                        float* out_xyzi, uint32_t out_capacity, uint32_t* out_count);
+/* K3 (filter flavour): NormalComputation::filter (normal_computation.cc:26-59), k-NN, viewpoint (0,0,0).
+   out = float[count][4] (nx, ny, nz, curvature) */
+lh_status lh_normals_knn(lh_ctx* ctx, const lh_cloud_view* in, int k, float* out_normals4);
+lh_status lh_normals_knn_cloud(lh_cloud* c, int k); /* in place: fills the cloud's normals on the device */
+
+/* ---- instrumentation (enableTimingOutput analogue) ------------------------- */
+typedef struct {
+  char name[32];
+  uint64_t launches;
+  double total_ms;  /* HIP-event time on the context's stream */
+  double bytes;     /* algorithmic bytes accumulated with SURVEY.md 8d's model */
+} lh_kernel_stat;
+lh_status lh_profile_enable(lh_ctx* ctx, int on);
+lh_status lh_profile_reset(lh_ctx* ctx);
+int lh_profile_get(lh_ctx* ctx, lh_kernel_stat* out, int cap); /* returns number of entries */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LOCUS_HIP_H_ */

@@ -1,0 +1,474 @@
+"""ctypes binding of the C ABI in include/locus_hip.h (locus_amd/csrc/liblocus_hip.so).
+
+The library is the product; this module only marshals numpy arrays into lh_cloud_view structs.
+There is no CPU fallback: if the shared library is missing, import fails loudly; if no HIP device
+is present, lh_create() returns LH_EDEVICE and Context() raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "liblocus_hip.so")
+LH_MAX_TRACE = 256
+UINT32_MAX = 0xFFFFFFFF
+
+LH_OK, LH_EINVAL, LH_ENOMEM, LH_EDEVICE, LH_ETOO_FEW_CORR, LH_ESOLVER, LH_ENO_NN = 0, -1, -2, -3, -4, -5, -6
+
+
+class LocusHipError(RuntimeError):
+    def __init__(self, status, what=""):
+        self.status = status
+        msg = lib().lh_status_string(status).decode() if _lib is not None else str(status)
+        super().__init__("locus_hip: %s failed: %s (%d)" % (what, msg, status))
+
+
+class CloudView(C.Structure):
+    _fields_ = [
+        ("base", C.c_void_p),
+        ("count", C.c_uint32),
+        ("stride", C.c_uint32),
+        ("off_xyz", C.c_uint32),
+        ("off_normal", C.c_uint32),
+        ("off_intensity", C.c_uint32),
+        ("off_curvature", C.c_uint32),
+    ]
+
+
+class GicpParams(C.Structure):
+    _fields_ = [
+        ("max_iterations", C.c_int),
+        ("max_inner_iterations", C.c_int),
+        ("corr_dist", C.c_double),
+        ("transformation_epsilon", C.c_double),
+        ("rotation_epsilon", C.c_double),
+        ("gicp_epsilon", C.c_double),
+        ("k_correspondences", C.c_int),
+        ("recompute_source_cov", C.c_int),
+        ("recompute_target_cov", C.c_int),
+        ("num_threads", C.c_int),
+        ("enable_timing", C.c_int),
+    ]
+
+
+class GicpResult(C.Structure):
+    _fields_ = [
+        ("T", C.c_float * 16),
+        ("converged", C.c_int),
+        ("iterations", C.c_int),
+        ("n_correspondences_last", C.c_int),
+        ("status", C.c_int),
+        ("fitness", C.c_double),
+        ("cost_passes", C.c_int),
+        ("reserved", C.c_int),
+    ]
+
+
+class GicpTrace(C.Structure):
+    _fields_ = [
+        ("n_iters", C.c_int),
+        ("T", (C.c_float * 16) * LH_MAX_TRACE),
+        ("n_corr", C.c_int * LH_MAX_TRACE),
+        ("n_passes", C.c_int * LH_MAX_TRACE),
+        ("n_inner", C.c_int * LH_MAX_TRACE),
+        ("f_end", C.c_double * LH_MAX_TRACE),
+        ("delta", C.c_double * LH_MAX_TRACE),
+    ]
+
+
+class KernelStat(C.Structure):
+    _fields_ = [("name", C.c_char * 32), ("launches", C.c_uint64), ("total_ms", C.c_double), ("bytes", C.c_double)]
+
+
+# every symbol include/locus_hip.h declares (tests check the library exports all of them)
+EXPORTS = [
+    "lh_abi_version", "lh_status_string", "lh_create", "lh_destroy", "lh_synchronize", "lh_default_gicp_params",
+    "lh_cloud_create", "lh_cloud_destroy", "lh_cloud_size", "lh_cloud_build_index", "lh_cloud_drop_index",
+    "lh_cloud_download", "lh_cloud_transform", "lh_gicp_create", "lh_gicp_destroy", "lh_gicp_set_params",
+    "lh_gicp_set_source", "lh_gicp_set_target", "lh_gicp_set_source_cloud", "lh_gicp_set_target_cloud",
+    "lh_gicp_promote_source_to_target", "lh_gicp_align", "lh_gicp_fitness", "lh_nn1", "lh_nn1_cloud", "lh_knn_cloud",
+    "lh_gicp_align_batch", "lh_cov_knn", "lh_gicp_debug_sweep", "lh_gicp_debug_cost", "lh_p2plane_information",
+    "lh_icp_covariance", "lh_voxel_grid", "lh_normals_knn", "lh_normals_knn_cloud", "lh_profile_enable",
+    "lh_profile_reset", "lh_profile_get",
+]
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "locus_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        vp, i32, u32, dbl = C.c_void_p, C.c_int, C.c_uint32, C.c_double
+        L.lh_abi_version.restype = i32
+        L.lh_status_string.restype = C.c_char_p
+        L.lh_status_string.argtypes = [i32]
+        L.lh_create.argtypes = [C.POINTER(vp), i32]
+        L.lh_destroy.argtypes = [vp]
+        L.lh_destroy.restype = None
+        L.lh_synchronize.argtypes = [vp]
+        L.lh_default_gicp_params.argtypes = [C.POINTER(GicpParams)]
+        L.lh_default_gicp_params.restype = None
+        L.lh_cloud_create.argtypes = [vp, C.POINTER(CloudView), C.POINTER(vp)]
+        L.lh_cloud_destroy.argtypes = [vp]
+        L.lh_cloud_destroy.restype = None
+        L.lh_cloud_size.argtypes = [vp]
+        L.lh_cloud_size.restype = u32
+        L.lh_cloud_build_index.argtypes = [vp]
+        L.lh_cloud_drop_index.argtypes = [vp]
+        L.lh_cloud_download.argtypes = [vp, vp, u32, u32, u32, u32, u32]
+        L.lh_cloud_transform.argtypes = [vp, vp, i32, C.POINTER(vp)]
+        L.lh_gicp_create.argtypes = [vp, C.POINTER(GicpParams), C.POINTER(vp)]
+        L.lh_gicp_destroy.argtypes = [vp]
+        L.lh_gicp_destroy.restype = None
+        L.lh_gicp_set_params.argtypes = [vp, C.POINTER(GicpParams)]
+        L.lh_gicp_set_source.argtypes = [vp, C.POINTER(CloudView)]
+        L.lh_gicp_set_target.argtypes = [vp, C.POINTER(CloudView)]
+        L.lh_gicp_set_source_cloud.argtypes = [vp, vp]
+        L.lh_gicp_set_target_cloud.argtypes = [vp, vp]
+        L.lh_gicp_promote_source_to_target.argtypes = [vp]
+        L.lh_gicp_align.argtypes = [vp, vp, C.POINTER(GicpResult), C.POINTER(GicpTrace), vp, u32, u32]
+        L.lh_gicp_fitness.argtypes = [vp, C.POINTER(dbl)]
+        L.lh_nn1.argtypes = [vp, C.POINTER(CloudView), vp, vp]
+        L.lh_nn1_cloud.argtypes = [vp, vp, vp, vp]
+        L.lh_knn_cloud.argtypes = [vp, vp, i32, vp, vp]
+        L.lh_gicp_align_batch.argtypes = [vp, C.POINTER(GicpParams), i32, C.POINTER(vp), C.POINTER(vp), vp,
+                                          C.POINTER(GicpResult), i32]
+        L.lh_cov_knn.argtypes = [vp, i32, dbl, vp]
+        L.lh_gicp_debug_sweep.argtypes = [vp, vp, vp, vp, vp]
+        L.lh_gicp_debug_cost.argtypes = [vp, vp, C.POINTER(dbl), vp, vp, C.POINTER(i32)]
+        L.lh_p2plane_information.argtypes = [vp, vp, vp, vp, vp]
+        L.lh_icp_covariance.argtypes = [vp, dbl, vp, C.POINTER(dbl)]
+        L.lh_voxel_grid.argtypes = [vp, C.POINTER(CloudView), C.c_float, i32, dbl, dbl, vp, u32, C.POINTER(u32)]
+        L.lh_normals_knn.argtypes = [vp, C.POINTER(CloudView), i32, vp]
+        L.lh_normals_knn_cloud.argtypes = [vp, i32]
+        L.lh_profile_enable.argtypes = [vp, i32]
+        L.lh_profile_reset.argtypes = [vp]
+        L.lh_profile_get.argtypes = [vp, C.POINTER(KernelStat), i32]
+        _lib = L
+    return _lib
+
+
+def _check(st, what):
+    if st != LH_OK:
+        raise LocusHipError(st, what)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+# ---- point-type layouts (pcl::PointXYZI = 32 B, pcl::PointXYZINormal = PointF = 48 B) --------------------
+POINT_XYZI = np.dtype({"names": ["x", "y", "z", "intensity"], "formats": ["f4"] * 4, "offsets": [0, 4, 8, 16],
+                       "itemsize": 32})
+POINT_XYZINORMAL = np.dtype({"names": ["x", "y", "z", "normal_x", "normal_y", "normal_z", "intensity", "curvature"],
+                             "formats": ["f4"] * 8, "offsets": [0, 4, 8, 16, 20, 24, 32, 36], "itemsize": 48})
+
+
+def make_pointf(xyz, normals=None, intensity=None, curvature=None):
+    """numpy structured array with pcl::PointXYZINormal layout (PointF, the type GICP consumes)."""
+    xyz = np.asarray(xyz, np.float32)
+    n = xyz.shape[0]
+    a = np.zeros(n, POINT_XYZINORMAL)
+    a["x"], a["y"], a["z"] = xyz[:, 0], xyz[:, 1], xyz[:, 2]
+    if normals is not None:
+        normals = np.asarray(normals, np.float32)
+        a["normal_x"], a["normal_y"], a["normal_z"] = normals[:, 0], normals[:, 1], normals[:, 2]
+        if curvature is None and normals.shape[1] > 3:
+            curvature = normals[:, 3]
+    if intensity is not None:
+        a["intensity"] = np.asarray(intensity, np.float32)
+    if curvature is not None:
+        a["curvature"] = np.asarray(curvature, np.float32)
+    return a
+
+
+def make_pointxyzi(xyz, intensity=None):
+    xyz = np.asarray(xyz, np.float32)
+    a = np.zeros(xyz.shape[0], POINT_XYZI)
+    a["x"], a["y"], a["z"] = xyz[:, 0], xyz[:, 1], xyz[:, 2]
+    if intensity is not None:
+        a["intensity"] = np.asarray(intensity, np.float32)
+    return a
+
+
+def view_of(points, with_normals=None):
+    """lh_cloud_view of a structured array (PointXYZI / PointXYZINormal) or of a float32 (n,3|4) xyz array.
+    Returns (view, keepalive)."""
+    if isinstance(points, np.ndarray) and points.dtype.names:
+        a = np.ascontiguousarray(points)
+        f = a.dtype.fields
+        has_n = "normal_x" in f if with_normals is None else (with_normals and "normal_x" in f)
+        v = CloudView(_ptr(a), a.shape[0], a.dtype.itemsize, f["x"][1],
+                      f["normal_x"][1] if has_n else UINT32_MAX,
+                      f["intensity"][1] if "intensity" in f else UINT32_MAX,
+                      f["curvature"][1] if (has_n and "curvature" in f) else UINT32_MAX)
+        return v, a
+    a = np.ascontiguousarray(points, np.float32)
+    assert a.ndim == 2 and a.shape[1] in (3, 4)
+    v = CloudView(_ptr(a), a.shape[0], a.shape[1] * 4, 0, UINT32_MAX, UINT32_MAX, UINT32_MAX)
+    return v, a
+
+
+def default_params(**kw):
+    p = GicpParams()
+    lib().lh_default_gicp_params(C.byref(p))
+    for k, v in kw.items():
+        assert hasattr(p, k), k
+        setattr(p, k, v)
+    return p
+
+
+class Context:
+    """lh_ctx: one per GPU / rank."""
+
+    def __init__(self, device=0):
+        self.h = C.c_void_p()
+        _check(lib().lh_create(C.byref(self.h), device), "lh_create")
+        self.device = device
+
+    def close(self):
+        if self.h:
+            lib().lh_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        _check(lib().lh_synchronize(self.h), "lh_synchronize")
+
+    def profile(self, on=True):
+        _check(lib().lh_profile_enable(self.h, 1 if on else 0), "lh_profile_enable")
+
+    def profile_reset(self):
+        _check(lib().lh_profile_reset(self.h), "lh_profile_reset")
+
+    def profile_get(self):
+        buf = (KernelStat * 64)()
+        n = lib().lh_profile_get(self.h, buf, 64)
+        return {buf[i].name.decode(): {"launches": int(buf[i].launches), "ms": buf[i].total_ms, "bytes": buf[i].bytes}
+                for i in range(min(n, 64))}
+
+    def voxel_grid(self, points, leaf, limit_axis=-1, lo=-np.inf, hi=np.inf, capacity=None):
+        v, keep = view_of(points)
+        cap = capacity if capacity is not None else v.count
+        out = np.empty((max(cap, 1), 4), np.float32)
+        cnt = C.c_uint32()
+        _check(lib().lh_voxel_grid(self.h, C.byref(v), leaf, limit_axis, float(max(lo, -3e38)), float(min(hi, 3e38)),
+                                   _ptr(out), cap, C.byref(cnt)), "lh_voxel_grid")
+        return out[: min(cnt.value, cap)].copy(), cnt.value
+
+    def normals_knn(self, points, k=20):
+        v, keep = view_of(points)
+        out = np.empty((v.count, 4), np.float32)
+        _check(lib().lh_normals_knn(self.h, C.byref(v), k, _ptr(out)), "lh_normals_knn")
+        return out
+
+    def p2plane_information(self, query, reference, corr):
+        corr = np.ascontiguousarray(corr, np.int64)
+        Ap = np.empty((6, 6), np.float64)
+        _check(lib().lh_p2plane_information(self.h, query.h, reference.h, _ptr(corr), _ptr(Ap)), "lh_p2plane_information")
+        return Ap
+
+
+def icp_covariance(Ap, icp_max_covariance=0.01):
+    Ap = np.ascontiguousarray(Ap, np.float64)
+    cov = np.empty((6, 6), np.float64)
+    cond = C.c_double()
+    st = lib().lh_icp_covariance(_ptr(Ap), icp_max_covariance, _ptr(cov), C.byref(cond))
+    return st == LH_OK, cov, cond.value
+
+
+class Cloud:
+    """lh_cloud: device-resident cloud."""
+
+    def __init__(self, ctx, points, _handle=None):
+        self.ctx = ctx
+        if _handle is not None:
+            self.h = _handle
+            return
+        v, keep = view_of(points)
+        self.h = C.c_void_p()
+        _check(lib().lh_cloud_create(ctx.h, C.byref(v), C.byref(self.h)), "lh_cloud_create")
+
+    def __len__(self):
+        return lib().lh_cloud_size(self.h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().lh_cloud_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            if self.ctx.h:
+                self.close()
+        except Exception:
+            pass
+
+    def build_index(self):
+        _check(lib().lh_cloud_build_index(self.h), "lh_cloud_build_index")
+
+    def drop_index(self):
+        _check(lib().lh_cloud_drop_index(self.h), "lh_cloud_drop_index")
+
+    def download(self):
+        a = np.zeros(len(self), POINT_XYZINORMAL)
+        f = a.dtype.fields
+        _check(lib().lh_cloud_download(self.h, _ptr(a), a.dtype.itemsize, f["x"][1], f["normal_x"][1], f["intensity"][1],
+                                       f["curvature"][1]), "lh_cloud_download")
+        return a
+
+    def transform(self, T16_colmajor, with_normals=False):
+        T = np.ascontiguousarray(T16_colmajor, np.float32).reshape(16)
+        out = C.c_void_p()
+        _check(lib().lh_cloud_transform(self.h, _ptr(T), 1 if with_normals else 0, C.byref(out)), "lh_cloud_transform")
+        return Cloud(self.ctx, None, _handle=out)
+
+    def nn1(self, query_cloud):
+        n = len(query_cloud)
+        idx = np.empty(n, np.int32)
+        d2 = np.empty(n, np.float32)
+        _check(lib().lh_nn1_cloud(self.h, query_cloud.h, _ptr(idx), _ptr(d2)), "lh_nn1_cloud")
+        return idx, d2
+
+    def knn(self, query_cloud, k):
+        n = len(query_cloud)
+        idx = np.empty((n, k), np.int32)
+        d2 = np.empty((n, k), np.float32)
+        _check(lib().lh_knn_cloud(self.h, query_cloud.h, k, _ptr(idx), _ptr(d2)), "lh_knn_cloud")
+        return idx, d2
+
+    def cov_knn(self, k=20, eps=1e-3):
+        cov = np.empty((len(self), 3, 3), np.float64)
+        _check(lib().lh_cov_knn(self.h, k, eps, _ptr(cov)), "lh_cov_knn")
+        return cov
+
+    def normals_knn(self, k=20):
+        _check(lib().lh_normals_knn_cloud(self.h, k), "lh_normals_knn_cloud")
+
+
+def _result_dict(r, trace=None):
+    out = {
+        "T": np.array(r.T[:], np.float32), "converged": r.converged, "iterations": r.iterations,
+        "n_corr_last": r.n_correspondences_last, "status": r.status, "fitness": r.fitness, "cost_passes": r.cost_passes,
+    }
+    if trace is not None:
+        k = trace.n_iters
+        out["trace"] = {
+            "T": np.array([trace.T[i][:] for i in range(k)], np.float32).reshape(k, 16),
+            "n_corr": np.array(trace.n_corr[:k]), "n_passes": np.array(trace.n_passes[:k]),
+            "n_inner": np.array(trace.n_inner[:k]), "f_end": np.array(trace.f_end[:k]), "delta": np.array(trace.delta[:k]),
+        }
+    return out
+
+
+class Gicp:
+    """lh_gicp: one registration object (the `icp_` member of PointCloudOdometry / PointCloudLocalization)."""
+
+    def __init__(self, ctx, params=None):
+        self.ctx = ctx
+        self.params = params or default_params()
+        self.h = C.c_void_p()
+        _check(lib().lh_gicp_create(ctx.h, C.byref(self.params), C.byref(self.h)), "lh_gicp_create")
+        self._keep = []
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().lh_gicp_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            if self.ctx.h:
+                self.close()
+        except Exception:
+            pass
+
+    def set_params(self, params):
+        self.params = params
+        _check(lib().lh_gicp_set_params(self.h, C.byref(params)), "lh_gicp_set_params")
+
+    def set_source(self, points):
+        if isinstance(points, Cloud):
+            self._src = points
+            _check(lib().lh_gicp_set_source_cloud(self.h, points.h), "lh_gicp_set_source_cloud")
+        else:
+            v, keep = view_of(points)
+            _check(lib().lh_gicp_set_source(self.h, C.byref(v)), "lh_gicp_set_source")
+
+    def set_target(self, points):
+        if isinstance(points, Cloud):
+            self._tgt = points
+            _check(lib().lh_gicp_set_target_cloud(self.h, points.h), "lh_gicp_set_target_cloud")
+        else:
+            v, keep = view_of(points)
+            _check(lib().lh_gicp_set_target(self.h, C.byref(v)), "lh_gicp_set_target")
+
+    def promote_source_to_target(self):
+        _check(lib().lh_gicp_promote_source_to_target(self.h), "lh_gicp_promote_source_to_target")
+
+    def align(self, guess=None, want_trace=True, aligned_out=None, raise_on_error=True):
+        r = GicpResult()
+        tr = GicpTrace() if want_trace else None
+        g = np.ascontiguousarray(guess, np.float32).reshape(16) if guess is not None else None
+        if aligned_out is not None:
+            f = aligned_out.dtype.fields
+            st = lib().lh_gicp_align(self.h, _ptr(g), C.byref(r), C.byref(tr) if tr is not None else None, _ptr(aligned_out),
+                                     aligned_out.dtype.itemsize, f["x"][1])
+        else:
+            st = lib().lh_gicp_align(self.h, _ptr(g), C.byref(r), C.byref(tr) if tr is not None else None, None, 0, 0)
+        if raise_on_error and st not in (LH_OK, LH_ETOO_FEW_CORR, LH_ESOLVER):
+            raise LocusHipError(st, "lh_gicp_align")
+        return _result_dict(r, tr)
+
+    def fitness(self):
+        f = C.c_double()
+        _check(lib().lh_gicp_fitness(self.h, C.byref(f)), "lh_gicp_fitness")
+        return f.value
+
+    def nn1(self, points):
+        v, keep = view_of(points)
+        idx = np.empty(v.count, np.int32)
+        d2 = np.empty(v.count, np.float32)
+        _check(lib().lh_nn1(self.h, C.byref(v), _ptr(idx), _ptr(d2)), "lh_nn1")
+        return idx, d2
+
+    def debug_sweep(self, T16, n_src, guess=None):
+        T = np.ascontiguousarray(T16, np.float32).reshape(16)
+        g = np.ascontiguousarray(guess, np.float32).reshape(16) if guess is not None else None
+        idx = np.empty(n_src, np.int32)
+        maha = np.zeros((n_src, 3, 3), np.float64)
+        _check(lib().lh_gicp_debug_sweep(self.h, _ptr(T), _ptr(g), _ptr(idx), _ptr(maha)), "lh_gicp_debug_sweep")
+        return idx, maha
+
+    def debug_cost(self, x6):
+        x = np.ascontiguousarray(x6, np.float64)
+        f = C.c_double()
+        g = np.empty(6, np.float64)
+        sums = np.empty(13, np.float64)
+        m = C.c_int()
+        _check(lib().lh_gicp_debug_cost(self.h, _ptr(x), C.byref(f), _ptr(g), _ptr(sums), C.byref(m)), "lh_gicp_debug_cost")
+        return f.value, g, sums, m.value
+
+
+def align_batch(ctx, params, src_clouds, tgt_clouds, guesses=None, max_in_flight=0):
+    n = len(src_clouds)
+    assert n == len(tgt_clouds)
+    S = (C.c_void_p * n)(*[c.h for c in src_clouds])
+    T = (C.c_void_p * n)(*[c.h for c in tgt_clouds])
+    out = (GicpResult * n)()
+    g = np.ascontiguousarray(guesses, np.float32).reshape(n * 16) if guesses is not None else None
+    st = lib().lh_gicp_align_batch(ctx.h, C.byref(params), n, S, T, _ptr(g), out, max_in_flight)
+    if st not in (LH_OK, LH_ETOO_FEW_CORR, LH_ESOLVER):
+        raise LocusHipError(st, "lh_gicp_align_batch")
+    return [_result_dict(out[i]) for i in range(n)]

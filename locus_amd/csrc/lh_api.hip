@@ -1,0 +1,1382 @@
+// lh_api.hip -- C ABI (include/locus_hip.h) + host runtime of the MI355X GICP hot path.
+//
+// Runtime model: one lh_ctx per GPU (one HIP stream).  An alignment is a stackful coroutine (ucontext) that runs
+// the reference's computeTransformation control flow (gicp.hpp:406-617) and yields two kinds of device requests:
+//   SWEEP(T)  -> k_sweep   (NN + Mahalanobis, gicp.hpp:464-498)
+//   COST(x)   -> k_cost    (fused f/df pass, gicp.hpp:362-402)
+// The scheduler resumes every in-flight pair, batches their requests into ONE launch per kind (grid.y = pair),
+// synchronises once per round and feeds the results back.  A single lh_gicp_align is the same machinery with one
+// task.  No CPU fallback exists: without a HIP device every entry point returns LH_EDEVICE.
+#include <ucontext.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/locus_hip.h"
+#include "lh_bfgs.hpp"
+#include "lh_kernels.hpp"
+
+using namespace lh;
+
+#define HIPCHK(expr)                                                                                      \
+  do {                                                                                                    \
+    hipError_t e_ = (expr);                                                                               \
+    if (e_ != hipSuccess) {                                                                               \
+      fprintf(stderr, "[locus_hip] %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return LH_EDEVICE;                                                                                  \
+    }                                                                                                     \
+  } while (0)
+
+static const float I16[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+
+// ---------------------------------------------------------------------------------------------------------
+struct ProfEntry { std::string name; uint64_t launches = 0; double ms = 0, bytes = 0; };
+struct ProfPending { int entry; hipEvent_t a, b; };
+
+struct lh_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  // index-build scratch (shared by all clouds of the context; builds are serial on the stream)
+  uint32_t *keys0 = nullptr, *keys1 = nullptr, *vals0 = nullptr, *vals1 = nullptr, *bbox = nullptr;
+  void* sort_temp = nullptr;
+  size_t sort_temp_bytes = 0;
+  int scratch_n = 0;
+  // pair slots
+  PairDesc* descs_dev = nullptr;   // [n_slots]
+  PairDesc* descs_host = nullptr;  // pinned staging
+  int n_slots = 0;
+  double* partials_host = nullptr; // pinned, device-visible: [n_slots][max_cost_blocks][COST_NSUM]
+  size_t partials_per_slot = 0;    // doubles
+  // misc pinned scratch for small downloads
+  double* small_host = nullptr;
+  size_t small_host_doubles = 0;
+  // profiling
+  bool prof = false;
+  std::vector<ProfEntry> prof_entries;
+  std::vector<ProfPending> prof_pending;
+  std::vector<hipEvent_t> ev_pool;
+
+  int prof_entry(const char* name) {
+    for (size_t i = 0; i < prof_entries.size(); i++)
+      if (prof_entries[i].name == name) return (int)i;
+    ProfEntry e;
+    e.name = name;
+    prof_entries.push_back(e);
+    return (int)prof_entries.size() - 1;
+  }
+  hipEvent_t get_event() {
+    if (!ev_pool.empty()) { hipEvent_t e = ev_pool.back(); ev_pool.pop_back(); return e; }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+  }
+  void prof_flush() {
+    if (prof_pending.empty()) return;
+    (void)hipStreamSynchronize(stream);
+    for (auto& p : prof_pending) {
+      float ms = 0;
+      (void)hipEventElapsedTime(&ms, p.a, p.b);
+      prof_entries[p.entry].ms += ms;
+      ev_pool.push_back(p.a);
+      ev_pool.push_back(p.b);
+    }
+    prof_pending.clear();
+  }
+};
+
+// RAII-ish profiling scope around one launch (HIP events on the context's own stream)
+struct ProfScope {
+  lh_ctx* c; int entry = -1; hipEvent_t a, b;
+  ProfScope(lh_ctx* ctx, const char* name, double bytes) : c(ctx) {
+    if (!c->prof) return;
+    entry = c->prof_entry(name);
+    c->prof_entries[entry].launches++;
+    c->prof_entries[entry].bytes += bytes;
+    a = c->get_event(); b = c->get_event();
+    (void)hipEventRecord(a, c->stream);
+  }
+  ~ProfScope() {
+    if (entry < 0) return;
+    (void)hipEventRecord(b, c->stream);
+    c->prof_pending.push_back({entry, a, b});
+    if (c->prof_pending.size() > 8192) c->prof_flush();
+  }
+};
+
+struct lh_cloud {
+  lh_ctx* ctx = nullptr;
+  int n = 0, n_pad = 0;
+  float4* xyz = nullptr;
+  float4* nrm = nullptr;       // null if the cloud has no normals
+  float* intensity = nullptr;  // null if none
+  // NN index
+  bool has_index = false;
+  float4* sorted = nullptr;
+  Node4* nodes = nullptr;
+  int depth = 0, first_leaf = 0, n_leaves = 0, sorted_cap = 0, nodes_cap = 0;
+  // k-NN covariances (6 planes of n_pad doubles), valid for (cov_k, cov_eps)
+  double* cov6 = nullptr;
+  int cov_k = 0;
+  double cov_eps = 0;
+  TreeView view() const { return TreeView{sorted, nodes, first_leaf, n}; }
+};
+
+static int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+static void cloud_free(lh_cloud* c) {
+  if (!c) return;
+  (void)hipFree(c->xyz); (void)hipFree(c->nrm); (void)hipFree(c->intensity);
+  (void)hipFree(c->sorted); (void)hipFree(c->nodes); (void)hipFree(c->cov6);
+  delete c;
+}
+
+static lh_status ctx_ensure_scratch(lh_ctx* c, int n) {
+  if (n <= c->scratch_n) return LH_OK;
+  (void)hipStreamSynchronize(c->stream);
+  (void)hipFree(c->keys0); (void)hipFree(c->keys1); (void)hipFree(c->vals0); (void)hipFree(c->vals1); (void)hipFree(c->sort_temp);
+  int cap = round_up(n + n / 4, 1024);
+  HIPCHK(hipMalloc(&c->keys0, sizeof(uint32_t) * cap));
+  HIPCHK(hipMalloc(&c->keys1, sizeof(uint32_t) * cap));
+  HIPCHK(hipMalloc(&c->vals0, sizeof(uint32_t) * cap));
+  HIPCHK(hipMalloc(&c->vals1, sizeof(uint32_t) * cap));
+  c->sort_temp_bytes = sort_temp_bytes(cap);
+  HIPCHK(hipMalloc(&c->sort_temp, c->sort_temp_bytes ? c->sort_temp_bytes : 16));
+  c->scratch_n = cap;
+  return LH_OK;
+}
+
+static lh_status ctx_ensure_small(lh_ctx* c, size_t doubles) {
+  if (doubles <= c->small_host_doubles) return LH_OK;
+  (void)hipStreamSynchronize(c->stream);
+  if (c->small_host) (void)hipHostFree(c->small_host);
+  size_t cap = std::max<size_t>(doubles, 4096);
+  HIPCHK(hipHostMalloc(&c->small_host, sizeof(double) * cap, hipHostMallocDefault));
+  c->small_host_doubles = cap;
+  return LH_OK;
+}
+
+// K2: Morton sort + implicit 4-ary box tree (replaces tree_->setInputCloud of pcl::Registration::initCompute)
+static lh_status cloud_build_index(lh_cloud* c) {
+  lh_ctx* x = c->ctx;
+  if (c->n <= 0) return LH_EINVAL;
+  lh_status st = ctx_ensure_scratch(x, c->n);
+  if (st) return st;
+  int n_leaves = (c->n + LEAF - 1) / LEAF;
+  int depth = 0;
+  while ((1ll << (2 * depth)) < n_leaves) depth++;
+  if (depth > MAX_DEPTH) return LH_EINVAL;
+  int n_padded = n_leaves * LEAF;
+  int n_nodes = (int)(((1ll << (2 * depth)) - 1) / 3);
+  if (n_padded > c->sorted_cap) {
+    (void)hipStreamSynchronize(x->stream);
+    (void)hipFree(c->sorted);
+    HIPCHK(hipMalloc(&c->sorted, sizeof(float4) * (size_t)n_padded));
+    c->sorted_cap = n_padded;
+  }
+  if (n_nodes > c->nodes_cap) {
+    (void)hipStreamSynchronize(x->stream);
+    (void)hipFree(c->nodes);
+    HIPCHK(hipMalloc(&c->nodes, sizeof(Node4) * (size_t)std::max(n_nodes, 1)));
+    c->nodes_cap = n_nodes;
+  }
+  c->depth = depth;
+  c->n_leaves = n_leaves;
+  c->first_leaf = n_nodes;
+  hipStream_t s = x->stream;
+  { ProfScope p(x, "index_bbox_morton", 16.0 * c->n * 2); launch_bbox(c->xyz, c->n, x->bbox, s); launch_morton(c->xyz, c->n, x->bbox, x->keys0, x->vals0, s); }
+  { ProfScope p(x, "index_radix_sort", 8.0 * c->n * 2 * 4); sort_pairs_u32(x->sort_temp, x->sort_temp_bytes, x->keys0, x->keys1, x->vals0, x->vals1, c->n, 30, s); }
+  { ProfScope p(x, "index_gather_boxes", 32.0 * c->n); launch_gather_sorted(c->xyz, x->vals1, c->n, n_padded, c->sorted, s); launch_build_nodes(c->sorted, c->n, depth, c->nodes, s); }
+  HIPCHK(hipGetLastError());
+  c->has_index = true;
+  return LH_OK;
+}
+
+static lh_status cloud_ensure_cov(lh_cloud* c, int k, double eps) {
+  if (c->cov6 && c->cov_k == k && c->cov_eps == eps) return LH_OK;
+  if (k > c->n || k > 64 || k < 1) return LH_EINVAL;  // gicp.hpp:72-79
+  if (!c->has_index) { lh_status st = cloud_build_index(c); if (st) return st; }
+  if (!c->cov6) HIPCHK(hipMalloc(&c->cov6, sizeof(double) * 6 * (size_t)c->n_pad));
+  { ProfScope p(c->ctx, "knn_cov", (16.0 + 20 * 16.0 + 48.0) * c->n); launch_knn_cov(c->xyz, c->n, c->n_pad, c->view(), k, eps, c->cov6, c->ctx->stream); }
+  HIPCHK(hipGetLastError());
+  c->cov_k = k;
+  c->cov_eps = eps;
+  return LH_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// per-pair device workspace
+struct Workspace {
+  int cap = 0;
+  float4* corr = nullptr;
+  double* maha6 = nullptr;
+  int32_t* prev_nn = nullptr;
+  float4* out_xyz = nullptr;  // guess * input when guess != I
+  int n_pad = 0;
+  lh_status ensure(lh_ctx* c, int n) {
+    if (n <= cap) return LH_OK;
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(corr); (void)hipFree(maha6); (void)hipFree(prev_nn); (void)hipFree(out_xyz);
+    int ncap = round_up(n, 256);
+    HIPCHK(hipMalloc(&corr, sizeof(float4) * (size_t)ncap));
+    HIPCHK(hipMalloc(&maha6, sizeof(double) * 6 * (size_t)ncap));
+    HIPCHK(hipMalloc(&prev_nn, sizeof(int32_t) * (size_t)ncap));
+    HIPCHK(hipMalloc(&out_xyz, sizeof(float4) * (size_t)ncap));
+    cap = ncap;
+    n_pad = ncap;
+    return LH_OK;
+  }
+  void release() {
+    (void)hipFree(corr); (void)hipFree(maha6); (void)hipFree(prev_nn); (void)hipFree(out_xyz);
+    corr = nullptr; maha6 = nullptr; prev_nn = nullptr; out_xyz = nullptr; cap = 0;
+  }
+};
+
+static lh_status ctx_ensure_slots(lh_ctx* c, int n_slots, int max_n) {
+  size_t per_slot = (size_t)cost_blocks(max_n) * COST_NSUM;
+  if (n_slots <= c->n_slots && per_slot <= c->partials_per_slot) return LH_OK;
+  (void)hipStreamSynchronize(c->stream);
+  n_slots = std::max(n_slots, c->n_slots);
+  per_slot = std::max(per_slot, c->partials_per_slot);
+  (void)hipFree(c->descs_dev);
+  if (c->descs_host) (void)hipHostFree(c->descs_host);
+  if (c->partials_host) (void)hipHostFree(c->partials_host);
+  HIPCHK(hipMalloc(&c->descs_dev, sizeof(PairDesc) * n_slots));
+  HIPCHK(hipHostMalloc(&c->descs_host, sizeof(PairDesc) * n_slots, hipHostMallocDefault));
+  HIPCHK(hipHostMalloc(&c->partials_host, sizeof(double) * per_slot * n_slots, hipHostMallocDefault));
+  c->n_slots = n_slots;
+  c->partials_per_slot = per_slot;
+  return LH_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// one alignment = one coroutine
+enum Req { REQ_NONE = 0, REQ_SWEEP, REQ_COST, REQ_DONE };
+
+struct Task;
+static thread_local Task* g_boot_task = nullptr;
+
+struct Task : public CostFn {
+  // inputs
+  lh_gicp_params P;
+  lh_cloud *src = nullptr, *tgt = nullptr;
+  Workspace* ws = nullptr;
+  float guess[16];
+  bool guess_is_identity = true;
+  int slot = 0;
+  lh_gicp_trace* trace = nullptr;
+  // coroutine
+  ucontext_t ctx, sched;
+  std::vector<char> stack;
+  Req req = REQ_NONE;
+  float req_T12[12];
+  double req_R9[9];
+  double res_sums[COST_NSUM];
+  bool sweep_bytes_pending = false;
+  // outputs
+  lh_gicp_result result;
+
+  void yield(Req r) {
+    req = r;
+    swapcontext(&ctx, &sched);
+  }
+  void resume() {
+    swapcontext(&sched, &ctx);
+  }
+  static void T16_to_T12(const float* T16, float* T12) {
+    for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 4; c++) T12[r * 4 + c] = T16[c * 4 + r];
+  }
+  // CostFn: one fused device pass (gicp.hpp:362-402)
+  void pass(const double x[6], double sums13[13], double* count) override {
+    float T16[16];
+    apply_state(x, T16);  // base_transformation_ = I (gicp.hpp:435, 367-368)
+    T16_to_T12(T16, req_T12);
+    yield(REQ_COST);
+    memcpy(sums13, res_sums, sizeof(double) * 13);
+    *count = res_sums[13];
+  }
+
+  // computeTransformation (gicp.hpp:406-617); covariances / index were prepared by the caller
+  void run() {
+    memset(&result, 0, sizeof(result));
+    result.fitness = NAN;
+    float transformation[16], previous[16];
+    memcpy(transformation, I16, sizeof(I16));  // pcl::Registration::align resets transformation_ to identity
+    memcpy(previous, I16, sizeof(I16));
+    int nr_iterations = 0;
+    bool converged = false;
+    double delta = 0;
+    if (trace) trace->n_iters = 0;
+    while (!converged) {
+      // transform_R = double(transformation_) * double(guess)   (gicp.hpp:450-460)
+      double TR[16];
+      for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) {
+          double s = 0.0;
+          for (int k = 0; k < 4; k++) s += (double)transformation[k * 4 + i] * (double)guess[j * 4 + k];
+          TR[i * 4 + j] = s;
+        }
+      for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) req_R9[r * 3 + c] = TR[r * 4 + c];
+      T16_to_T12(transformation, req_T12);
+      yield(REQ_SWEEP);                                   // gicp.hpp:464-498
+      memcpy(previous, transformation, sizeof(previous)); // gicp.hpp:518
+      have = false;                                       // new correspondences invalidate the functor cache
+      int before = passes, n_inner = 0;
+      double f_end = 0;
+      int st = estimate_rigid_bfgs(this, P.max_inner_iterations, transformation, &n_inner, &f_end);
+      result.n_correspondences_last = (int)count();
+      if (st != 0) {                                      // exception caught -> break (gicp.hpp:542-547)
+        result.status = (st == -4) ? LH_ETOO_FEW_CORR : LH_ESOLVER;
+        break;
+      }
+      delta = 0.;                                         // gicp.hpp:526-541
+      for (int k = 0; k < 4; k++)
+        for (int l = 0; l < 4; l++) {
+          double ratio = (k < 3 && l < 3) ? 1. / P.rotation_epsilon : 1. / P.transformation_epsilon;
+          double c_delta = ratio * fabs((double)previous[l * 4 + k] - (double)transformation[l * 4 + k]);
+          if (c_delta > delta) delta = c_delta;
+        }
+      if (trace && nr_iterations < LH_MAX_TRACE) {
+        int it = nr_iterations;
+        memcpy(trace->T[it], transformation, sizeof(transformation));
+        trace->n_corr[it] = (int)count();
+        trace->n_passes[it] = passes - before;
+        trace->n_inner[it] = n_inner;
+        trace->f_end[it] = f_end;
+        trace->delta[it] = delta;
+        trace->n_iters = it + 1;
+      }
+      nr_iterations++;
+      if (nr_iterations >= P.max_iterations || delta < 1) {  // gicp.hpp:566
+        converged = true;
+        memcpy(previous, transformation, sizeof(previous));
+      }
+    }
+    // final_transformation_ = previous_transformation_ * guess (gicp.hpp:583), float
+    for (int c = 0; c < 4; c++)
+      for (int r = 0; r < 4; r++) {
+        float s = 0.0f;
+        for (int k = 0; k < 4; k++) s += previous[k * 4 + r] * guess[c * 4 + k];
+        result.T[c * 4 + r] = s;
+      }
+    result.converged = converged ? 1 : 0;
+    result.iterations = nr_iterations;
+    result.cost_passes = passes;
+    yield(REQ_DONE);
+  }
+
+  static void entry() {
+    Task* t = g_boot_task;
+    t->run();
+    for (;;) t->yield(REQ_DONE);
+  }
+  void start() {
+    stack.resize(256 * 1024);
+    getcontext(&ctx);
+    ctx.uc_stack.ss_sp = stack.data();
+    ctx.uc_stack.ss_size = stack.size();
+    ctx.uc_link = &sched;
+    makecontext(&ctx, (void (*)())entry, 0);
+    g_boot_task = this;
+    have = false;
+    passes = 0;
+    req = REQ_NONE;
+    resume();  // runs until the first request
+  }
+};
+
+// prepare device state of one pair in its slot: index, covariances, output cloud, descriptor
+static lh_status task_prepare(lh_ctx* c, Task* t, bool rebuild_index) {
+  lh_cloud *src = t->src, *tgt = t->tgt;
+  if (!src || !tgt || src->n <= 0 || tgt->n <= 0) return LH_EINVAL;
+  const lh_gicp_params& P = t->P;
+  if (!P.recompute_source_cov && !src->nrm) return LH_EINVAL;
+  if (!P.recompute_target_cov && !tgt->nrm) return LH_EINVAL;
+  lh_status st;
+  if (rebuild_index || !tgt->has_index) { st = cloud_build_index(tgt); if (st) return st; }
+  if (P.recompute_target_cov) { st = cloud_ensure_cov(tgt, P.k_correspondences, P.gicp_epsilon); if (st) return st; }
+  if (P.recompute_source_cov) { st = cloud_ensure_cov(src, P.k_correspondences, P.gicp_epsilon); if (st) return st; }
+  st = t->ws->ensure(c, src->n);
+  if (st) return st;
+  t->guess_is_identity = memcmp(t->guess, I16, sizeof(I16)) == 0;
+  const float4* out = src->xyz;
+  if (!t->guess_is_identity) {  // pcl::transformPointCloud(output, output, guess) (gicp.hpp:440)
+    float T12[12];
+    Task::T16_to_T12(t->guess, T12);
+    ProfScope p(c, "transform", 32.0 * src->n);
+    launch_transform(src->xyz, nullptr, src->n, T12, t->ws->out_xyz, nullptr, c->stream);
+    out = t->ws->out_xyz;
+  }
+  { ProfScope p(c, "fill", 4.0 * src->n); launch_fill_i32(t->ws->prev_nn, src->n, -1, c->stream); }
+  PairDesc& d = c->descs_host[t->slot];
+  d.src = out;
+  d.src_nrm = P.recompute_source_cov ? nullptr : src->nrm;
+  d.src_cov6 = P.recompute_source_cov ? src->cov6 : nullptr;
+  d.tgt_xyz = tgt->xyz;
+  d.tgt_nrm = P.recompute_target_cov ? nullptr : tgt->nrm;
+  d.tgt_cov6 = P.recompute_target_cov ? tgt->cov6 : nullptr;
+  d.tgt_sorted = tgt->sorted;
+  d.tgt_nodes = tgt->nodes;
+  d.prev_nn = t->ws->prev_nn;
+  d.corr = t->ws->corr;
+  d.maha6 = t->ws->maha6;
+  d.n = src->n;
+  d.n_pad = t->ws->n_pad;
+  d.m = tgt->n;
+  d.m_pad = tgt->n_pad;
+  d.first_leaf = tgt->first_leaf;
+  d.src_cov_pad = src->n_pad;
+  d.corr_dist2 = P.corr_dist * P.corr_dist;  // gicp.hpp:438
+  d.gicp_eps = P.gicp_epsilon;
+  HIPCHK(hipMemcpyAsync(&c->descs_dev[t->slot], &d, sizeof(PairDesc), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipGetLastError());
+  return LH_OK;
+}
+
+// run a set of tasks to completion, at most `in_flight` concurrently; tasks[i]->slot must be unique in flight
+static lh_status run_tasks(lh_ctx* c, std::vector<Task*>& tasks, int in_flight, bool rebuild_index,
+                          std::vector<Workspace>* slot_ws = nullptr) {
+  size_t next = 0;
+  std::vector<Task*> active;
+  std::vector<int> free_slots;
+  for (int s = in_flight - 1; s >= 0; s--) free_slots.push_back(s);
+  lh_status err = LH_OK;
+  while (next < tasks.size() || !active.empty()) {
+    // admit new pairs
+    while (next < tasks.size() && !free_slots.empty()) {
+      Task* t = tasks[next++];
+      t->slot = free_slots.back();
+      free_slots.pop_back();
+      if (slot_ws) t->ws = &(*slot_ws)[t->slot];  // batch mode: workspaces belong to slots
+      lh_status st = task_prepare(c, t, rebuild_index);
+      if (st) {
+        memset(&t->result, 0, sizeof(t->result));
+        memcpy(t->result.T, I16, sizeof(I16));
+        t->result.status = st;
+        t->result.fitness = NAN;
+        free_slots.push_back(t->slot);
+        err = st;
+        continue;
+      }
+      t->start();
+      active.push_back(t);
+    }
+    if (active.empty()) break;
+    // phase 1: sweeps
+    std::vector<Task*> sweeps;
+    for (Task* t : active)
+      if (t->req == REQ_SWEEP) sweeps.push_back(t);
+    for (size_t o = 0; o < sweeps.size(); o += MAX_JOBS) {
+      SweepArgs a;
+      a.njobs = (int)std::min<size_t>(MAX_JOBS, sweeps.size() - o);
+      a.pad = 0;
+      int max_n = 0;
+      double bytes = 0;
+      for (int j = 0; j < a.njobs; j++) {
+        Task* t = sweeps[o + j];
+        a.job[j].slot = t->slot;
+        a.job[j].pad = 0;
+        memcpy(a.job[j].T, t->req_T12, sizeof(t->req_T12));
+        memcpy(a.job[j].R, t->req_R9, sizeof(t->req_R9));
+        max_n = std::max(max_n, t->src->n);
+        bytes += 20.0 * t->src->n;  // SURVEY 8d B_nn = 20 N + 232 K_t; the K_t term is added when the count is known
+        t->sweep_bytes_pending = true;
+      }
+      ProfScope p(c, "nn_sweep", bytes);
+      launch_sweep(c->descs_dev, a, max_n, c->stream);
+    }
+    for (Task* t : sweeps) t->resume();  // each now yields its first COST request (or DONE)
+    // phase 2: cost passes
+    std::vector<Task*> costs;
+    for (Task* t : active)
+      if (t->req == REQ_COST) costs.push_back(t);
+    for (size_t o = 0; o < costs.size(); o += MAX_JOBS) {
+      CostArgs a;
+      a.njobs = (int)std::min<size_t>(MAX_JOBS, costs.size() - o);
+      a.pad = 0;
+      int max_n = 0;
+      double bytes = 0;
+      for (int j = 0; j < a.njobs; j++) {
+        Task* t = costs[o + j];
+        a.job[j].slot = t->slot;
+        a.job[j].out_offset = (int)((size_t)t->slot * c->partials_per_slot);
+        memcpy(a.job[j].T, t->req_T12, sizeof(t->req_T12));
+        max_n = std::max(max_n, t->src->n);
+      }
+      ProfScope p(c, "cost_fdf", bytes);
+      launch_cost(c->descs_dev, a, max_n, c->partials_host, c->stream);
+    }
+    if (!costs.empty() || !sweeps.empty()) {
+      HIPCHK(hipGetLastError());
+      HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    for (Task* t : costs) {
+      const double* part = c->partials_host + (size_t)t->slot * c->partials_per_slot;
+      int nb = cost_blocks(t->src->n);
+      double S[COST_NSUM];
+      for (int k = 0; k < COST_NSUM; k++) S[k] = 0.0;
+      for (int b = 0; b < nb; b++)  // fixed order => bitwise reproducible
+        for (int k = 0; k < COST_NSUM; k++) S[k] += part[(size_t)b * COST_NSUM + k];
+      memcpy(t->res_sums, S, sizeof(S));
+      if (c->prof) {  // algorithmic bytes with the measured K_t: B_fdf = 108 K_t, B_nn += 232 K_t
+        c->prof_entries[c->prof_entry("cost_fdf")].bytes += 108.0 * S[13];
+        if (t->sweep_bytes_pending) c->prof_entries[c->prof_entry("nn_sweep")].bytes += 232.0 * S[13];
+      }
+      t->sweep_bytes_pending = false;
+      t->resume();
+    }
+    // retire finished pairs
+    for (size_t i = 0; i < active.size();) {
+      if (active[i]->req == REQ_DONE) {
+        free_slots.push_back(active[i]->slot);
+        active.erase(active.begin() + i);
+      } else
+        i++;
+    }
+  }
+  return err;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+struct lh_gicp {
+  lh_ctx* ctx = nullptr;
+  lh_gicp_params P;
+  lh_cloud *src = nullptr, *tgt = nullptr;
+  bool own_src = false, own_tgt = false;
+  Workspace ws;
+  Task task;
+  float last_T[16];
+  bool have_result = false;
+  // debug sweep state
+  bool dbg_ready = false;
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// host <-> device cloud conversion
+static lh_status upload_view(lh_ctx* c, const lh_cloud_view* v, lh_cloud** out) {
+  if (!v || !v->base || v->count == 0 || v->stride < 12) return LH_EINVAL;
+  HIPCHK(hipSetDevice(c->device));
+  lh_cloud* cl = new lh_cloud();
+  cl->ctx = c;
+  cl->n = (int)v->count;
+  cl->n_pad = round_up(cl->n, 256);
+  size_t n = v->count;
+  bool has_n = v->off_normal != UINT32_MAX, has_i = v->off_intensity != UINT32_MAX;
+  std::vector<float> xyz(n * 4), nrm(has_n ? n * 4 : 0), inten(has_i ? n : 0);
+  const char* base = (const char*)v->base;
+  for (size_t i = 0; i < n; i++) {
+    const char* p = base + i * v->stride;
+    const float* f = (const float*)(p + v->off_xyz);
+    xyz[4 * i] = f[0]; xyz[4 * i + 1] = f[1]; xyz[4 * i + 2] = f[2]; xyz[4 * i + 3] = 1.0f;
+    if (has_n) {
+      const float* g = (const float*)(p + v->off_normal);
+      nrm[4 * i] = g[0]; nrm[4 * i + 1] = g[1]; nrm[4 * i + 2] = g[2];
+      nrm[4 * i + 3] = (v->off_curvature != UINT32_MAX) ? *(const float*)(p + v->off_curvature) : 0.0f;
+    }
+    if (has_i) inten[i] = *(const float*)(p + v->off_intensity);
+  }
+  hipError_t e = hipMalloc(&cl->xyz, sizeof(float4) * (size_t)cl->n_pad);
+  if (e == hipSuccess && has_n) e = hipMalloc(&cl->nrm, sizeof(float4) * (size_t)cl->n_pad);
+  if (e == hipSuccess && has_i) e = hipMalloc(&cl->intensity, sizeof(float) * (size_t)cl->n_pad);
+  if (e == hipSuccess) e = hipMemcpyAsync(cl->xyz, xyz.data(), sizeof(float) * 4 * n, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess && has_n) e = hipMemcpyAsync(cl->nrm, nrm.data(), sizeof(float) * 4 * n, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess && has_i) e = hipMemcpyAsync(cl->intensity, inten.data(), sizeof(float) * n, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);  // staging vectors die at scope exit
+  if (e != hipSuccess) {
+    fprintf(stderr, "[locus_hip] cloud upload failed: %s\n", hipGetErrorString(e));
+    cloud_free(cl);
+    return e == hipErrorOutOfMemory ? LH_ENOMEM : LH_EDEVICE;
+  }
+  *out = cl;
+  return LH_OK;
+}
+
+static void fill_T12(const float* T16, float* T12) { Task::T16_to_T12(T16, T12); }
+
+// =========================================================================================================
+extern "C" {
+
+int lh_abi_version(void) { return LH_ABI_VERSION; }
+
+const char* lh_status_string(lh_status s) {
+  switch (s) {
+    case LH_OK: return "ok";
+    case LH_EINVAL: return "invalid argument";
+    case LH_ENOMEM: return "out of memory";
+    case LH_EDEVICE: return "HIP device error / no device";
+    case LH_ETOO_FEW_CORR: return "fewer than 4 correspondences";
+    case LH_ESOLVER: return "BFGS solver did not converge";
+    case LH_ENO_NN: return "no nearest neighbour";
+    default: return "unknown";
+  }
+}
+
+void lh_default_gicp_params(lh_gicp_params* p) {
+  if (!p) return;
+  p->max_iterations = 200;           // gicp.h:129
+  p->max_inner_iterations = 20;      // gicp.h:121
+  p->corr_dist = 5.0;                // gicp.h:131
+  p->transformation_epsilon = 5e-4;  // gicp.h:130
+  p->rotation_epsilon = 2e-3;        // gicp.h:119
+  p->gicp_epsilon = 1e-3;            // gicp.h:118
+  p->k_correspondences = 20;         // gicp.h:112
+  p->recompute_source_cov = 0;       // gicp.h:115
+  p->recompute_target_cov = 0;       // gicp.h:116
+  p->num_threads = 1;
+  p->enable_timing = 0;
+}
+
+lh_status lh_create(lh_ctx** out, int device_id) {
+  if (!out) return LH_EINVAL;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    fprintf(stderr, "[locus_hip] no HIP device available: this library has no CPU fallback\n");
+    return LH_EDEVICE;
+  }
+  if (device_id < 0 || device_id >= ndev) return LH_EINVAL;
+  HIPCHK(hipSetDevice(device_id));
+  lh_ctx* c = new lh_ctx();
+  c->device = device_id;
+  HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  HIPCHK(hipMalloc(&c->bbox, sizeof(uint32_t) * 8));
+  *out = c;
+  return LH_OK;
+}
+
+void lh_destroy(lh_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  c->prof_flush();
+  for (auto e : c->ev_pool) (void)hipEventDestroy(e);
+  (void)hipFree(c->keys0); (void)hipFree(c->keys1); (void)hipFree(c->vals0); (void)hipFree(c->vals1);
+  (void)hipFree(c->sort_temp); (void)hipFree(c->bbox); (void)hipFree(c->descs_dev);
+  if (c->descs_host) (void)hipHostFree(c->descs_host);
+  if (c->partials_host) (void)hipHostFree(c->partials_host);
+  if (c->small_host) (void)hipHostFree(c->small_host);
+  (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+lh_status lh_synchronize(lh_ctx* c) {
+  if (!c) return LH_EINVAL;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return LH_OK;
+}
+
+// ---- clouds ----------------------------------------------------------------------------------------------
+lh_status lh_cloud_create(lh_ctx* ctx, const lh_cloud_view* view, lh_cloud** out) {
+  if (!ctx || !out) return LH_EINVAL;
+  return upload_view(ctx, view, out);
+}
+void lh_cloud_destroy(lh_cloud* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->ctx->device);
+  (void)hipStreamSynchronize(c->ctx->stream);
+  cloud_free(c);
+}
+uint32_t lh_cloud_size(const lh_cloud* c) { return c ? (uint32_t)c->n : 0; }
+lh_status lh_cloud_build_index(lh_cloud* c) {
+  if (!c) return LH_EINVAL;
+  HIPCHK(hipSetDevice(c->ctx->device));
+  return cloud_build_index(c);
+}
+lh_status lh_cloud_drop_index(lh_cloud* c) {
+  if (!c) return LH_EINVAL;
+  c->has_index = false;
+  c->cov_k = 0;
+  return LH_OK;
+}
+lh_status lh_cloud_download(const lh_cloud* c, void* out_base, uint32_t stride, uint32_t off_xyz, uint32_t off_normal,
+                            uint32_t off_intensity, uint32_t off_curvature) {
+  if (!c || !out_base || stride < 12) return LH_EINVAL;
+  HIPCHK(hipSetDevice(c->ctx->device));
+  size_t n = (size_t)c->n;
+  std::vector<float> xyz(n * 4), nrm, inten;
+  HIPCHK(hipMemcpyAsync(xyz.data(), c->xyz, sizeof(float) * 4 * n, hipMemcpyDeviceToHost, c->ctx->stream));
+  if (c->nrm && off_normal != UINT32_MAX) {
+    nrm.resize(n * 4);
+    HIPCHK(hipMemcpyAsync(nrm.data(), c->nrm, sizeof(float) * 4 * n, hipMemcpyDeviceToHost, c->ctx->stream));
+  }
+  if (c->intensity && off_intensity != UINT32_MAX) {
+    inten.resize(n);
+    HIPCHK(hipMemcpyAsync(inten.data(), c->intensity, sizeof(float) * n, hipMemcpyDeviceToHost, c->ctx->stream));
+  }
+  HIPCHK(hipStreamSynchronize(c->ctx->stream));
+  char* base = (char*)out_base;
+  for (size_t i = 0; i < n; i++) {
+    char* p = base + i * stride;
+    memcpy(p + off_xyz, &xyz[4 * i], 12);
+    if (!nrm.empty()) {
+      memcpy(p + off_normal, &nrm[4 * i], 12);
+      if (off_curvature != UINT32_MAX) memcpy(p + off_curvature, &nrm[4 * i + 3], 4);
+    }
+    if (!inten.empty()) memcpy(p + off_intensity, &inten[i], 4);
+  }
+  return LH_OK;
+}
+lh_status lh_cloud_transform(const lh_cloud* in, const float T[16], int with_normals, lh_cloud** out) {
+  if (!in || !T || !out) return LH_EINVAL;
+  lh_ctx* c = in->ctx;
+  HIPCHK(hipSetDevice(c->device));
+  lh_cloud* o = (*out == in) ? const_cast<lh_cloud*>(in) : new lh_cloud();
+  if (o != in) {
+    o->ctx = c; o->n = in->n; o->n_pad = in->n_pad;
+    HIPCHK(hipMalloc(&o->xyz, sizeof(float4) * (size_t)o->n_pad));
+    if (in->nrm) HIPCHK(hipMalloc(&o->nrm, sizeof(float4) * (size_t)o->n_pad));
+    if (in->intensity) {
+      HIPCHK(hipMalloc(&o->intensity, sizeof(float) * (size_t)o->n_pad));
+      HIPCHK(hipMemcpyAsync(o->intensity, in->intensity, sizeof(float) * (size_t)in->n, hipMemcpyDeviceToDevice, c->stream));
+    }
+    if (in->nrm && !with_normals) HIPCHK(hipMemcpyAsync(o->nrm, in->nrm, sizeof(float4) * (size_t)in->n, hipMemcpyDeviceToDevice, c->stream));
+  }
+  float T12[12];
+  fill_T12(T, T12);
+  { ProfScope p(c, "transform", (with_normals ? 64.0 : 32.0) * in->n);
+    launch_transform(in->xyz, with_normals ? in->nrm : nullptr, in->n, T12, o->xyz, with_normals ? o->nrm : nullptr, c->stream); }
+  HIPCHK(hipGetLastError());
+  o->has_index = false;
+  o->cov_k = 0;
+  *out = o;
+  return LH_OK;
+}
+
+// ---- registration object ----------------------------------------------------------------------------------
+lh_status lh_gicp_create(lh_ctx* ctx, const lh_gicp_params* p, lh_gicp** out) {
+  if (!ctx || !out) return LH_EINVAL;
+  lh_gicp* g = new lh_gicp();
+  g->ctx = ctx;
+  if (p) g->P = *p; else lh_default_gicp_params(&g->P);
+  memcpy(g->last_T, I16, sizeof(I16));
+  *out = g;
+  return LH_OK;
+}
+void lh_gicp_destroy(lh_gicp* g) {
+  if (!g) return;
+  (void)hipSetDevice(g->ctx->device);
+  (void)hipStreamSynchronize(g->ctx->stream);
+  if (g->own_src) cloud_free(g->src);
+  if (g->own_tgt && g->tgt != g->src) cloud_free(g->tgt);
+  g->ws.release();
+  delete g;
+}
+lh_status lh_gicp_set_params(lh_gicp* g, const lh_gicp_params* p) {
+  if (!g || !p) return LH_EINVAL;
+  g->P = *p;
+  return LH_OK;
+}
+static void gicp_drop_src(lh_gicp* g) {
+  if (g->own_src && g->src && g->src != g->tgt) { (void)hipStreamSynchronize(g->ctx->stream); cloud_free(g->src); }
+  g->src = nullptr; g->own_src = false;
+}
+static void gicp_drop_tgt(lh_gicp* g) {
+  if (g->own_tgt && g->tgt && g->tgt != g->src) { (void)hipStreamSynchronize(g->ctx->stream); cloud_free(g->tgt); }
+  g->tgt = nullptr; g->own_tgt = false;
+}
+lh_status lh_gicp_set_source(lh_gicp* g, const lh_cloud_view* v) {
+  if (!g) return LH_EINVAL;
+  lh_cloud* c = nullptr;
+  lh_status st = upload_view(g->ctx, v, &c);
+  if (st) return st;
+  gicp_drop_src(g);
+  g->src = c; g->own_src = true; g->have_result = false; g->dbg_ready = false;
+  return LH_OK;
+}
+lh_status lh_gicp_set_target(lh_gicp* g, const lh_cloud_view* v) {
+  if (!g) return LH_EINVAL;
+  lh_cloud* c = nullptr;
+  lh_status st = upload_view(g->ctx, v, &c);
+  if (st) return st;
+  gicp_drop_tgt(g);
+  g->tgt = c; g->own_tgt = true; g->have_result = false; g->dbg_ready = false;
+  return LH_OK;
+}
+lh_status lh_gicp_set_source_cloud(lh_gicp* g, lh_cloud* c) {
+  if (!g || !c || c->ctx != g->ctx) return LH_EINVAL;
+  gicp_drop_src(g);
+  g->src = c; g->own_src = false; g->have_result = false; g->dbg_ready = false;
+  return LH_OK;
+}
+lh_status lh_gicp_set_target_cloud(lh_gicp* g, lh_cloud* c) {
+  if (!g || !c || c->ctx != g->ctx) return LH_EINVAL;
+  gicp_drop_tgt(g);
+  g->tgt = c; g->own_tgt = false; g->have_result = false; g->dbg_ready = false;
+  return LH_OK;
+}
+lh_status lh_gicp_promote_source_to_target(lh_gicp* g) {
+  if (!g || !g->src) return LH_EINVAL;
+  lh_cloud* s = g->src;
+  bool own = g->own_src;
+  g->src = nullptr; g->own_src = false;
+  gicp_drop_tgt(g);
+  g->tgt = s; g->own_tgt = own;
+  g->tgt->has_index = false;  // align() rebuilds the index (target changed)
+  g->have_result = false; g->dbg_ready = false;
+  return LH_OK;
+}
+
+lh_status lh_gicp_align(lh_gicp* g, const float guess[16], lh_gicp_result* out, lh_gicp_trace* trace, void* aligned_out,
+                        uint32_t stride, uint32_t off_xyz) {
+  if (!g || !out) return LH_EINVAL;
+  lh_ctx* c = g->ctx;
+  HIPCHK(hipSetDevice(c->device));
+  memset(out, 0, sizeof(*out));
+  memcpy(out->T, I16, sizeof(I16));
+  out->fitness = NAN;
+  if (!g->src || !g->tgt) { out->status = LH_EINVAL; return LH_EINVAL; }
+  lh_status st = ctx_ensure_slots(c, 1, std::max(g->src->n, 1));
+  if (st) { out->status = st; return st; }
+  Task& t = g->task;
+  t.P = g->P; t.src = g->src; t.tgt = g->tgt; t.ws = &g->ws; t.trace = trace;
+  memcpy(t.guess, guess ? guess : I16, sizeof(I16));
+  std::vector<Task*> tasks{&t};
+  st = run_tasks(c, tasks, 1, /*rebuild_index=*/!g->tgt->has_index);
+  *out = t.result;
+  if (st) { out->status = st; return st; }
+  memcpy(g->last_T, out->T, sizeof(I16));
+  g->have_result = true;
+  g->dbg_ready = true;
+  if (aligned_out) {  // pcl::transformPointCloud(*input_, output, final_transformation_) (gicp.hpp:586)
+    float T12[12];
+    fill_T12(out->T, T12);
+    { ProfScope p(c, "transform", 32.0 * g->src->n); launch_transform(g->src->xyz, nullptr, g->src->n, T12, g->ws.out_xyz, nullptr, c->stream); }
+    std::vector<float> host((size_t)g->src->n * 4);
+    HIPCHK(hipMemcpyAsync(host.data(), g->ws.out_xyz, sizeof(float) * host.size(), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < g->src->n; i++) memcpy((char*)aligned_out + (size_t)i * stride + off_xyz, &host[4 * (size_t)i], 12);
+  }
+  return (lh_status)out->status;
+}
+
+static lh_status nn1_device(lh_ctx* c, lh_cloud* target, const float4* q, int nq, const float* T16, int32_t* idx, float* d2,
+                            double* fitness_sum) {
+  if (!target->has_index) { lh_status st = cloud_build_index(target); if (st) return st; }
+  int32_t* d_idx = nullptr;
+  float* d_d2 = nullptr;
+  double* d_part = nullptr;
+  HIPCHK(hipMalloc(&d_idx, sizeof(int32_t) * (size_t)nq));
+  HIPCHK(hipMalloc(&d_d2, sizeof(float) * (size_t)nq));
+  float T12[12];
+  if (T16) fill_T12(T16, T12);
+  { ProfScope p(c, "nn1", 24.0 * nq); launch_nn1(q, nq, T16 ? T12 : nullptr, target->view(), d_idx, d_d2, c->stream); }
+  lh_status rc = LH_OK;
+  if (fitness_sum) {
+    int nb = sum_blocks(nq);
+    rc = ctx_ensure_small(c, (size_t)nb);
+    if (!rc) {
+      HIPCHK(hipMalloc(&d_part, sizeof(double) * (size_t)nb));
+      launch_sum_f32(d_d2, nq, d_part, c->stream);
+      HIPCHK(hipMemcpyAsync(c->small_host, d_part, sizeof(double) * nb, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(hipStreamSynchronize(c->stream));
+      double s = 0;
+      for (int b = 0; b < nb; b++) s += c->small_host[b];
+      *fitness_sum = s;
+    }
+  }
+  if (idx) HIPCHK(hipMemcpyAsync(idx, d_idx, sizeof(int32_t) * (size_t)nq, hipMemcpyDeviceToHost, c->stream));
+  if (d2) HIPCHK(hipMemcpyAsync(d2, d_d2, sizeof(float) * (size_t)nq, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  (void)hipFree(d_idx); (void)hipFree(d_d2); (void)hipFree(d_part);
+  return rc;
+}
+
+lh_status lh_gicp_fitness(lh_gicp* g, double* fitness) {
+  if (!g || !fitness || !g->src || !g->tgt || !g->have_result) return LH_EINVAL;
+  HIPCHK(hipSetDevice(g->ctx->device));
+  double s = 0;
+  lh_status st = nn1_device(g->ctx, g->tgt, g->src->xyz, g->src->n, g->last_T, nullptr, nullptr, &s);
+  if (st) return st;
+  *fitness = s / (double)g->src->n;  // every query finds a neighbour (max_range = DBL_MAX)
+  return LH_OK;
+}
+
+lh_status lh_nn1(lh_gicp* g, const lh_cloud_view* q, int32_t* idx, float* d2) {
+  if (!g || !g->tgt || !q) return LH_EINVAL;
+  HIPCHK(hipSetDevice(g->ctx->device));
+  lh_cloud* qc = nullptr;
+  lh_status st = upload_view(g->ctx, q, &qc);
+  if (st) return st;
+  st = nn1_device(g->ctx, g->tgt, qc->xyz, qc->n, nullptr, idx, d2, nullptr);
+  cloud_free(qc);
+  return st;
+}
+lh_status lh_nn1_cloud(lh_cloud* target, const lh_cloud* q, int32_t* idx, float* d2) {
+  if (!target || !q || target->ctx != q->ctx) return LH_EINVAL;
+  HIPCHK(hipSetDevice(target->ctx->device));
+  return nn1_device(target->ctx, target, q->xyz, q->n, nullptr, idx, d2, nullptr);
+}
+lh_status lh_knn_cloud(lh_cloud* target, const lh_cloud* q, int k, int32_t* idx, float* d2) {
+  if (!target || !q || target->ctx != q->ctx || k < 1 || k > 64) return LH_EINVAL;
+  lh_ctx* c = target->ctx;
+  HIPCHK(hipSetDevice(c->device));
+  if (!target->has_index) { lh_status st = cloud_build_index(target); if (st) return st; }
+  int32_t* d_idx = nullptr;
+  float* d_d2 = nullptr;
+  size_t cnt = (size_t)q->n * k;
+  HIPCHK(hipMalloc(&d_idx, sizeof(int32_t) * cnt));
+  HIPCHK(hipMalloc(&d_d2, sizeof(float) * cnt));
+  { ProfScope p(c, "knn", (16.0 + 8.0 * k) * q->n); launch_knn(q->xyz, q->n, target->view(), k, d_idx, d_d2, c->stream); }
+  HIPCHK(hipGetLastError());
+  if (idx) HIPCHK(hipMemcpyAsync(idx, d_idx, sizeof(int32_t) * cnt, hipMemcpyDeviceToHost, c->stream));
+  if (d2) HIPCHK(hipMemcpyAsync(d2, d_d2, sizeof(float) * cnt, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  (void)hipFree(d_idx); (void)hipFree(d_d2);
+  return LH_OK;
+}
+
+lh_status lh_gicp_align_batch(lh_ctx* ctx, const lh_gicp_params* p, int n_pairs, lh_cloud* const* src, lh_cloud* const* tgt,
+                              const float* guesses, lh_gicp_result* out, int max_in_flight) {
+  if (!ctx || !p || n_pairs < 0 || !src || !tgt || !out) return LH_EINVAL;
+  if (n_pairs == 0) return LH_OK;
+  HIPCHK(hipSetDevice(ctx->device));
+  int in_flight = max_in_flight > 0 ? max_in_flight : 16;
+  in_flight = std::min(in_flight, n_pairs);
+  int max_n = 1;
+  for (int i = 0; i < n_pairs; i++) {
+    if (!src[i] || !tgt[i] || src[i]->ctx != ctx || tgt[i]->ctx != ctx) return LH_EINVAL;
+    max_n = std::max(max_n, src[i]->n);
+  }
+  lh_status st = ctx_ensure_slots(ctx, in_flight, max_n);
+  if (st) return st;
+  static thread_local std::vector<Workspace> ws_pool;  // grow-only, reused across calls
+  if ((int)ws_pool.size() < in_flight) ws_pool.resize(in_flight);
+  std::vector<Task> tasks(n_pairs);
+  std::vector<Task*> ptrs(n_pairs);
+  for (int i = 0; i < n_pairs; i++) {
+    Task& t = tasks[i];
+    t.P = *p; t.src = src[i]; t.tgt = tgt[i]; t.trace = nullptr;
+    memcpy(t.guess, guesses ? guesses + 16 * (size_t)i : I16, sizeof(I16));
+    ptrs[i] = &t;
+  }
+  st = run_tasks(ctx, ptrs, in_flight, /*rebuild_index=*/true, &ws_pool);
+  for (int i = 0; i < n_pairs; i++) out[i] = tasks[i].result;
+  return st;
+}
+
+// ---- building blocks for parity tests ---------------------------------------------------------------------
+lh_status lh_cov_knn(lh_cloud* c, int k, double gicp_epsilon, double* cov9_out) {
+  if (!c || !cov9_out) return LH_EINVAL;
+  HIPCHK(hipSetDevice(c->ctx->device));
+  lh_status st = cloud_ensure_cov(c, k, gicp_epsilon);
+  if (st) return st;
+  std::vector<double> planes((size_t)6 * c->n_pad);
+  HIPCHK(hipMemcpyAsync(planes.data(), c->cov6, sizeof(double) * planes.size(), hipMemcpyDeviceToHost, c->ctx->stream));
+  HIPCHK(hipStreamSynchronize(c->ctx->stream));
+  for (int i = 0; i < c->n; i++) {
+    double s6[6];
+    for (int q = 0; q < 6; q++) s6[q] = planes[(size_t)q * c->n_pad + i];
+    sym6_to_mat9(s6, cov9_out + 9 * (size_t)i);
+  }
+  return LH_OK;
+}
+
+lh_status lh_gicp_debug_sweep(lh_gicp* g, const float T[16], const float guess[16], int32_t* tgt_idx, double* maha9) {
+  if (!g || !g->src || !g->tgt || !T) return LH_EINVAL;
+  lh_ctx* c = g->ctx;
+  HIPCHK(hipSetDevice(c->device));
+  lh_status st = ctx_ensure_slots(c, 1, g->src->n);
+  if (st) return st;
+  Task& t = g->task;
+  t.P = g->P; t.src = g->src; t.tgt = g->tgt; t.ws = &g->ws; t.trace = nullptr; t.slot = 0;
+  memcpy(t.guess, guess ? guess : I16, sizeof(I16));
+  st = task_prepare(c, &t, !g->tgt->has_index);
+  if (st) return st;
+  SweepArgs a;
+  a.njobs = 1; a.pad = 0; a.job[0].slot = 0; a.job[0].pad = 0;
+  Task::T16_to_T12(T, a.job[0].T);
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      double s = 0.0;
+      for (int k = 0; k < 4; k++) s += (double)T[k * 4 + i] * (double)t.guess[j * 4 + k];
+      a.job[0].R[i * 3 + j] = s;
+    }
+  { ProfScope p(c, "nn_sweep", 252.0 * g->src->n); launch_sweep(c->descs_dev, a, g->src->n, c->stream); }
+  HIPCHK(hipGetLastError());
+  int n = g->src->n;
+  std::vector<float> corr((size_t)n * 4);
+  std::vector<double> planes((size_t)6 * g->ws.n_pad);
+  HIPCHK(hipMemcpyAsync(corr.data(), g->ws.corr, sizeof(float) * 4 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(planes.data(), g->ws.maha6, sizeof(double) * planes.size(), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  for (int i = 0; i < n; i++) {
+    int32_t j;
+    memcpy(&j, &corr[4 * (size_t)i + 3], 4);
+    if (tgt_idx) tgt_idx[i] = j;
+    if (maha9) {
+      double s6[6];
+      for (int q = 0; q < 6; q++) s6[q] = planes[(size_t)q * g->ws.n_pad + i];
+      sym6_to_mat9(s6, maha9 + 9 * (size_t)i);
+    }
+  }
+  g->dbg_ready = true;
+  return LH_OK;
+}
+
+lh_status lh_gicp_debug_cost(lh_gicp* g, const double x[6], double* f, double g6[6], double sums13[13], int* m) {
+  if (!g || !g->dbg_ready || !x) return LH_EINVAL;
+  lh_ctx* c = g->ctx;
+  HIPCHK(hipSetDevice(c->device));
+  float T16[16];
+  apply_state(x, T16);
+  CostArgs a;
+  a.njobs = 1; a.pad = 0; a.job[0].slot = 0; a.job[0].out_offset = 0;
+  Task::T16_to_T12(T16, a.job[0].T);
+  { ProfScope p(c, "cost_fdf", 108.0 * g->src->n); launch_cost(c->descs_dev, a, g->src->n, c->partials_host, c->stream); }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(c->stream));
+  int nb = cost_blocks(g->src->n);
+  double S[COST_NSUM];
+  for (int k = 0; k < COST_NSUM; k++) S[k] = 0.0;
+  for (int b = 0; b < nb; b++)
+    for (int k = 0; k < COST_NSUM; k++) S[k] += c->partials_host[(size_t)b * COST_NSUM + k];
+  if (sums13) memcpy(sums13, S, sizeof(double) * 13);
+  if (m) *m = (int)S[13];
+  double ff = 0, gg[6] = {0, 0, 0, 0, 0, 0};
+  if (S[13] > 0) cost_finish(S, S[13], x, &ff, gg);
+  if (f) *f = ff;
+  if (g6) memcpy(g6, gg, sizeof(gg));
+  return LH_OK;
+}
+
+// ---- K8 / H2 -----------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_centroid_partials(const float4* __restrict__ xyz, int n, double* __restrict__ part) {
+  // per-block sums of x, y, z over finite points + count (pcl::compute3DCentroid), fixed reduction shape
+  double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+  int base = blockIdx.x * 1024;
+  for (int r = 0; r < 4; r++) {
+    int i = base + r * 256 + threadIdx.x;
+    if (i < n) {
+      float4 p = xyz[i];
+      if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) { a0 += p.x; a1 += p.y; a2 += p.z; a3 += 1.0; }
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    a0 += __shfl_down(a0, off, 64); a1 += __shfl_down(a1, off, 64); a2 += __shfl_down(a2, off, 64); a3 += __shfl_down(a3, off, 64);
+  }
+  __shared__ double sm[4][4];
+  if ((threadIdx.x & 63) == 0) { sm[threadIdx.x >> 6][0] = a0; sm[threadIdx.x >> 6][1] = a1; sm[threadIdx.x >> 6][2] = a2; sm[threadIdx.x >> 6][3] = a3; }
+  __syncthreads();
+  if (threadIdx.x < 4) part[blockIdx.x * 4 + threadIdx.x] = ((sm[0][threadIdx.x] + sm[1][threadIdx.x]) + sm[2][threadIdx.x]) + sm[3][threadIdx.x];
+}
+__global__ void __launch_bounds__(256) k_dist_partials(const float4* __restrict__ xyz, int n, float cx, float cy, float cz,
+                                                      double* __restrict__ part) {
+  double a = 0;
+  int base = blockIdx.x * 1024;
+  for (int r = 0; r < 4; r++) {
+    int i = base + r * 256 + threadIdx.x;
+    if (i < n) {
+      float4 p = xyz[i];
+      float dx = p.x - cx, dy = p.y - cy, dz = p.z - cz;
+      a += (double)sqrtf((dx * dx + dy * dy) + dz * dz);  // utils.cc:118
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off, 64);
+  __shared__ double sm[4];
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = ((sm[0] + sm[1]) + sm[2]) + sm[3];
+}
+
+lh_status lh_p2plane_information(lh_ctx* c, const lh_cloud* query, const lh_cloud* reference, const int64_t* corr, double Ap[36]) {
+  if (!c || !query || !reference || !corr || !Ap || !reference->nrm) return LH_EINVAL;
+  HIPCHK(hipSetDevice(c->device));
+  int n = query->n;
+  for (int i = 0; i < n; i++)
+    if (corr[i] < 0 || corr[i] >= reference->n) return LH_EINVAL;
+  int nb = sum_blocks(n);
+  lh_status st = ctx_ensure_small(c, (size_t)nb * 21);
+  if (st) return st;
+  double* d_part = nullptr;
+  float4* d_qn = nullptr;
+  int64_t* d_corr = nullptr;
+  HIPCHK(hipMalloc(&d_part, sizeof(double) * (size_t)nb * 21));
+  HIPCHK(hipMalloc(&d_qn, sizeof(float4) * (size_t)n));
+  HIPCHK(hipMalloc(&d_corr, sizeof(int64_t) * (size_t)n));
+  HIPCHK(hipMemcpyAsync(d_corr, corr, sizeof(int64_t) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+  // normalizePCloud (utils.cc:106-128): centroid, factor = N / sum |p - c|, q' = factor*(p - c).
+  // The reference accumulates both sums sequentially in float; here the sums are double with a fixed tree
+  // (more accurate; differences vs the float-sequential reference are O(1e-6) relative -- see DESIGN.md).
+  hipLaunchKernelGGL(k_centroid_partials, dim3(nb), dim3(256), 0, c->stream, query->xyz, n, d_part);
+  HIPCHK(hipMemcpyAsync(c->small_host, d_part, sizeof(double) * (size_t)nb * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  double sx = 0, sy = 0, sz = 0, cnt = 0;
+  for (int b = 0; b < nb; b++) { sx += c->small_host[b * 4]; sy += c->small_host[b * 4 + 1]; sz += c->small_host[b * 4 + 2]; cnt += c->small_host[b * 4 + 3]; }
+  float cx = (float)(sx / cnt), cy = (float)(sy / cnt), cz = (float)(sz / cnt);
+  hipLaunchKernelGGL(k_dist_partials, dim3(nb), dim3(256), 0, c->stream, query->xyz, n, cx, cy, cz, d_part);
+  HIPCHK(hipMemcpyAsync(c->small_host, d_part, sizeof(double) * (size_t)nb, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  double dist = 0;
+  for (int b = 0; b < nb; b++) dist += c->small_host[b];
+  float factor = (float)n / (float)dist;  // utils.cc:120
+  float T12[12] = {factor, 0, 0, -factor * cx, 0, factor, 0, -factor * cy, 0, 0, factor, -factor * cz};
+  launch_transform(query->xyz, nullptr, n, T12, d_qn, nullptr, c->stream);
+  { ProfScope p(c, "p2plane_Ap", 40.0 * n); launch_ap(d_qn, n, reference->nrm, d_corr, d_part, c->stream); }
+  HIPCHK(hipMemcpyAsync(c->small_host, d_part, sizeof(double) * (size_t)nb * 21, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  double U[21];
+  for (int k = 0; k < 21; k++) U[k] = 0;
+  for (int b = 0; b < nb; b++)
+    for (int k = 0; k < 21; k++) U[k] += c->small_host[(size_t)b * 21 + k];
+  int t = 0;
+  for (int r = 0; r < 6; r++)
+    for (int cc = r; cc < 6; cc++) { Ap[r * 6 + cc] = U[t]; Ap[cc * 6 + r] = U[t]; t++; }
+  (void)hipFree(d_part); (void)hipFree(d_qn); (void)hipFree(d_corr);
+  return LH_OK;
+}
+
+// ComputePoint2PlaneICPCovariance conditioning (PointCloudLocalization.cc:487-538): 6x6, host-side by nature
+static void sym_eig6(const double* Ain, double* ev) {  // cyclic Jacobi, eigenvalues only
+  double A[36];
+  memcpy(A, Ain, sizeof(A));
+  const int n = 6;
+  for (int sweep = 0; sweep < 64; sweep++) {
+    double off = 0;
+    for (int i = 0; i < n; i++)
+      for (int j = i + 1; j < n; j++) off += A[i * n + j] * A[i * n + j];
+    if (off < 1e-300) break;
+    for (int p = 0; p < n; p++)
+      for (int q = p + 1; q < n; q++) {
+        double apq = A[p * n + q];
+        if (fabs(apq) < 1e-300) continue;
+        double theta = (A[q * n + q] - A[p * n + p]) / (2.0 * apq);
+        double tt = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        double cs = 1.0 / sqrt(tt * tt + 1.0), sn = tt * cs;
+        for (int k = 0; k < n; k++) { double akp = A[k * n + p], akq = A[k * n + q]; A[k * n + p] = cs * akp - sn * akq; A[k * n + q] = sn * akp + cs * akq; }
+        for (int k = 0; k < n; k++) { double apk = A[p * n + k], aqk = A[q * n + k]; A[p * n + k] = cs * apk - sn * aqk; A[q * n + k] = sn * apk + cs * aqk; }
+      }
+  }
+  for (int i = 0; i < n; i++) ev[i] = A[i * n + i];
+}
+
+lh_status lh_icp_covariance(const double Ap[36], double upper_bound, double cov[36], double* condition_number) {
+  if (!Ap || !cov) return LH_EINVAL;
+  const int n = 6;
+  // cov = 0.05^2 * Ap^-1 (Gauss-Jordan with partial pivoting; Eigen uses PartialPivLU)
+  double a[6][12];
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j < n; j++) { a[i][j] = Ap[i * n + j]; a[i][n + j] = (i == j); }
+  for (int col = 0; col < n; col++) {
+    int piv = col;
+    for (int r = col + 1; r < n; r++)
+      if (fabs(a[r][col]) > fabs(a[piv][col])) piv = r;
+    if (piv != col)
+      for (int j = 0; j < 2 * n; j++) std::swap(a[col][j], a[piv][j]);
+    double d = a[col][col];
+    for (int j = 0; j < 2 * n; j++) a[col][j] /= d;
+    for (int r = 0; r < n; r++) {
+      if (r == col) continue;
+      double f = a[r][col];
+      if (f != 0.0 || std::isnan(f))
+        for (int j = 0; j < 2 * n; j++) a[r][j] -= f * a[col][j];
+    }
+  }
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j < n; j++) cov[i * n + j] = 0.05 * 0.05 * a[i][n + j];
+  // Eigen LDLT (lower, diagonal pivoting); the reference recomposes L*D*L^T without the permutation (:518)
+  double M[36];
+  memcpy(M, cov, sizeof(M));
+  for (int k = 0; k < n; k++) {
+    int big = k;
+    double bv = fabs(M[k * n + k]);
+    for (int i = k + 1; i < n; i++)
+      if (fabs(M[i * n + i]) > bv) { bv = fabs(M[i * n + i]); big = i; }
+    if (big != k) {
+      int s = n - big - 1;
+      for (int j = 0; j < k; j++) std::swap(M[k * n + j], M[big * n + j]);
+      for (int i = 0; i < s; i++) std::swap(M[(big + 1 + i) * n + k], M[(big + 1 + i) * n + big]);
+      std::swap(M[k * n + k], M[big * n + big]);
+      for (int i = k + 1; i < big; i++) std::swap(M[i * n + k], M[big * n + i]);
+    }
+    int rs = n - k - 1;
+    if (k > 0) {
+      double temp[6];
+      for (int j = 0; j < k; j++) temp[j] = M[j * n + j] * M[k * n + j];
+      double s = 0;
+      for (int j = 0; j < k; j++) s += M[k * n + j] * temp[j];
+      M[k * n + k] -= s;
+      for (int i = 0; i < rs; i++) {
+        double tt = 0;
+        for (int j = 0; j < k; j++) tt += M[(k + 1 + i) * n + j] * temp[j];
+        M[(k + 1 + i) * n + k] -= tt;
+      }
+    }
+    double akk = M[k * n + k];
+    bool valid = fabs(akk) > 0.0;
+    if (k == 0 && !valid) break;
+    if (rs > 0 && valid)
+      for (int i = 0; i < rs; i++) M[(k + 1 + i) * n + k] /= akk;
+  }
+  double L[36], D[6];
+  for (int i = 0; i < n; i++) {
+    D[i] = M[i * n + i];
+    for (int j = 0; j < n; j++) L[i * n + j] = (i == j) ? 1.0 : (i > j ? M[i * n + j] : 0.0);
+  }
+  for (int i = 0; i < n; i++)
+    if (std::isnan(D[i])) {  // :499-503
+      for (int q = 0; q < 36; q++) cov[q] = (q % 7 == 0) ? upper_bound : 0.0;
+      if (condition_number) *condition_number = 1.0;
+      return LH_ESOLVER;
+    }
+  bool recompute = false;
+  for (int i = 0; i < n; i++) {
+    if (D[i] <= 0) { D[i] = 1e-12; recompute = true; }
+    if (D[i] > upper_bound) { D[i] = upper_bound; recompute = true; }
+  }
+  if (recompute)
+    for (int i = 0; i < n; i++)
+      for (int j = 0; j < n; j++) {
+        double s = 0;
+        for (int k = 0; k < n; k++) s += L[i * n + k] * D[k] * L[j * n + k];
+        cov[i * n + j] = s;
+      }
+  bool has_nan = false;
+  for (int q = 0; q < 36; q++)
+    if (std::isnan(cov[q])) has_nan = true;
+  if (has_nan)
+    for (int q = 0; q < 36; q++) cov[q] = (q % 7 == 0) ? upper_bound : 0.0;
+  if (condition_number) {
+    double sym[36], ev[6];
+    for (int i = 0; i < n; i++)
+      for (int j = 0; j < n; j++) sym[i * n + j] = 0.5 * (cov[i * n + j] + cov[j * n + i]);
+    sym_eig6(sym, ev);
+    double smax = 0, smin = 1e300;
+    for (int i = 0; i < n; i++) { smax = std::max(smax, fabs(ev[i])); smin = std::min(smin, fabs(ev[i])); }
+    *condition_number = smax / smin;
+  }
+  return LH_OK;
+}
+
+// ---- K3 filter flavour ---------------------------------------------------------------------------------------
+lh_status lh_normals_knn_cloud(lh_cloud* c, int k) {
+  if (!c || k < 3 || k > 64) return LH_EINVAL;
+  lh_ctx* x = c->ctx;
+  HIPCHK(hipSetDevice(x->device));
+  if (!c->has_index) { lh_status st = cloud_build_index(c); if (st) return st; }
+  if (!c->nrm) HIPCHK(hipMalloc(&c->nrm, sizeof(float4) * (size_t)c->n_pad));
+  { ProfScope p(x, "knn_normals", (16.0 + 16.0 * k + 16.0) * c->n); launch_knn_normals(c->xyz, c->n, c->view(), k, c->nrm, x->stream); }
+  HIPCHK(hipGetLastError());
+  return LH_OK;
+}
+lh_status lh_normals_knn(lh_ctx* ctx, const lh_cloud_view* in, int k, float* out_normals4) {
+  if (!ctx || !in || !out_normals4) return LH_EINVAL;
+  lh_cloud* c = nullptr;
+  lh_status st = upload_view(ctx, in, &c);
+  if (st) return st;
+  st = lh_normals_knn_cloud(c, k);
+  if (!st) {
+    hipError_t e = hipMemcpyAsync(out_normals4, c->nrm, sizeof(float4) * (size_t)c->n, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) st = LH_EDEVICE;
+  }
+  (void)hipStreamSynchronize(ctx->stream);
+  cloud_free(c);
+  return st;
+}
+
+// ---- K1: CustomVoxelGrid::filter (custom_voxel_grid.cc:76-87 -> pcl::VoxelGrid::applyFilter) ------------------
+static float dec_ordered_host(uint32_t e) {
+  uint32_t u = (e & 0x80000000u) ? (e & 0x7fffffffu) : ~e;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+lh_status lh_voxel_grid(lh_ctx* c, const lh_cloud_view* in, float leaf, int limit_axis, double lo, double hi, float* out_xyzi,
+                        uint32_t out_capacity, uint32_t* out_count) {
+  if (!c || !in || !in->base || !out_count || !(leaf > 0.0f) || limit_axis > 2) return LH_EINVAL;
+  if (out_capacity > 0 && !out_xyzi) return LH_EINVAL;
+  HIPCHK(hipSetDevice(c->device));
+  *out_count = 0;
+  int n = (int)in->count;
+  if (n == 0) return LH_OK;
+  // pack x,y,z,intensity
+  std::vector<float> host((size_t)n * 4);
+  const char* base = (const char*)in->base;
+  for (int i = 0; i < n; i++) {
+    const char* p = base + (size_t)i * in->stride;
+    memcpy(&host[4 * (size_t)i], p + in->off_xyz, 12);
+    host[4 * (size_t)i + 3] = (in->off_intensity != UINT32_MAX) ? *(const float*)(p + in->off_intensity) : 0.0f;
+  }
+  lh_status st = ctx_ensure_scratch(c, n);
+  if (st) return st;
+  float4 *d_in = nullptr, *d_out = nullptr;
+  uint32_t *d_heads = nullptr, *d_rank = nullptr;
+  void* d_scan_tmp = nullptr;
+  size_t scan_bytes = scan_temp_bytes(n);
+  uint32_t cap = std::min<uint32_t>(out_capacity, (uint32_t)n);
+  HIPCHK(hipMalloc(&d_in, sizeof(float4) * (size_t)n));
+  HIPCHK(hipMalloc(&d_out, sizeof(float4) * (size_t)std::max<uint32_t>(cap, 1)));
+  HIPCHK(hipMalloc(&d_heads, sizeof(uint32_t) * (size_t)n));
+  HIPCHK(hipMalloc(&d_rank, sizeof(uint32_t) * (size_t)n));
+  HIPCHK(hipMalloc(&d_scan_tmp, scan_bytes ? scan_bytes : 16));
+  auto cleanup = [&]() { (void)hipFree(d_in); (void)hipFree(d_out); (void)hipFree(d_heads); (void)hipFree(d_rank); (void)hipFree(d_scan_tmp); };
+  HIPCHK(hipMemcpyAsync(d_in, host.data(), sizeof(float) * host.size(), hipMemcpyHostToDevice, c->stream));
+  float flo = (float)std::max(lo, -3.0e38), fhi = (float)std::min(hi, 3.0e38);
+  { ProfScope p(c, "voxel_bbox", 16.0 * n); launch_voxel_bbox(d_in, n, limit_axis, flo, fhi, c->bbox, c->stream); }
+  uint32_t enc[6];
+  HIPCHK(hipMemcpyAsync(enc, c->bbox, sizeof(enc), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  float mn[3], mx[3];
+  for (int a = 0; a < 3; a++) { mn[a] = dec_ordered_host(enc[a]); mx[a] = dec_ordered_host(enc[3 + a]); }
+  if (!(mn[0] <= mx[0])) { cleanup(); return LH_OK; }  // no point passed the filter
+  float inv = 1.0f / leaf;
+  int64_t dx = (int64_t)((mx[0] - mn[0]) * inv) + 1, dy = (int64_t)((mx[1] - mn[1]) * inv) + 1, dz = (int64_t)((mx[2] - mn[2]) * inv) + 1;
+  if (dx * dy * dz > (int64_t)INT32_MAX) { cleanup(); return LH_EINVAL; }  // PCL: "Leaf size is too small ... Integer indices would overflow"
+  VoxelGridDesc g;
+  g.inv_leaf = inv; g.limit_axis = limit_axis; g.lo = flo; g.hi = fhi;
+  int divb[3];
+  for (int a = 0; a < 3; a++) {
+    g.minb[a] = (int)floorf(mn[a] * inv);
+    divb[a] = (int)floorf(mx[a] * inv) - g.minb[a] + 1;
+  }
+  g.mul[0] = 1; g.mul[1] = divb[0]; g.mul[2] = divb[0] * divb[1];
+  { ProfScope p(c, "voxel_keys", 24.0 * n); launch_voxel_keys(d_in, n, g, c->keys0, c->vals0, c->stream); }
+  { ProfScope p(c, "voxel_radix_sort", 64.0 * n); sort_pairs_u32(c->sort_temp, c->sort_temp_bytes, c->keys0, c->keys1, c->vals0, c->vals1, n, 32, c->stream); }
+  { ProfScope p(c, "voxel_segments", 16.0 * n);
+    launch_voxel_heads(c->keys1, n, d_heads, c->stream);
+    inclusive_scan_u32(d_scan_tmp, scan_bytes, d_heads, d_rank, n, c->stream); }
+  { ProfScope p(c, "voxel_centroids", 32.0 * n); launch_voxel_centroids(d_in, c->keys1, c->vals1, d_heads, d_rank, n, d_out, cap, c->stream); }
+  HIPCHK(hipGetLastError());
+  uint32_t total = 0;
+  HIPCHK(hipMemcpyAsync(&total, d_rank + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  *out_count = total;
+  uint32_t ncopy = std::min(total, cap);
+  if (ncopy) HIPCHK(hipMemcpy(out_xyzi, d_out, sizeof(float4) * (size_t)ncopy, hipMemcpyDeviceToHost));
+  cleanup();
+  return LH_OK;
+}
+
+// ---- instrumentation -------------------------------------------------------------------------------------------
+lh_status lh_profile_enable(lh_ctx* c, int on) {
+  if (!c) return LH_EINVAL;
+  c->prof_flush();
+  c->prof = on != 0;
+  return LH_OK;
+}
+lh_status lh_profile_reset(lh_ctx* c) {
+  if (!c) return LH_EINVAL;
+  c->prof_flush();
+  c->prof_entries.clear();
+  return LH_OK;
+}
+int lh_profile_get(lh_ctx* c, lh_kernel_stat* out, int cap) {
+  if (!c) return 0;
+  c->prof_flush();
+  int n = (int)c->prof_entries.size();
+  for (int i = 0; i < n && i < cap && out; i++) {
+    memset(&out[i], 0, sizeof(out[i]));
+    strncpy(out[i].name, c->prof_entries[i].name.c_str(), sizeof(out[i].name) - 1);
+    out[i].launches = c->prof_entries[i].launches;
+    out[i].total_ms = c->prof_entries[i].ms;
+    out[i].bytes = c->prof_entries[i].bytes;
+  }
+  return n;
+}
+
+}  // extern "C"

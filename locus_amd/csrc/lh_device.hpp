@@ -1,0 +1,267 @@
+// lh_device.hpp -- data layout + per-thread device functions of the GICP hot path (gfx950).
+//
+// The functions here are __host__ __device__ so that tests/host_emu can exercise the traversal logic on
+// the CPU against brute force; the product only ever calls them from HIP kernels (lh_kernels.hip).
+//
+// NN index ("K2", replaces the FLANN kd-tree built by tree_->setInputCloud in pcl::Registration::initCompute):
+//   * target points are sorted by 30-bit Morton code; leaf L owns sorted points [8L, 8L+8)
+//   * an implicit complete 4-ary tree sits on the leaves (heap numbering: children of node i are 4i+1..4i+4);
+//     an internal node stores the float AABBs of its 4 children as SoA (96 B = six float4 loads)
+//   * sorted point = float4(x, y, z, bitcast(original index)) so one 16-B load yields position + id
+// Exactness: distances are float ((dx*dx+dy*dy)+dz*dz), no FMA contraction (the TU is compiled with
+// -ffp-contract=off).  The box distance uses the same operation order, and float rounding is monotone, so
+// box_d2 <= d2(any point inside) holds exactly; pruning on box_d2 > best is therefore exact, and ties are
+// resolved to the lowest original index -- the same rule as the CPU oracle, so indices match bit-for-bit.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define LH_HD __host__ __device__ __forceinline__
+
+namespace lh {
+
+constexpr int LEAF = 8;        // points per leaf (128 B = one cache line of sorted points)
+constexpr int MAX_DEPTH = 12;  // 4^12 leaves * 8 pts = 134 M points
+constexpr int STACK_MAX = 3 * MAX_DEPTH + 1;
+
+struct alignas(16) Node4 {
+  float lox[4], loy[4], loz[4], hix[4], hiy[4], hiz[4];
+};
+
+struct TreeView {
+  const float4* pts;   // sorted points, padded to n_leaves*LEAF with +inf / id INT_MAX
+  const Node4* nodes;  // internal nodes, heap order
+  int first_leaf;      // heap index of leaf 0 = (4^depth - 1) / 3
+  int n_points;
+};
+
+LH_HD uint32_t f2u(float f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __float_as_uint(f);
+#else
+  union { float f; uint32_t u; } v; v.f = f; return v.u;
+#endif
+}
+LH_HD float u2f(uint32_t u) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __uint_as_float(u);
+#else
+  union { float f; uint32_t u; } v; v.u = u; return v.f;
+#endif
+}
+LH_HD float inf_f() { return u2f(0x7f800000u); }
+
+LH_HD float d2f(float qx, float qy, float qz, float px, float py, float pz) {
+  float dx = qx - px, dy = qy - py, dz = qz - pz;
+  return (dx * dx + dy * dy) + dz * dz;
+}
+LH_HD float boxd2(float qx, float qy, float qz, float lx, float ly, float lz, float hx, float hy, float hz) {
+  float dx = fmaxf(fmaxf(lx - qx, qx - hx), 0.0f);
+  float dy = fmaxf(fmaxf(ly - qy, qy - hy), 0.0f);
+  float dz = fmaxf(fmaxf(lz - qz, qz - hz), 0.0f);
+  return (dx * dx + dy * dy) + dz * dz;
+}
+
+// y = T * (x,y,z,1) in float: ((m0*x + m1*y) + m2*z) + m3 per row; T = 12 floats row-major 3x4.
+// Same operation order as the oracle's xform_pt (stands in for Eigen's Matrix4f * Vector4f at gicp.hpp:469,382).
+LH_HD void xform_pt(const float* T, float x, float y, float z, float& ox, float& oy, float& oz) {
+  ox = ((T[0] * x + T[1] * y) + T[2] * z) + T[3];
+  oy = ((T[4] * x + T[5] * y) + T[6] * z) + T[7];
+  oz = ((T[8] * x + T[9] * y) + T[10] * z) + T[11];
+}
+LH_HD void xform_nrm(const float* T, float x, float y, float z, float& ox, float& oy, float& oz) {
+  ox = (T[0] * x + T[1] * y) + T[2] * z;
+  oy = (T[4] * x + T[5] * y) + T[6] * z;
+  oz = (T[8] * x + T[9] * y) + T[10] * z;
+}
+
+LH_HD uint32_t expand10(uint32_t v) {  // 10 bits -> every third bit
+  v &= 0x3ffu;
+  v = (v | (v << 16)) & 0x030000FFu;
+  v = (v | (v << 8)) & 0x0300F00Fu;
+  v = (v | (v << 4)) & 0x030C30C3u;
+  v = (v | (v << 2)) & 0x09249249u;
+  return v;
+}
+LH_HD uint32_t morton30(uint32_t ix, uint32_t iy, uint32_t iz) { return (expand10(ix) << 2) | (expand10(iy) << 1) | expand10(iz); }
+
+LH_HD void cswap(uint64_t& a, uint64_t& b) {
+  uint64_t lo = a < b ? a : b, hi = a < b ? b : a;
+  a = lo; b = hi;
+}
+
+// Collector concept: float bound() const; void offer(float d2, int id);
+// A subtree / leaf is visited iff box_d2 <= bound() (ties must be visited for the lowest-index rule).
+template <class Collector>
+LH_HD void tree_search(const TreeView& t, float qx, float qy, float qz, Collector& col) {
+  uint64_t stack[STACK_MAX];
+  int sp = 0;
+  int lin = 0;
+  const uint64_t INVALID = ~0ull;
+  for (;;) {
+    if (lin < t.first_leaf) {
+      const Node4& nd = t.nodes[lin];
+      float4 lx = *reinterpret_cast<const float4*>(nd.lox), ly = *reinterpret_cast<const float4*>(nd.loy),
+             lz = *reinterpret_cast<const float4*>(nd.loz), hx = *reinterpret_cast<const float4*>(nd.hix),
+             hy = *reinterpret_cast<const float4*>(nd.hiy), hz = *reinterpret_cast<const float4*>(nd.hiz);
+      float bd = col.bound();
+      float d0 = boxd2(qx, qy, qz, lx.x, ly.x, lz.x, hx.x, hy.x, hz.x);
+      float d1 = boxd2(qx, qy, qz, lx.y, ly.y, lz.y, hx.y, hy.y, hz.y);
+      float d2 = boxd2(qx, qy, qz, lx.z, ly.z, lz.z, hx.z, hy.z, hz.z);
+      float d3 = boxd2(qx, qy, qz, lx.w, ly.w, lz.w, hx.w, hy.w, hz.w);
+      const uint32_t c0 = 4u * (uint32_t)lin + 1u;
+      const float INF = inf_f();
+      uint64_t k0 = (d0 <= bd && d0 < INF) ? (((uint64_t)f2u(d0) << 32) | (c0 + 0u)) : INVALID;
+      uint64_t k1 = (d1 <= bd && d1 < INF) ? (((uint64_t)f2u(d1) << 32) | (c0 + 1u)) : INVALID;
+      uint64_t k2 = (d2 <= bd && d2 < INF) ? (((uint64_t)f2u(d2) << 32) | (c0 + 2u)) : INVALID;
+      uint64_t k3 = (d3 <= bd && d3 < INF) ? (((uint64_t)f2u(d3) << 32) | (c0 + 3u)) : INVALID;
+      cswap(k0, k1); cswap(k2, k3); cswap(k0, k2); cswap(k1, k3); cswap(k1, k2);
+      if (k3 != INVALID) stack[sp++] = k3;
+      if (k2 != INVALID) stack[sp++] = k2;
+      if (k1 != INVALID) stack[sp++] = k1;
+      if (k0 != INVALID) { lin = (int)(uint32_t)k0; continue; }
+    } else {
+      const float4* p = t.pts + (size_t)(lin - t.first_leaf) * LEAF;
+#pragma unroll
+      for (int e = 0; e < LEAF; e++) {
+        float4 v = p[e];
+        col.offer(d2f(qx, qy, qz, v.x, v.y, v.z), (int)f2u(v.w));
+      }
+    }
+    uint64_t key;
+    do {
+      if (sp == 0) return;
+      key = stack[--sp];
+    } while (u2f((uint32_t)(key >> 32)) > col.bound());
+    lin = (int)(uint32_t)key;
+  }
+}
+
+struct Nn1Collector {
+  float bd;
+  int bi;
+  LH_HD float bound() const { return bd; }
+  LH_HD void offer(float d, int id) {
+    if (d < bd || (d == bd && id < bi)) { bd = d; bi = id; }
+  }
+};
+
+// k best (d2, id) ascending, lexicographic; storage strided so that a workgroup can keep the lists in LDS
+// as [element][thread] (conflict-free) -- stride 1 on the host.
+struct KnnCollector {
+  float* kd;
+  int* ki;
+  int k, stride, cnt;
+  LH_HD float bound() const { return cnt < k ? inf_f() : kd[(k - 1) * stride]; }
+  LH_HD void offer(float d, int id) {
+    if (id == 0x7fffffff) return;  // padding point
+    if (cnt == k) {
+      float ld = kd[(k - 1) * stride];
+      int li = ki[(k - 1) * stride];
+      if (!(d < ld || (d == ld && id < li))) return;
+    }
+    int p = (cnt < k) ? cnt++ : k - 1;
+    while (p > 0) {
+      float pd = kd[(p - 1) * stride];
+      int pi = ki[(p - 1) * stride];
+      if (!(d < pd || (d == pd && id < pi))) break;
+      kd[p * stride] = pd;
+      ki[p * stride] = pi;
+      p--;
+    }
+    kd[p * stride] = d;
+    ki[p * stride] = id;
+  }
+};
+
+// ---- 3x3 double helpers (row-major) ------------------------------------------------------------------
+// C = I - (1-eps) n n^T  (CalculateCovarianceFromNormals restated; zero / non-finite normal => I)
+LH_HD void cov_from_normal(float nx, float ny, float nz, double eps, double* C) {
+  double n0 = nx, n1 = ny, n2 = nz;
+  double l2 = n0 * n0 + n1 * n1 + n2 * n2;
+  C[0] = 1.0; C[1] = 0.0; C[2] = 0.0; C[3] = 0.0; C[4] = 1.0; C[5] = 0.0; C[6] = 0.0; C[7] = 0.0; C[8] = 1.0;
+  if (!(l2 > 0.0) || !(l2 < 1.0e300)) return;
+  double inv = 1.0 / sqrt(l2);
+  n0 *= inv; n1 *= inv; n2 *= inv;
+  double s = 1.0 - eps;
+  C[0] -= s * n0 * n0; C[1] -= s * n0 * n1; C[2] -= s * n0 * n2;
+  C[3] -= s * n1 * n0; C[4] -= s * n1 * n1; C[5] -= s * n1 * n2;
+  C[6] -= s * n2 * n0; C[7] -= s * n2 * n1; C[8] -= s * n2 * n2;
+}
+LH_HD void sym6_to_mat9(const double* s, double* C) {  // (00,01,02,11,12,22)
+  C[0] = s[0]; C[1] = s[1]; C[2] = s[2]; C[3] = s[1]; C[4] = s[3]; C[5] = s[4]; C[6] = s[2]; C[7] = s[4]; C[8] = s[5];
+}
+LH_HD double cof3(const double* m, int i, int j) {
+  int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+  return m[i1 * 3 + j1] * m[i2 * 3 + j2] - m[i1 * 3 + j2] * m[i2 * 3 + j1];
+}
+// M = (R C1 R^T + C2)^-1 (gicp.hpp:488-493), Eigen's 3x3 cofactor inverse
+LH_HD void mahalanobis(const double* R, const double* C1, const double* C2, double* Minv) {
+  double M[9], t[9];
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) M[i * 3 + j] = R[i * 3 + 0] * C1[0 * 3 + j] + R[i * 3 + 1] * C1[1 * 3 + j] + R[i * 3 + 2] * C1[2 * 3 + j];
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+      t[i * 3 + j] = (M[i * 3 + 0] * R[j * 3 + 0] + M[i * 3 + 1] * R[j * 3 + 1] + M[i * 3 + 2] * R[j * 3 + 2]) + C2[i * 3 + j];
+  double c00 = cof3(t, 0, 0), c10 = cof3(t, 1, 0), c20 = cof3(t, 2, 0);
+  double det = c00 * t[0] + c10 * t[3] + c20 * t[6];
+  double invdet = 1.0 / det;
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) Minv[i * 3 + j] = cof3(t, j, i) * invdet;
+}
+
+// cyclic Jacobi eigen-decomposition of a symmetric 3x3 (double); returns eigenvector of the smallest |eigenvalue|.
+// Stands in for Eigen::JacobiSVD<Matrix3d> at gicp.hpp:140 (U's last column).
+LH_HD void smallest_sv_vector3(const double* Ain, double* u) {
+  double A[9], V[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  for (int i = 0; i < 9; i++) A[i] = Ain[i];
+  for (int sweep = 0; sweep < 64; sweep++) {
+    double off = A[1] * A[1] + A[2] * A[2] + A[5] * A[5];
+    if (off < 1e-300) break;
+    for (int p = 0; p < 3; p++)
+      for (int q = p + 1; q < 3; q++) {
+        double apq = A[p * 3 + q];
+        if (fabs(apq) < 1e-300) continue;
+        double theta = (A[q * 3 + q] - A[p * 3 + p]) / (2.0 * apq);
+        double tt = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        double c = 1.0 / sqrt(tt * tt + 1.0), s = tt * c;
+        for (int k = 0; k < 3; k++) {
+          double akp = A[k * 3 + p], akq = A[k * 3 + q];
+          A[k * 3 + p] = c * akp - s * akq;
+          A[k * 3 + q] = s * akp + c * akq;
+        }
+        for (int k = 0; k < 3; k++) {
+          double apk = A[p * 3 + k], aqk = A[q * 3 + k];
+          A[p * 3 + k] = c * apk - s * aqk;
+          A[q * 3 + k] = s * apk + c * aqk;
+        }
+        for (int k = 0; k < 3; k++) {
+          double vkp = V[k * 3 + p], vkq = V[k * 3 + q];
+          V[k * 3 + p] = c * vkp - s * vkq;
+          V[k * 3 + q] = s * vkp + c * vkq;
+        }
+      }
+  }
+  // ascending eigenvalue order first (like the oracle's sort), then smallest |ev|, first index on ties
+  double ev[3] = {A[0], A[4], A[8]};
+  int ord[3] = {0, 1, 2};
+  for (int i = 0; i < 3; i++) {
+    int m = i;
+    for (int j = i + 1; j < 3; j++)
+      if (ev[ord[j]] < ev[ord[m]]) m = j;
+    int tmp = ord[i]; ord[i] = ord[m]; ord[m] = tmp;
+  }
+  int s = 0;
+  for (int a = 1; a < 3; a++)
+    if (fabs(ev[ord[a]]) < fabs(ev[ord[s]])) s = a;
+  int col = ord[s];
+  u[0] = V[0 * 3 + col]; u[1] = V[1 * 3 + col]; u[2] = V[2 * 3 + col];
+}
+
+}  // namespace lh

@@ -1,0 +1,642 @@
+// lh_kernels.hip -- hand-written HIP kernels of the GICP hot path for gfx950 (MI355X, wave64).
+// Compiled with -ffp-contract=off: float/double expressions keep one rounding per operation so that the
+// results can be compared bit-for-bit (indices) / to 1e-12 (doubles) with the CPU oracle.
+//
+// Kernel <-> reference loop:
+//   k_bbox / k_morton / k_gather_sorted / k_leaf_level / k_level_up   K2  tree_->setInputCloud (initCompute)
+//   k_sweep                                                           K4  gicp.hpp:464-498 (+K3' fused, gicp.hpp:81-82)
+//   k_cost                                                            K5  gicp.hpp:362-402
+//   k_transform                                                       K6  gicp.hpp:440,586
+//   k_nn1 / k_sum_f32                                                 K7  getFitnessScore; PointCloudLocalization.cc:327-336
+//   k_knn / k_knn_cov / k_knn_normals                                 K3  gicp.hpp:85-154; normal_computation.cc:26-59
+//   k_ap                                                              K8  PointCloudLocalization.cc:723-750
+#include "lh_kernels.hpp"
+
+namespace lh {
+
+// ===== K2: index build ===================================================================================
+__device__ __forceinline__ uint32_t enc_ordered(float f) {
+  uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float dec_ordered(uint32_t e) {
+  uint32_t u = (e & 0x80000000u) ? (e & 0x7fffffffu) : ~e;
+  return __uint_as_float(u);
+}
+
+__global__ void __launch_bounds__(256) k_bbox_init(uint32_t* bbox) {
+  if (threadIdx.x < 3) bbox[threadIdx.x] = 0xffffffffu;       // min slots
+  else if (threadIdx.x < 6) bbox[threadIdx.x] = 0u;           // max slots
+}
+
+__global__ void __launch_bounds__(256) k_bbox(const float4* __restrict__ xyz, int n, uint32_t* bbox) {
+  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    float4 p = xyz[i];
+    lo[0] = fminf(lo[0], p.x); hi[0] = fmaxf(hi[0], p.x);
+    lo[1] = fminf(lo[1], p.y); hi[1] = fmaxf(hi[1], p.y);
+    lo[2] = fminf(lo[2], p.z); hi[2] = fmaxf(hi[2], p.z);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      lo[a] = fminf(lo[a], __shfl_down(lo[a], off, 64));
+      hi[a] = fmaxf(hi[a], __shfl_down(hi[a], off, 64));
+    }
+  }
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      atomicMin(&bbox[a], enc_ordered(lo[a]));
+      atomicMax(&bbox[3 + a], enc_ordered(hi[a]));
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) k_morton(const float4* __restrict__ xyz, int n, const uint32_t* __restrict__ bbox,
+                                                uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float lx = dec_ordered(bbox[0]), ly = dec_ordered(bbox[1]), lz = dec_ordered(bbox[2]);
+  float hx = dec_ordered(bbox[3]), hy = dec_ordered(bbox[4]), hz = dec_ordered(bbox[5]);
+  // one isotropic cell size so Morton cells are cubes (better boxes than per-axis scaling)
+  float ext = fmaxf(fmaxf(hx - lx, hy - ly), fmaxf(hz - lz, 1e-30f));
+  float sc = 1023.999f / ext;
+  float4 p = xyz[i];
+  int ix = min(1023, max(0, (int)((p.x - lx) * sc)));
+  int iy = min(1023, max(0, (int)((p.y - ly) * sc)));
+  int iz = min(1023, max(0, (int)((p.z - lz) * sc)));
+  keys[i] = morton30((uint32_t)ix, (uint32_t)iy, (uint32_t)iz);
+  vals[i] = (uint32_t)i;
+}
+
+__global__ void __launch_bounds__(256) k_gather_sorted(const float4* __restrict__ xyz, const uint32_t* __restrict__ vals, int n,
+                                                       int n_padded, float4* __restrict__ sorted) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_padded) return;
+  float4 o;
+  if (i < n) {
+    uint32_t j = vals[i];
+    float4 p = xyz[j];
+    o = make_float4(p.x, p.y, p.z, __uint_as_float(j));
+  } else {
+    o = make_float4(INFINITY, INFINITY, INFINITY, __uint_as_float(0x7fffffffu));
+  }
+  sorted[i] = o;
+}
+
+__device__ __forceinline__ int level_offset(int l) { return (int)(((1ll << (2 * l)) - 1) / 3); }
+
+// one thread per leaf slot: box of its (<= 8) points -> child slot of the last internal level
+__global__ void __launch_bounds__(256) k_leaf_level(const float4* __restrict__ sorted, int n, int depth, Node4* __restrict__ nodes) {
+  int L = blockIdx.x * blockDim.x + threadIdx.x;
+  int slots = 1 << (2 * depth);
+  if (L >= slots) return;
+  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  int base = L * LEAF;
+#pragma unroll
+  for (int e = 0; e < LEAF; e++) {
+    if (base + e < n) {
+      float4 p = sorted[base + e];
+      lo[0] = fminf(lo[0], p.x); hi[0] = fmaxf(hi[0], p.x);
+      lo[1] = fminf(lo[1], p.y); hi[1] = fmaxf(hi[1], p.y);
+      lo[2] = fminf(lo[2], p.z); hi[2] = fmaxf(hi[2], p.z);
+    }
+  }
+  Node4& nd = nodes[level_offset(depth - 1) + (L >> 2)];
+  int c = L & 3;
+  nd.lox[c] = lo[0]; nd.loy[c] = lo[1]; nd.loz[c] = lo[2];
+  nd.hix[c] = hi[0]; nd.hiy[c] = hi[1]; nd.hiz[c] = hi[2];
+}
+
+// one thread per (node of level l, child c): union of the child's four boxes
+__global__ void __launch_bounds__(256) k_level_up(int l, Node4* __restrict__ nodes) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  int cnt = 1 << (2 * l + 2);
+  if (t >= cnt) return;
+  int j = t >> 2, c = t & 3;
+  const Node4& ch = nodes[level_offset(l + 1) + 4 * j + c];
+  float lx = fminf(fminf(ch.lox[0], ch.lox[1]), fminf(ch.lox[2], ch.lox[3]));
+  float ly = fminf(fminf(ch.loy[0], ch.loy[1]), fminf(ch.loy[2], ch.loy[3]));
+  float lz = fminf(fminf(ch.loz[0], ch.loz[1]), fminf(ch.loz[2], ch.loz[3]));
+  float hx = fmaxf(fmaxf(ch.hix[0], ch.hix[1]), fmaxf(ch.hix[2], ch.hix[3]));
+  float hy = fmaxf(fmaxf(ch.hiy[0], ch.hiy[1]), fmaxf(ch.hiy[2], ch.hiy[3]));
+  float hz = fmaxf(fmaxf(ch.hiz[0], ch.hiz[1]), fmaxf(ch.hiz[2], ch.hiz[3]));
+  Node4& nd = nodes[level_offset(l) + j];
+  nd.lox[c] = lx; nd.loy[c] = ly; nd.loz[c] = lz;
+  nd.hix[c] = hx; nd.hiy[c] = hy; nd.hiz[c] = hz;
+}
+
+void launch_bbox(const float4* xyz, int n, uint32_t* bbox, hipStream_t s) {
+  hipLaunchKernelGGL(k_bbox_init, dim3(1), dim3(64), 0, s, bbox);
+  int blocks = (n + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(k_bbox, dim3(blocks), dim3(256), 0, s, xyz, n, bbox);
+}
+void launch_morton(const float4* xyz, int n, const uint32_t* bbox, uint32_t* keys, uint32_t* vals, hipStream_t s) {
+  hipLaunchKernelGGL(k_morton, dim3((n + 255) / 256), dim3(256), 0, s, xyz, n, bbox, keys, vals);
+}
+void launch_gather_sorted(const float4* xyz, const uint32_t* vals, int n, int n_padded, float4* sorted, hipStream_t s) {
+  hipLaunchKernelGGL(k_gather_sorted, dim3((n_padded + 255) / 256), dim3(256), 0, s, xyz, vals, n, n_padded, sorted);
+}
+void launch_build_nodes(const float4* sorted, int n, int depth, Node4* nodes, hipStream_t s) {
+  if (depth <= 0) return;
+  int slots = 1 << (2 * depth);
+  hipLaunchKernelGGL(k_leaf_level, dim3((slots + 255) / 256), dim3(256), 0, s, sorted, n, depth, nodes);
+  for (int l = depth - 2; l >= 0; l--) {
+    int cnt = 1 << (2 * l + 2);
+    hipLaunchKernelGGL(k_level_up, dim3((cnt + 255) / 256), dim3(256), 0, s, l, nodes);
+  }
+}
+
+// ===== K4: NN + Mahalanobis sweep ==========================================================================
+__global__ void __launch_bounds__(256) k_sweep(const PairDesc* __restrict__ descs, SweepArgs a) {
+  const SweepJob& job = a.job[blockIdx.y];
+  const PairDesc d = descs[job.slot];
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= d.n) return;
+  float4 p = d.src[i];
+  float qx, qy, qz;
+  xform_pt(job.T, p.x, p.y, p.z, qx, qy, qz);  // gicp.hpp:469
+  TreeView tv{d.tgt_sorted, d.tgt_nodes, d.first_leaf, d.m};
+  Nn1Collector col{INFINITY, 0x7fffffff};
+  int w = d.prev_nn[i];
+  if (w >= 0) {  // warm start: last sweep's neighbour is a valid candidate => tight initial bound, still exact
+    float4 t = d.tgt_xyz[w];
+    col.bd = d2f(qx, qy, qz, t.x, t.y, t.z);
+    col.bi = w;
+  }
+  tree_search(tv, qx, qy, qz, col);
+  int j = (col.bi == 0x7fffffff) ? -1 : col.bi;
+  d.prev_nn[i] = j;
+  float4 c = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
+  if (j >= 0 && (double)col.bd < d.corr_dist2) {  // gicp.hpp:483
+    double C1[9], C2[9], M[9];
+    if (d.src_cov6) {
+      double s6[6];
+#pragma unroll
+      for (int k = 0; k < 6; k++) s6[k] = d.src_cov6[(size_t)k * d.src_cov_pad + i];
+      sym6_to_mat9(s6, C1);
+    } else {
+      float4 nn = d.src_nrm[i];
+      cov_from_normal(nn.x, nn.y, nn.z, d.gicp_eps, C1);
+    }
+    if (d.tgt_cov6) {
+      double s6[6];
+#pragma unroll
+      for (int k = 0; k < 6; k++) s6[k] = d.tgt_cov6[(size_t)k * d.m_pad + j];
+      sym6_to_mat9(s6, C2);
+    } else {
+      float4 nn = d.tgt_nrm[j];
+      cov_from_normal(nn.x, nn.y, nn.z, d.gicp_eps, C2);
+    }
+    mahalanobis(job.R, C1, C2, M);  // gicp.hpp:488-493
+    d.maha6[(size_t)0 * d.n_pad + i] = M[0];
+    d.maha6[(size_t)1 * d.n_pad + i] = M[1];
+    d.maha6[(size_t)2 * d.n_pad + i] = M[2];
+    d.maha6[(size_t)3 * d.n_pad + i] = M[4];
+    d.maha6[(size_t)4 * d.n_pad + i] = M[5];
+    d.maha6[(size_t)5 * d.n_pad + i] = M[8];
+    float4 t = d.tgt_xyz[j];
+    c = make_float4(t.x, t.y, t.z, __int_as_float(j));
+  }
+  d.corr[i] = c;
+}
+
+void launch_sweep(const PairDesc* descs, const SweepArgs& a, int max_n, hipStream_t s) {
+  hipLaunchKernelGGL(k_sweep, dim3((max_n + 255) / 256, a.njobs), dim3(256), 0, s, descs, a);
+}
+
+// ===== K5: cost / gradient reduction =======================================================================
+__global__ void __launch_bounds__(256) k_cost(const PairDesc* __restrict__ descs, CostArgs a, double* __restrict__ out) {
+  const CostJob& job = a.job[blockIdx.y];
+  const PairDesc d = descs[job.slot];
+  int base = blockIdx.x * COST_CHUNK;
+  if (base >= d.n) return;
+  double acc[COST_NSUM];
+#pragma unroll
+  for (int k = 0; k < COST_NSUM; k++) acc[k] = 0.0;
+#pragma unroll
+  for (int r = 0; r < COST_CHUNK / 256; r++) {
+    int i = base + r * 256 + threadIdx.x;
+    if (i < d.n) {
+      float4 c = d.corr[i];
+      if (__float_as_int(c.w) >= 0) {
+        float4 p = d.src[i];
+        float px, py, pz;
+        xform_pt(job.T, p.x, p.y, p.z, px, py, pz);                       // gicp.hpp:382
+        double r0 = (double)(px - c.x), r1 = (double)(py - c.y), r2 = (double)(pz - c.z);  // :384 (float subtract)
+        double m00 = d.maha6[(size_t)0 * d.n_pad + i], m01 = d.maha6[(size_t)1 * d.n_pad + i],
+               m02 = d.maha6[(size_t)2 * d.n_pad + i], m11 = d.maha6[(size_t)3 * d.n_pad + i],
+               m12 = d.maha6[(size_t)4 * d.n_pad + i], m22 = d.maha6[(size_t)5 * d.n_pad + i];
+        double t0 = (m00 * r0 + m01 * r1) + m02 * r2;                     // temp = M*res  :386
+        double t1 = (m01 * r0 + m11 * r1) + m12 * r2;
+        double t2 = (m02 * r0 + m12 * r1) + m22 * r2;
+        acc[0] += (r0 * t0 + r1 * t1) + r2 * t2;                          // :388
+        acc[1] += t0; acc[2] += t1; acc[3] += t2;                         // :392
+        double p0 = p.x, p1 = p.y, p2 = p.z;                              // :393-394 (base_transformation_ = I)
+        acc[4] += p0 * t0; acc[5] += p0 * t1; acc[6] += p0 * t2;          // :396
+        acc[7] += p1 * t0; acc[8] += p1 * t1; acc[9] += p1 * t2;
+        acc[10] += p2 * t0; acc[11] += p2 * t1; acc[12] += p2 * t2;
+        acc[13] += 1.0;
+      }
+    }
+  }
+  // fixed-shape reduction: wave64 shuffle tree, then the 4 waves in order => bitwise reproducible
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+    for (int k = 0; k < COST_NSUM; k++) acc[k] += __shfl_down(acc[k], off, 64);
+  }
+  __shared__ double sm[4][COST_NSUM];
+  int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < COST_NSUM; k++) sm[wave][k] = acc[k];
+  }
+  __syncthreads();
+  if (threadIdx.x < COST_NSUM) {
+    double v = ((sm[0][threadIdx.x] + sm[1][threadIdx.x]) + sm[2][threadIdx.x]) + sm[3][threadIdx.x];
+    out[job.out_offset + blockIdx.x * COST_NSUM + threadIdx.x] = v;
+  }
+}
+
+void launch_cost(const PairDesc* descs, const CostArgs& a, int max_n, double* out, hipStream_t s) {
+  hipLaunchKernelGGL(k_cost, dim3(cost_blocks(max_n), a.njobs), dim3(256), 0, s, descs, a, out);
+}
+
+// ===== K6 / misc ===========================================================================================
+struct T12 { float v[12]; };
+__global__ void __launch_bounds__(256) k_transform(const float4* __restrict__ in_xyz, const float4* __restrict__ in_nrm, int n, T12 T,
+                                                   float4* __restrict__ out_xyz, float4* __restrict__ out_nrm) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float4 p = in_xyz[i];
+  float x, y, z;
+  xform_pt(T.v, p.x, p.y, p.z, x, y, z);
+  out_xyz[i] = make_float4(x, y, z, 1.0f);
+  if (in_nrm && out_nrm) {
+    float4 nn = in_nrm[i];
+    xform_nrm(T.v, nn.x, nn.y, nn.z, x, y, z);
+    out_nrm[i] = make_float4(x, y, z, nn.w);
+  }
+}
+void launch_transform(const float4* in_xyz, const float4* in_nrm, int n, const float* T12p, float4* out_xyz, float4* out_nrm,
+                      hipStream_t s) {
+  T12 T;
+  for (int k = 0; k < 12; k++) T.v[k] = T12p[k];
+  hipLaunchKernelGGL(k_transform, dim3((n + 255) / 256), dim3(256), 0, s, in_xyz, in_nrm, n, T, out_xyz, out_nrm);
+}
+
+__global__ void __launch_bounds__(256) k_fill_i32(int32_t* p, int n, int32_t v) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+void launch_fill_i32(int32_t* p, int n, int32_t v, hipStream_t s) {
+  hipLaunchKernelGGL(k_fill_i32, dim3((n + 255) / 256), dim3(256), 0, s, p, n, v);
+}
+
+__global__ void __launch_bounds__(256) k_nn1(const float4* __restrict__ q, int nq, T12 T, int has_T, TreeView tv,
+                                             int32_t* __restrict__ idx, float* __restrict__ d2) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nq) return;
+  float4 p = q[i];
+  float x = p.x, y = p.y, z = p.z;
+  if (has_T) xform_pt(T.v, p.x, p.y, p.z, x, y, z);
+  Nn1Collector col{INFINITY, 0x7fffffff};
+  tree_search(tv, x, y, z, col);
+  idx[i] = (col.bi == 0x7fffffff) ? -1 : col.bi;
+  d2[i] = col.bd;
+}
+void launch_nn1(const float4* q, int nq, const float* T12p, TreeView tree, int32_t* idx, float* d2, hipStream_t s) {
+  T12 T;
+  for (int k = 0; k < 12; k++) T.v[k] = T12p ? T12p[k] : 0.f;
+  hipLaunchKernelGGL(k_nn1, dim3((nq + 255) / 256), dim3(256), 0, s, q, nq, T, T12p ? 1 : 0, tree, idx, d2);
+}
+
+// double sum of floats: 1024 values per block, fixed tree
+__global__ void __launch_bounds__(256) k_sum_f32(const float* __restrict__ v, int n, double* __restrict__ partials) {
+  int base = blockIdx.x * 1024;
+  double acc = 0.0;
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    int i = base + r * 256 + threadIdx.x;
+    if (i < n) acc += (double)v[i];
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  __shared__ double sm[4];
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partials[blockIdx.x] = ((sm[0] + sm[1]) + sm[2]) + sm[3];
+}
+void launch_sum_f32(const float* v, int n, double* partials, hipStream_t s) {
+  hipLaunchKernelGGL(k_sum_f32, dim3(sum_blocks(n)), dim3(256), 0, s, v, n, partials);
+}
+
+// ===== K3: k-NN, covariances, normals ======================================================================
+constexpr int KNN_BLOCK = 128;
+
+__global__ void __launch_bounds__(KNN_BLOCK) k_knn(const float4* __restrict__ q, int nq, TreeView tv, int k, int32_t* __restrict__ idx,
+                                                   float* __restrict__ d2) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* kd = reinterpret_cast<float*>(smem);
+  int* ki = reinterpret_cast<int*>(smem + sizeof(float) * (size_t)k * KNN_BLOCK);
+  int i = blockIdx.x * KNN_BLOCK + threadIdx.x;
+  if (i >= nq) return;
+  float4 p = q[i];
+  KnnCollector col{kd + threadIdx.x, ki + threadIdx.x, k, KNN_BLOCK, 0};
+  tree_search(tv, p.x, p.y, p.z, col);
+  for (int e = 0; e < k; e++) {
+    bool ok = e < col.cnt;
+    idx[(size_t)i * k + e] = ok ? ki[e * KNN_BLOCK + threadIdx.x] : -1;
+    d2[(size_t)i * k + e] = ok ? kd[e * KNN_BLOCK + threadIdx.x] : INFINITY;
+  }
+}
+void launch_knn(const float4* q, int nq, TreeView tree, int k, int32_t* idx, float* d2, hipStream_t s) {
+  size_t sh = (size_t)k * KNN_BLOCK * 8;
+  hipLaunchKernelGGL(k_knn, dim3((nq + KNN_BLOCK - 1) / KNN_BLOCK), dim3(KNN_BLOCK), sh, s, q, nq, tree, k, idx, d2);
+}
+
+// computeCovariances k-NN branch (gicp.hpp:85-154)
+__global__ void __launch_bounds__(KNN_BLOCK) k_knn_cov(const float4* __restrict__ xyz, int n, int n_pad, TreeView tv, int k, double eps,
+                                                       double* __restrict__ cov6) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* kd = reinterpret_cast<float*>(smem);
+  int* ki = reinterpret_cast<int*>(smem + sizeof(float) * (size_t)k * KNN_BLOCK);
+  int i = blockIdx.x * KNN_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  float4 p = xyz[i];
+  KnnCollector col{kd + threadIdx.x, ki + threadIdx.x, k, KNN_BLOCK, 0};
+  tree_search(tv, p.x, p.y, p.z, col);
+  double mean[3] = {0, 0, 0}, c00 = 0, c10 = 0, c11 = 0, c20 = 0, c21 = 0, c22 = 0;
+  for (int e = 0; e < k; e++) {  // neighbours in ascending (d2, id) order, like the search returns them
+    float4 t = xyz[ki[e * KNN_BLOCK + threadIdx.x]];
+    double x = t.x, y = t.y, z = t.z;
+    mean[0] += x; mean[1] += y; mean[2] += z;
+    c00 += x * x;
+    c10 += y * x; c11 += y * y;
+    c20 += z * x; c21 += z * y; c22 += z * z;
+  }
+  double kk = (double)k;
+  mean[0] /= kk; mean[1] /= kk; mean[2] /= kk;
+  double cov[9];
+  cov[0] = c00 / kk - mean[0] * mean[0];
+  cov[3] = c10 / kk - mean[1] * mean[0];
+  cov[4] = c11 / kk - mean[1] * mean[1];
+  cov[6] = c20 / kk - mean[2] * mean[0];
+  cov[7] = c21 / kk - mean[2] * mean[1];
+  cov[8] = c22 / kk - mean[2] * mean[2];
+  cov[1] = cov[3]; cov[2] = cov[6]; cov[5] = cov[7];
+  double u[3];
+  smallest_sv_vector3(cov, u);
+  double s = 1.0 - eps;
+  cov6[(size_t)0 * n_pad + i] = 1.0 - s * u[0] * u[0];
+  cov6[(size_t)1 * n_pad + i] = 0.0 - s * u[0] * u[1];
+  cov6[(size_t)2 * n_pad + i] = 0.0 - s * u[0] * u[2];
+  cov6[(size_t)3 * n_pad + i] = 1.0 - s * u[1] * u[1];
+  cov6[(size_t)4 * n_pad + i] = 0.0 - s * u[1] * u[2];
+  cov6[(size_t)5 * n_pad + i] = 1.0 - s * u[2] * u[2];
+}
+void launch_knn_cov(const float4* xyz, int n, int n_pad, TreeView tree, int k, double eps, double* cov6, hipStream_t s) {
+  size_t sh = (size_t)k * KNN_BLOCK * 8;
+  hipLaunchKernelGGL(k_knn_cov, dim3((n + KNN_BLOCK - 1) / KNN_BLOCK), dim3(KNN_BLOCK), sh, s, xyz, n, n_pad, tree, k, eps, cov6);
+}
+
+// pcl::eigen33 smallest eigenpair, float closed form (PCL 1.10 common/eigen.hpp restated)
+__device__ void roots2f(float b, float c, float* r) {
+  r[0] = 0.0f;
+  float d = b * b - 4.0f * c;
+  if (d < 0.0f) d = 0.0f;
+  float sd = sqrtf(d);
+  r[2] = 0.5f * (b + sd);
+  r[1] = 0.5f * (b - sd);
+}
+__device__ void roots3f(float m00, float m01, float m02, float m11, float m12, float m22, float* r) {
+  float c0 = m00 * m11 * m22 + 2.0f * m01 * m02 * m12 - m00 * m12 * m12 - m11 * m02 * m02 - m22 * m01 * m01;
+  float c1 = m00 * m11 - m01 * m01 + m00 * m22 - m02 * m02 + m11 * m22 - m12 * m12;
+  float c2 = m00 + m11 + m22;
+  if (fabsf(c0) < 1.1920929e-07f) {
+    roots2f(c2, c1, r);
+    return;
+  }
+  const float s_inv3 = 1.0f / 3.0f, s_sqrt3 = sqrtf(3.0f);
+  float c2_over_3 = c2 * s_inv3;
+  float a_over_3 = (c1 - c2 * c2_over_3) * s_inv3;
+  if (a_over_3 > 0.0f) a_over_3 = 0.0f;
+  float half_b = 0.5f * (c0 + c2_over_3 * (2.0f * c2_over_3 * c2_over_3 - c1));
+  float q = half_b * half_b + a_over_3 * a_over_3 * a_over_3;
+  if (q > 0.0f) q = 0.0f;
+  float rho = sqrtf(-a_over_3);
+  float theta = atan2f(sqrtf(-q), half_b) * s_inv3;
+  float ct = cosf(theta), st = sinf(theta);
+  r[0] = c2_over_3 + 2.0f * rho * ct;
+  r[1] = c2_over_3 - rho * (ct + s_sqrt3 * st);
+  r[2] = c2_over_3 - rho * (ct - s_sqrt3 * st);
+  float t;
+  if (r[0] >= r[1]) { t = r[0]; r[0] = r[1]; r[1] = t; }
+  if (r[1] >= r[2]) {
+    t = r[1]; r[1] = r[2]; r[2] = t;
+    if (r[0] >= r[1]) { t = r[0]; r[0] = r[1]; r[1] = t; }
+  }
+  if (r[0] <= 0.0f) roots2f(c2, c1, r);
+}
+
+__global__ void __launch_bounds__(KNN_BLOCK) k_knn_normals(const float4* __restrict__ xyz, int n, TreeView tv, int k,
+                                                           float4* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* kd = reinterpret_cast<float*>(smem);
+  int* ki = reinterpret_cast<int*>(smem + sizeof(float) * (size_t)k * KNN_BLOCK);
+  int i = blockIdx.x * KNN_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  float4 p = xyz[i];
+  KnnCollector col{kd + threadIdx.x, ki + threadIdx.x, k, KNN_BLOCK, 0};
+  tree_search(tv, p.x, p.y, p.z, col);
+  const float qnan = __uint_as_float(0x7fc00000u);
+  if (col.cnt < 3) {
+    out[i] = make_float4(qnan, qnan, qnan, qnan);
+    return;
+  }
+  float a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, a6 = 0, a7 = 0, a8 = 0;
+  for (int e = 0; e < col.cnt; e++) {  // computeMeanAndCovarianceMatrix, float accumulators (PCL 1.10)
+    float4 t = xyz[ki[e * KNN_BLOCK + threadIdx.x]];
+    a0 += t.x * t.x; a1 += t.x * t.y; a2 += t.x * t.z;
+    a3 += t.y * t.y; a4 += t.y * t.z; a5 += t.z * t.z;
+    a6 += t.x; a7 += t.y; a8 += t.z;
+  }
+  float c = (float)col.cnt;
+  a0 /= c; a1 /= c; a2 /= c; a3 /= c; a4 /= c; a5 /= c; a6 /= c; a7 /= c; a8 /= c;
+  float m00 = a0 - a6 * a6, m01 = a1 - a6 * a7, m02 = a2 - a6 * a8, m11 = a3 - a7 * a7, m12 = a4 - a7 * a8, m22 = a5 - a8 * a8;
+  // pcl::eigen33(mat, eigenvalue, eigenvector)
+  float scale = fmaxf(fmaxf(fmaxf(fabsf(m00), fabsf(m01)), fmaxf(fabsf(m02), fabsf(m11))), fmaxf(fabsf(m12), fabsf(m22)));
+  if (scale <= 1.17549435e-38f) scale = 1.0f;
+  float s00 = m00 / scale, s01 = m01 / scale, s02 = m02 / scale, s11 = m11 / scale, s12 = m12 / scale, s22 = m22 / scale;
+  float r[3];
+  roots3f(s00, s01, s02, s11, s12, s22, r);
+  float ev = r[0] * scale;
+  s00 -= r[0]; s11 -= r[0]; s22 -= r[0];
+  // rows: r0 = (s00,s01,s02) r1 = (s01,s11,s12) r2 = (s02,s12,s22)
+  float v1x = s01 * s12 - s02 * s11, v1y = s02 * s01 - s00 * s12, v1z = s00 * s11 - s01 * s01;  // r0 x r1
+  float v2x = s01 * s22 - s02 * s12, v2y = s02 * s02 - s00 * s22, v2z = s00 * s12 - s01 * s02;  // r0 x r2
+  float v3x = s11 * s22 - s12 * s12, v3y = s12 * s02 - s01 * s22, v3z = s01 * s12 - s11 * s02;  // r1 x r2
+  float l1 = (v1x * v1x + v1y * v1y) + v1z * v1z;
+  float l2 = (v2x * v2x + v2y * v2y) + v2z * v2z;
+  float l3 = (v3x * v3x + v3y * v3y) + v3z * v3z;
+  float nx, ny, nz, l;
+  if (l1 >= l2 && l1 >= l3) { nx = v1x; ny = v1y; nz = v1z; l = l1; }
+  else if (l2 >= l1 && l2 >= l3) { nx = v2x; ny = v2y; nz = v2z; l = l2; }
+  else { nx = v3x; ny = v3y; nz = v3z; l = l3; }
+  float sl = sqrtf(l);
+  nx /= sl; ny /= sl; nz /= sl;
+  float eig_sum = m00 + m11 + m22;
+  float curv = (eig_sum != 0.0f) ? fabsf(ev / eig_sum) : 0.0f;
+  float vx = 0.0f - p.x, vy = 0.0f - p.y, vz = 0.0f - p.z;  // flipNormalTowardsViewpoint, vp = 0
+  float cos_theta = (vx * nx + vy * ny) + vz * nz;
+  if (cos_theta < 0) { nx = -nx; ny = -ny; nz = -nz; }
+  out[i] = make_float4(nx, ny, nz, curv);
+}
+void launch_knn_normals(const float4* xyz, int n, TreeView tree, int k, float4* out_nrm, hipStream_t s) {
+  size_t sh = (size_t)k * KNN_BLOCK * 8;
+  hipLaunchKernelGGL(k_knn_normals, dim3((n + KNN_BLOCK - 1) / KNN_BLOCK), dim3(KNN_BLOCK), sh, s, xyz, n, tree, k, out_nrm);
+}
+
+// ===== K8: point-to-plane information matrix ===============================================================
+// Ap = sum H^T H, H = [a x n, n]; 21 unique entries per block of 1024 points, fixed reduction shape
+__global__ void __launch_bounds__(256) k_ap(const float4* __restrict__ qn, int n, const float4* __restrict__ ref_nrm,
+                                            const int64_t* __restrict__ corr, double* __restrict__ partials) {
+  double acc[21];
+#pragma unroll
+  for (int k = 0; k < 21; k++) acc[k] = 0.0;
+  int base = blockIdx.x * 1024;
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    int i = base + r * 256 + threadIdx.x;
+    if (i < n) {
+      float4 a4 = qn[i];
+      float4 n4 = ref_nrm[corr[i]];
+      double a0 = a4.x, a1 = a4.y, a2 = a4.z, n0 = n4.x, n1 = n4.y, n2 = n4.z;
+      bool bad = (a0 != a0) || (a1 != a1) || (a2 != a2) || (n0 != n0) || (n1 != n1) || (n2 != n2);  // PointCloudLocalization.cc:742
+      if (!bad) {
+        double H[6] = {a1 * n2 - a2 * n1, a2 * n0 - a0 * n2, a0 * n1 - a1 * n0, n0, n1, n2};
+        int t = 0;
+#pragma unroll
+        for (int rr = 0; rr < 6; rr++)
+#pragma unroll
+          for (int cc = rr; cc < 6; cc++) acc[t++] += H[rr] * H[cc];
+      }
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+    for (int k = 0; k < 21; k++) acc[k] += __shfl_down(acc[k], off, 64);
+  }
+  __shared__ double sm[4][21];
+  int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 21; k++) sm[wave][k] = acc[k];
+  }
+  __syncthreads();
+  if (threadIdx.x < 21) partials[blockIdx.x * 21 + threadIdx.x] = ((sm[0][threadIdx.x] + sm[1][threadIdx.x]) + sm[2][threadIdx.x]) + sm[3][threadIdx.x];
+}
+void launch_ap(const float4* qnorm, int n, const float4* ref_nrm, const int64_t* corr, double* partials, hipStream_t s) {
+  hipLaunchKernelGGL(k_ap, dim3(ap_blocks(n)), dim3(256), 0, s, qnorm, n, ref_nrm, corr, partials);
+}
+
+// ===== K1: voxel-grid centroid downsample (pcl::VoxelGrid semantics) =======================================
+__device__ __forceinline__ bool voxel_accept(float4 p, int limit_axis, float lo, float hi) {
+  if (!(isfinite(p.x) && isfinite(p.y) && isfinite(p.z))) return false;
+  if (limit_axis >= 0) {
+    float v = limit_axis == 0 ? p.x : (limit_axis == 1 ? p.y : p.z);
+    if (v > hi || v < lo) return false;
+  }
+  return true;
+}
+
+__global__ void __launch_bounds__(256) k_voxel_bbox(const float4* __restrict__ xyzi, int n, int limit_axis, float lo_, float hi_, uint32_t* bbox) {
+  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    float4 p = xyzi[i];
+    if (voxel_accept(p, limit_axis, lo_, hi_)) {
+      lo[0] = fminf(lo[0], p.x); hi[0] = fmaxf(hi[0], p.x);
+      lo[1] = fminf(lo[1], p.y); hi[1] = fmaxf(hi[1], p.y);
+      lo[2] = fminf(lo[2], p.z); hi[2] = fmaxf(hi[2], p.z);
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      lo[a] = fminf(lo[a], __shfl_down(lo[a], off, 64));
+      hi[a] = fmaxf(hi[a], __shfl_down(hi[a], off, 64));
+    }
+  }
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      atomicMin(&bbox[a], enc_ordered(lo[a]));
+      atomicMax(&bbox[3 + a], enc_ordered(hi[a]));
+    }
+  }
+}
+void launch_voxel_bbox(const float4* xyzi, int n, int limit_axis, float lo, float hi, uint32_t* bbox, hipStream_t s) {
+  hipLaunchKernelGGL(k_bbox_init, dim3(1), dim3(64), 0, s, bbox);
+  int blocks = (n + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(k_voxel_bbox, dim3(blocks), dim3(256), 0, s, xyzi, n, limit_axis, lo, hi, bbox);
+}
+
+__global__ void __launch_bounds__(256) k_voxel_keys(const float4* __restrict__ xyzi, int n, VoxelGridDesc g, uint32_t* __restrict__ keys,
+                                                    uint32_t* __restrict__ vals) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float4 p = xyzi[i];
+  uint32_t key = 0xFFFFFFFFu;
+  if (voxel_accept(p, g.limit_axis, g.lo, g.hi)) {
+    int i0 = (int)(floorf(p.x * g.inv_leaf) - (float)g.minb[0]);
+    int i1 = (int)(floorf(p.y * g.inv_leaf) - (float)g.minb[1]);
+    int i2 = (int)(floorf(p.z * g.inv_leaf) - (float)g.minb[2]);
+    key = (uint32_t)(i0 * g.mul[0] + i1 * g.mul[1] + i2 * g.mul[2]);
+  }
+  keys[i] = key;
+  vals[i] = (uint32_t)i;
+}
+void launch_voxel_keys(const float4* xyzi, int n, VoxelGridDesc g, uint32_t* keys, uint32_t* vals, hipStream_t s) {
+  hipLaunchKernelGGL(k_voxel_keys, dim3((n + 255) / 256), dim3(256), 0, s, xyzi, n, g, keys, vals);
+}
+
+__global__ void __launch_bounds__(256) k_voxel_heads(const uint32_t* __restrict__ keys, int n, uint32_t* __restrict__ heads) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t k = keys[i];
+  heads[i] = (k != 0xFFFFFFFFu && (i == 0 || keys[i - 1] != k)) ? 1u : 0u;
+}
+void launch_voxel_heads(const uint32_t* keys, int n, uint32_t* heads, hipStream_t s) {
+  hipLaunchKernelGGL(k_voxel_heads, dim3((n + 255) / 256), dim3(256), 0, s, keys, n, heads);
+}
+
+__global__ void __launch_bounds__(256) k_voxel_centroids(const float4* __restrict__ xyzi, const uint32_t* __restrict__ keys,
+                                                         const uint32_t* __restrict__ vals, const uint32_t* __restrict__ heads,
+                                                         const uint32_t* __restrict__ rank, int n, float4* __restrict__ out, uint32_t cap) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || !heads[i]) return;
+  uint32_t k = keys[i];
+  float ax = 0.f, ay = 0.f, az = 0.f, ai = 0.f;
+  int cnt = 0;
+  for (int j = i; j < n && keys[j] == k; j++) {  // stable radix sort => ascending point index inside a voxel
+    float4 p = xyzi[vals[j]];
+    ax += p.x; ay += p.y; az += p.z; ai += p.w;
+    cnt++;
+  }
+  float c = (float)cnt;
+  uint32_t r = rank[i] - 1u;
+  if (r < cap) out[r] = make_float4(ax / c, ay / c, az / c, ai / c);
+}
+void launch_voxel_centroids(const float4* xyzi, const uint32_t* keys, const uint32_t* vals, const uint32_t* heads,
+                            const uint32_t* rank_incl, int n, float4* out, uint32_t out_cap, hipStream_t s) {
+  hipLaunchKernelGGL(k_voxel_centroids, dim3((n + 255) / 256), dim3(256), 0, s, xyzi, keys, vals, heads, rank_incl, n, out, out_cap);
+}
+
+}  // namespace lh

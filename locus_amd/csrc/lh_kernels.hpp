@@ -1,0 +1,110 @@
+// lh_kernels.hpp -- launch interface of the HIP kernels (implemented in lh_kernels.hip / lh_sort.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "lh_device.hpp"
+
+namespace lh {
+
+constexpr int MAX_JOBS = 24;       // jobs (scan pairs) per batched launch; kernarg stays < 4 KB
+constexpr int COST_CHUNK = 512;    // source points per cost-kernel workgroup (fixed => deterministic sums)
+constexpr int COST_NSUM = 14;      // f, g_t[3], R[9], count
+
+// static description of one scan pair's device buffers (lives in device memory, indexed by slot)
+struct PairDesc {
+  const float4* src;        // "output" cloud = guess * input, xyz1                      [n]
+  const float4* src_nrm;    // source normals (cov-from-normals mode) or null
+  const double* src_cov6;   // source covariances (k-NN mode), 6 planes of n_pad doubles, or null
+  const float4* tgt_xyz;    // target xyz1 in ORIGINAL order                             [m]
+  const float4* tgt_nrm;    // target normals or null
+  const double* tgt_cov6;   // target covariances planes (stride m_pad) or null
+  const float4* tgt_sorted; // Morton-sorted target (x,y,z,id)
+  const Node4* tgt_nodes;
+  int32_t* prev_nn;         // warm-start NN index per source point                      [n]
+  float4* corr;             // per source point: (tgt x, y, z, bitcast tgt idx | -1)     [n]
+  double* maha6;            // 6 planes of n_pad doubles: M00 M01 M02 M11 M12 M22
+  int n, n_pad, m, m_pad;
+  int first_leaf;
+  int src_cov_pad;  // plane stride of src_cov6
+  double corr_dist2;
+  double gicp_eps;
+};
+
+struct SweepJob {  // dynamic per-launch part
+  int slot;
+  int pad;
+  float T[12];     // transformation_ (row-major 3x4 float)
+  double R[9];     // (double(transformation_) * double(guess)) 3x3, row-major
+};
+struct SweepArgs {
+  int njobs;
+  int pad;
+  SweepJob job[MAX_JOBS];
+};
+
+struct CostJob {
+  int slot;
+  int out_offset;  // offset (in doubles) of this job's partial sums in the output buffer
+  float T[12];
+};
+struct CostArgs {
+  int njobs;
+  int pad;
+  CostJob job[MAX_JOBS];
+};
+
+// ---- K2: index build -------------------------------------------------------------------------------
+size_t sort_temp_bytes(int n);
+// keys/vals double buffers: on return sorted keys are in keys_out / vals_out
+void sort_pairs_u32(void* temp, size_t temp_bytes, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in,
+                    uint32_t* vals_out, int n, int end_bit, hipStream_t s);
+
+void launch_bbox(const float4* xyz, int n, uint32_t* bbox_enc /*6, ordered-uint*/, hipStream_t s);
+void launch_morton(const float4* xyz, int n, const uint32_t* bbox_enc, uint32_t* keys, uint32_t* vals, hipStream_t s);
+void launch_gather_sorted(const float4* xyz, const uint32_t* vals, int n, int n_padded, float4* sorted, hipStream_t s);
+// builds all internal levels; depth = number of internal levels (4^depth >= n_leaves)
+void launch_build_nodes(const float4* sorted, int n, int depth, Node4* nodes, hipStream_t s);
+
+// ---- K4 / K5 ---------------------------------------------------------------------------------------
+void launch_sweep(const PairDesc* descs, const SweepArgs& a, int max_n, hipStream_t s);
+void launch_cost(const PairDesc* descs, const CostArgs& a, int max_n, double* out, hipStream_t s);
+inline int cost_blocks(int n) { return (n + COST_CHUNK - 1) / COST_CHUNK; }
+
+// ---- K6 / K7 / misc ---------------------------------------------------------------------------------
+void launch_transform(const float4* in_xyz, const float4* in_nrm, int n, const float* T12, float4* out_xyz, float4* out_nrm,
+                      hipStream_t s);
+void launch_fill_i32(int32_t* p, int n, int32_t v, hipStream_t s);
+// ungated 1-NN of T*q against a tree; T12 may be null (identity)
+void launch_nn1(const float4* q, int nq, const float* T12, TreeView tree, int32_t* idx, float* d2, hipStream_t s);
+// deterministic double sum of float d2 (fitness): partials[ceil(n/1024)]
+void launch_sum_f32(const float* v, int n, double* partials, hipStream_t s);
+inline int sum_blocks(int n) { return (n + 1023) / 1024; }
+
+// ---- K3 ----------------------------------------------------------------------------------------------
+void launch_knn(const float4* q, int nq, TreeView tree, int k, int32_t* idx, float* d2, hipStream_t s);
+// k-NN covariance (gicp.hpp:85-154) -> 6 planes of n_pad doubles
+void launch_knn_cov(const float4* xyz, int n, int n_pad, TreeView tree, int k, double eps, double* cov6, hipStream_t s);
+// NormalEstimationOMP k-NN restated (normal_computation.cc:26-59): out = (nx,ny,nz,curvature)
+void launch_knn_normals(const float4* xyz, int n, TreeView tree, int k, float4* out_nrm, hipStream_t s);
+
+// ---- K8 ----------------------------------------------------------------------------------------------
+// stage 1: per-block partial sums (x,y,z float-in-double) for the centroid; stage 2 etc. are in lh_api.hip
+void launch_ap(const float4* qnorm, int n, const float4* ref_nrm, const int64_t* corr, double* partials /*blocks*21*/, hipStream_t s);
+inline int ap_blocks(int n) { return (n + 1023) / 1024; }
+
+// ---- K1 (pcl::VoxelGrid, custom_voxel_grid.cc:76-87) ------------------------------------------------------
+// bbox over finite points passing the pass-through limits on one axis (ordered-uint encoding, 6 values)
+void launch_voxel_bbox(const float4* xyzi, int n, int limit_axis, float lo, float hi, uint32_t* bbox_enc, hipStream_t s);
+struct VoxelGridDesc { float inv_leaf; int limit_axis; float lo, hi; int minb[3]; int mul[3]; };
+// key = linear voxel index (0xFFFFFFFF for rejected points), val = point index
+void launch_voxel_keys(const float4* xyzi, int n, VoxelGridDesc g, uint32_t* keys, uint32_t* vals, hipStream_t s);
+// heads[i] = 1 where a new voxel starts in the sorted key array
+void launch_voxel_heads(const uint32_t* keys, int n, uint32_t* heads, hipStream_t s);
+// one thread per voxel head: sequential float centroid of the segment in sorted (= input) order
+void launch_voxel_centroids(const float4* xyzi, const uint32_t* keys, const uint32_t* vals, const uint32_t* heads,
+                            const uint32_t* rank_incl, int n, float4* out, uint32_t out_cap, hipStream_t s);
+size_t scan_temp_bytes(int n);
+void inclusive_scan_u32(void* temp, size_t temp_bytes, const uint32_t* in, uint32_t* out, int n, hipStream_t s);
+
+}  // namespace lh

@@ -946,6 +946,14 @@ static int estimate_rigid_bfgs(cost_ctx* c, int max_inner, float* T16, int* n_in
   return LO_ESOLVER;
 }
 
+int lo_estimate_rigid_bfgs(const float* out_xyz4, const float* tgt_xyz4, const int32_t* src_idx, const int32_t* tgt_idx, int m,
+                           const double* maha9, int max_inner, float* T16, int* n_inner, double* f_end, int* passes) {
+  cost_ctx c = {out_xyz4, tgt_xyz4, src_idx, tgt_idx, m, maha9, 0, 1, 0};
+  int st = estimate_rigid_bfgs(&c, max_inner, T16, n_inner, f_end);
+  if (passes) *passes = (int)c.passes;
+  return st;
+}
+
 /* ------------------------------------------------------------------------------------------
  * a3 + a6: pcl::Registration::align -> computeTransformation (gicp.hpp:406-617)
  * ------------------------------------------------------------------------------------------ */

@@ -96,6 +96,9 @@ void lo_nn_mahalanobis(const float* out_xyz4, int n, const lo_tree* tgt_tree, co
    x = (tx,ty,tz, roll,pitch,yaw); out f, g[6]; also raw sums[13] (f, g_t[3], R[9]) before /m. */
 void lo_cost_fdf(const float* out_xyz4, const float* tgt_xyz4, const int32_t* src_idx, const int32_t* tgt_idx,
                  int m, const double* maha9, const double* x6, double* f, double* g6, double* sums13);
+/* estimateRigidTransformationBFGS (gicp.hpp:218-287) on given correspondences; T16 in/out */
+int lo_estimate_rigid_bfgs(const float* out_xyz4, const float* tgt_xyz4, const int32_t* src_idx, const int32_t* tgt_idx, int m,
+                           const double* maha9, int max_inner, float* T16, int* n_inner, double* f_end, int* passes);
 /* applyState (gicp.hpp:619-634): T = [Rz(x5)Ry(x4)Rx(x3) | x0..2] in float, column-major out */
 void lo_apply_state(const double* x6, float* T16);
 

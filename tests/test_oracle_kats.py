@@ -1,0 +1,196 @@
+"""CPU suite (-m "not gpu"): pins the oracle against every known-answer test the reference's own test-suite holds
+for the hot path and against its own brute-force variants."""
+import numpy as np
+import pytest
+
+from locus_amd import synth
+
+
+def test_eig3_kat(oracle):
+    # doEigenDecomp3x3 KAT (point_cloud_localization/test/test_point_cloud_localization.cpp:550-561); lower triangle is used
+    data = np.array([[-2.0, -4.0, 2.0], [-2.0, 1.0, 2.0], [4.0, 2.0, 5.0]])
+    ev, V = oracle.eig_sym(data)
+    assert np.allclose(ev, [-5.0, 2.0, 7.0], atol=1e-4)
+    S = np.tril(data) + np.tril(data, -1).T
+    assert np.allclose(S @ V, V * ev, atol=1e-10)
+
+
+def test_kdtree_equals_bruteforce(oracle):
+    rng = np.random.default_rng(0)
+    P = oracle.xyz4(np.concatenate([rng.normal(size=(3000, 3)), np.repeat(rng.normal(size=(200, 3)), 3, 0)]))  # with duplicates
+    Q = oracle.xyz4(np.concatenate([rng.normal(size=(800, 3)), P[:200, :3]]))
+    t = oracle.Tree(P)
+    i1, d1 = t.nn1(Q)
+    i2, d2 = oracle.nn1_brute(P, Q)
+    assert (i1 == i2).all() and (d1 == d2).all()
+    k1, e1 = t.knn(Q, 20)
+    k2, e2 = oracle.knn_brute(P, Q, 20)
+    assert (k1 == k2).all() and (e1 == e2).all()
+    i4, d4 = t.nn1(Q, threads=4)
+    assert (i4 == i1).all()
+
+
+def test_empty_and_tiny_clouds(oracle):
+    P = oracle.xyz4(np.array([[0.0, 0, 0], [1, 0, 0], [0, 1, 0]]))
+    t = oracle.Tree(P)
+    idx, d2 = t.knn(oracle.xyz4(np.array([[0.1, 0, 0]])), 5)
+    assert list(idx[0][:3]) == [0, 1, 2] and (idx[0][3:] == -1).all()
+    p = oracle.default_params()
+    r = oracle.gicp_align(P, oracle.nrm4(np.zeros((3, 3))), P, oracle.nrm4(np.zeros((3, 3))), p)
+    assert r["status"] == -4  # < 4 correspondences: NotEnoughPointsException (gicp.hpp:225)
+    assert r["converged"] == 0
+
+
+def test_gradient_matches_finite_differences(oracle):
+    rng = np.random.default_rng(1)
+    n = 400
+    src = oracle.xyz4(rng.normal(size=(n, 3)) * 3)
+    tgt = oracle.xyz4(src[:, :3] + rng.normal(size=(n, 3)) * 0.05)
+    A = rng.normal(size=(n, 3, 3))
+    M = np.einsum("nij,nkj->nik", A, A) + np.eye(3)
+    idx = np.arange(n, dtype=np.int32)
+    x = np.array([0.1, -0.2, 0.05, 0.02, -0.03, 0.04])
+    f, g, s = oracle.cost_fdf(src, tgt, idx, idx, M, x)
+    for i in range(6):
+        h = 1e-3
+        xp, xm = x.copy(), x.copy()
+        xp[i] += h
+        xm[i] -= h
+        num = (oracle.cost_fdf(src, tgt, idx, idx, M, xp)[0] - oracle.cost_fdf(src, tgt, idx, idx, M, xm)[0]) / (2 * h)
+        assert abs(num - g[i]) < 2e-3 * max(1.0, abs(g[i]))
+
+
+def test_apply_state_is_zyx(oracle):
+    x = np.array([0.3, -0.2, 0.1, 0.05, -0.07, 0.2])
+    T = oracle.T_to_mat(oracle.apply_state(x))
+    R = synth.rot_zyx(x[3], x[4], x[5])
+    assert np.allclose(T[:3, :3], R, atol=2e-7)
+    assert np.allclose(T[:3, 3], x[:3], atol=1e-7)
+
+
+def test_cov_from_normals_and_knn_agree_on_a_plane(oracle):
+    pts, nrm = synth.plane_grid(12, 12, 0.1)
+    P = oracle.xyz4(pts)
+    c1 = oracle.cov_from_normals(oracle.nrm4(nrm))
+    c2 = oracle.cov_knn(P, k=9)
+    expect = np.diag([1.0, 1.0, 1e-3])
+    assert np.allclose(c1, expect, atol=1e-12)
+    assert np.allclose(c2, expect, atol=1e-9)
+    z = oracle.cov_from_normals(oracle.nrm4(np.zeros((2, 3))))
+    assert np.allclose(z, np.eye(3))  # zero normal => identity (documented assumption)
+
+
+def test_hollow_cube_translation_kat(oracle):
+    # UpdateEstimateUpdateICP (point_cloud_odometry/test/test_point_cloud_odometry.cpp:280-305), odometry yaml params
+    cube = synth.hollow_cube()
+    tree = oracle.Tree(oracle.xyz4(cube))
+    nrm = oracle.normals_knn(oracle.xyz4(cube), k=5, tree=tree)
+    moved = cube + np.array([0.05, 0.05, 0.0], np.float32)
+    p = oracle.default_params(max_iterations=20, corr_dist=1.0, transformation_epsilon=1e-3, num_threads=2)
+    # reference cloud = first scan (with normals); query = translated cloud whose normals are all zero
+    r = oracle.gicp_align(oracle.xyz4(moved), oracle.nrm4(np.zeros_like(moved)), oracle.xyz4(cube), nrm, p)
+    assert r["status"] == 0 and r["converged"] == 1
+    T = oracle.T_to_mat(r["T"])
+    Tinv = np.linalg.inv(T)
+    assert abs(Tinv[0, 3] - 0.05) < 1e-2 and abs(Tinv[1, 3] - 0.05) < 1e-2 and abs(Tinv[2, 3]) < 1e-2
+    fit = oracle.fitness(oracle.xyz4(moved), r["T"], tree)
+    assert fit < 0.1
+
+
+def test_plane_Ap_kat(oracle):
+    # ComputeAp KAT (test_point_cloud_localization.cpp:288-394): 10x10 plane, normal (0,0,1), identity correspondences
+    pts, nrm = synth.plane_grid(10, 10, 0.1)
+    qn = oracle.normalize_cloud(oracle.xyz4(pts))
+    Ap = oracle.p2plane_Ap(qn, oracle.nrm4(nrm), np.arange(100))
+    assert abs(Ap[0, 0] - 56.7753) < 1e-3 and abs(Ap[1, 1] - 56.7753) < 1e-3 and abs(Ap[5, 5] - 100.0) < 1e-4
+    # hand-rolled sum (same KAT compares against an explicit loop)
+    a = qn[:, :3].astype(np.float64)
+    n = np.tile([0.0, 0, 1], (100, 1))
+    H = np.concatenate([np.cross(a, n), n], 1)
+    assert np.allclose(Ap, H.T @ H, atol=1e-9)
+    ev, _ = oracle.eig_sym(Ap)
+    assert np.allclose(ev, [0, 0, 0, 56.7753, 56.7753, 100], atol=1e-3)  # observability eigenvalues (:479-507)
+
+
+def test_icp_covariance_kats(oracle):
+    # test_point_cloud_localization.cpp:398-476
+    pts, nrm = synth.plane_grid(10, 10, 0.1)
+    qn = oracle.normalize_cloud(oracle.xyz4(pts))
+    Ap = oracle.p2plane_Ap(oracle.normalize_cloud(qn), oracle.nrm4(nrm), np.arange(100))
+    ok, cov, cond = oracle.icp_covariance(Ap, 0.01)
+    assert np.allclose(cov, np.eye(6) * 0.01, atol=1e-4)  # single plane: clamp
+    # three orthogonal planes + yaw-30deg tf
+    T1 = np.array([[1, 0, 0, 0], [0, 0, -1, 0], [0, 1, 0, 0], [0, 0, 0, 1.0]])
+    T2 = np.array([[0, 0, 1, 0], [0, 1, 0, 0], [-1, 0, 0, 0], [0, 0, 0, 1.0]])
+    n4 = oracle.nrm4(nrm)
+    p1, n1 = oracle.transform(qn, oracle.mat_to_T(T1), n4)
+    p2, n2 = oracle.transform(qn, oracle.mat_to_T(T2), n4)
+    allp = np.concatenate([qn, p1, p2])
+    alln = np.concatenate([n4, n1, n2])
+    tf = np.array([[0.866, -0.5, 0, 0.001], [0.5, 0.866, 0, 0], [0, 0, 0, 0], [0, 0, 0, 1.0]])
+    off, _ = oracle.transform(allp, oracle.mat_to_T(tf), alln)
+    Ap = oracle.p2plane_Ap(oracle.normalize_cloud(off), alln, np.arange(300))
+    ok, cov, cond = oracle.icp_covariance(Ap, 0.01)
+    assert ok
+    assert np.allclose(cov, np.eye(6) * 1e-6, atol=1e-4)
+
+
+def test_frame_transform_kat(oracle):
+    # TransformPointsToFixedFrame KAT (test_point_cloud_localization.cpp:243-276): z +/- 3
+    pts, nrm = synth.plane_grid(4, 4, 0.1)
+    T = np.eye(4)
+    T[2, 3] = 3.0
+    out, on = oracle.transform(oracle.xyz4(pts), oracle.mat_to_T(T), oracle.nrm4(nrm))
+    assert np.allclose(out[:, 2], 3.0) and np.allclose(on[:, :3], nrm)
+    back = oracle.transform(out, oracle.mat_to_T(np.linalg.inv(T)))
+    assert np.allclose(back[:, :3], pts, atol=1e-6)
+
+
+def test_voxel_grid_semantics(oracle):
+    rng = np.random.default_rng(3)
+    pts = rng.uniform(-2, 2, size=(5000, 3)).astype(np.float32)
+    xyzi = np.concatenate([pts, rng.uniform(0, 100, size=(5000, 1)).astype(np.float32)], 1)
+    out = oracle.voxel_grid(xyzi, 0.25)
+    # every output is the centroid of the points that fall in its cell; cells are visited in ascending index
+    inv = np.float32(1.0) / np.float32(0.25)
+    ijk = np.floor(pts * inv).astype(np.int64)
+    ijk -= np.floor(pts.min(0) * inv).astype(np.int64)
+    div = ijk.max(0) + 1
+    lin = ijk[:, 0] + ijk[:, 1] * div[0] + ijk[:, 2] * div[0] * div[1]
+    uniq = np.unique(lin)
+    assert out.shape[0] == uniq.shape[0]
+    for r in (0, len(uniq) // 2, len(uniq) - 1):
+        sel = xyzi[lin == uniq[r]]
+        assert np.allclose(out[r], sel.mean(0), rtol=1e-5, atol=1e-5)
+    # pass-through limits drop points, overflow guard returns None
+    out2 = oracle.voxel_grid(xyzi, 0.25, limit_axis=2, lo=-1.0, hi=1.0)
+    assert out2[:, 2].min() >= -1.0 and out2[:, 2].max() <= 1.0 and out2.shape[0] < out.shape[0]
+    assert oracle.voxel_grid(xyzi, 1e-4) is None
+
+
+def test_normals_on_a_plane_and_sphere(oracle):
+    pts, nrm = synth.plane_grid(15, 15, 0.1, z=2.0)
+    out = oracle.normals_knn(oracle.xyz4(pts), k=10)
+    # viewpoint (0,0,0) is below the plane z=2 -> normals flipped to -z
+    assert np.allclose(np.abs(out[:, 2]), 1.0, atol=1e-3) and (out[:, 2] < 0).all()
+    assert (out[:, 3] < 1e-3).all()
+
+
+def test_garage_fixture_thread_invariance(oracle, garage):
+    # multithreaded_gicp/test/test_same_output_different_num_threads.cpp: identical Matrix4f for 1..8 threads
+    q, r = garage
+    assert q.shape == (811, 4) and r.shape == (8112, 4)
+    base = None
+    for th in (1, 2, 4, 8):
+        p = oracle.default_params(transformation_epsilon=1e-10, corr_dist=0.2, max_iterations=20, max_inner_iterations=50,
+                                  recompute_source_cov=1, recompute_target_cov=1, num_threads=th)
+        res = oracle.gicp_align(oracle.xyz4(q), None, oracle.xyz4(r), None, p)
+        assert res["status"] == 0
+        if base is None:
+            base = res
+        else:
+            assert (res["T"] == base["T"]).all()
+    tree = oracle.Tree(oracle.xyz4(r))
+    fit = oracle.fitness(oracle.xyz4(q), base["T"], tree)
+    fit0 = oracle.fitness(oracle.xyz4(q), oracle.mat_to_T(np.eye(4)), tree)
+    assert fit <= fit0 * 1.05  # alignment does not make the fit worse
