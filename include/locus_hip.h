@@ -66,6 +66,12 @@ typedef struct {
   int recompute_target_cov;
   int num_threads;               /* accepted for surface compatibility (setNumThreads, gicp.h:134-141); ignored */
   int enable_timing;             /* enableTimingOutput (gicp.h:143): collect per-kernel HIP-event times */
+  int cost_mode;                 /* how OptimizationFunctorWithIndices (gicp.hpp:291-402) is evaluated on the device:
+                                    0 = one pass over the correspondences per evaluation, reference arithmetic (float T*p);
+                                    1 = (default) second-order moments: the sums are exactly quadratic in the 12 entries of T,
+                                        so ONE 74-moment reduction per outer iteration serves every BFGS evaluation (double
+                                        T*p instead of float: differs from mode 0 by the reference's own float rounding noise) */
+  int reserved0;
 } lh_gicp_params;
 
 typedef struct {
@@ -152,8 +158,11 @@ lh_status lh_gicp_align_batch(lh_ctx* ctx, const lh_gicp_params* p, int n_pairs,
 /* K3: computeCovariances k-NN branch (gicp.hpp:85-154) -> row-major 3x3 doubles [n][9] on the host */
 lh_status lh_cov_knn(lh_cloud* c, int k, double gicp_epsilon, double* cov9_out);
 /* K4: one NN + Mahalanobis sweep (gicp.hpp:464-498) with explicit transformation_ (col-major float) and guess.
-   tgt_idx[n] (-1 unmatched), maha9 [n][9] row-major (entries of unmatched points are unspecified). */
+   tgt_idx[n] (-1 unmatched), maha9 [n][9] row-major (entries of unmatched points are unspecified).
+   Consecutive calls without changing the clouds are warm (previous neighbours + certificates), like align()'s sweeps. */
 lh_status lh_gicp_debug_sweep(lh_gicp* g, const float T[16], const float guess[16], int32_t* tgt_idx, double* maha9);
+/* instrumentation: out[0] = source points whose sweep ran the tree traversal, out[1] = source points swept (cumulative) */
+lh_status lh_gicp_debug_stats(lh_gicp* g, uint64_t out[2], int reset);
 /* K5: one cost-functor pass fdf(x) (gicp.hpp:362-402) on the correspondences of the last sweep */
 lh_status lh_gicp_debug_cost(lh_gicp* g, const double x[6], double* f, double g6[6], double sums13[13], int* m);
 

@@ -49,6 +49,8 @@ class GicpParams(C.Structure):
         ("recompute_target_cov", C.c_int),
         ("num_threads", C.c_int),
         ("enable_timing", C.c_int),
+        ("cost_mode", C.c_int),
+        ("reserved0", C.c_int),
     ]
 
 
@@ -88,7 +90,7 @@ EXPORTS = [
     "lh_cloud_download", "lh_cloud_transform", "lh_gicp_create", "lh_gicp_destroy", "lh_gicp_set_params",
     "lh_gicp_set_source", "lh_gicp_set_target", "lh_gicp_set_source_cloud", "lh_gicp_set_target_cloud",
     "lh_gicp_promote_source_to_target", "lh_gicp_align", "lh_gicp_fitness", "lh_nn1", "lh_nn1_cloud", "lh_knn_cloud",
-    "lh_gicp_align_batch", "lh_cov_knn", "lh_gicp_debug_sweep", "lh_gicp_debug_cost", "lh_p2plane_information",
+    "lh_gicp_align_batch", "lh_cov_knn", "lh_gicp_debug_sweep", "lh_gicp_debug_stats", "lh_gicp_debug_cost", "lh_p2plane_information",
     "lh_icp_covariance", "lh_voxel_grid", "lh_normals_knn", "lh_normals_knn_cloud", "lh_profile_enable",
     "lh_profile_reset", "lh_profile_get",
 ]
@@ -141,6 +143,7 @@ def lib():
                                           C.POINTER(GicpResult), i32]
         L.lh_cov_knn.argtypes = [vp, i32, dbl, vp]
         L.lh_gicp_debug_sweep.argtypes = [vp, vp, vp, vp, vp]
+        L.lh_gicp_debug_stats.argtypes = [vp, vp, i32]
         L.lh_gicp_debug_cost.argtypes = [vp, vp, C.POINTER(dbl), vp, vp, C.POINTER(i32)]
         L.lh_p2plane_information.argtypes = [vp, vp, vp, vp, vp]
         L.lh_icp_covariance.argtypes = [vp, dbl, vp, C.POINTER(dbl)]
@@ -450,6 +453,11 @@ class Gicp:
         maha = np.zeros((n_src, 3, 3), np.float64)
         _check(lib().lh_gicp_debug_sweep(self.h, _ptr(T), _ptr(g), _ptr(idx), _ptr(maha)), "lh_gicp_debug_sweep")
         return idx, maha
+
+    def debug_stats(self, reset=True):
+        out = np.zeros(2, np.uint64)
+        _check(lib().lh_gicp_debug_stats(self.h, _ptr(out), 1 if reset else 0), "lh_gicp_debug_stats")
+        return int(out[0]), int(out[1])
 
     def debug_cost(self, x6):
         x = np.ascontiguousarray(x6, np.float64)

@@ -52,6 +52,8 @@ struct lh_ctx {
   int n_slots = 0;
   double* partials_host = nullptr; // pinned, device-visible: [n_slots][max_cost_blocks][COST_NSUM]
   size_t partials_per_slot = 0;    // doubles
+  double* mom_partials_dev = nullptr;  // [n_slots][mom_stride] per-block moment partials (device)
+  int mom_stride = 0;
   // misc pinned scratch for small downloads
   double* small_host = nullptr;
   size_t small_host_doubles = 0;
@@ -215,37 +217,46 @@ struct Workspace {
   float4* corr = nullptr;
   double* maha6 = nullptr;
   int32_t* prev_nn = nullptr;
+  float4* cert = nullptr;     // NN certificates (see Nn1CertCollector)
+  unsigned long long* stats = nullptr;  // 2 counters
   float4* out_xyz = nullptr;  // guess * input when guess != I
   int n_pad = 0;
   lh_status ensure(lh_ctx* c, int n) {
     if (n <= cap) return LH_OK;
     (void)hipStreamSynchronize(c->stream);
-    (void)hipFree(corr); (void)hipFree(maha6); (void)hipFree(prev_nn); (void)hipFree(out_xyz);
+    (void)hipFree(corr); (void)hipFree(maha6); (void)hipFree(prev_nn); (void)hipFree(out_xyz); (void)hipFree(cert);
     int ncap = round_up(n, 256);
     HIPCHK(hipMalloc(&corr, sizeof(float4) * (size_t)ncap));
     HIPCHK(hipMalloc(&maha6, sizeof(double) * 6 * (size_t)ncap));
     HIPCHK(hipMalloc(&prev_nn, sizeof(int32_t) * (size_t)ncap));
     HIPCHK(hipMalloc(&out_xyz, sizeof(float4) * (size_t)ncap));
+    HIPCHK(hipMalloc(&cert, sizeof(float4) * (size_t)ncap));
+    if (!stats) { HIPCHK(hipMalloc(&stats, 16)); HIPCHK(hipMemset(stats, 0, 16)); }
     cap = ncap;
     n_pad = ncap;
     return LH_OK;
   }
   void release() {
-    (void)hipFree(corr); (void)hipFree(maha6); (void)hipFree(prev_nn); (void)hipFree(out_xyz);
-    corr = nullptr; maha6 = nullptr; prev_nn = nullptr; out_xyz = nullptr; cap = 0;
+    (void)hipFree(corr); (void)hipFree(maha6); (void)hipFree(prev_nn); (void)hipFree(out_xyz); (void)hipFree(cert);
+    corr = nullptr; maha6 = nullptr; prev_nn = nullptr; out_xyz = nullptr; cert = nullptr; cap = 0;
   }
 };
 
 static lh_status ctx_ensure_slots(lh_ctx* c, int n_slots, int max_n) {
-  size_t per_slot = (size_t)cost_blocks(max_n) * COST_NSUM;
-  if (n_slots <= c->n_slots && per_slot <= c->partials_per_slot) return LH_OK;
+  size_t per_slot = std::max<size_t>((size_t)cost_blocks(max_n) * COST_NSUM, MOM_NSUM);
+  int mom_stride = mom_blocks(max_n) * MOM_NSUM;
+  if (n_slots <= c->n_slots && per_slot <= c->partials_per_slot && mom_stride <= c->mom_stride) return LH_OK;
   (void)hipStreamSynchronize(c->stream);
   n_slots = std::max(n_slots, c->n_slots);
   per_slot = std::max(per_slot, c->partials_per_slot);
+  mom_stride = std::max(mom_stride, c->mom_stride);
   (void)hipFree(c->descs_dev);
+  (void)hipFree(c->mom_partials_dev);
   if (c->descs_host) (void)hipHostFree(c->descs_host);
   if (c->partials_host) (void)hipHostFree(c->partials_host);
   HIPCHK(hipMalloc(&c->descs_dev, sizeof(PairDesc) * n_slots));
+  HIPCHK(hipMalloc(&c->mom_partials_dev, sizeof(double) * (size_t)mom_stride * n_slots));
+  c->mom_stride = mom_stride;
   HIPCHK(hipHostMalloc(&c->descs_host, sizeof(PairDesc) * n_slots, hipHostMallocDefault));
   HIPCHK(hipHostMalloc(&c->partials_host, sizeof(double) * per_slot * n_slots, hipHostMallocDefault));
   c->n_slots = n_slots;
@@ -276,6 +287,7 @@ struct Task : public CostFn {
   float req_T12[12];
   double req_R9[9];
   double res_sums[COST_NSUM];
+  MomentModel mom;  // cost_mode 1: filled by the scheduler after each sweep
   bool sweep_bytes_pending = false;
   // outputs
   lh_gicp_result result;
@@ -295,6 +307,11 @@ struct Task : public CostFn {
   void pass(const double x[6], double sums13[13], double* count) override {
     float T16[16];
     apply_state(x, T16);  // base_transformation_ = I (gicp.hpp:435, 367-368)
+    if (P.cost_mode == 1) {  // every evaluation of this outer iteration comes from the 74 moments of the last sweep
+      mom.sums(T16, sums13);
+      *count = mom.count();
+      return;
+    }
     T16_to_T12(T16, req_T12);
     yield(REQ_COST);
     memcpy(sums13, res_sums, sizeof(double) * 13);
@@ -424,6 +441,8 @@ static lh_status task_prepare(lh_ctx* c, Task* t, bool rebuild_index) {
   d.tgt_sorted = tgt->sorted;
   d.tgt_nodes = tgt->nodes;
   d.prev_nn = t->ws->prev_nn;
+  d.cert = t->ws->cert;
+  d.stats = t->ws->stats;
   d.corr = t->ws->corr;
   d.maha6 = t->ws->maha6;
   d.n = src->n;
@@ -491,7 +510,27 @@ static lh_status run_tasks(lh_ctx* c, std::vector<Task*>& tasks, int in_flight, 
       ProfScope p(c, "nn_sweep", bytes);
       launch_sweep(c->descs_dev, a, max_n, c->stream);
     }
-    for (Task* t : sweeps) t->resume();  // each now yields its first COST request (or DONE)
+    // cost_mode 1: one moment reduction per sweep replaces every per-evaluation pass of this outer iteration
+    std::vector<Task*> moms;
+    for (Task* t : sweeps)
+      if (t->P.cost_mode == 1) moms.push_back(t);
+    for (size_t o = 0; o < moms.size(); o += MAX_JOBS) {
+      CostArgs a;
+      a.njobs = (int)std::min<size_t>(MAX_JOBS, moms.size() - o);
+      a.pad = 0;
+      int max_n = 0;
+      for (int j = 0; j < a.njobs; j++) {
+        Task* t = moms[o + j];
+        a.job[j].slot = t->slot;
+        a.job[j].out_offset = (int)((size_t)t->slot * c->partials_per_slot);
+        memcpy(a.job[j].T, t->req_T12, sizeof(t->req_T12));
+        max_n = std::max(max_n, t->src->n);
+      }
+      ProfScope p(c, "cost_moments", 0.0);
+      launch_moments(c->descs_dev, a, max_n, c->mom_partials_dev, c->mom_stride, c->partials_host, c->stream);
+    }
+    for (Task* t : sweeps)
+      if (t->P.cost_mode != 1) t->resume();  // each now yields its first COST request (or DONE)
     // phase 2: cost passes
     std::vector<Task*> costs;
     for (Task* t : active)
@@ -531,6 +570,19 @@ static lh_status run_tasks(lh_ctx* c, std::vector<Task*>& tasks, int in_flight, 
       t->sweep_bytes_pending = false;
       t->resume();
     }
+    for (Task* t : moms) {  // deliver the moments; the task then runs its whole BFGS solve on the host
+      const double* S = c->partials_host + (size_t)t->slot * c->partials_per_slot;
+      memcpy(t->mom.S, S, sizeof(double) * MOM_NSUM);
+      for (int r = 0; r < 3; r++)
+        for (int cc = 0; cc < 4; cc++) t->mom.T0[cc * 4 + r] = t->req_T12[r * 4 + cc];
+      t->mom.T0[3] = t->mom.T0[7] = t->mom.T0[11] = 0.f; t->mom.T0[15] = 1.f;
+      if (c->prof) {
+        c->prof_entries[c->prof_entry("cost_moments")].bytes += 108.0 * S[73];
+        c->prof_entries[c->prof_entry("nn_sweep")].bytes += 232.0 * S[73];
+      }
+      t->sweep_bytes_pending = false;
+      t->resume();
+    }
     // retire finished pairs
     for (size_t i = 0; i < active.size();) {
       if (active[i]->req == REQ_DONE) {
@@ -554,7 +606,7 @@ struct lh_gicp {
   float last_T[16];
   bool have_result = false;
   // debug sweep state
-  bool dbg_ready = false;
+  bool dbg_ready = false, dbg_prepared = false;
 };
 
 // ---------------------------------------------------------------------------------------------------------
@@ -630,6 +682,8 @@ void lh_default_gicp_params(lh_gicp_params* p) {
   p->recompute_target_cov = 0;       // gicp.h:116
   p->num_threads = 1;
   p->enable_timing = 0;
+  p->cost_mode = 1;
+  p->reserved0 = 0;
 }
 
 lh_status lh_create(lh_ctx** out, int device_id) {
@@ -656,7 +710,7 @@ void lh_destroy(lh_ctx* c) {
   c->prof_flush();
   for (auto e : c->ev_pool) (void)hipEventDestroy(e);
   (void)hipFree(c->keys0); (void)hipFree(c->keys1); (void)hipFree(c->vals0); (void)hipFree(c->vals1);
-  (void)hipFree(c->sort_temp); (void)hipFree(c->bbox); (void)hipFree(c->descs_dev);
+  (void)hipFree(c->sort_temp); (void)hipFree(c->bbox); (void)hipFree(c->descs_dev); (void)hipFree(c->mom_partials_dev);
   if (c->descs_host) (void)hipHostFree(c->descs_host);
   if (c->partials_host) (void)hipHostFree(c->partials_host);
   if (c->small_host) (void)hipHostFree(c->small_host);
@@ -785,7 +839,7 @@ lh_status lh_gicp_set_source(lh_gicp* g, const lh_cloud_view* v) {
   lh_status st = upload_view(g->ctx, v, &c);
   if (st) return st;
   gicp_drop_src(g);
-  g->src = c; g->own_src = true; g->have_result = false; g->dbg_ready = false;
+  g->src = c; g->own_src = true; g->have_result = false; g->dbg_ready = false; g->dbg_prepared = false;
   return LH_OK;
 }
 lh_status lh_gicp_set_target(lh_gicp* g, const lh_cloud_view* v) {
@@ -794,19 +848,19 @@ lh_status lh_gicp_set_target(lh_gicp* g, const lh_cloud_view* v) {
   lh_status st = upload_view(g->ctx, v, &c);
   if (st) return st;
   gicp_drop_tgt(g);
-  g->tgt = c; g->own_tgt = true; g->have_result = false; g->dbg_ready = false;
+  g->tgt = c; g->own_tgt = true; g->have_result = false; g->dbg_ready = false; g->dbg_prepared = false;
   return LH_OK;
 }
 lh_status lh_gicp_set_source_cloud(lh_gicp* g, lh_cloud* c) {
   if (!g || !c || c->ctx != g->ctx) return LH_EINVAL;
   gicp_drop_src(g);
-  g->src = c; g->own_src = false; g->have_result = false; g->dbg_ready = false;
+  g->src = c; g->own_src = false; g->have_result = false; g->dbg_ready = false; g->dbg_prepared = false;
   return LH_OK;
 }
 lh_status lh_gicp_set_target_cloud(lh_gicp* g, lh_cloud* c) {
   if (!g || !c || c->ctx != g->ctx) return LH_EINVAL;
   gicp_drop_tgt(g);
-  g->tgt = c; g->own_tgt = false; g->have_result = false; g->dbg_ready = false;
+  g->tgt = c; g->own_tgt = false; g->have_result = false; g->dbg_ready = false; g->dbg_prepared = false;
   return LH_OK;
 }
 lh_status lh_gicp_promote_source_to_target(lh_gicp* g) {
@@ -817,7 +871,7 @@ lh_status lh_gicp_promote_source_to_target(lh_gicp* g) {
   gicp_drop_tgt(g);
   g->tgt = s; g->own_tgt = own;
   g->tgt->has_index = false;  // align() rebuilds the index (target changed)
-  g->have_result = false; g->dbg_ready = false;
+  g->have_result = false; g->dbg_ready = false; g->dbg_prepared = false;
   return LH_OK;
 }
 
@@ -832,6 +886,7 @@ lh_status lh_gicp_align(lh_gicp* g, const float guess[16], lh_gicp_result* out, 
   if (!g->src || !g->tgt) { out->status = LH_EINVAL; return LH_EINVAL; }
   lh_status st = ctx_ensure_slots(c, 1, std::max(g->src->n, 1));
   if (st) { out->status = st; return st; }
+  g->dbg_prepared = false;
   Task& t = g->task;
   t.P = g->P; t.src = g->src; t.tgt = g->tgt; t.ws = &g->ws; t.trace = trace;
   memcpy(t.guess, guess ? guess : I16, sizeof(I16));
@@ -985,8 +1040,11 @@ lh_status lh_gicp_debug_sweep(lh_gicp* g, const float T[16], const float guess[1
   Task& t = g->task;
   t.P = g->P; t.src = g->src; t.tgt = g->tgt; t.ws = &g->ws; t.trace = nullptr; t.slot = 0;
   memcpy(t.guess, guess ? guess : I16, sizeof(I16));
-  st = task_prepare(c, &t, !g->tgt->has_index);
-  if (st) return st;
+  if (!g->dbg_prepared) {  // first debug sweep after a change of clouds: cold state; later ones are warm (like align's sweeps)
+    st = task_prepare(c, &t, !g->tgt->has_index);
+    if (st) return st;
+    g->dbg_prepared = true;
+  }
   SweepArgs a;
   a.njobs = 1; a.pad = 0; a.job[0].slot = 0; a.job[0].pad = 0;
   Task::T16_to_T12(T, a.job[0].T);
@@ -1015,6 +1073,15 @@ lh_status lh_gicp_debug_sweep(lh_gicp* g, const float T[16], const float guess[1
     }
   }
   g->dbg_ready = true;
+  return LH_OK;
+}
+
+lh_status lh_gicp_debug_stats(lh_gicp* g, uint64_t out[2], int reset) {
+  if (!g || !out || !g->ws.stats) return LH_EINVAL;
+  HIPCHK(hipSetDevice(g->ctx->device));
+  HIPCHK(hipStreamSynchronize(g->ctx->stream));
+  HIPCHK(hipMemcpy(out, g->ws.stats, 16, hipMemcpyDeviceToHost));
+  if (reset) HIPCHK(hipMemset(g->ws.stats, 0, 16));
   return LH_OK;
 }
 

@@ -90,8 +90,9 @@ LH_HD void cswap(uint64_t& a, uint64_t& b) {
   a = lo; b = hi;
 }
 
-// Collector concept: float bound() const; void offer(float d2, int id);
-// A subtree / leaf is visited iff box_d2 <= bound() (ties must be visited for the lowest-index rule).
+// Collector concept: float bound() const; void offer(float d2, int id); void skip(float box_d2);
+// A subtree / leaf is visited iff box_d2 <= bound() (ties must be visited for the lowest-index rule); skip() is told the
+// box distance of every subtree that is pruned (so a collector can keep a lower bound on everything it never looked at).
 template <class Collector>
 LH_HD void tree_search(const TreeView& t, float qx, float qy, float qz, Collector& col) {
   uint64_t stack[STACK_MAX];
@@ -115,6 +116,7 @@ LH_HD void tree_search(const TreeView& t, float qx, float qy, float qz, Collecto
       uint64_t k1 = (d1 <= bd && d1 < INF) ? (((uint64_t)f2u(d1) << 32) | (c0 + 1u)) : INVALID;
       uint64_t k2 = (d2 <= bd && d2 < INF) ? (((uint64_t)f2u(d2) << 32) | (c0 + 2u)) : INVALID;
       uint64_t k3 = (d3 <= bd && d3 < INF) ? (((uint64_t)f2u(d3) << 32) | (c0 + 3u)) : INVALID;
+      col.skip(d0 <= bd ? INF : d0); col.skip(d1 <= bd ? INF : d1); col.skip(d2 <= bd ? INF : d2); col.skip(d3 <= bd ? INF : d3);
       cswap(k0, k1); cswap(k2, k3); cswap(k0, k2); cswap(k1, k3); cswap(k1, k2);
       if (k3 != INVALID) stack[sp++] = k3;
       if (k2 != INVALID) stack[sp++] = k2;
@@ -129,10 +131,13 @@ LH_HD void tree_search(const TreeView& t, float qx, float qy, float qz, Collecto
       }
     }
     uint64_t key;
-    do {
+    for (;;) {
       if (sp == 0) return;
       key = stack[--sp];
-    } while (u2f((uint32_t)(key >> 32)) > col.bound());
+      float dk = u2f((uint32_t)(key >> 32));
+      if (dk <= col.bound()) break;
+      col.skip(dk);
+    }
     lin = (int)(uint32_t)key;
   }
 }
@@ -144,6 +149,29 @@ struct Nn1Collector {
   LH_HD void offer(float d, int id) {
     if (d < bd || (d == bd && id < bi)) { bd = d; bi = id; }
   }
+  LH_HD void skip(float) {}
+};
+
+// 1-NN plus a certificate: `lb` = lower bound on the squared distance of every point other than the winner
+// (second best among the examined points, and the box distance of every pruned subtree).  A later query q' within
+// distance e of this query keeps the same winner whenever d(q', winner) + e < sqrt(lb) (triangle inequality), which
+// lets the next GICP sweep skip the traversal for that point without changing its result.
+struct Nn1CertCollector {
+  float bd;
+  int bi;
+  float lb;
+  LH_HD float bound() const { return bd; }
+  LH_HD void offer(float d, int id) {
+    if (id == bi) return;  // the warm-start candidate met again
+    if (d < bd || (d == bd && id < bi)) {
+      lb = fminf(lb, bd);  // the dethroned winner becomes a runner-up (bd is +inf while there is no winner yet)
+      bd = d;
+      bi = id;
+    } else {
+      lb = fminf(lb, d);
+    }
+  }
+  LH_HD void skip(float d) { lb = fminf(lb, d); }
 };
 
 // k best (d2, id) ascending, lexicographic; storage strided so that a workgroup can keep the lists in LDS
@@ -153,6 +181,7 @@ struct KnnCollector {
   int* ki;
   int k, stride, cnt;
   LH_HD float bound() const { return cnt < k ? inf_f() : kd[(k - 1) * stride]; }
+  LH_HD void skip(float) {}
   LH_HD void offer(float d, int id) {
     if (id == 0x7fffffff) return;  // padding point
     if (cnt == k) {

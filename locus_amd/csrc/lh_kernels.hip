@@ -45,13 +45,16 @@ __global__ void __launch_bounds__(256) k_bbox(const float4* __restrict__ xyz, in
       hi[a] = fmaxf(hi[a], __shfl_down(hi[a], off, 64));
     }
   }
+  __shared__ float sm[4][6];
   if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-    for (int a = 0; a < 3; a++) {
-      atomicMin(&bbox[a], enc_ordered(lo[a]));
-      atomicMax(&bbox[3 + a], enc_ordered(hi[a]));
-    }
+    for (int a = 0; a < 3; a++) { sm[threadIdx.x >> 6][a] = lo[a]; sm[threadIdx.x >> 6][3 + a] = hi[a]; }
   }
+  __syncthreads();
+  if (threadIdx.x < 3)
+    atomicMin(&bbox[threadIdx.x], enc_ordered(fminf(fminf(sm[0][threadIdx.x], sm[1][threadIdx.x]), fminf(sm[2][threadIdx.x], sm[3][threadIdx.x]))));
+  else if (threadIdx.x < 6)
+    atomicMax(&bbox[threadIdx.x], enc_ordered(fmaxf(fmaxf(sm[0][threadIdx.x], sm[1][threadIdx.x]), fmaxf(sm[2][threadIdx.x], sm[3][threadIdx.x]))));
 }
 
 __global__ void __launch_bounds__(256) k_morton(const float4* __restrict__ xyz, int n, const uint32_t* __restrict__ bbox,
@@ -131,7 +134,7 @@ __global__ void __launch_bounds__(256) k_level_up(int l, Node4* __restrict__ nod
 void launch_bbox(const float4* xyz, int n, uint32_t* bbox, hipStream_t s) {
   hipLaunchKernelGGL(k_bbox_init, dim3(1), dim3(64), 0, s, bbox);
   int blocks = (n + 255) / 256;
-  if (blocks > 1024) blocks = 1024;
+  if (blocks > 128) blocks = 128;  // few contended atomics: one per block and component
   hipLaunchKernelGGL(k_bbox, dim3(blocks), dim3(256), 0, s, xyz, n, bbox);
 }
 void launch_morton(const float4* xyz, int n, const uint32_t* bbox, uint32_t* keys, uint32_t* vals, hipStream_t s) {
@@ -160,14 +163,28 @@ __global__ void __launch_bounds__(256) k_sweep(const PairDesc* __restrict__ desc
   float qx, qy, qz;
   xform_pt(job.T, p.x, p.y, p.z, qx, qy, qz);  // gicp.hpp:469
   TreeView tv{d.tgt_sorted, d.tgt_nodes, d.first_leaf, d.m};
-  Nn1Collector col{INFINITY, 0x7fffffff};
+  Nn1CertCollector col{INFINITY, 0x7fffffff, INFINITY};
   int w = d.prev_nn[i];
-  if (w >= 0) {  // warm start: last sweep's neighbour is a valid candidate => tight initial bound, still exact
+  bool need_search = true;
+  if (w >= 0) {
+    // warm start: last sweep's neighbour is a valid candidate => tight initial bound, still exact
     float4 t = d.tgt_xyz[w];
     col.bd = d2f(qx, qy, qz, t.x, t.y, t.z);
     col.bi = w;
+    // certificate from the last full search at query position cq: every other target point was at squared distance
+    // >= cq.w from cq, so it is at distance >= sqrt(cq.w) - |q - cq| from q.  If the candidate is strictly closer
+    // (1e-5 relative margin >> float rounding of the d2 evaluations), the traversal cannot change the result.
+    float4 cq = d.cert[i];
+    double e = sqrt((double)d2f(qx, qy, qz, cq.x, cq.y, cq.z));
+    double dw = sqrt((double)col.bd), lo = sqrt((double)cq.w);
+    if (dw * (1.0 + 1e-5) + e * (1.0 + 1e-5) + 1e-12 < lo * (1.0 - 1e-5)) need_search = false;
   }
-  tree_search(tv, qx, qy, qz, col);
+  if (need_search) {
+    tree_search(tv, qx, qy, qz, col);
+    d.cert[i] = make_float4(qx, qy, qz, col.lb);
+    atomicAdd(&d.stats[0], 1ull);  // wave-aggregated by the compiler: one atomic per wave
+  }
+  atomicAdd(&d.stats[1], 1ull);
   int j = (col.bi == 0x7fffffff) ? -1 : col.bi;
   d.prev_nn[i] = j;
   float4 c = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
@@ -264,6 +281,97 @@ __global__ void __launch_bounds__(256) k_cost(const PairDesc* __restrict__ descs
 
 void launch_cost(const PairDesc* descs, const CostArgs& a, int max_n, double* out, hipStream_t s) {
   hipLaunchKernelGGL(k_cost, dim3(cost_blocks(max_n), a.njobs), dim3(256), 0, s, descs, a, out);
+}
+
+// ===== K5': second-order moments of the cost about T0 =====================================================
+// res(T) = a + D*[p;1] with a = T0*p - q (double), D = T - T0 (3x4).  Then
+//   sum res^T M res = c0 + 2 d.B + d.(H d),  B[r][c] = sum (M a)_r pt_c,  H[(r,s)][(c,e)] = sum M_rs pt_c pt_e,  pt = (p,1)
+// and sum (M res)_r pt_c = B[r][c] + (H d)[r][c] gives the translation gradient and the rotation-gradient matrix R of
+// gicp.hpp:392-396.  74 doubles per workgroup, fixed-shape reduction.
+__global__ void __launch_bounds__(256) k_moments(const PairDesc* __restrict__ descs, CostArgs a, double* __restrict__ partials,
+                                                 int partials_stride) {
+  const CostJob& job = a.job[blockIdx.y];
+  const PairDesc d = descs[job.slot];
+  int base = blockIdx.x * MOM_CHUNK;
+  if (base >= d.n) return;
+  double acc[MOM_NSUM];
+#pragma unroll
+  for (int k = 0; k < MOM_NSUM; k++) acc[k] = 0.0;
+  double T0[12];
+#pragma unroll
+  for (int k = 0; k < 12; k++) T0[k] = (double)job.T[k];
+#pragma unroll 1
+  for (int r = 0; r < MOM_CHUNK / 256; r++) {
+    int i = base + r * 256 + threadIdx.x;
+    if (i < d.n) {
+      float4 c = d.corr[i];
+      if (__float_as_int(c.w) >= 0) {
+        float4 p = d.src[i];
+        double pt[4] = {(double)p.x, (double)p.y, (double)p.z, 1.0};
+        double a0 = (((T0[0] * pt[0] + T0[1] * pt[1]) + T0[2] * pt[2]) + T0[3]) - (double)c.x;
+        double a1 = (((T0[4] * pt[0] + T0[5] * pt[1]) + T0[6] * pt[2]) + T0[7]) - (double)c.y;
+        double a2 = (((T0[8] * pt[0] + T0[9] * pt[1]) + T0[10] * pt[2]) + T0[11]) - (double)c.z;
+        double M6[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) M6[k] = d.maha6[(size_t)k * d.n_pad + i];
+        double Ma[3] = {(M6[0] * a0 + M6[1] * a1) + M6[2] * a2, (M6[1] * a0 + M6[3] * a1) + M6[4] * a2,
+                        (M6[2] * a0 + M6[4] * a1) + M6[5] * a2};
+        acc[0] += (a0 * Ma[0] + a1 * Ma[1]) + a2 * Ma[2];
+#pragma unroll
+        for (int rr = 0; rr < 3; rr++)
+#pragma unroll
+          for (int cc = 0; cc < 4; cc++) acc[1 + rr * 4 + cc] += Ma[rr] * pt[cc];
+        double pp[10];
+        {
+          int t = 0;
+#pragma unroll
+          for (int cc = 0; cc < 4; cc++)
+#pragma unroll
+            for (int ee = cc; ee < 4; ee++) pp[t++] = pt[cc] * pt[ee];
+        }
+#pragma unroll
+        for (int rs = 0; rs < 6; rs++)
+#pragma unroll
+          for (int ce = 0; ce < 10; ce++) acc[13 + rs * 10 + ce] += M6[rs] * pp[ce];
+        acc[73] += 1.0;
+      }
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+    for (int k = 0; k < MOM_NSUM; k++) acc[k] += __shfl_down(acc[k], off, 64);
+  }
+  __shared__ double sm[4][MOM_NSUM];
+  int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < MOM_NSUM; k++) sm[wave][k] = acc[k];
+  }
+  __syncthreads();
+  if (threadIdx.x < MOM_NSUM) {
+    double v = ((sm[0][threadIdx.x] + sm[1][threadIdx.x]) + sm[2][threadIdx.x]) + sm[3][threadIdx.x];
+    partials[(size_t)job.slot * partials_stride + (size_t)blockIdx.x * MOM_NSUM + threadIdx.x] = v;
+  }
+}
+
+__global__ void __launch_bounds__(128) k_moments_final(const PairDesc* __restrict__ descs, CostArgs a, const double* __restrict__ partials,
+                                                       int partials_stride, double* __restrict__ out) {
+  const CostJob& job = a.job[blockIdx.x];
+  int n = descs[job.slot].n;
+  int nb = (n + MOM_CHUNK - 1) / MOM_CHUNK;
+  if (threadIdx.x < MOM_NSUM) {
+    const double* p = partials + (size_t)job.slot * partials_stride + threadIdx.x;
+    double s = 0.0;
+    for (int b = 0; b < nb; b++) s += p[(size_t)b * MOM_NSUM];  // block order => bitwise reproducible
+    out[job.out_offset + threadIdx.x] = s;
+  }
+}
+
+void launch_moments(const PairDesc* descs, const CostArgs& a, int max_n, double* partials_dev, int partials_stride, double* out,
+                    hipStream_t s) {
+  hipLaunchKernelGGL(k_moments, dim3(mom_blocks(max_n), a.njobs), dim3(256), 0, s, descs, a, partials_dev, partials_stride);
+  hipLaunchKernelGGL(k_moments_final, dim3(a.njobs), dim3(128), 0, s, descs, a, partials_dev, partials_stride, out);
 }
 
 // ===== K6 / misc ===========================================================================================

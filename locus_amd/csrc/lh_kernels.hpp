@@ -10,6 +10,8 @@ namespace lh {
 constexpr int MAX_JOBS = 24;       // jobs (scan pairs) per batched launch; kernarg stays < 4 KB
 constexpr int COST_CHUNK = 512;    // source points per cost-kernel workgroup (fixed => deterministic sums)
 constexpr int COST_NSUM = 14;      // f, g_t[3], R[9], count
+constexpr int MOM_CHUNK = 1024;    // source points per moment-kernel workgroup
+constexpr int MOM_NSUM = 74;       // c0, B[3][4], H[6][10], count
 
 // static description of one scan pair's device buffers (lives in device memory, indexed by slot)
 struct PairDesc {
@@ -22,6 +24,8 @@ struct PairDesc {
   const float4* tgt_sorted; // Morton-sorted target (x,y,z,id)
   const Node4* tgt_nodes;
   int32_t* prev_nn;         // warm-start NN index per source point                      [n]
+  float4* cert;             // (query x,y,z at the last full search, lower bound on the other points' d2) [n]
+  unsigned long long* stats; // [0] += queries that ran the tree traversal, [1] += queries (instrumentation)
   float4* corr;             // per source point: (tgt x, y, z, bitcast tgt idx | -1)     [n]
   double* maha6;            // 6 planes of n_pad doubles: M00 M01 M02 M11 M12 M22
   int n, n_pad, m, m_pad;
@@ -70,6 +74,11 @@ void launch_build_nodes(const float4* sorted, int n, int depth, Node4* nodes, hi
 void launch_sweep(const PairDesc* descs, const SweepArgs& a, int max_n, hipStream_t s);
 void launch_cost(const PairDesc* descs, const CostArgs& a, int max_n, double* out, hipStream_t s);
 inline int cost_blocks(int n) { return (n + COST_CHUNK - 1) / COST_CHUNK; }
+// second-order moments of the cost about T0 = job.T (see lh_bfgs.hpp MomentModel): per-block partials on the device,
+// then one workgroup per job sums them in block order into out[job.out_offset + k], k < MOM_NSUM
+void launch_moments(const PairDesc* descs, const CostArgs& a, int max_n, double* partials_dev, int partials_stride, double* out,
+                    hipStream_t s);
+inline int mom_blocks(int n) { return (n + MOM_CHUNK - 1) / MOM_CHUNK; }
 
 // ---- K6 / K7 / misc ---------------------------------------------------------------------------------
 void launch_transform(const float4* in_xyz, const float4* in_nrm, int n, const float* T12, float4* out_xyz, float4* out_nrm,

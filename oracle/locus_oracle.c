@@ -556,6 +556,18 @@ typedef struct {
   long passes;
 } cost_ctx;
 
+/* Sensitivity probe (analysis only, see DESIGN.md "float noise floor"): variant 1 evaluates the functor's float
+ * T*p with fused multiply-adds, as a -march=native (FMA) build of the reference would; variant 0 (default) = no FMA. */
+static int g_cost_variant = 0;
+void lo_set_cost_variant(int v) { g_cost_variant = v; }
+static inline void xform_pt_cost(const float* T, const float* p, float* o) {
+  if (g_cost_variant == 1) {
+    for (int r = 0; r < 3; r++) o[r] = fmaf(T[8 + r], p[2], fmaf(T[4 + r], p[1], T[0 + r] * p[0])) + T[12 + r];
+  } else {
+    for (int r = 0; r < 3; r++) o[r] = ((T[0 + r] * p[0] + T[4 + r] * p[1]) + T[8 + r] * p[2]) + T[12 + r];
+  }
+}
+
 static void cost_sums(const cost_ctx* c, const double* x, double* S /*13*/) {
   float T[16];
   lo_apply_state(x, T); /* base_transformation_ = I  (gicp.hpp:435, 367-368) */
@@ -565,7 +577,7 @@ static void cost_sums(const cost_ctx* c, const double* x, double* S /*13*/) {
       const float* ps = c->src + 4 * (size_t)c->src_idx[i];
       const float* pt = c->tgt + 4 * (size_t)c->tgt_idx[i];
       float pp[3];
-      xform_pt(T, ps, pp);                                            /* gicp.hpp:382 */
+      xform_pt_cost(T, ps, pp);                                       /* gicp.hpp:382 */
       double res[3] = {(double)(pp[0] - pt[0]), (double)(pp[1] - pt[1]), (double)(pp[2] - pt[2])}; /* :384 float subtract */
       const double* M = c->maha9 + 9 * (size_t)c->src_idx[i];
       double t0 = M[0] * res[0] + M[1] * res[1] + M[2] * res[2];

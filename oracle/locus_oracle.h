@@ -68,6 +68,7 @@ typedef struct {
 enum { LO_OK = 0, LO_EINVAL = -1, LO_ENOMEM = -2, LO_ETOO_FEW = -4, LO_ESOLVER = -5, LO_ENO_NN = -6 };
 
 void lo_default_params(lo_params* p);
+void lo_set_cost_variant(int v); /* analysis only: 1 = FMA-contracted float T*p in the cost functor */
 
 /* exact nearest-neighbour index (stands in for pcl::search::KdTree -> FLANN KDTreeSingleIndex);
    distances are float ((dx*dx+dy*dy)+dz*dz), ties -> lowest original index. */

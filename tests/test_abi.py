@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol(capi):
 
 def test_struct_layouts_match_header(capi):
     assert C.sizeof(capi.CloudView) == 32
-    assert C.sizeof(capi.GicpParams) == 64
+    assert C.sizeof(capi.GicpParams) == 72
     assert C.sizeof(capi.GicpResult) == 96
     assert capi.POINT_XYZI.itemsize == 32 and capi.POINT_XYZINORMAL.itemsize == 48
 

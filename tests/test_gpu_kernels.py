@@ -101,6 +101,32 @@ def test_sweep_and_cost_match_oracle(ctx, capi, oracle):
     assert f2 == f and (sums2 == sums).all()
 
 
+def test_warm_sweeps_with_certificates_stay_bit_exact(ctx, capi, oracle):
+    # consecutive sweeps reuse the previous neighbour as a bound and skip the traversal when a triangle-inequality
+    # certificate proves the neighbour cannot change; every sweep must still equal the exhaustive (oracle) search
+    src, tgt, delta = synth.scan_pair(n_rings=32, n_az=700, scale=2.0, noise=0.02, seed=17)
+    ttree = oracle.Tree(oracle.xyz4(tgt))
+    nt = oracle.normals_knn(oracle.xyz4(tgt), 20, threads=4, tree=ttree)
+    ns = oracle.normals_knn(oracle.xyz4(src), 20, threads=4)
+    g = capi.Gicp(ctx, capi.default_params(corr_dist=1.0))
+    g.set_source(capi.make_pointf(src, ns))
+    g.set_target(capi.make_pointf(tgt, nt))
+    x_true = np.array([delta[0, 3], delta[1, 3], delta[2, 3], 0.0, 0.0, np.arctan2(delta[1, 0], delta[0, 0])])
+    fracs = []
+    g.debug_stats()
+    for s in [0.0, 0.5, 0.8, 0.95, 0.99, 0.999, 0.9999, 1.0, 1.0, 0.3]:  # converging iterates, a repeat, then a jump back
+        T16 = oracle.apply_state(x_true * s)
+        idx, _ = g.debug_sweep(T16, src.shape[0])
+        q = oracle.transform(oracle.xyz4(src), T16)
+        io, do = ttree.nn1(q, threads=4)
+        io = np.where(do.astype(np.float64) < 1.0, io, -1)
+        assert (idx == io).all(), (s, int((idx != io).sum()))
+        searched, total = g.debug_stats()
+        fracs.append(searched / total)
+    print("fraction of queries that ran the traversal per sweep:", np.round(fracs, 4))
+    assert fracs[0] == 1.0 and fracs[8] < 0.01  # a repeated transform needs (almost) no traversal
+
+
 def test_voxel_grid_bit_exact(ctx, capi, oracle):
     pts = synth.scan(rings=32, azimuths=900, scale=2.0, seed=8)
     rng = np.random.default_rng(9)

@@ -194,3 +194,28 @@ def test_garage_fixture_thread_invariance(oracle, garage):
     fit = oracle.fitness(oracle.xyz4(q), base["T"], tree)
     fit0 = oracle.fitness(oracle.xyz4(q), oracle.mat_to_T(np.eye(4)), tree)
     assert fit <= fit0 * 1.05  # alignment does not make the fit worse
+
+
+def test_reference_float_noise_floor(oracle):
+    """The reference evaluates T*p in float inside the cost functor (gicp.hpp:382).  Building the SAME source with or
+    without FMA contraction changes those roundings, the BFGS trajectory, and the result: this measures how far the
+    reference's own output moves, which bounds what any bit-different but equally valid evaluation (our cost_mode 1)
+    can be held to."""
+    L = oracle.lib()
+    worst_t, worst_r = 0.0, 0.0
+    for seed in (21, 22, 23):
+        src, tgt, _ = synth.scan_pair(n_rings=16, n_az=600, scale=1.0, noise=0.01, seed=seed)
+        ns = oracle.normals_knn(oracle.xyz4(src), 20, threads=4)
+        nt = oracle.normals_knn(oracle.xyz4(tgt), 20, threads=4)
+        res = []
+        for v in (0, 1):
+            L.lo_set_cost_variant(v)
+            res.append(oracle.gicp_align(oracle.xyz4(src), ns, oracle.xyz4(tgt), nt,
+                                         oracle.default_params(num_threads=4, max_iterations=20, corr_dist=1.0,
+                                                               transformation_epsilon=1e-3)))
+        L.lo_set_cost_variant(0)
+        A, B = oracle.T_to_mat(res[0]["T"]), oracle.T_to_mat(res[1]["T"])
+        worst_t = max(worst_t, np.abs(A[:3, 3] - B[:3, 3]).max())
+        worst_r = max(worst_r, np.abs(A[:3, :3] - B[:3, :3]).max())
+    print("FMA vs non-FMA reference builds differ by up to |dt| = %.2e m, |dR| = %.2e" % (worst_t, worst_r))
+    assert 1e-6 < worst_t < 5e-3  # noise floor is real (not bit-stable) and of order 1e-4..1e-3 m
