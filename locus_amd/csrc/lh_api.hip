@@ -289,6 +289,7 @@ struct Task : public CostFn {
   double res_sums[COST_NSUM];
   MomentModel mom;  // cost_mode 1: filled by the scheduler after each sweep
   bool sweep_bytes_pending = false;
+  bool count_stats = false;  // debug sweeps only
   // outputs
   lh_gicp_result result;
 
@@ -442,7 +443,7 @@ static lh_status task_prepare(lh_ctx* c, Task* t, bool rebuild_index) {
   d.tgt_nodes = tgt->nodes;
   d.prev_nn = t->ws->prev_nn;
   d.cert = t->ws->cert;
-  d.stats = t->ws->stats;
+  d.stats = t->count_stats ? t->ws->stats : nullptr;
   d.corr = t->ws->corr;
   d.maha6 = t->ws->maha6;
   d.n = src->n;
@@ -888,6 +889,7 @@ lh_status lh_gicp_align(lh_gicp* g, const float guess[16], lh_gicp_result* out, 
   if (st) { out->status = st; return st; }
   g->dbg_prepared = false;
   Task& t = g->task;
+  t.count_stats = false;
   t.P = g->P; t.src = g->src; t.tgt = g->tgt; t.ws = &g->ws; t.trace = trace;
   memcpy(t.guess, guess ? guess : I16, sizeof(I16));
   std::vector<Task*> tasks{&t};
@@ -1040,6 +1042,7 @@ lh_status lh_gicp_debug_sweep(lh_gicp* g, const float T[16], const float guess[1
   Task& t = g->task;
   t.P = g->P; t.src = g->src; t.tgt = g->tgt; t.ws = &g->ws; t.trace = nullptr; t.slot = 0;
   memcpy(t.guess, guess ? guess : I16, sizeof(I16));
+  t.count_stats = true;
   if (!g->dbg_prepared) {  // first debug sweep after a change of clouds: cold state; later ones are warm (like align's sweeps)
     st = task_prepare(c, &t, !g->tgt->has_index);
     if (st) return st;
@@ -1077,7 +1080,9 @@ lh_status lh_gicp_debug_sweep(lh_gicp* g, const float T[16], const float guess[1
 }
 
 lh_status lh_gicp_debug_stats(lh_gicp* g, uint64_t out[2], int reset) {
-  if (!g || !out || !g->ws.stats) return LH_EINVAL;
+  if (!g || !out) return LH_EINVAL;
+  out[0] = out[1] = 0;
+  if (!g->ws.stats) return LH_OK;  // nothing swept yet
   HIPCHK(hipSetDevice(g->ctx->device));
   HIPCHK(hipStreamSynchronize(g->ctx->stream));
   HIPCHK(hipMemcpy(out, g->ws.stats, 16, hipMemcpyDeviceToHost));

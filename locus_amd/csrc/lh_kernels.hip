@@ -182,9 +182,9 @@ __global__ void __launch_bounds__(256) k_sweep(const PairDesc* __restrict__ desc
   if (need_search) {
     tree_search(tv, qx, qy, qz, col);
     d.cert[i] = make_float4(qx, qy, qz, col.lb);
-    atomicAdd(&d.stats[0], 1ull);  // wave-aggregated by the compiler: one atomic per wave
+    if (d.stats) atomicAdd(&d.stats[0], 1ull);  // instrumentation only (lh_gicp_debug_sweep): contended atomics
   }
-  atomicAdd(&d.stats[1], 1ull);
+  if (d.stats) atomicAdd(&d.stats[1], 1ull);
   int j = (col.bi == 0x7fffffff) ? -1 : col.bi;
   d.prev_nn[i] = j;
   float4 c = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
