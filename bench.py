@@ -22,6 +22,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from locus_amd import capi, synth  # noqa: E402
+from locus_amd import dist as ldist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
@@ -110,10 +111,8 @@ def main():
         for t in T:
             t.drop_index()  # align() rebuilds the target index every scan, like pcl::Registration::initCompute
         out = capi.align_batch(ctx, P, S, T, max_in_flight=args.in_flight)
-        if world > 1:  # result gather over RCCL/xGMI: 16 floats per pair
-            poses = torch.tensor(np.stack([o["T"] for o in out]), device="cuda")
-            gathered = torch.empty((world,) + tuple(poses.shape), device="cuda", dtype=poses.dtype)
-            dist.all_gather_into_tensor(gathered, poses)
+        if world > 1:  # result gather over RCCL/xGMI: 16 floats per pair; no data-path collective
+            ldist.gather_poses(np.stack([o["T"] for o in out]), world, device="cuda")
         return out
 
     def barrier():
@@ -131,10 +130,7 @@ def main():
         out = step()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = ldist.max_over_ranks(elapsed, world, device="cuda")
     total_pairs = args.pairs * args.steps * world
     value = total_pairs / elapsed
     ok = all(o["status"] == 0 for o in out)

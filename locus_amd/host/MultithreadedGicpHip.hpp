@@ -1,0 +1,111 @@
+// MultithreadedGicpHip.hpp -- the registration object the wrappers hold as `icp_`.
+// Same public surface as pcl::MultithreadedGeneralizedIterativeClosestPoint<PointF,PointF> (gicp.h:134-298 + the
+// pcl::Registration methods LOCUS calls: setInputSource/Target, align, getFinalTransformation, hasConverged,
+// getFitnessScore), implemented on the C ABI.  In a PCL environment the adapter in INTEGRATION.md derives from
+// pcl::Registration instead and forwards to the same calls.
+#pragma once
+#include <cmath>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "point_types.hpp"
+
+namespace locus_hip {
+
+class MultithreadedGicpHip {
+public:
+  typedef std::shared_ptr<MultithreadedGicpHip> Ptr;
+
+  explicit MultithreadedGicpHip(lh_ctx* ctx) : ctx_(ctx) {
+    lh_default_gicp_params(&p_);  // gicp.h:111-132
+    if (lh_gicp_create(ctx_, &p_, &g_) != LH_OK) throw std::runtime_error("lh_gicp_create failed (no HIP device?)");
+    for (int i = 0; i < 16; i++) final_[i] = (i % 5 == 0) ? 1.0f : 0.0f;
+  }
+  ~MultithreadedGicpHip() { lh_gicp_destroy(g_); }
+  MultithreadedGicpHip(const MultithreadedGicpHip&) = delete;
+  MultithreadedGicpHip& operator=(const MultithreadedGicpHip&) = delete;
+
+  // gicp.h setters (names kept)
+  void setNumThreads(int n) { p_.num_threads = n; push(); }                                  // gicp.h:134-141 (ignored on GPU)
+  void enableTimingOutput(bool on) { p_.enable_timing = on ? 1 : 0; push(); }                // gicp.h:143
+  void setRotationEpsilon(double e) { p_.rotation_epsilon = e; push(); }                     // gicp.h:236
+  double getRotationEpsilon() const { return p_.rotation_epsilon; }
+  void setCorrespondenceRandomness(int k) { p_.k_correspondences = k; push(); }              // gicp.h:250
+  int getCorrespondenceRandomness() const { return p_.k_correspondences; }
+  void setMaximumOptimizerIterations(int n) { p_.max_inner_iterations = n; push(); }         // gicp.h:263
+  int getMaximumOptimizerIterations() const { return p_.max_inner_iterations; }
+  void RecomputeTargetCovariance(bool r) { p_.recompute_target_cov = r ? 1 : 0; push(); }    // gicp.h:277
+  void RecomputeSourceCovariance(bool r) { p_.recompute_source_cov = r ? 1 : 0; push(); }    // gicp.h:285
+  // pcl::Registration setters used by SetupICP (PointCloudOdometry.cc:147-155)
+  void setTransformationEpsilon(double e) { p_.transformation_epsilon = e; push(); }
+  double getTransformationEpsilon() const { return p_.transformation_epsilon; }
+  void setMaxCorrespondenceDistance(double d) { p_.corr_dist = d; push(); }
+  double getMaxCorrespondenceDistance() const { return p_.corr_dist; }
+  void setMaximumIterations(int n) { p_.max_iterations = n; push(); }
+  int getMaximumIterations() const { return p_.max_iterations; }
+  void setRANSACIterations(int) {}            // accepted, unused by this computeTransformation
+  void setEuclideanFitnessEpsilon(double) {}  // set by SetupICP but never consulted
+  void setCostMode(int mode) { p_.cost_mode = mode; push(); }
+
+  void setInputSource(const PointCloudF::Ptr& cloud) {  // gicp.h:162-179
+    src_ = cloud;
+    lh_cloud_view v = ViewOf(*cloud);
+    check(lh_gicp_set_source(g_, &v), "setInputSource");
+  }
+  void setInputTarget(const PointCloudF::Ptr& cloud) {  // gicp.h:196-200
+    tgt_ = cloud;
+    lh_cloud_view v = ViewOf(*cloud);
+    check(lh_gicp_set_target(g_, &v), "setInputTarget");
+  }
+  // odometry fast path: the previous query becomes the reference without leaving the GPU
+  void promoteSourceToTarget() { tgt_ = src_; check(lh_gicp_promote_source_to_target(g_), "promoteSourceToTarget"); }
+
+  // pcl::Registration::align(output) / align(output, guess): column-major 4x4 like Eigen::Matrix4f
+  void align(PointCloudF& output, const float* guess = nullptr) {
+    output.points = src_->points;  // PCL copies the input (all fields) and overwrites xyz with the aligned positions
+    output.stamp = src_->stamp;
+    lh_gicp_result r;
+    lh_status st = lh_gicp_align(g_, guess, &r, nullptr, output.points.data(), sizeof(PointF), offsetof(PointF, x));
+    if (st != LH_OK && st != LH_ETOO_FEW_CORR && st != LH_ESOLVER) check(st, "align");
+    for (int i = 0; i < 16; i++) final_[i] = r.T[i];
+    converged_ = r.converged != 0;
+    iterations_ = r.iterations;
+    last_status_ = r.status;
+  }
+  const float* getFinalTransformation() const { return final_; }  // column-major
+  float T(int r, int c) const { return final_[c * 4 + r]; }
+  bool hasConverged() const { return converged_; }
+  int getNumIterations() const { return iterations_; }
+  int getLastStatus() const { return last_status_; }
+  double getFitnessScore() {
+    double f = 0;
+    check(lh_gicp_fitness(g_, &f), "getFitnessScore");
+    return f;
+  }
+  // getSearchMethodTarget()->nearestKSearch(pt, 1, ...) for a whole cloud (PointCloudLocalization.cc:327-336)
+  void nearestTargetIndices(const PointCloudF& q, std::vector<size_t>* out) {
+    std::vector<int32_t> idx(q.size());
+    lh_cloud_view v = ViewOf(q);
+    check(lh_nn1(g_, &v, idx.data(), nullptr), "nearestTargetIndices");
+    out->resize(q.size());
+    for (size_t i = 0; i < idx.size(); i++) (*out)[i] = (size_t)idx[i];
+  }
+  lh_gicp* handle() { return g_; }
+  lh_ctx* context() { return ctx_; }
+
+private:
+  void push() { lh_gicp_set_params(g_, &p_); }
+  static void check(lh_status st, const char* what) {
+    if (st != LH_OK) throw std::runtime_error(std::string("locus_hip: ") + what + ": " + lh_status_string(st));
+  }
+  lh_ctx* ctx_;
+  lh_gicp* g_ = nullptr;
+  lh_gicp_params p_;
+  PointCloudF::Ptr src_, tgt_;
+  float final_[16];
+  bool converged_ = false;
+  int iterations_ = 0, last_status_ = 0;
+};
+
+}  // namespace locus_hip

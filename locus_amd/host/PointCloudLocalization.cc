@@ -1,0 +1,197 @@
+// PointCloudLocalization.cc -- control flow of point_cloud_localization/src/PointCloudLocalization.cc:174-541 on the HIP path.
+#include "PointCloudLocalization.hpp"
+
+#include <cmath>
+#include <cstring>
+
+namespace locus_hip {
+
+PointCloudLocalization::PointCloudLocalization(lh_ctx* ctx) : ctx_(ctx) {
+  memset(icp_covariance_, 0, sizeof(icp_covariance_));
+  memset(observability_matrix_, 0, sizeof(observability_matrix_));
+}
+PointCloudLocalization::~PointCloudLocalization() {}
+
+bool PointCloudLocalization::Initialize(const Config& cfg) {
+  params_ = cfg;
+  b_is_flat_ground_assumption_ = cfg.b_is_flat_ground_assumption;
+  integrated_estimate_ = cfg.initial_pose;
+  if (b_is_flat_ground_assumption_) integrated_estimate_.rotation = gu::Rot3(0, 0, integrated_estimate_.rotation.Yaw());
+  return SetupICP();
+}
+
+bool PointCloudLocalization::SetupICP() {  // :223-289
+  if (params_.registration_method != "gicp" && params_.registration_method != "gicp_hip")
+    throw std::runtime_error("No such Registration mode or not implemented yet " + params_.registration_method);
+  icp_.reset(new MultithreadedGicpHip(ctx_));
+  icp_->setTransformationEpsilon(params_.tf_epsilon);
+  icp_->setMaxCorrespondenceDistance(params_.corr_dist);
+  icp_->setMaximumIterations(params_.iterations);
+  icp_->setMaximumOptimizerIterations(50);  // :238
+  icp_->setRANSACIterations(0);
+  icp_->setNumThreads(params_.num_threads);
+  icp_->enableTimingOutput(params_.enable_timing_output);
+  icp_->RecomputeTargetCovariance(params_.recompute_covariance_local_map);
+  icp_->RecomputeSourceCovariance(params_.recompute_covariance_scan);
+  return true;
+}
+
+bool PointCloudLocalization::MotionUpdate(const gu::Transform3& incremental_odom) {  // :174-179
+  incremental_estimate_ = incremental_odom;
+  return true;
+}
+
+// pcl::transformPointCloudWithNormals with a double 4x4 cast to float (PCL casts the matrix to the point scalar)
+static void TransformWithNormals(const PointCloudF& in, PointCloudF* out, const gu::Transform3& e) {
+  float R[9], t[3] = {(float)e.translation.x, (float)e.translation.y, (float)e.translation.z};
+  for (int i = 0; i < 9; i++) R[i] = (float)e.rotation.m[i];
+  if (out != &in) *out = in;
+  for (auto& p : out->points) {
+    float x = p.x, y = p.y, z = p.z, nx = p.normal_x, ny = p.normal_y, nz = p.normal_z;
+    p.x = ((R[0] * x + R[1] * y) + R[2] * z) + t[0];
+    p.y = ((R[3] * x + R[4] * y) + R[5] * z) + t[1];
+    p.z = ((R[6] * x + R[7] * y) + R[8] * z) + t[2];
+    p.normal_x = (R[0] * nx + R[1] * ny) + R[2] * nz;
+    p.normal_y = (R[3] * nx + R[4] * ny) + R[5] * nz;
+    p.normal_z = (R[6] * nx + R[7] * ny) + R[8] * nz;
+  }
+}
+
+bool PointCloudLocalization::TransformPointsToFixedFrame(const PointCloudF& points, PointCloudF* out) const {  // :181-200
+  if (out == NULL) return false;
+  TransformWithNormals(points, out, gu::PoseUpdate(integrated_estimate_, incremental_estimate_));
+  return true;
+}
+bool PointCloudLocalization::TransformPointsToSensorFrame(const PointCloudF& points, PointCloudF* out) const {  // :202-221
+  if (out == NULL) return false;
+  TransformWithNormals(points, out, gu::PoseInverse(gu::PoseUpdate(integrated_estimate_, incremental_estimate_)));
+  return true;
+}
+
+bool PointCloudLocalization::MeasurementUpdate(const PointCloudF::Ptr& query, const PointCloudF::Ptr& reference,
+                                               PointCloudF* aligned_query) {  // :291-427
+  if (aligned_query == NULL) {
+    is_healthy_ = false;
+    return false;
+  }
+  icp_->setInputSource(query);
+  icp_->setInputTarget(reference);
+  PointCloudF icpAlignedPointsLocalization_;
+  icp_->align(icpAlignedPointsLocalization_);
+  const float* T = icp_->getFinalTransformation();  // column-major
+  auto Tm = [&](int r, int c) { return (double)T[c * 4 + r]; };
+  // transformPointCloudWithNormals(*query, *aligned_query, T) (:325)
+  gu::Transform3 Tt;
+  Tt.translation = gu::Vec3(Tm(0, 3), Tm(1, 3), Tm(2, 3));
+  Tt.rotation = gu::Rot3(Tm(0, 0), Tm(0, 1), Tm(0, 2), Tm(1, 0), Tm(1, 1), Tm(1, 2), Tm(2, 0), Tm(2, 1), Tm(2, 2));
+  TransformWithNormals(*query, aligned_query, Tt);
+  // correspondences: ungated 1-NN of every aligned point in the target tree (:327-336) -- one GPU sweep
+  std::vector<size_t> correspondences;
+  icp_->nearestTargetIndices(*aligned_query, &correspondences);
+
+  gu::Transform3 pose_update;
+  if (b_is_flat_ground_assumption_) {  // :340-353
+    double yaw = Tt.rotation.Yaw();
+    pose_update.translation = gu::Vec3(Tm(0, 3), Tm(1, 3), 0);
+    pose_update.rotation = gu::Rot3(cos(yaw), -sin(yaw), 0, sin(yaw), cos(yaw), 0, 0, 0, 1);
+  } else {
+    pose_update = Tt;
+  }
+  if (!params_.transform_thresholding || (pose_update.translation.Norm() <= params_.max_translation &&
+                                          pose_update.rotation.ToEulerZYX().Norm() <= params_.max_rotation)) {  // :369-379
+    incremental_estimate_ = gu::PoseUpdate(incremental_estimate_, pose_update);
+  }
+  integrated_estimate_ = gu::PoseUpdate(integrated_estimate_, incremental_estimate_);  // :381-382
+
+  if (params_.compute_icp_observability) {  // :384-396
+    double evec[36], eval[6];
+    ComputeIcpObservability(*query, *reference, correspondences, T, evec, eval, observability_matrix_);
+  }
+  {
+    std::lock_guard<std::mutex> lock(icp_covariance_mutex_);  // :398-421
+    memset(icp_covariance_, 0, sizeof(icp_covariance_));
+    if (params_.compute_icp_covariance && params_.icp_covariance_method == 1)
+      ComputePoint2PlaneICPCovariance(*query, *reference, correspondences, T, icp_covariance_);
+  }
+  is_healthy_ = true;
+  return true;
+}
+
+bool PointCloudLocalization::ComputeAp(const PointCloudF& query_cloud, const PointCloudF& reference_cloud,
+                                       const std::vector<size_t>& corr, double Ap[36]) {
+  // normalizePCloud + ComputeAp_ForPoint2PlaneICP (utils.cc:106-128, PointCloudLocalization.cc:723-750) on the GPU
+  lh_cloud *q = nullptr, *r = nullptr;
+  lh_cloud_view vq = ViewOf(query_cloud), vr = ViewOf(reference_cloud);
+  if (lh_cloud_create(ctx_, &vq, &q) != LH_OK) return false;
+  if (lh_cloud_create(ctx_, &vr, &r) != LH_OK) { lh_cloud_destroy(q); return false; }
+  std::vector<int64_t> c64(corr.begin(), corr.end());
+  lh_status st = lh_p2plane_information(ctx_, q, r, c64.data(), Ap);
+  lh_cloud_destroy(q);
+  lh_cloud_destroy(r);
+  return st == LH_OK;
+}
+
+bool PointCloudLocalization::ComputePoint2PlaneICPCovariance(const PointCloudF& query_cloud, const PointCloudF& reference_cloud,
+                                                             const std::vector<size_t>& correspondences, const float*,
+                                                             double covariance[36]) {  // :469-541
+  double Ap[36];
+  if (!ComputeAp(query_cloud, reference_cloud, correspondences, Ap)) return false;
+  return lh_icp_covariance(Ap, params_.icp_max_covariance, covariance, &condition_number_) == LH_OK;
+}
+
+void PointCloudLocalization::ComputeIcpObservability(const PointCloudF& query_cloud, const PointCloudF& reference_cloud,
+                                                     const std::vector<size_t>& correspondences, const float*, double eigenvectors[36],
+                                                     double eigenvalues[6], double A[36]) {  // :439-467
+  double Ap[36];
+  if (!ComputeAp(query_cloud, reference_cloud, correspondences, Ap)) return;
+  memcpy(A, Ap, sizeof(Ap));
+  // doEigenDecomp6x6 (utils.cc:130-142): cyclic Jacobi, ascending eigenvalues, eigenvectors in columns
+  const int n = 6;
+  double M[36], V[36];
+  memcpy(M, Ap, sizeof(M));
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j < n; j++) V[i * n + j] = (i == j);
+  for (int sweep = 0; sweep < 64; sweep++) {
+    double off = 0;
+    for (int i = 0; i < n; i++)
+      for (int j = i + 1; j < n; j++) off += M[i * n + j] * M[i * n + j];
+    if (off < 1e-300) break;
+    for (int p = 0; p < n; p++)
+      for (int q = p + 1; q < n; q++) {
+        double apq = M[p * n + q];
+        if (std::fabs(apq) < 1e-300) continue;
+        double theta = (M[q * n + q] - M[p * n + p]) / (2.0 * apq);
+        double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+        double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
+        for (int k = 0; k < n; k++) { double a = M[k * n + p], b = M[k * n + q]; M[k * n + p] = c * a - s * b; M[k * n + q] = s * a + c * b; }
+        for (int k = 0; k < n; k++) { double a = M[p * n + k], b = M[q * n + k]; M[p * n + k] = c * a - s * b; M[q * n + k] = s * a + c * b; }
+        for (int k = 0; k < n; k++) { double a = V[k * n + p], b = V[k * n + q]; V[k * n + p] = c * a - s * b; V[k * n + q] = s * a + c * b; }
+      }
+  }
+  int ord[6] = {0, 1, 2, 3, 4, 5};
+  for (int i = 0; i < n; i++)
+    for (int j = i + 1; j < n; j++)
+      if (M[ord[j] * n + ord[j]] < M[ord[i] * n + ord[i]]) std::swap(ord[i], ord[j]);
+  for (int i = 0; i < n; i++) {
+    eigenvalues[i] = M[ord[i] * n + ord[i]];
+    for (int k = 0; k < n; k++) eigenvectors[k * n + i] = V[k * n + ord[i]];
+  }
+}
+
+void PointCloudLocalization::SetIntegratedEstimate(const gu::Transform3& e) {  // :543-553
+  integrated_estimate_ = e;
+  incremental_estimate_ = gu::Transform3();
+}
+void PointCloudLocalization::GetLatestDeltaCovariance(double out[36]) {  // :771-774
+  std::lock_guard<std::mutex> lock(icp_covariance_mutex_);
+  memcpy(out, icp_covariance_, sizeof(icp_covariance_));
+}
+void PointCloudLocalization::SetFlatGroundAssumptionValue(const bool& value) {  // :429-437
+  b_is_flat_ground_assumption_ = value;
+  if (value) integrated_estimate_.rotation = gu::Rot3(0, 0, integrated_estimate_.rotation.Yaw());
+}
+PointCloudLocalization::Diagnostics PointCloudLocalization::GetDiagnostics() const {  // :752-769
+  return is_healthy_ ? Diagnostics{0, "Healthy"} : Diagnostics{2, "Non healthy - Null-pointer error."};
+}
+
+}  // namespace locus_hip

@@ -1,0 +1,162 @@
+// host_check.cc -- the reference's own gtest cases for the hot path, replayed against the C++ host mirror on a GPU
+// (test_point_cloud_odometry.cpp:280-305; test_point_cloud_localization.cpp:243-276, 288-507, 509-528).
+#include <cmath>
+#include <cstdio>
+#include <numeric>
+
+#include "PointCloudLocalization.hpp"
+#include "PointCloudOdometry.hpp"
+
+using namespace locus_hip;
+
+static int g_fail = 0;
+#define EXPECT(cond)                                                     \
+  do {                                                                   \
+    if (!(cond)) { printf("FAILED %s:%d  %s\n", __FILE__, __LINE__, #cond); g_fail++; } \
+  } while (0)
+#define EXPECT_NEAR(a, b, eps) EXPECT(std::fabs((double)(a) - (double)(b)) <= (eps))
+
+static PointCloudF::Ptr GenerateHollowCubic(lh_ctx* ctx, size_t nx = 10, size_t ny = 10, size_t nz = 10, float step = 0.1f) {
+  PointCloudF::Ptr pc(new PointCloudF);  // test_point_cloud_odometry.cpp:60-97
+  for (size_t ix = 0; ix < nx; ix++)
+    for (size_t iy = 0; iy < ny; iy++)
+      for (size_t iz = 0; iz < nz; iz++)
+        if (ix == 0 || iy == 0 || ix == nx - 1 || iy == ny - 1) {
+          PointF p;
+          p.x = ix * step; p.y = iy * step; p.z = iz * step;
+          pc->points.push_back(p);
+        }
+  std::vector<float> nrm(pc->size() * 4);
+  lh_cloud_view v = ViewOf(*pc);
+  v.off_normal = UINT32_MAX;
+  EXPECT(lh_normals_knn(ctx, &v, 5, nrm.data()) == LH_OK);  // ne.setKSearch(5)
+  for (size_t i = 0; i < pc->size(); i++) {
+    pc->points[i].normal_x = nrm[4 * i]; pc->points[i].normal_y = nrm[4 * i + 1]; pc->points[i].normal_z = nrm[4 * i + 2];
+  }
+  return pc;
+}
+
+static PointCloudF::Ptr GeneratePlane(size_t nx = 10, size_t ny = 10, float step = 0.1f) {
+  PointCloudF::Ptr pc(new PointCloudF);  // test_point_cloud_localization.cpp:26-42, normal (0,0,1)
+  for (size_t ix = 0; ix < nx; ix++)
+    for (size_t iy = 0; iy < ny; iy++) {
+      PointF p;
+      p.x = ix * step; p.y = iy * step; p.z = 0; p.normal_z = 1.0f;
+      pc->points.push_back(p);
+    }
+  return pc;
+}
+
+static void Inverse4(const float* Tc, double* inv /*row-major*/) {  // rigid inverse
+  double R[9], t[3];
+  for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) R[r * 3 + c] = Tc[c * 4 + r]; t[r] = Tc[12 + r]; }
+  for (int r = 0; r < 3; r++) {
+    for (int c = 0; c < 3; c++) inv[r * 4 + c] = R[c * 3 + r];
+    inv[r * 4 + 3] = -(R[0 * 3 + r] * t[0] + R[1 * 3 + r] * t[1] + R[2 * 3 + r] * t[2]);
+  }
+}
+
+int main() {
+  lh_ctx* ctx = nullptr;
+  if (lh_create(&ctx, 0) != LH_OK) { printf("no HIP device: the host mirror has no CPU fallback\n"); return 2; }
+  const double epsiliond = 1e-2, epsilion = 1e-4;
+
+  {  // TEST_F(PointCloudOdometryTest, UpdateEstimateUpdateICP)
+    PointCloudOdometry pco(ctx);
+    PointCloudOdometry::Config cfg;  // config/parameters.yaml + icp/num_threads 2
+    cfg.num_threads = 2;
+    auto pc_box = GenerateHollowCubic(ctx);
+    PointCloudF translated = *pc_box;
+    for (auto& p : translated.points) { p.x += 0.05f; p.y += 0.05f; p.normal_x = p.normal_y = p.normal_z = 0; }
+    EXPECT(pco.Initialize(cfg));
+    EXPECT(pco.GetDiagnostics().level == 2);
+    EXPECT(pco.SetLidar(*pc_box));
+    EXPECT(!pco.UpdateEstimate());
+    EXPECT(pco.SetLidar(translated));
+    EXPECT(pco.UpdateEstimate());
+    EXPECT(pco.icp_->hasConverged());
+    EXPECT(pco.icp_->getFitnessScore() < 0.1);
+    double inv[12];
+    Inverse4(pco.icp_->getFinalTransformation(), inv);
+    EXPECT_NEAR(inv[3], 0.05, epsiliond);
+    EXPECT_NEAR(inv[7], 0.05, epsiliond);
+    EXPECT_NEAR(inv[11], 0.0, epsiliond);
+    EXPECT(pco.GetDiagnostics().level == 0);
+    EXPECT_NEAR(pco.GetIntegratedEstimate().translation.x, pco.GetIncrementalEstimate().translation.x, 1e-12);
+    PointCloudF::Ptr last(new PointCloudF);
+    EXPECT(pco.GetLastPointCloud(last) && last->size() == translated.size());
+    // flat-ground + imu prior paths run
+    pco.SetFlatGroundAssumptionValue(true);
+    pco.EnableImuIntegration();
+    double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    pco.SetImuDelta(I3);
+    EXPECT(pco.SetLidar(*pc_box) && pco.UpdateEstimate());
+    EXPECT_NEAR(pco.GetIncrementalEstimate().translation.z, 0.0, 1e-12);
+  }
+
+  {  // TransformPointsToFixedFrame / ToSensorFrame (z = +-3) and the covariance KATs
+    PointCloudLocalization pcl_(ctx);
+    PointCloudLocalization::Config cfg;
+    cfg.num_threads = 2;
+    EXPECT(pcl_.Initialize(cfg));
+    gu::Transform3 e;
+    e.translation = gu::Vec3(0, 0, 3);
+    pcl_.SetIntegratedEstimate(e);
+    auto plane = GeneratePlane();
+    PointCloudF out, back;
+    EXPECT(pcl_.TransformPointsToFixedFrame(*plane, &out));
+    for (auto& p : out.points) { EXPECT_NEAR(p.z, 3.0, 1e-6); EXPECT_NEAR(p.normal_z, 1.0, 1e-6); }
+    EXPECT(pcl_.TransformPointsToSensorFrame(out, &back));
+    for (size_t i = 0; i < back.size(); i++) EXPECT_NEAR(back.points[i].z, 0.0, 1e-6);
+    EXPECT(!pcl_.TransformPointsToFixedFrame(*plane, NULL));
+
+    // ComputePoint2PlaneICPCovariance: single plane -> diag 0.01 (clamp)
+    std::vector<size_t> corr(plane->size());
+    std::iota(corr.begin(), corr.end(), 0);
+    float I16[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    double cov[36];
+    pcl_.ComputePoint2PlaneICPCovariance(*plane, *plane, corr, I16, cov);
+    for (int i = 0; i < 6; i++)
+      for (int j = 0; j < 6; j++) EXPECT_NEAR(cov[i * 6 + j], i == j ? 0.01 : 0.0, epsilion);
+    // observability eigenvalues of the plane: (0,0,0,56.7753,56.7753,100), Ap diag KAT
+    double evec[36], eval[6], A[36];
+    pcl_.ComputeIcpObservability(*plane, *plane, corr, I16, evec, eval, A);
+    EXPECT_NEAR(A[0], 56.7753, epsilion * 10); EXPECT_NEAR(A[7], 56.7753, epsilion * 10); EXPECT_NEAR(A[35], 100.0, epsilion);
+    EXPECT_NEAR(eval[0], 0, 1e-3); EXPECT_NEAR(eval[2], 0, 1e-3); EXPECT_NEAR(eval[3], 56.7753, 1e-3); EXPECT_NEAR(eval[5], 100.0, 1e-3);
+
+    // three orthogonal planes + yaw-30deg offset -> ~1e-6 on the diagonal
+    PointCloudF all = *plane, p1 = *plane, p2 = *plane;
+    for (auto& p : p1.points) { float y = p.y, z = p.z, ny = p.normal_y, nz = p.normal_z; p.y = -z; p.z = y; p.normal_y = -nz; p.normal_z = ny; }
+    for (auto& p : p2.points) { float x = p.x, z = p.z, nx = p.normal_x, nz = p.normal_z; p.x = z; p.z = -x; p.normal_x = nz; p.normal_z = -nx; }
+    all.points.insert(all.points.end(), p1.points.begin(), p1.points.end());
+    all.points.insert(all.points.end(), p2.points.begin(), p2.points.end());
+    PointCloudF offset = all;
+    for (auto& p : offset.points) {
+      float x = p.x, y = p.y, nx = p.normal_x, ny = p.normal_y;
+      p.x = 0.866f * x - 0.5f * y + 0.001f; p.y = 0.5f * x + 0.866f * y; p.z = 0;
+      p.normal_x = 0.866f * nx - 0.5f * ny; p.normal_y = 0.5f * nx + 0.866f * ny; p.normal_z = 0;
+    }
+    std::vector<size_t> corr2(all.size());
+    std::iota(corr2.begin(), corr2.end(), 0);
+    EXPECT(pcl_.ComputePoint2PlaneICPCovariance(offset, all, corr2, I16, cov));
+    for (int i = 0; i < 6; i++)
+      for (int j = 0; j < 6; j++) EXPECT_NEAR(cov[i * 6 + j], i == j ? 1e-6 : 0.0, epsilion);
+
+    // MeasurementUpdate: null output -> level 2; plane vs plane -> level 0
+    PointCloudF::Ptr q = GeneratePlane(), r = GeneratePlane();
+    EXPECT(!pcl_.MeasurementUpdate(q, r, NULL));
+    EXPECT(pcl_.GetDiagnostics().level == 2);
+    PointCloudF aligned;
+    EXPECT(pcl_.MeasurementUpdate(q, r, &aligned));
+    EXPECT(pcl_.GetDiagnostics().level == 0);
+    EXPECT(aligned.size() == q->size());
+    double dc[36];
+    pcl_.GetLatestDeltaCovariance(dc);
+    EXPECT_NEAR(dc[0], 0.01, epsilion);
+    EXPECT(pcl_.MotionUpdate(gu::Transform3()));
+  }
+
+  lh_destroy(ctx);
+  printf(g_fail ? "HOST_CHECK_FAILED (%d)\n" : "HOST_CHECK_OK\n", g_fail);
+  return g_fail ? 1 : 0;
+}

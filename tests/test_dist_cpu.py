@@ -1,0 +1,67 @@
+"""CPU suite: the N>1 path of bench.py (pair sharding, pose all_gather, max-over-ranks timing, trajectory chaining)
+under torch.distributed with the gloo backend, world_size 2."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from locus_amd import dist as ldist
+
+
+def test_shard_range_partitions_everything():
+    for n in (0, 1, 7, 16, 512, 513):
+        for world in (1, 2, 3, 8):
+            covered = []
+            for r in range(world):
+                lo, hi = ldist.shard_range(n, r, world)
+                covered += list(range(lo, hi))
+                assert hi - lo in (n // world, n // world + 1)
+            assert covered == list(range(n))
+
+
+def _fake_pose(i):
+    T = np.eye(4, dtype=np.float32)
+    T[:3, 3] = [0.1 * i, -0.01 * i, 0.0]
+    c, s = np.cos(0.01 * i), np.sin(0.01 * i)
+    T[:2, :2] = [[c, -s], [s, c]]
+    return np.ascontiguousarray(T.T).reshape(16)  # column-major like lh_gicp_result.T
+
+
+def _worker(rank, world, port, n_pairs, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    lo, hi = ldist.shard_range(n_pairs, rank, world)
+    local = np.stack([_fake_pose(i) for i in range(lo, hi)]) if hi > lo else np.zeros((0, 16), np.float32)
+    gathered = ldist.gather_poses(local, world)
+    t = ldist.max_over_ranks(1.0 + rank, world)
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, np.concatenate(gathered), t))
+
+
+@pytest.mark.parametrize("n_pairs", [5, 8])
+def test_two_rank_gather_over_gloo(n_pairs):
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_pairs, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    expect = np.stack([_fake_pose(i) for i in range(n_pairs)])
+    for rank, allposes, t in res:
+        assert np.array_equal(allposes, expect)  # every rank sees every pair, in pair order
+        assert t == 2.0                          # max over ranks
+    traj = ldist.chain_poses(res[0][1])
+    assert traj.shape == (n_pairs + 1, 4, 4)
+    assert np.allclose(traj[-1][:3, :3] @ traj[-1][:3, :3].T, np.eye(3), atol=1e-5)
