@@ -131,6 +131,29 @@ __global__ void __launch_bounds__(256) k_level_up(int l, Node4* __restrict__ nod
   nd.hix[c] = hx; nd.hiy[c] = hy; nd.hiz[c] = hz;
 }
 
+// levels l_top .. 0 in ONE workgroup (level l has 4^(l+1) <= 1024 (node, child) slots for l <= 4)
+__global__ void __launch_bounds__(1024) k_levels_top(int l_top, Node4* __restrict__ nodes) {
+  for (int l = l_top; l >= 0; l--) {
+    int cnt = 1 << (2 * l + 2);
+    int t = threadIdx.x;
+    if (t < cnt) {
+      int j = t >> 2, c = t & 3;
+      const Node4& ch = nodes[level_offset(l + 1) + 4 * j + c];
+      float lx = fminf(fminf(ch.lox[0], ch.lox[1]), fminf(ch.lox[2], ch.lox[3]));
+      float ly = fminf(fminf(ch.loy[0], ch.loy[1]), fminf(ch.loy[2], ch.loy[3]));
+      float lz = fminf(fminf(ch.loz[0], ch.loz[1]), fminf(ch.loz[2], ch.loz[3]));
+      float hx = fmaxf(fmaxf(ch.hix[0], ch.hix[1]), fmaxf(ch.hix[2], ch.hix[3]));
+      float hy = fmaxf(fmaxf(ch.hiy[0], ch.hiy[1]), fmaxf(ch.hiy[2], ch.hiy[3]));
+      float hz = fmaxf(fmaxf(ch.hiz[0], ch.hiz[1]), fmaxf(ch.hiz[2], ch.hiz[3]));
+      Node4& nd = nodes[level_offset(l) + j];
+      nd.lox[c] = lx; nd.loy[c] = ly; nd.loz[c] = lz;
+      nd.hix[c] = hx; nd.hiy[c] = hy; nd.hiz[c] = hz;
+    }
+    __threadfence_block();
+    __syncthreads();  // same workgroup wrote the level it reads next
+  }
+}
+
 void launch_bbox(const float4* xyz, int n, uint32_t* bbox, hipStream_t s) {
   hipLaunchKernelGGL(k_bbox_init, dim3(1), dim3(64), 0, s, bbox);
   int blocks = (n + 255) / 256;
@@ -147,17 +170,76 @@ void launch_build_nodes(const float4* sorted, int n, int depth, Node4* nodes, hi
   if (depth <= 0) return;
   int slots = 1 << (2 * depth);
   hipLaunchKernelGGL(k_leaf_level, dim3((slots + 255) / 256), dim3(256), 0, s, sorted, n, depth, nodes);
-  for (int l = depth - 2; l >= 0; l--) {
+  int l = depth - 2;
+  for (; l > 4; l--) {
     int cnt = 1 << (2 * l + 2);
     hipLaunchKernelGGL(k_level_up, dim3((cnt + 255) / 256), dim3(256), 0, s, l, nodes);
   }
+  if (l >= 0) hipLaunchKernelGGL(k_levels_top, dim3(1), dim3(1024), 0, s, l, nodes);
 }
 
 // ===== K4: NN + Mahalanobis sweep ==========================================================================
-__global__ void __launch_bounds__(256) k_sweep(const PairDesc* __restrict__ descs, SweepArgs a) {
-  const SweepJob& job = a.job[blockIdx.y];
+// XCD-aware workgroup -> (job, block) map.  The dispatcher places workgroup b on XCD b % 8 (observed, used for speed
+// only): all workgroups of one job are given ids congruent mod 8, so a job's tree (2 MB for 100 k points) is walked
+// from ONE XCD's 4-MB L2 instead of being pulled into all eight.
+// Only complete groups of 8 jobs are pinned; the remaining (njobs % 8) jobs -- e.g. a single lh_gicp_align -- use the
+// plain map and spread over all XCDs.
+__device__ __forceinline__ bool xcd_job_map(int njobs, int bpj, int& job, int& blk) {
+  int L = blockIdx.x;
+  int pinned = njobs & ~7;
+  int npin = pinned * bpj;
+  if (L < npin) {
+    int xcd = L & 7, s = L >> 3;
+    int jl = s / bpj;
+    blk = s - jl * bpj;
+    job = jl * 8 + xcd;
+    return true;
+  }
+  L -= npin;
+  int jl = L / bpj;
+  blk = L - jl * bpj;
+  job = pinned + jl;
+  return job < njobs;
+}
+static inline int xcd_grid(int njobs, int bpj) { return njobs * bpj; }
+
+// K2': seeds for a cold sweep.  One thread per group of SEED_GROUP consecutive source points runs the exact search for
+// the group's first point and hands its neighbour to the whole group as warm-start candidate (any target point is a
+// valid candidate, so exactness is untouched; consecutive lidar returns are spatial neighbours, so the bound is tight).
+__global__ void __launch_bounds__(256) k_seed(const PairDesc* __restrict__ descs, SweepArgs a) {
+  int jb, blk;
+  if (!xcd_job_map(a.njobs, a.bpj, jb, blk)) return;
+  const SweepJob& job = a.job[jb];
   const PairDesc d = descs[job.slot];
-  int i = blockIdx.x * 256 + threadIdx.x;
+  int g = blk * 256 + threadIdx.x;
+  int i = g * SEED_GROUP;
+  if (i >= d.n) return;
+  float4 p = d.src[i];
+  float qx, qy, qz;
+  xform_pt(job.T, p.x, p.y, p.z, qx, qy, qz);
+  TreeView tv{d.tgt_sorted, d.tgt_nodes, d.first_leaf, d.m};
+  Nn1Collector col{INFINITY, 0x7fffffff};
+  tree_search(tv, qx, qy, qz, col);
+  int j = (col.bi == 0x7fffffff) ? -1 : col.bi;
+#pragma unroll
+  for (int e = 0; e < SEED_GROUP; e++)
+    if (i + e < d.n) {
+      d.prev_nn[i + e] = j;
+      d.cert[i + e] = make_float4(0.f, 0.f, 0.f, 0.f);  // lower bound 0 => the certificate can never skip the search
+    }
+}
+void launch_seed(const PairDesc* descs, SweepArgs& a, int max_n, hipStream_t s) {
+  int groups = (max_n + SEED_GROUP - 1) / SEED_GROUP;
+  a.bpj = (groups + 255) / 256;
+  hipLaunchKernelGGL(k_seed, dim3(xcd_grid(a.njobs, a.bpj)), dim3(256), 0, s, descs, a);
+}
+
+__global__ void __launch_bounds__(256) k_sweep(const PairDesc* __restrict__ descs, SweepArgs a) {
+  int jb, blk;
+  if (!xcd_job_map(a.njobs, a.bpj, jb, blk)) return;
+  const SweepJob& job = a.job[jb];
+  const PairDesc d = descs[job.slot];
+  int i = blk * 256 + threadIdx.x;
   if (i >= d.n) return;
   float4 p = d.src[i];
   float qx, qy, qz;
@@ -221,8 +303,9 @@ __global__ void __launch_bounds__(256) k_sweep(const PairDesc* __restrict__ desc
   d.corr[i] = c;
 }
 
-void launch_sweep(const PairDesc* descs, const SweepArgs& a, int max_n, hipStream_t s) {
-  hipLaunchKernelGGL(k_sweep, dim3((max_n + 255) / 256, a.njobs), dim3(256), 0, s, descs, a);
+void launch_sweep(const PairDesc* descs, SweepArgs& a, int max_n, hipStream_t s) {
+  a.bpj = (max_n + 255) / 256;
+  hipLaunchKernelGGL(k_sweep, dim3(xcd_grid(a.njobs, a.bpj)), dim3(256), 0, s, descs, a);
 }
 
 // ===== K5: cost / gradient reduction =======================================================================
@@ -300,58 +383,85 @@ __global__ void __launch_bounds__(256) k_moments(const PairDesc* __restrict__ de
   double T0[12];
 #pragma unroll
   for (int k = 0; k < 12; k++) T0[k] = (double)job.T[k];
-#pragma unroll 1
-  for (int r = 0; r < MOM_CHUNK / 256; r++) {
-    int i = base + r * 256 + threadIdx.x;
+  // software-pipelined: the next point's 80 bytes are requested before the current point's ~110 double FMAs, so the
+  // single resident wave per SIMD (148 accumulator VGPRs) still overlaps HBM latency with arithmetic
+  struct Raw { float4 c, p; double m[6]; bool ok; };
+  auto load = [&](int i) {
+    Raw r;
+    r.ok = false;
+    r.c = make_float4(0.f, 0.f, 0.f, 0.f); r.p = r.c;
+#pragma unroll
+    for (int k = 0; k < 6; k++) r.m[k] = 0.0;
     if (i < d.n) {
-      float4 c = d.corr[i];
-      if (__float_as_int(c.w) >= 0) {
-        float4 p = d.src[i];
-        double pt[4] = {(double)p.x, (double)p.y, (double)p.z, 1.0};
-        double a0 = (((T0[0] * pt[0] + T0[1] * pt[1]) + T0[2] * pt[2]) + T0[3]) - (double)c.x;
-        double a1 = (((T0[4] * pt[0] + T0[5] * pt[1]) + T0[6] * pt[2]) + T0[7]) - (double)c.y;
-        double a2 = (((T0[8] * pt[0] + T0[9] * pt[1]) + T0[10] * pt[2]) + T0[11]) - (double)c.z;
-        double M6[6];
+      r.c = d.corr[i];
+      r.ok = __float_as_int(r.c.w) >= 0;
+      r.p = d.src[i];
+      if (r.ok) {
 #pragma unroll
-        for (int k = 0; k < 6; k++) M6[k] = d.maha6[(size_t)k * d.n_pad + i];
-        double Ma[3] = {(M6[0] * a0 + M6[1] * a1) + M6[2] * a2, (M6[1] * a0 + M6[3] * a1) + M6[4] * a2,
-                        (M6[2] * a0 + M6[4] * a1) + M6[5] * a2};
-        acc[0] += (a0 * Ma[0] + a1 * Ma[1]) + a2 * Ma[2];
-#pragma unroll
-        for (int rr = 0; rr < 3; rr++)
-#pragma unroll
-          for (int cc = 0; cc < 4; cc++) acc[1 + rr * 4 + cc] += Ma[rr] * pt[cc];
-        double pp[10];
-        {
-          int t = 0;
-#pragma unroll
-          for (int cc = 0; cc < 4; cc++)
-#pragma unroll
-            for (int ee = cc; ee < 4; ee++) pp[t++] = pt[cc] * pt[ee];
-        }
-#pragma unroll
-        for (int rs = 0; rs < 6; rs++)
-#pragma unroll
-          for (int ce = 0; ce < 10; ce++) acc[13 + rs * 10 + ce] += M6[rs] * pp[ce];
-        acc[73] += 1.0;
+        for (int k = 0; k < 6; k++) r.m[k] = d.maha6[(size_t)k * d.n_pad + i];
       }
     }
-  }
+    return r;
+  };
+  Raw cur = load(base + threadIdx.x);
+#pragma unroll 1
+  for (int r = 0; r < MOM_CHUNK / 256; r++) {
+    Raw nxt = load(base + (r + 1) * 256 + threadIdx.x < base + MOM_CHUNK ? base + (r + 1) * 256 + threadIdx.x : d.n);
+    if (cur.ok) {
+      double pt[4] = {(double)cur.p.x, (double)cur.p.y, (double)cur.p.z, 1.0};
+      double a0 = (((T0[0] * pt[0] + T0[1] * pt[1]) + T0[2] * pt[2]) + T0[3]) - (double)cur.c.x;
+      double a1 = (((T0[4] * pt[0] + T0[5] * pt[1]) + T0[6] * pt[2]) + T0[7]) - (double)cur.c.y;
+      double a2 = (((T0[8] * pt[0] + T0[9] * pt[1]) + T0[10] * pt[2]) + T0[11]) - (double)cur.c.z;
+      const double* M6 = cur.m;
+      double Ma[3] = {(M6[0] * a0 + M6[1] * a1) + M6[2] * a2, (M6[1] * a0 + M6[3] * a1) + M6[4] * a2,
+                      (M6[2] * a0 + M6[4] * a1) + M6[5] * a2};
+      acc[0] += (a0 * Ma[0] + a1 * Ma[1]) + a2 * Ma[2];
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
+      for (int rr = 0; rr < 3; rr++)
 #pragma unroll
-    for (int k = 0; k < MOM_NSUM; k++) acc[k] += __shfl_down(acc[k], off, 64);
-  }
-  __shared__ double sm[4][MOM_NSUM];
-  int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  if (lane == 0) {
+        for (int cc = 0; cc < 4; cc++) acc[1 + rr * 4 + cc] += Ma[rr] * pt[cc];
+      double pp[10];
+      {
+        int t = 0;
 #pragma unroll
-    for (int k = 0; k < MOM_NSUM; k++) sm[wave][k] = acc[k];
+        for (int cc = 0; cc < 4; cc++)
+#pragma unroll
+          for (int ee = cc; ee < 4; ee++) pp[t++] = pt[cc] * pt[ee];
+      }
+#pragma unroll
+      for (int rs = 0; rs < 6; rs++)
+#pragma unroll
+        for (int ce = 0; ce < 10; ce++) acc[13 + rs * 10 + ce] += M6[rs] * pp[ce];
+      acc[73] += 1.0;
+    }
+    cur = nxt;
   }
-  __syncthreads();
-  if (threadIdx.x < MOM_NSUM) {
-    double v = ((sm[0][threadIdx.x] + sm[1][threadIdx.x]) + sm[2][threadIdx.x]) + sm[3][threadIdx.x];
-    partials[(size_t)job.slot * partials_stride + (size_t)blockIdx.x * MOM_NSUM + threadIdx.x] = v;
+  // workgroup reduction through LDS in rounds of 16 values: [16][256] staging, fixed tree 256 -> 16 -> 1 per value
+  // (a 74-value shuffle tree costs ~900 ds_bpermute per wave; this costs ~5 x 48 LDS ops per thread)
+  __shared__ double st[16][256];
+  __shared__ double st2[16][16];
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int g = 0; g < (MOM_NSUM + 15) / 16; g++) {
+#pragma unroll
+    for (int v = 0; v < 16; v++)
+      if (g * 16 + v < MOM_NSUM) st[v][tid] = acc[g * 16 + v];
+    __syncthreads();
+    {
+      int v = tid >> 4, part = tid & 15;
+      double s = 0.0;
+#pragma unroll
+      for (int j = 0; j < 16; j++) s += st[v][j * 16 + part];
+      st2[v][part] = s;
+    }
+    __syncthreads();
+    if (tid < 16 && g * 16 + tid < MOM_NSUM) {
+      double s = 0.0;
+#pragma unroll
+      for (int j = 0; j < 16; j++) s += st2[tid][j];
+      partials[(size_t)job.slot * partials_stride + (size_t)blockIdx.x * MOM_NSUM + g * 16 + tid] = s;
+    }
+    __syncthreads();
   }
 }
 
@@ -363,7 +473,15 @@ __global__ void __launch_bounds__(128) k_moments_final(const PairDesc* __restric
   if (threadIdx.x < MOM_NSUM) {
     const double* p = partials + (size_t)job.slot * partials_stride + threadIdx.x;
     double s = 0.0;
-    for (int b = 0; b < nb; b++) s += p[(size_t)b * MOM_NSUM];  // block order => bitwise reproducible
+    int b = 0;
+    for (; b + 16 <= nb; b += 16) {  // 16 independent loads in flight, summed in block order => bitwise reproducible
+      double v[16];
+#pragma unroll
+      for (int k = 0; k < 16; k++) v[k] = p[(size_t)(b + k) * MOM_NSUM];
+#pragma unroll
+      for (int k = 0; k < 16; k++) s += v[k];
+    }
+    for (; b < nb; b++) s += p[(size_t)b * MOM_NSUM];
     out[job.out_offset + threadIdx.x] = s;
   }
 }

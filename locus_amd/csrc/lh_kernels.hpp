@@ -43,7 +43,7 @@ struct SweepJob {  // dynamic per-launch part
 };
 struct SweepArgs {
   int njobs;
-  int pad;
+  int bpj;         // workgroups per job
   SweepJob job[MAX_JOBS];
 };
 
@@ -71,7 +71,10 @@ void launch_gather_sorted(const float4* xyz, const uint32_t* vals, int n, int n_
 void launch_build_nodes(const float4* sorted, int n, int depth, Node4* nodes, hipStream_t s);
 
 // ---- K4 / K5 ---------------------------------------------------------------------------------------
-void launch_sweep(const PairDesc* descs, const SweepArgs& a, int max_n, hipStream_t s);
+void launch_sweep(const PairDesc* descs, SweepArgs& a, int max_n, hipStream_t s);
+// cold-start helper: exact NN of every 8th source point, written as the warm-start candidate of its 8-point group
+void launch_seed(const PairDesc* descs, SweepArgs& a, int max_n, hipStream_t s);
+constexpr int SEED_GROUP = 8;
 void launch_cost(const PairDesc* descs, const CostArgs& a, int max_n, double* out, hipStream_t s);
 inline int cost_blocks(int n) { return (n + COST_CHUNK - 1) / COST_CHUNK; }
 // second-order moments of the cost about T0 = job.T (see lh_bfgs.hpp MomentModel): per-block partials on the device,
