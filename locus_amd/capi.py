@@ -90,7 +90,7 @@ EXPORTS = [
     "lh_cloud_download", "lh_cloud_transform", "lh_gicp_create", "lh_gicp_destroy", "lh_gicp_set_params",
     "lh_gicp_set_source", "lh_gicp_set_target", "lh_gicp_set_source_cloud", "lh_gicp_set_target_cloud",
     "lh_gicp_promote_source_to_target", "lh_gicp_align", "lh_gicp_fitness", "lh_nn1", "lh_nn1_cloud", "lh_knn_cloud",
-    "lh_gicp_align_batch", "lh_cov_knn", "lh_gicp_debug_sweep", "lh_gicp_debug_stats", "lh_gicp_debug_cost", "lh_p2plane_information",
+    "lh_gicp_align_batch", "lh_cov_knn", "lh_gicp_debug_sweep", "lh_gicp_debug_stats", "lh_debug_traversal_stats", "lh_gicp_debug_cost", "lh_p2plane_information",
     "lh_icp_covariance", "lh_voxel_grid", "lh_normals_knn", "lh_normals_knn_cloud", "lh_profile_enable",
     "lh_profile_reset", "lh_profile_get",
 ]
@@ -144,6 +144,7 @@ def lib():
         L.lh_cov_knn.argtypes = [vp, i32, dbl, vp]
         L.lh_gicp_debug_sweep.argtypes = [vp, vp, vp, vp, vp]
         L.lh_gicp_debug_stats.argtypes = [vp, vp, i32]
+        L.lh_debug_traversal_stats.argtypes = [vp, vp, vp, vp]
         L.lh_gicp_debug_cost.argtypes = [vp, vp, C.POINTER(dbl), vp, vp, C.POINTER(i32)]
         L.lh_p2plane_information.argtypes = [vp, vp, vp, vp, vp]
         L.lh_icp_covariance.argtypes = [vp, dbl, vp, C.POINTER(dbl)]
@@ -350,6 +351,14 @@ class Cloud:
         d2 = np.empty((n, k), np.float32)
         _check(lib().lh_knn_cloud(self.h, query_cloud.h, k, _ptr(idx), _ptr(d2)), "lh_knn_cloud")
         return idx, d2
+
+    def traversal_stats(self, query_cloud, T16=None):
+        out = np.zeros(5, np.uint64)
+        T = np.ascontiguousarray(T16, np.float32).reshape(16) if T16 is not None else None
+        _check(lib().lh_debug_traversal_stats(self.h, query_cloud.h, _ptr(T), _ptr(out)), "lh_debug_traversal_stats")
+        n, w = len(query_cloud), int(out[3])
+        return {"nodes_per_query": out[0] / n, "leaves_per_query": out[1] / n, "wave_max_visits_avg": out[2] / max(w, 1),
+                "max_visits": int(out[4])}
 
     def cov_knn(self, k=20, eps=1e-3):
         cov = np.empty((len(self), 3, 3), np.float64)

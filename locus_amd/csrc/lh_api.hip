@@ -46,6 +46,14 @@ struct lh_ctx {
   void* sort_temp = nullptr;
   size_t sort_temp_bytes = 0;
   int scratch_n = 0;
+  // batched index build scratch
+  uint64_t *k64a = nullptr, *k64b = nullptr;
+  uint32_t *v32a = nullptr, *v32b = nullptr, *idx_bbox = nullptr;
+  void* sort64_temp = nullptr;
+  size_t sort64_temp_bytes = 0;
+  int idx_cap = 0;
+  IndexDesc *idx_descs_dev = nullptr, *idx_descs_host = nullptr;
+  hipEvent_t idx_copy_done = nullptr;
   // pair slots
   PairDesc* descs_dev = nullptr;   // [n_slots]
   PairDesc* descs_host = nullptr;  // pinned staging
@@ -162,41 +170,82 @@ static lh_status ctx_ensure_small(lh_ctx* c, size_t doubles) {
   return LH_OK;
 }
 
-// K2: Morton sort + implicit 4-ary box tree (replaces tree_->setInputCloud of pcl::Registration::initCompute)
-static lh_status cloud_build_index(lh_cloud* c) {
-  lh_ctx* x = c->ctx;
-  if (c->n <= 0) return LH_EINVAL;
-  lh_status st = ctx_ensure_scratch(x, c->n);
-  if (st) return st;
-  int n_leaves = (c->n + LEAF - 1) / LEAF;
-  int depth = 0;
-  while ((1ll << (2 * depth)) < n_leaves) depth++;
-  if (depth > MAX_DEPTH) return LH_EINVAL;
-  int n_padded = n_leaves * LEAF;
-  int n_nodes = (int)(((1ll << (2 * depth)) - 1) / 3);
-  if (n_padded > c->sorted_cap) {
-    (void)hipStreamSynchronize(x->stream);
-    (void)hipFree(c->sorted);
-    HIPCHK(hipMalloc(&c->sorted, sizeof(float4) * (size_t)n_padded));
-    c->sorted_cap = n_padded;
+// K2: Hilbert sort + implicit 4-ary box tree (replaces tree_->setInputCloud of pcl::Registration::initCompute).
+// All clouds of a batch are built by the same launches and one radix sort (see lh_kernels.hpp "K2 batched").
+static lh_status build_indices(lh_ctx* x, lh_cloud* const* clouds, int n_clouds) {
+  if (n_clouds <= 0) return LH_OK;
+  for (int o = 0; o < n_clouds; o += MAX_INDEX_BATCH) {
+    int nb = std::min(MAX_INDEX_BATCH, n_clouds - o);
+    long total = 0;
+    int max_n = 0, max_np = 0, max_depth = 0;
+    if (!x->idx_descs_dev) {
+      HIPCHK(hipMalloc(&x->idx_descs_dev, sizeof(IndexDesc) * MAX_INDEX_BATCH));
+      HIPCHK(hipHostMalloc(&x->idx_descs_host, sizeof(IndexDesc) * MAX_INDEX_BATCH, hipHostMallocDefault));
+      HIPCHK(hipMalloc(&x->idx_bbox, sizeof(uint32_t) * 8 * MAX_INDEX_BATCH));
+      HIPCHK(hipEventCreateWithFlags(&x->idx_copy_done, hipEventDisableTiming));
+    } else {
+      HIPCHK(hipEventSynchronize(x->idx_copy_done));  // the previous batch's descriptor upload left the staging buffer
+    }
+    for (int k = 0; k < nb; k++) {
+      lh_cloud* c = clouds[o + k];
+      if (!c || c->n <= 0 || c->ctx != x) return LH_EINVAL;
+      int n_leaves = (c->n + LEAF - 1) / LEAF;
+      int depth = 0;
+      while ((1ll << (2 * depth)) < n_leaves) depth++;
+      if (depth > MAX_DEPTH) return LH_EINVAL;
+      int n_padded = n_leaves * LEAF;
+      int n_nodes = (int)(((1ll << (2 * depth)) - 1) / 3);
+      if (n_padded > c->sorted_cap) {
+        (void)hipStreamSynchronize(x->stream);
+        (void)hipFree(c->sorted);
+        HIPCHK(hipMalloc(&c->sorted, sizeof(float4) * (size_t)n_padded));
+        c->sorted_cap = n_padded;
+      }
+      if (n_nodes > c->nodes_cap) {
+        (void)hipStreamSynchronize(x->stream);
+        (void)hipFree(c->nodes);
+        HIPCHK(hipMalloc(&c->nodes, sizeof(Node4) * (size_t)std::max(n_nodes, 1)));
+        c->nodes_cap = n_nodes;
+      }
+      c->depth = depth;
+      c->n_leaves = n_leaves;
+      c->first_leaf = n_nodes;
+      IndexDesc& d = x->idx_descs_host[k];
+      d.xyz = c->xyz; d.sorted = c->sorted; d.nodes = c->nodes;
+      d.n = c->n; d.n_padded = n_padded; d.depth = depth; d.offset = (int)total;
+      total += c->n;
+      max_n = std::max(max_n, c->n);
+      max_np = std::max(max_np, n_padded);
+      max_depth = std::max(max_depth, depth);
+    }
+    if (total > 0x7fffffffL) return LH_EINVAL;
+    if ((int)total > x->idx_cap) {
+      (void)hipStreamSynchronize(x->stream);
+      (void)hipFree(x->k64a); (void)hipFree(x->k64b); (void)hipFree(x->v32a); (void)hipFree(x->v32b); (void)hipFree(x->sort64_temp);
+      int cap = round_up((int)std::min<long>(total + total / 4, 0x7fffff00L), 1024);
+      HIPCHK(hipMalloc(&x->k64a, sizeof(uint64_t) * (size_t)cap));
+      HIPCHK(hipMalloc(&x->k64b, sizeof(uint64_t) * (size_t)cap));
+      HIPCHK(hipMalloc(&x->v32a, sizeof(uint32_t) * (size_t)cap));
+      HIPCHK(hipMalloc(&x->v32b, sizeof(uint32_t) * (size_t)cap));
+      x->sort64_temp_bytes = sort64_temp_bytes(cap);
+      HIPCHK(hipMalloc(&x->sort64_temp, x->sort64_temp_bytes ? x->sort64_temp_bytes : 16));
+      x->idx_cap = cap;
+    }
+    hipStream_t s = x->stream;
+    HIPCHK(hipMemcpyAsync(x->idx_descs_dev, x->idx_descs_host, sizeof(IndexDesc) * nb, hipMemcpyHostToDevice, s));
+    HIPCHK(hipEventRecord(x->idx_copy_done, s));
+    int id_bits = 0;
+    while ((1 << id_bits) < nb) id_bits++;
+    { ProfScope p(x, "index_bbox_keys", 16.0 * total * 2); launch_index_keys(x->idx_descs_dev, nb, max_n, x->idx_bbox, x->k64a, x->v32a, s); }
+    { ProfScope p(x, "index_radix_sort", 12.0 * total * 2 * 4);
+      sort_pairs_u64(x->sort64_temp, x->sort64_temp_bytes, x->k64a, x->k64b, x->v32a, x->v32b, (int)total, 32 + id_bits, s); }
+    { ProfScope p(x, "index_gather_boxes", 32.0 * total); launch_index_trees(x->idx_descs_dev, nb, max_np, max_depth, x->v32b, s); }
+    HIPCHK(hipGetLastError());
+    for (int k = 0; k < nb; k++) clouds[o + k]->has_index = true;
   }
-  if (n_nodes > c->nodes_cap) {
-    (void)hipStreamSynchronize(x->stream);
-    (void)hipFree(c->nodes);
-    HIPCHK(hipMalloc(&c->nodes, sizeof(Node4) * (size_t)std::max(n_nodes, 1)));
-    c->nodes_cap = n_nodes;
-  }
-  c->depth = depth;
-  c->n_leaves = n_leaves;
-  c->first_leaf = n_nodes;
-  hipStream_t s = x->stream;
-  { ProfScope p(x, "index_bbox_morton", 16.0 * c->n * 2); launch_bbox(c->xyz, c->n, x->bbox, s); launch_morton(c->xyz, c->n, x->bbox, x->keys0, x->vals0, s); }
-  { ProfScope p(x, "index_radix_sort", 8.0 * c->n * 2 * 4); sort_pairs_u32(x->sort_temp, x->sort_temp_bytes, x->keys0, x->keys1, x->vals0, x->vals1, c->n, 30, s); }
-  { ProfScope p(x, "index_gather_boxes", 32.0 * c->n); launch_gather_sorted(c->xyz, x->vals1, c->n, n_padded, c->sorted, s); launch_build_nodes(c->sorted, c->n, depth, c->nodes, s); }
-  HIPCHK(hipGetLastError());
-  c->has_index = true;
   return LH_OK;
 }
+static lh_status cloud_build_index(lh_cloud* c) { return build_indices(c->ctx, &c, 1); }
 
 static lh_status cloud_ensure_cov(lh_cloud* c, int k, double eps) {
   if (c->cov6 && c->cov_k == k && c->cov_eps == eps) return LH_OK;
@@ -433,7 +482,10 @@ static lh_status task_prepare(lh_ctx* c, Task* t, bool rebuild_index) {
     launch_transform(src->xyz, nullptr, src->n, T12, t->ws->out_xyz, nullptr, c->stream);
     out = t->ws->out_xyz;
   }
-  { ProfScope p(c, "fill", 4.0 * src->n); launch_fill_i32(t->ws->prev_nn, src->n, -1, c->stream); }
+  if (t->count_stats) {  // debug sweeps run without the seed pre-pass: start from "no candidate"
+    ProfScope p(c, "fill", 4.0 * src->n);
+    launch_fill_i32(t->ws->prev_nn, src->n, -1, c->stream);
+  }
   PairDesc& d = c->descs_host[t->slot];
   d.src = out;
   d.src_nrm = P.recompute_source_cov ? nullptr : src->nrm;
@@ -470,13 +522,27 @@ static lh_status run_tasks(lh_ctx* c, std::vector<Task*>& tasks, int in_flight, 
   for (int s = in_flight - 1; s >= 0; s--) free_slots.push_back(s);
   lh_status err = LH_OK;
   while (next < tasks.size() || !active.empty()) {
-    // admit new pairs
+    // admit new pairs: the NN indexes of all newly admitted targets are built together (batched launches + one sort)
+    {
+      std::vector<lh_cloud*> to_build;
+      size_t nn = next;
+      for (size_t k = 0; k < free_slots.size() && nn < tasks.size(); k++, nn++) {
+        lh_cloud* tg = tasks[nn]->tgt;
+        if (tg && tg->n > 0 && (rebuild_index || !tg->has_index) &&
+            std::find(to_build.begin(), to_build.end(), tg) == to_build.end())
+          to_build.push_back(tg);
+      }
+      if (!to_build.empty()) {
+        lh_status st = build_indices(c, to_build.data(), (int)to_build.size());
+        if (st) return st;
+      }
+    }
     while (next < tasks.size() && !free_slots.empty()) {
       Task* t = tasks[next++];
       t->slot = free_slots.back();
       free_slots.pop_back();
       if (slot_ws) t->ws = &(*slot_ws)[t->slot];  // batch mode: workspaces belong to slots
-      lh_status st = task_prepare(c, t, rebuild_index);
+      lh_status st = task_prepare(c, t, false);
       if (st) {
         memset(&t->result, 0, sizeof(t->result));
         memcpy(t->result.T, I16, sizeof(I16));
@@ -730,6 +796,10 @@ void lh_destroy(lh_ctx* c) {
   c->prof_flush();
   for (auto e : c->ev_pool) (void)hipEventDestroy(e);
   (void)hipFree(c->keys0); (void)hipFree(c->keys1); (void)hipFree(c->vals0); (void)hipFree(c->vals1);
+  (void)hipFree(c->k64a); (void)hipFree(c->k64b); (void)hipFree(c->v32a); (void)hipFree(c->v32b); (void)hipFree(c->sort64_temp);
+  (void)hipFree(c->idx_bbox); (void)hipFree(c->idx_descs_dev);
+  if (c->idx_descs_host) (void)hipHostFree(c->idx_descs_host);
+  if (c->idx_copy_done) (void)hipEventDestroy(c->idx_copy_done);
   (void)hipFree(c->sort_temp); (void)hipFree(c->bbox); (void)hipFree(c->descs_dev); (void)hipFree(c->mom_partials_dev);
   if (c->descs_host) (void)hipHostFree(c->descs_host);
   if (c->partials_host) (void)hipHostFree(c->partials_host);
@@ -1106,6 +1176,23 @@ lh_status lh_gicp_debug_stats(lh_gicp* g, uint64_t out[2], int reset) {
   HIPCHK(hipStreamSynchronize(g->ctx->stream));
   HIPCHK(hipMemcpy(out, g->ws.stats, 16, hipMemcpyDeviceToHost));
   if (reset) HIPCHK(hipMemset(g->ws.stats, 0, 16));
+  return LH_OK;
+}
+
+lh_status lh_debug_traversal_stats(lh_cloud* target, const lh_cloud* q, const float T[16], uint64_t out[5]) {
+  if (!target || !q || !out || target->ctx != q->ctx) return LH_EINVAL;
+  lh_ctx* c = target->ctx;
+  HIPCHK(hipSetDevice(c->device));
+  if (!target->has_index) { lh_status st = cloud_build_index(target); if (st) return st; }
+  unsigned long long* d = nullptr;
+  HIPCHK(hipMalloc(&d, 40));
+  HIPCHK(hipMemsetAsync(d, 0, 40, c->stream));
+  float T12[12];
+  if (T) fill_T12(T, T12);
+  launch_nn1_stats(q->xyz, q->n, T ? T12 : nullptr, target->view(), d, c->stream);
+  HIPCHK(hipMemcpyAsync(out, d, 40, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  (void)hipFree(d);
   return LH_OK;
 }
 

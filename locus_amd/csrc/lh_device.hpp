@@ -4,7 +4,7 @@
 // the CPU against brute force; the product only ever calls them from HIP kernels (lh_kernels.hip).
 //
 // NN index ("K2", replaces the FLANN kd-tree built by tree_->setInputCloud in pcl::Registration::initCompute):
-//   * target points are sorted by 30-bit Morton code; leaf L owns sorted points [8L, 8L+8)
+//   * target points are sorted by a 30-bit Hilbert-curve index; leaf L owns sorted points [8L, 8L+8)
 //   * an implicit complete 4-ary tree sits on the leaves (heap numbering: children of node i are 4i+1..4i+4);
 //     an internal node stores the float AABBs of its 4 children as SoA (96 B = six float4 loads)
 //   * sorted point = float4(x, y, z, bitcast(original index)) so one 16-B load yields position + id
@@ -85,6 +85,41 @@ LH_HD uint32_t expand10(uint32_t v) {  // 10 bits -> every third bit
 }
 LH_HD uint32_t morton30(uint32_t ix, uint32_t iy, uint32_t iz) { return (expand10(ix) << 2) | (expand10(iy) << 1) | expand10(iz); }
 
+// 30-bit 3-D Hilbert index of 10-bit cell coordinates (Skilling's axes-to-transpose transform, then bit interleave).
+// A contiguous run of a Hilbert curve is a compact connected region, so the implicit tree's equal-count splits of the
+// sorted array give tight boxes at every level; a Z-order (Morton) run can straddle the curve's long jumps.
+LH_HD uint32_t hilbert30(uint32_t x0, uint32_t x1, uint32_t x2) {
+  uint32_t X[3] = {x0 & 0x3ffu, x1 & 0x3ffu, x2 & 0x3ffu};
+  const uint32_t M = 1u << 9;
+  for (uint32_t Q = M; Q > 1; Q >>= 1) {
+    uint32_t P = Q - 1;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      if (X[i] & Q) X[0] ^= P;
+      else { uint32_t t = (X[0] ^ X[i]) & P; X[0] ^= t; X[i] ^= t; }
+    }
+  }
+  X[1] ^= X[0];
+  X[2] ^= X[1];
+  uint32_t t = 0;
+  for (uint32_t Q = M; Q > 1; Q >>= 1)
+    if (X[2] & Q) t ^= Q - 1;
+  X[0] ^= t; X[1] ^= t; X[2] ^= t;
+  return morton30(X[0], X[1], X[2]);
+}
+
+// sort key of a point given the cloud's bounding box (shared by the build kernel and the host-side traversal check)
+LH_HD uint32_t spatial_key30(float px, float py, float pz, float lx, float ly, float lz, float hx, float hy, float hz) {
+  // one isotropic cell size so cells are cubes
+  float ext = fmaxf(fmaxf(hx - lx, hy - ly), fmaxf(hz - lz, 1e-30f));
+  float sc = 1023.999f / ext;
+  int ix = (int)((px - lx) * sc), iy = (int)((py - ly) * sc), iz = (int)((pz - lz) * sc);
+  ix = ix < 0 ? 0 : (ix > 1023 ? 1023 : ix);
+  iy = iy < 0 ? 0 : (iy > 1023 ? 1023 : iy);
+  iz = iz < 0 ? 0 : (iz > 1023 ? 1023 : iz);
+  return hilbert30((uint32_t)ix, (uint32_t)iy, (uint32_t)iz);
+}
+
 LH_HD void cswap(uint64_t& a, uint64_t& b) {
   uint64_t lo = a < b ? a : b, hi = a < b ? b : a;
   a = lo; b = hi;
@@ -101,6 +136,7 @@ LH_HD void tree_search(const TreeView& t, float qx, float qy, float qz, Collecto
   const uint64_t INVALID = ~0ull;
   for (;;) {
     if (lin < t.first_leaf) {
+      col.count_node();
       const Node4& nd = t.nodes[lin];
       float4 lx = *reinterpret_cast<const float4*>(nd.lox), ly = *reinterpret_cast<const float4*>(nd.loy),
              lz = *reinterpret_cast<const float4*>(nd.loz), hx = *reinterpret_cast<const float4*>(nd.hix),
@@ -123,6 +159,7 @@ LH_HD void tree_search(const TreeView& t, float qx, float qy, float qz, Collecto
       if (k1 != INVALID) stack[sp++] = k1;
       if (k0 != INVALID) { lin = (int)(uint32_t)k0; continue; }
     } else {
+      col.count_leaf();
       const float4* p = t.pts + (size_t)(lin - t.first_leaf) * LEAF;
 #pragma unroll
       for (int e = 0; e < LEAF; e++) {
@@ -150,6 +187,22 @@ struct Nn1Collector {
     if (d < bd || (d == bd && id < bi)) { bd = d; bi = id; }
   }
   LH_HD void skip(float) {}
+  LH_HD void count_node() {}
+  LH_HD void count_leaf() {}
+};
+
+// instrumented 1-NN (lh_debug_traversal_stats): counts node / leaf visits of the query
+struct Nn1CountCollector {
+  float bd;
+  int bi;
+  int nodes, leaves;
+  LH_HD float bound() const { return bd; }
+  LH_HD void offer(float d, int id) {
+    if (d < bd || (d == bd && id < bi)) { bd = d; bi = id; }
+  }
+  LH_HD void skip(float) {}
+  LH_HD void count_node() { nodes++; }
+  LH_HD void count_leaf() { leaves++; }
 };
 
 // 1-NN plus a certificate: `lb` = lower bound on the squared distance of every point other than the winner
@@ -172,6 +225,8 @@ struct Nn1CertCollector {
     }
   }
   LH_HD void skip(float d) { lb = fminf(lb, d); }
+  LH_HD void count_node() {}
+  LH_HD void count_leaf() {}
 };
 
 // k best (d2, id) ascending, lexicographic; storage strided so that a workgroup can keep the lists in LDS
@@ -182,6 +237,8 @@ struct KnnCollector {
   int k, stride, cnt;
   LH_HD float bound() const { return cnt < k ? inf_f() : kd[(k - 1) * stride]; }
   LH_HD void skip(float) {}
+  LH_HD void count_node() {}
+  LH_HD void count_leaf() {}
   LH_HD void offer(float d, int id) {
     if (id == 0x7fffffff) return;  // padding point
     if (cnt == k) {

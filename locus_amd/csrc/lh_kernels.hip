@@ -63,14 +63,8 @@ __global__ void __launch_bounds__(256) k_morton(const float4* __restrict__ xyz, 
   if (i >= n) return;
   float lx = dec_ordered(bbox[0]), ly = dec_ordered(bbox[1]), lz = dec_ordered(bbox[2]);
   float hx = dec_ordered(bbox[3]), hy = dec_ordered(bbox[4]), hz = dec_ordered(bbox[5]);
-  // one isotropic cell size so Morton cells are cubes (better boxes than per-axis scaling)
-  float ext = fmaxf(fmaxf(hx - lx, hy - ly), fmaxf(hz - lz, 1e-30f));
-  float sc = 1023.999f / ext;
   float4 p = xyz[i];
-  int ix = min(1023, max(0, (int)((p.x - lx) * sc)));
-  int iy = min(1023, max(0, (int)((p.y - ly) * sc)));
-  int iz = min(1023, max(0, (int)((p.z - lz) * sc)));
-  keys[i] = morton30((uint32_t)ix, (uint32_t)iy, (uint32_t)iz);
+  keys[i] = spatial_key30(p.x, p.y, p.z, lx, ly, lz, hx, hy, hz);
   vals[i] = (uint32_t)i;
 }
 
@@ -152,6 +146,137 @@ __global__ void __launch_bounds__(1024) k_levels_top(int l_top, Node4* __restric
     __threadfence_block();
     __syncthreads();  // same workgroup wrote the level it reads next
   }
+}
+
+// ----- batched index build -----------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_bbox_init_b(uint32_t* bbox, int n_clouds) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_clouds * 8) return;
+  int slot = t & 7;
+  bbox[t] = slot < 3 ? 0xffffffffu : 0u;
+}
+__global__ void __launch_bounds__(256) k_bbox_b(const IndexDesc* __restrict__ descs, uint32_t* bbox) {
+  const IndexDesc d = descs[blockIdx.y];
+  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < d.n; i += gridDim.x * blockDim.x) {
+    float4 p = d.xyz[i];
+    lo[0] = fminf(lo[0], p.x); hi[0] = fmaxf(hi[0], p.x);
+    lo[1] = fminf(lo[1], p.y); hi[1] = fmaxf(hi[1], p.y);
+    lo[2] = fminf(lo[2], p.z); hi[2] = fmaxf(hi[2], p.z);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      lo[a] = fminf(lo[a], __shfl_down(lo[a], off, 64));
+      hi[a] = fmaxf(hi[a], __shfl_down(hi[a], off, 64));
+    }
+  }
+  __shared__ float sm[4][6];
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int a = 0; a < 3; a++) { sm[threadIdx.x >> 6][a] = lo[a]; sm[threadIdx.x >> 6][3 + a] = hi[a]; }
+  }
+  __syncthreads();
+  uint32_t* bb = bbox + blockIdx.y * 8;
+  if (threadIdx.x < 3)
+    atomicMin(&bb[threadIdx.x], enc_ordered(fminf(fminf(sm[0][threadIdx.x], sm[1][threadIdx.x]), fminf(sm[2][threadIdx.x], sm[3][threadIdx.x]))));
+  else if (threadIdx.x < 6)
+    atomicMax(&bb[threadIdx.x], enc_ordered(fmaxf(fmaxf(sm[0][threadIdx.x], sm[1][threadIdx.x]), fmaxf(sm[2][threadIdx.x], sm[3][threadIdx.x]))));
+}
+__global__ void __launch_bounds__(256) k_key_b(const IndexDesc* __restrict__ descs, const uint32_t* __restrict__ bbox,
+                                               uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+  const IndexDesc d = descs[blockIdx.y];
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= d.n) return;
+  const uint32_t* bb = bbox + blockIdx.y * 8;
+  float4 p = d.xyz[i];
+  uint32_t k = spatial_key30(p.x, p.y, p.z, dec_ordered(bb[0]), dec_ordered(bb[1]), dec_ordered(bb[2]), dec_ordered(bb[3]),
+                             dec_ordered(bb[4]), dec_ordered(bb[5]));
+  keys[d.offset + i] = ((uint64_t)blockIdx.y << 32) | k;
+  vals[d.offset + i] = (uint32_t)(d.offset + i);
+}
+__global__ void __launch_bounds__(256) k_gather_b(const IndexDesc* __restrict__ descs, const uint32_t* __restrict__ vals) {
+  const IndexDesc d = descs[blockIdx.y];
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= d.n_padded) return;
+  float4 o;
+  if (i < d.n) {
+    uint32_t j = vals[d.offset + i] - (uint32_t)d.offset;
+    float4 p = d.xyz[j];
+    o = make_float4(p.x, p.y, p.z, __uint_as_float(j));
+  } else {
+    o = make_float4(INFINITY, INFINITY, INFINITY, __uint_as_float(0x7fffffffu));
+  }
+  d.sorted[i] = o;
+}
+__global__ void __launch_bounds__(256) k_leaf_level_b(const IndexDesc* __restrict__ descs) {
+  const IndexDesc d = descs[blockIdx.y];
+  if (d.depth <= 0) return;
+  int L = blockIdx.x * blockDim.x + threadIdx.x;
+  int slots = 1 << (2 * d.depth);
+  if (L >= slots) return;
+  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  int base = L * LEAF;
+#pragma unroll
+  for (int e = 0; e < LEAF; e++) {
+    if (base + e < d.n) {
+      float4 p = d.sorted[base + e];
+      lo[0] = fminf(lo[0], p.x); hi[0] = fmaxf(hi[0], p.x);
+      lo[1] = fminf(lo[1], p.y); hi[1] = fmaxf(hi[1], p.y);
+      lo[2] = fminf(lo[2], p.z); hi[2] = fmaxf(hi[2], p.z);
+    }
+  }
+  Node4& nd = d.nodes[level_offset(d.depth - 1) + (L >> 2)];
+  int c = L & 3;
+  nd.lox[c] = lo[0]; nd.loy[c] = lo[1]; nd.loz[c] = lo[2];
+  nd.hix[c] = hi[0]; nd.hiy[c] = hi[1]; nd.hiz[c] = hi[2];
+}
+__device__ __forceinline__ void level_up_slot(Node4* nodes, int l, int t) {
+  int j = t >> 2, c = t & 3;
+  const Node4& ch = nodes[level_offset(l + 1) + 4 * j + c];
+  float lx = fminf(fminf(ch.lox[0], ch.lox[1]), fminf(ch.lox[2], ch.lox[3]));
+  float ly = fminf(fminf(ch.loy[0], ch.loy[1]), fminf(ch.loy[2], ch.loy[3]));
+  float lz = fminf(fminf(ch.loz[0], ch.loz[1]), fminf(ch.loz[2], ch.loz[3]));
+  float hx = fmaxf(fmaxf(ch.hix[0], ch.hix[1]), fmaxf(ch.hix[2], ch.hix[3]));
+  float hy = fmaxf(fmaxf(ch.hiy[0], ch.hiy[1]), fmaxf(ch.hiy[2], ch.hiy[3]));
+  float hz = fmaxf(fmaxf(ch.hiz[0], ch.hiz[1]), fmaxf(ch.hiz[2], ch.hiz[3]));
+  Node4& nd = nodes[level_offset(l) + j];
+  nd.lox[c] = lx; nd.loy[c] = ly; nd.loz[c] = lz;
+  nd.hix[c] = hx; nd.hiy[c] = hy; nd.hiz[c] = hz;
+}
+__global__ void __launch_bounds__(256) k_level_up_b(const IndexDesc* __restrict__ descs, int l) {
+  const IndexDesc d = descs[blockIdx.y];
+  if (l > d.depth - 2) return;
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (1 << (2 * l + 2))) return;
+  level_up_slot(d.nodes, l, t);
+}
+__global__ void __launch_bounds__(1024) k_levels_top_b(const IndexDesc* __restrict__ descs) {
+  const IndexDesc d = descs[blockIdx.x];
+  int l_top = min(d.depth - 2, 4);
+  for (int l = l_top; l >= 0; l--) {
+    if ((int)threadIdx.x < (1 << (2 * l + 2))) level_up_slot(d.nodes, l, threadIdx.x);
+    __threadfence_block();
+    __syncthreads();
+  }
+}
+void launch_index_keys(const IndexDesc* descs, int n_clouds, int max_n, uint32_t* bbox, uint64_t* keys, uint32_t* vals, hipStream_t s) {
+  hipLaunchKernelGGL(k_bbox_init_b, dim3((n_clouds * 8 + 255) / 256), dim3(256), 0, s, bbox, n_clouds);
+  int blocks = (max_n + 255) / 256;
+  hipLaunchKernelGGL(k_bbox_b, dim3(blocks > 128 ? 128 : blocks, n_clouds), dim3(256), 0, s, descs, bbox);
+  hipLaunchKernelGGL(k_key_b, dim3(blocks, n_clouds), dim3(256), 0, s, descs, bbox, keys, vals);
+}
+void launch_index_trees(const IndexDesc* descs, int n_clouds, int max_n_padded, int max_depth, const uint32_t* vals_sorted, hipStream_t s) {
+  hipLaunchKernelGGL(k_gather_b, dim3((max_n_padded + 255) / 256, n_clouds), dim3(256), 0, s, descs, vals_sorted);
+  if (max_depth <= 0) return;
+  int slots = 1 << (2 * max_depth);
+  hipLaunchKernelGGL(k_leaf_level_b, dim3((slots + 255) / 256, n_clouds), dim3(256), 0, s, descs);
+  for (int l = max_depth - 2; l > 4; l--) {
+    int cnt = 1 << (2 * l + 2);
+    hipLaunchKernelGGL(k_level_up_b, dim3((cnt + 255) / 256, n_clouds), dim3(256), 0, s, descs, l);
+  }
+  if (max_depth >= 2) hipLaunchKernelGGL(k_levels_top_b, dim3(n_clouds), dim3(1024), 0, s, descs);
 }
 
 void launch_bbox(const float4* xyz, int n, uint32_t* bbox, hipStream_t s) {
@@ -539,6 +664,38 @@ void launch_nn1(const float4* q, int nq, const float* T12p, TreeView tree, int32
   T12 T;
   for (int k = 0; k < 12; k++) T.v[k] = T12p ? T12p[k] : 0.f;
   hipLaunchKernelGGL(k_nn1, dim3((nq + 255) / 256), dim3(256), 0, s, q, nq, T, T12p ? 1 : 0, tree, idx, d2);
+}
+
+__global__ void __launch_bounds__(256) k_nn1_stats(const float4* __restrict__ q, int nq, T12 T, int has_T, TreeView tv,
+                                                   unsigned long long* __restrict__ stats) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  int nodes = 0, leaves = 0;
+  if (i < nq) {
+    float4 p = q[i];
+    float x = p.x, y = p.y, z = p.z;
+    if (has_T) xform_pt(T.v, p.x, p.y, p.z, x, y, z);
+    Nn1CountCollector col{INFINITY, 0x7fffffff, 0, 0};
+    tree_search(tv, x, y, z, col);
+    nodes = col.nodes; leaves = col.leaves;
+  }
+  int tot = nodes + leaves, mx = tot, sn = nodes, sl = leaves;
+  for (int off = 32; off > 0; off >>= 1) {
+    mx = max(mx, __shfl_down(mx, off, 64));
+    sn += __shfl_down(sn, off, 64);
+    sl += __shfl_down(sl, off, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(&stats[0], (unsigned long long)sn);
+    atomicAdd(&stats[1], (unsigned long long)sl);
+    atomicAdd(&stats[2], (unsigned long long)mx);
+    atomicAdd(&stats[3], 1ull);
+    atomicMax(&stats[4], (unsigned long long)mx);
+  }
+}
+void launch_nn1_stats(const float4* q, int nq, const float* T12p, TreeView tree, unsigned long long* stats, hipStream_t s) {
+  T12 T;
+  for (int k = 0; k < 12; k++) T.v[k] = T12p ? T12p[k] : 0.f;
+  hipLaunchKernelGGL(k_nn1_stats, dim3((nq + 255) / 256), dim3(256), 0, s, q, nq, T, T12p ? 1 : 0, tree, stats);
 }
 
 // double sum of floats: 1024 values per block, fixed tree

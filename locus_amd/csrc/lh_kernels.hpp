@@ -70,6 +70,23 @@ void launch_gather_sorted(const float4* xyz, const uint32_t* vals, int n, int n_
 // builds all internal levels; depth = number of internal levels (4^depth >= n_leaves)
 void launch_build_nodes(const float4* sorted, int n, int depth, Node4* nodes, hipStream_t s);
 
+// ---- K2 batched: the indexes of several clouds are built by the same launches (grid.y = cloud) and ONE radix sort of
+// the concatenated 64-bit keys (cloud id << 32 | 30-bit Hilbert index); the per-pair build was launch-bound.
+struct IndexDesc {
+  const float4* xyz;
+  float4* sorted;
+  Node4* nodes;
+  int n, n_padded, depth, offset;  // offset = start of this cloud in the concatenated key/value arrays
+};
+constexpr int MAX_INDEX_BATCH = 64;
+size_t sort64_temp_bytes(int n);
+void sort_pairs_u64(void* temp, size_t temp_bytes, const uint64_t* keys_in, uint64_t* keys_out, const uint32_t* vals_in,
+                    uint32_t* vals_out, int n, int end_bit, hipStream_t s);
+void launch_index_keys(const IndexDesc* descs, int n_clouds, int max_n, uint32_t* bbox_enc /*[n_clouds][8]*/, uint64_t* keys,
+                       uint32_t* vals, hipStream_t s);
+void launch_index_trees(const IndexDesc* descs, int n_clouds, int max_n_padded, int max_depth, const uint32_t* vals_sorted,
+                        hipStream_t s);
+
 // ---- K4 / K5 ---------------------------------------------------------------------------------------
 void launch_sweep(const PairDesc* descs, SweepArgs& a, int max_n, hipStream_t s);
 // cold-start helper: exact NN of every 8th source point, written as the warm-start candidate of its 8-point group
@@ -89,6 +106,9 @@ void launch_transform(const float4* in_xyz, const float4* in_nrm, int n, const f
 void launch_fill_i32(int32_t* p, int n, int32_t v, hipStream_t s);
 // ungated 1-NN of T*q against a tree; T12 may be null (identity)
 void launch_nn1(const float4* q, int nq, const float* T12, TreeView tree, int32_t* idx, float* d2, hipStream_t s);
+// instrumentation: per-query visit counts of a cold 1-NN search; stats[0..4] = sum nodes, sum leaves, sum over waves of
+// the per-wave max (nodes+leaves), number of waves, max (nodes+leaves) of any query
+void launch_nn1_stats(const float4* q, int nq, const float* T12, TreeView tree, unsigned long long* stats, hipStream_t s);
 // deterministic double sum of float d2 (fitness): partials[ceil(n/1024)]
 void launch_sum_f32(const float* v, int n, double* partials, hipStream_t s);
 inline int sum_blocks(int n) { return (n + 1023) / 1024; }

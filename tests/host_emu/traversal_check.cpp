@@ -31,15 +31,8 @@ static HostTree build(const std::vector<float4>& pts) {
     lo[1] = fminf(lo[1], p.y); hi[1] = fmaxf(hi[1], p.y);
     lo[2] = fminf(lo[2], p.z); hi[2] = fmaxf(hi[2], p.z);
   }
-  float ext = fmaxf(fmaxf(hi[0] - lo[0], hi[1] - lo[1]), fmaxf(hi[2] - lo[2], 1e-30f));
-  float sc = 1023.999f / ext;
   std::vector<std::pair<uint32_t, uint32_t>> kv(n);
-  for (int i = 0; i < n; i++) {
-    int ix = std::min(1023, std::max(0, (int)((pts[i].x - lo[0]) * sc)));
-    int iy = std::min(1023, std::max(0, (int)((pts[i].y - lo[1]) * sc)));
-    int iz = std::min(1023, std::max(0, (int)((pts[i].z - lo[2]) * sc)));
-    kv[i] = {morton30(ix, iy, iz), (uint32_t)i};
-  }
+  for (int i = 0; i < n; i++) kv[i] = {spatial_key30(pts[i].x, pts[i].y, pts[i].z, lo[0], lo[1], lo[2], hi[0], hi[1], hi[2]), (uint32_t)i};
   std::stable_sort(kv.begin(), kv.end(), [](auto& a, auto& b) { return a.first < b.first; });
   int n_leaves = (n + LEAF - 1) / LEAF;
   int depth = 0;

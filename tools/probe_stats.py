@@ -1,0 +1,15 @@
+import sys, os, json
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from locus_amd import capi, synth
+ctx = capi.Context(0)
+src, tgt, delta = synth.scan_pair(n_rings=64, n_az=1563, scale=2.0, noise=0.02, seed=10)
+cs, ct = capi.Cloud(ctx, src), capi.Cloud(ctx, tgt)
+I = np.eye(4, dtype=np.float32).T.reshape(16)
+Td = np.ascontiguousarray(delta.astype(np.float32).T).reshape(16)
+print("cold, identity pose:", ct.traversal_stats(cs, I))
+print("cold, true pose    :", ct.traversal_stats(cs, Td))
+print("cold, self         :", ct.traversal_stats(ct, None))
+rng = np.random.default_rng(0)
+cs2 = capi.Cloud(ctx, src[rng.permutation(len(src))])
+print("cold, shuffled     :", ct.traversal_stats(cs2, I))
