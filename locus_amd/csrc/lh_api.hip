@@ -40,7 +40,7 @@ struct ProfPending { int entry; hipEvent_t a, b; };
 
 struct lh_ctx {
   int device = 0;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr, stream2 = nullptr;  // stream2: second half-batch of the pipelined scheduler
   // index-build scratch (shared by all clouds of the context; builds are serial on the stream)
   uint32_t *keys0 = nullptr, *keys1 = nullptr, *vals0 = nullptr, *vals1 = nullptr, *bbox = nullptr;
   void* sort_temp = nullptr;
@@ -53,7 +53,7 @@ struct lh_ctx {
   size_t sort64_temp_bytes = 0;
   int idx_cap = 0;
   IndexDesc *idx_descs_dev = nullptr, *idx_descs_host = nullptr;
-  hipEvent_t idx_copy_done = nullptr;
+  hipEvent_t idx_copy_done = nullptr, idx_build_done = nullptr;
   // pair slots
   PairDesc* descs_dev = nullptr;   // [n_slots]
   PairDesc* descs_host = nullptr;  // pinned staging
@@ -87,9 +87,9 @@ struct lh_ctx {
   }
   void prof_flush() {
     if (prof_pending.empty()) return;
-    (void)hipStreamSynchronize(stream);
     for (auto& p : prof_pending) {
       float ms = 0;
+      (void)hipEventSynchronize(p.b);
       (void)hipEventElapsedTime(&ms, p.a, p.b);
       prof_entries[p.entry].ms += ms;
       ev_pool.push_back(p.a);
@@ -102,17 +102,19 @@ struct lh_ctx {
 // RAII-ish profiling scope around one launch (HIP events on the context's own stream)
 struct ProfScope {
   lh_ctx* c; int entry = -1; hipEvent_t a, b;
-  ProfScope(lh_ctx* ctx, const char* name, double bytes) : c(ctx) {
+  hipStream_t st;
+  ProfScope(lh_ctx* ctx, const char* name, double bytes, hipStream_t stream = nullptr) : c(ctx) {
     if (!c->prof) return;
+    st = stream ? stream : c->stream;
     entry = c->prof_entry(name);
     c->prof_entries[entry].launches++;
     c->prof_entries[entry].bytes += bytes;
     a = c->get_event(); b = c->get_event();
-    (void)hipEventRecord(a, c->stream);
+    (void)hipEventRecord(a, st);
   }
   ~ProfScope() {
     if (entry < 0) return;
-    (void)hipEventRecord(b, c->stream);
+    (void)hipEventRecord(b, st);
     c->prof_pending.push_back({entry, a, b});
     if (c->prof_pending.size() > 8192) c->prof_flush();
   }
@@ -172,8 +174,9 @@ static lh_status ctx_ensure_small(lh_ctx* c, size_t doubles) {
 
 // K2: Hilbert sort + implicit 4-ary box tree (replaces tree_->setInputCloud of pcl::Registration::initCompute).
 // All clouds of a batch are built by the same launches and one radix sort (see lh_kernels.hpp "K2 batched").
-static lh_status build_indices(lh_ctx* x, lh_cloud* const* clouds, int n_clouds) {
+static lh_status build_indices(lh_ctx* x, lh_cloud* const* clouds, int n_clouds, hipStream_t s_in = nullptr) {
   if (n_clouds <= 0) return LH_OK;
+  hipStream_t s = s_in ? s_in : x->stream;
   for (int o = 0; o < n_clouds; o += MAX_INDEX_BATCH) {
     int nb = std::min(MAX_INDEX_BATCH, n_clouds - o);
     long total = 0;
@@ -183,6 +186,7 @@ static lh_status build_indices(lh_ctx* x, lh_cloud* const* clouds, int n_clouds)
       HIPCHK(hipHostMalloc(&x->idx_descs_host, sizeof(IndexDesc) * MAX_INDEX_BATCH, hipHostMallocDefault));
       HIPCHK(hipMalloc(&x->idx_bbox, sizeof(uint32_t) * 8 * MAX_INDEX_BATCH));
       HIPCHK(hipEventCreateWithFlags(&x->idx_copy_done, hipEventDisableTiming));
+      HIPCHK(hipEventCreateWithFlags(&x->idx_build_done, hipEventDisableTiming));
     } else {
       HIPCHK(hipEventSynchronize(x->idx_copy_done));  // the previous batch's descriptor upload left the staging buffer
     }
@@ -231,15 +235,16 @@ static lh_status build_indices(lh_ctx* x, lh_cloud* const* clouds, int n_clouds)
       HIPCHK(hipMalloc(&x->sort64_temp, x->sort64_temp_bytes ? x->sort64_temp_bytes : 16));
       x->idx_cap = cap;
     }
-    hipStream_t s = x->stream;
+    HIPCHK(hipStreamWaitEvent(s, x->idx_build_done, 0));  // the shared build scratch may still be in use on the other stream
     HIPCHK(hipMemcpyAsync(x->idx_descs_dev, x->idx_descs_host, sizeof(IndexDesc) * nb, hipMemcpyHostToDevice, s));
     HIPCHK(hipEventRecord(x->idx_copy_done, s));
     int id_bits = 0;
     while ((1 << id_bits) < nb) id_bits++;
-    { ProfScope p(x, "index_bbox_keys", 16.0 * total * 2); launch_index_keys(x->idx_descs_dev, nb, max_n, x->idx_bbox, x->k64a, x->v32a, s); }
-    { ProfScope p(x, "index_radix_sort", 12.0 * total * 2 * 4);
+    { ProfScope p(x, "index_bbox_keys", 16.0 * total * 2, s); launch_index_keys(x->idx_descs_dev, nb, max_n, x->idx_bbox, x->k64a, x->v32a, s); }
+    { ProfScope p(x, "index_radix_sort", 12.0 * total * 2 * 4, s);
       sort_pairs_u64(x->sort64_temp, x->sort64_temp_bytes, x->k64a, x->k64b, x->v32a, x->v32b, (int)total, 32 + id_bits, s); }
-    { ProfScope p(x, "index_gather_boxes", 32.0 * total); launch_index_trees(x->idx_descs_dev, nb, max_np, max_depth, x->v32b, s); }
+    { ProfScope p(x, "index_gather_boxes", 32.0 * total, s); launch_index_trees(x->idx_descs_dev, nb, max_np, max_depth, x->v32b, s); }
+    HIPCHK(hipEventRecord(x->idx_build_done, s));
     HIPCHK(hipGetLastError());
     for (int k = 0; k < nb; k++) clouds[o + k]->has_index = true;
   }
@@ -328,6 +333,7 @@ struct Task : public CostFn {
   float guess[16];
   bool guess_is_identity = true;
   int slot = 0;
+  hipStream_t stream = nullptr;  // the stream of the scheduler group that owns the task
   lh_gicp_trace* trace = nullptr;
   // coroutine
   ucontext_t ctx, sched;
@@ -473,18 +479,19 @@ static lh_status task_prepare(lh_ctx* c, Task* t, bool rebuild_index) {
   if (P.recompute_source_cov) { st = cloud_ensure_cov(src, P.k_correspondences, P.gicp_epsilon); if (st) return st; }
   st = t->ws->ensure(c, src->n);
   if (st) return st;
+  hipStream_t ts = t->stream ? t->stream : c->stream;
   t->guess_is_identity = memcmp(t->guess, I16, sizeof(I16)) == 0;
   const float4* out = src->xyz;
   if (!t->guess_is_identity) {  // pcl::transformPointCloud(output, output, guess) (gicp.hpp:440)
     float T12[12];
     Task::T16_to_T12(t->guess, T12);
-    ProfScope p(c, "transform", 32.0 * src->n);
-    launch_transform(src->xyz, nullptr, src->n, T12, t->ws->out_xyz, nullptr, c->stream);
+    ProfScope p(c, "transform", 32.0 * src->n, ts);
+    launch_transform(src->xyz, nullptr, src->n, T12, t->ws->out_xyz, nullptr, ts);
     out = t->ws->out_xyz;
   }
   if (t->count_stats) {  // debug sweeps run without the seed pre-pass: start from "no candidate"
     ProfScope p(c, "fill", 4.0 * src->n);
-    launch_fill_i32(t->ws->prev_nn, src->n, -1, c->stream);
+    launch_fill_i32(t->ws->prev_nn, src->n, -1, ts);
   }
   PairDesc& d = c->descs_host[t->slot];
   d.src = out;
@@ -508,174 +515,210 @@ static lh_status task_prepare(lh_ctx* c, Task* t, bool rebuild_index) {
   d.src_cov_pad = src->n_pad;
   d.corr_dist2 = P.corr_dist * P.corr_dist;  // gicp.hpp:438
   d.gicp_eps = P.gicp_epsilon;
-  HIPCHK(hipMemcpyAsync(&c->descs_dev[t->slot], &d, sizeof(PairDesc), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(&c->descs_dev[t->slot], &d, sizeof(PairDesc), hipMemcpyHostToDevice, ts));
   HIPCHK(hipGetLastError());
   return LH_OK;
 }
 
-// run a set of tasks to completion, at most `in_flight` concurrently; tasks[i]->slot must be unique in flight
+// ---- scheduler ------------------------------------------------------------------------------------------------
+// In-flight pairs are split into groups (two half-batches when >= 16 pairs are in flight, each with its own HIP
+// stream): while the host delivers results / runs the BFGS solves of one group, the other group's kernels keep the
+// GPU busy.  Slots, descriptors, partial-sum buffers are per slot, so groups never share mutable device state; the
+// index-build scratch is shared and ordered across streams by an event.
+struct Group {
+  hipStream_t stream = nullptr;
+  std::vector<Task*> active, sweeps, moms, costs;
+  std::vector<int> free_slots;
+  bool inflight = false;
+};
+
+static lh_status group_launch(lh_ctx* c, Group& g) {
+  hipStream_t st = g.stream;
+  g.sweeps.clear(); g.moms.clear(); g.costs.clear();
+  // phase 1: sweeps (+ seed pre-pass for cold pairs)
+  for (Task* t : g.active)
+    if (t->req == REQ_SWEEP) g.sweeps.push_back(t);
+  for (size_t o = 0; o < g.sweeps.size(); o += MAX_JOBS) {
+    SweepArgs a;
+    a.njobs = (int)std::min<size_t>(MAX_JOBS, g.sweeps.size() - o);
+    a.bpj = 0;
+    int max_n = 0;
+    double bytes = 0;
+    for (int j = 0; j < a.njobs; j++) {
+      Task* t = g.sweeps[o + j];
+      a.job[j].slot = t->slot;
+      a.job[j].pad = 0;
+      memcpy(a.job[j].T, t->req_T12, sizeof(t->req_T12));
+      memcpy(a.job[j].R, t->req_R9, sizeof(t->req_R9));
+      max_n = std::max(max_n, t->src->n);
+      bytes += 20.0 * t->src->n;  // SURVEY 8d B_nn = 20 N + 232 K_t; the K_t term is added when the count is known
+      t->sweep_bytes_pending = true;
+    }
+    {  // cold tasks (first sweep of a pair): seed pre-pass so the sweep starts warm
+      SweepArgs sa;
+      sa.njobs = 0;
+      int smax = 0;
+      for (int j = 0; j < a.njobs; j++) {
+        Task* t = g.sweeps[o + j];
+        if (t->first_sweep) {
+          sa.job[sa.njobs++] = a.job[j];
+          smax = std::max(smax, t->src->n);
+          t->first_sweep = false;
+        }
+      }
+      if (sa.njobs > 0) {
+        ProfScope p(c, "nn_seed", 0.0, st);
+        launch_seed(c->descs_dev, sa, smax, st);
+      }
+    }
+    ProfScope p(c, "nn_sweep", bytes, st);
+    launch_sweep(c->descs_dev, a, max_n, st);
+  }
+  // cost_mode 1: one moment reduction per sweep replaces every per-evaluation pass of this outer iteration
+  for (Task* t : g.sweeps)
+    if (t->P.cost_mode == 1) g.moms.push_back(t);
+  for (size_t o = 0; o < g.moms.size(); o += MAX_JOBS) {
+    CostArgs a;
+    a.njobs = (int)std::min<size_t>(MAX_JOBS, g.moms.size() - o);
+    a.pad = 0;
+    int max_n = 0;
+    for (int j = 0; j < a.njobs; j++) {
+      Task* t = g.moms[o + j];
+      a.job[j].slot = t->slot;
+      a.job[j].out_offset = (int)((size_t)t->slot * c->partials_per_slot);
+      memcpy(a.job[j].T, t->req_T12, sizeof(t->req_T12));
+      max_n = std::max(max_n, t->src->n);
+    }
+    ProfScope p(c, "cost_moments", 0.0, st);
+    launch_moments(c->descs_dev, a, max_n, c->mom_partials_dev, c->mom_stride, c->partials_host, st);
+  }
+  for (Task* t : g.sweeps)
+    if (t->P.cost_mode != 1) t->resume();  // each now yields its first COST request (or DONE)
+  // phase 2: per-evaluation cost passes (cost_mode 0)
+  for (Task* t : g.active)
+    if (t->req == REQ_COST) g.costs.push_back(t);
+  for (size_t o = 0; o < g.costs.size(); o += MAX_JOBS) {
+    CostArgs a;
+    a.njobs = (int)std::min<size_t>(MAX_JOBS, g.costs.size() - o);
+    a.pad = 0;
+    int max_n = 0;
+    for (int j = 0; j < a.njobs; j++) {
+      Task* t = g.costs[o + j];
+      a.job[j].slot = t->slot;
+      a.job[j].out_offset = (int)((size_t)t->slot * c->partials_per_slot);
+      memcpy(a.job[j].T, t->req_T12, sizeof(t->req_T12));
+      max_n = std::max(max_n, t->src->n);
+    }
+    ProfScope p(c, "cost_fdf", 0.0, st);
+    launch_cost(c->descs_dev, a, max_n, c->partials_host, st);
+  }
+  HIPCHK(hipGetLastError());
+  g.inflight = !g.costs.empty() || !g.sweeps.empty();
+  return LH_OK;
+}
+
+static lh_status group_collect(lh_ctx* c, Group& g) {
+  if (g.inflight) HIPCHK(hipStreamSynchronize(g.stream));
+  g.inflight = false;
+  for (Task* t : g.costs) {
+    const double* part = c->partials_host + (size_t)t->slot * c->partials_per_slot;
+    int nb = cost_blocks(t->src->n);
+    double S[COST_NSUM];
+    for (int k = 0; k < COST_NSUM; k++) S[k] = 0.0;
+    for (int b = 0; b < nb; b++)  // fixed order => bitwise reproducible
+      for (int k = 0; k < COST_NSUM; k++) S[k] += part[(size_t)b * COST_NSUM + k];
+    memcpy(t->res_sums, S, sizeof(S));
+    if (c->prof) {  // algorithmic bytes with the measured K_t: B_fdf = 108 K_t, B_nn += 232 K_t
+      c->prof_entries[c->prof_entry("cost_fdf")].bytes += 108.0 * S[13];
+      if (t->sweep_bytes_pending) c->prof_entries[c->prof_entry("nn_sweep")].bytes += 232.0 * S[13];
+    }
+    t->sweep_bytes_pending = false;
+    t->resume();
+  }
+  for (Task* t : g.moms) {  // deliver the moments; the task then runs its whole BFGS solve on the host
+    const double* S = c->partials_host + (size_t)t->slot * c->partials_per_slot;
+    memcpy(t->mom.S, S, sizeof(double) * MOM_NSUM);
+    for (int r = 0; r < 3; r++)
+      for (int cc = 0; cc < 4; cc++) t->mom.T0[cc * 4 + r] = t->req_T12[r * 4 + cc];
+    t->mom.T0[3] = t->mom.T0[7] = t->mom.T0[11] = 0.f; t->mom.T0[15] = 1.f;
+    if (c->prof) {
+      c->prof_entries[c->prof_entry("cost_moments")].bytes += 108.0 * S[73];
+      c->prof_entries[c->prof_entry("nn_sweep")].bytes += 232.0 * S[73];
+    }
+    t->sweep_bytes_pending = false;
+    t->resume();
+  }
+  g.costs.clear(); g.moms.clear(); g.sweeps.clear();
+  for (size_t i = 0; i < g.active.size();) {  // retire finished pairs
+    if (g.active[i]->req == REQ_DONE) {
+      g.free_slots.push_back(g.active[i]->slot);
+      g.active.erase(g.active.begin() + i);
+    } else
+      i++;
+  }
+  return LH_OK;
+}
+
+// run a set of tasks to completion, at most `in_flight` concurrently
 static lh_status run_tasks(lh_ctx* c, std::vector<Task*>& tasks, int in_flight, bool rebuild_index,
                           std::vector<Workspace>* slot_ws = nullptr) {
+  const int G = (in_flight >= 16 && !c->prof) ? 2 : 1;  // profiling keeps one group so HIP-event times do not overlap
+  if (G == 2 && !c->stream2) HIPCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+  Group groups[2];
+  groups[0].stream = c->stream;
+  groups[1].stream = c->stream2;
+  {
+    int per = (in_flight + G - 1) / G, s = 0;
+    for (int gi = 0; gi < G; gi++)
+      for (int k = 0; k < per && s < in_flight; k++, s++) groups[gi].free_slots.push_back(s);
+  }
   size_t next = 0;
-  std::vector<Task*> active;
-  std::vector<int> free_slots;
-  for (int s = in_flight - 1; s >= 0; s--) free_slots.push_back(s);
   lh_status err = LH_OK;
-  while (next < tasks.size() || !active.empty()) {
-    // admit new pairs: the NN indexes of all newly admitted targets are built together (batched launches + one sort)
-    {
-      std::vector<lh_cloud*> to_build;
-      size_t nn = next;
-      for (size_t k = 0; k < free_slots.size() && nn < tasks.size(); k++, nn++) {
-        lh_cloud* tg = tasks[nn]->tgt;
-        if (tg && tg->n > 0 && (rebuild_index || !tg->has_index) &&
-            std::find(to_build.begin(), to_build.end(), tg) == to_build.end())
-          to_build.push_back(tg);
-      }
-      if (!to_build.empty()) {
-        lh_status st = build_indices(c, to_build.data(), (int)to_build.size());
-        if (st) return st;
-      }
-    }
-    while (next < tasks.size() && !free_slots.empty()) {
-      Task* t = tasks[next++];
-      t->slot = free_slots.back();
-      free_slots.pop_back();
-      if (slot_ws) t->ws = &(*slot_ws)[t->slot];  // batch mode: workspaces belong to slots
-      lh_status st = task_prepare(c, t, false);
-      if (st) {
-        memset(&t->result, 0, sizeof(t->result));
-        memcpy(t->result.T, I16, sizeof(I16));
-        t->result.status = st;
-        t->result.fitness = NAN;
-        free_slots.push_back(t->slot);
-        err = st;
-        continue;
-      }
-      t->start();
-      active.push_back(t);
-    }
-    if (active.empty()) break;
-    // phase 1: sweeps
-    std::vector<Task*> sweeps;
-    for (Task* t : active)
-      if (t->req == REQ_SWEEP) sweeps.push_back(t);
-    for (size_t o = 0; o < sweeps.size(); o += MAX_JOBS) {
-      SweepArgs a;
-      a.njobs = (int)std::min<size_t>(MAX_JOBS, sweeps.size() - o);
-      a.bpj = 0;
-      int max_n = 0;
-      double bytes = 0;
-      for (int j = 0; j < a.njobs; j++) {
-        Task* t = sweeps[o + j];
-        a.job[j].slot = t->slot;
-        a.job[j].pad = 0;
-        memcpy(a.job[j].T, t->req_T12, sizeof(t->req_T12));
-        memcpy(a.job[j].R, t->req_R9, sizeof(t->req_R9));
-        max_n = std::max(max_n, t->src->n);
-        bytes += 20.0 * t->src->n;  // SURVEY 8d B_nn = 20 N + 232 K_t; the K_t term is added when the count is known
-        t->sweep_bytes_pending = true;
-      }
-      {  // cold tasks (first sweep of a pair): seed pre-pass so the sweep starts warm
-        SweepArgs sa;
-        sa.njobs = 0;
-        int smax = 0;
-        for (int j = 0; j < a.njobs; j++) {
-          Task* t = sweeps[o + j];
-          if (t->first_sweep) {
-            sa.job[sa.njobs++] = a.job[j];
-            smax = std::max(smax, t->src->n);
-            t->first_sweep = false;
+  auto busy = [&]() {
+    for (int gi = 0; gi < G; gi++)
+      if (!groups[gi].active.empty() || groups[gi].inflight) return true;
+    return false;
+  };
+  while (next < tasks.size() || busy()) {
+    for (int gi = 0; gi < G; gi++) {
+      Group& g = groups[gi];
+      lh_status st = group_collect(c, g);  // waits for THIS group's kernels; the other group's are still queued/running
+      if (st) return st;
+      // admit new pairs: the NN indexes of all newly admitted targets are built together (batched launches + one sort)
+      if (next < tasks.size() && !g.free_slots.empty()) {
+        std::vector<lh_cloud*> to_build;
+        size_t nn = next;
+        for (size_t k = 0; k < g.free_slots.size() && nn < tasks.size(); k++, nn++) {
+          lh_cloud* tg = tasks[nn]->tgt;
+          if (tg && tg->n > 0 && (rebuild_index || !tg->has_index) && std::find(to_build.begin(), to_build.end(), tg) == to_build.end())
+            to_build.push_back(tg);
+        }
+        if (!to_build.empty()) {
+          st = build_indices(c, to_build.data(), (int)to_build.size(), g.stream);
+          if (st) return st;
+        }
+        while (next < tasks.size() && !g.free_slots.empty()) {
+          Task* t = tasks[next++];
+          t->slot = g.free_slots.back();
+          g.free_slots.pop_back();
+          t->stream = g.stream;
+          if (slot_ws) t->ws = &(*slot_ws)[t->slot];  // batch mode: workspaces belong to slots
+          st = task_prepare(c, t, false);
+          if (st) {
+            memset(&t->result, 0, sizeof(t->result));
+            memcpy(t->result.T, I16, sizeof(I16));
+            t->result.status = st;
+            t->result.fitness = NAN;
+            g.free_slots.push_back(t->slot);
+            err = st;
+            continue;
           }
-        }
-        if (sa.njobs > 0) {
-          ProfScope p(c, "nn_seed", 0.0);
-          launch_seed(c->descs_dev, sa, smax, c->stream);
+          t->start();
+          g.active.push_back(t);
         }
       }
-      ProfScope p(c, "nn_sweep", bytes);
-      launch_sweep(c->descs_dev, a, max_n, c->stream);
-    }
-    // cost_mode 1: one moment reduction per sweep replaces every per-evaluation pass of this outer iteration
-    std::vector<Task*> moms;
-    for (Task* t : sweeps)
-      if (t->P.cost_mode == 1) moms.push_back(t);
-    for (size_t o = 0; o < moms.size(); o += MAX_JOBS) {
-      CostArgs a;
-      a.njobs = (int)std::min<size_t>(MAX_JOBS, moms.size() - o);
-      a.pad = 0;
-      int max_n = 0;
-      for (int j = 0; j < a.njobs; j++) {
-        Task* t = moms[o + j];
-        a.job[j].slot = t->slot;
-        a.job[j].out_offset = (int)((size_t)t->slot * c->partials_per_slot);
-        memcpy(a.job[j].T, t->req_T12, sizeof(t->req_T12));
-        max_n = std::max(max_n, t->src->n);
-      }
-      ProfScope p(c, "cost_moments", 0.0);
-      launch_moments(c->descs_dev, a, max_n, c->mom_partials_dev, c->mom_stride, c->partials_host, c->stream);
-    }
-    for (Task* t : sweeps)
-      if (t->P.cost_mode != 1) t->resume();  // each now yields its first COST request (or DONE)
-    // phase 2: cost passes
-    std::vector<Task*> costs;
-    for (Task* t : active)
-      if (t->req == REQ_COST) costs.push_back(t);
-    for (size_t o = 0; o < costs.size(); o += MAX_JOBS) {
-      CostArgs a;
-      a.njobs = (int)std::min<size_t>(MAX_JOBS, costs.size() - o);
-      a.pad = 0;
-      int max_n = 0;
-      double bytes = 0;
-      for (int j = 0; j < a.njobs; j++) {
-        Task* t = costs[o + j];
-        a.job[j].slot = t->slot;
-        a.job[j].out_offset = (int)((size_t)t->slot * c->partials_per_slot);
-        memcpy(a.job[j].T, t->req_T12, sizeof(t->req_T12));
-        max_n = std::max(max_n, t->src->n);
-      }
-      ProfScope p(c, "cost_fdf", bytes);
-      launch_cost(c->descs_dev, a, max_n, c->partials_host, c->stream);
-    }
-    if (!costs.empty() || !sweeps.empty()) {
-      HIPCHK(hipGetLastError());
-      HIPCHK(hipStreamSynchronize(c->stream));
-    }
-    for (Task* t : costs) {
-      const double* part = c->partials_host + (size_t)t->slot * c->partials_per_slot;
-      int nb = cost_blocks(t->src->n);
-      double S[COST_NSUM];
-      for (int k = 0; k < COST_NSUM; k++) S[k] = 0.0;
-      for (int b = 0; b < nb; b++)  // fixed order => bitwise reproducible
-        for (int k = 0; k < COST_NSUM; k++) S[k] += part[(size_t)b * COST_NSUM + k];
-      memcpy(t->res_sums, S, sizeof(S));
-      if (c->prof) {  // algorithmic bytes with the measured K_t: B_fdf = 108 K_t, B_nn += 232 K_t
-        c->prof_entries[c->prof_entry("cost_fdf")].bytes += 108.0 * S[13];
-        if (t->sweep_bytes_pending) c->prof_entries[c->prof_entry("nn_sweep")].bytes += 232.0 * S[13];
-      }
-      t->sweep_bytes_pending = false;
-      t->resume();
-    }
-    for (Task* t : moms) {  // deliver the moments; the task then runs its whole BFGS solve on the host
-      const double* S = c->partials_host + (size_t)t->slot * c->partials_per_slot;
-      memcpy(t->mom.S, S, sizeof(double) * MOM_NSUM);
-      for (int r = 0; r < 3; r++)
-        for (int cc = 0; cc < 4; cc++) t->mom.T0[cc * 4 + r] = t->req_T12[r * 4 + cc];
-      t->mom.T0[3] = t->mom.T0[7] = t->mom.T0[11] = 0.f; t->mom.T0[15] = 1.f;
-      if (c->prof) {
-        c->prof_entries[c->prof_entry("cost_moments")].bytes += 108.0 * S[73];
-        c->prof_entries[c->prof_entry("nn_sweep")].bytes += 232.0 * S[73];
-      }
-      t->sweep_bytes_pending = false;
-      t->resume();
-    }
-    // retire finished pairs
-    for (size_t i = 0; i < active.size();) {
-      if (active[i]->req == REQ_DONE) {
-        free_slots.push_back(active[i]->slot);
-        active.erase(active.begin() + i);
-      } else
-        i++;
+      st = group_launch(c, g);
+      if (st) return st;
     }
   }
   return err;
@@ -800,6 +843,8 @@ void lh_destroy(lh_ctx* c) {
   (void)hipFree(c->idx_bbox); (void)hipFree(c->idx_descs_dev);
   if (c->idx_descs_host) (void)hipHostFree(c->idx_descs_host);
   if (c->idx_copy_done) (void)hipEventDestroy(c->idx_copy_done);
+  if (c->idx_build_done) (void)hipEventDestroy(c->idx_build_done);
+  if (c->stream2) (void)hipStreamDestroy(c->stream2);
   (void)hipFree(c->sort_temp); (void)hipFree(c->bbox); (void)hipFree(c->descs_dev); (void)hipFree(c->mom_partials_dev);
   if (c->descs_host) (void)hipHostFree(c->descs_host);
   if (c->partials_host) (void)hipHostFree(c->partials_host);
@@ -1132,6 +1177,7 @@ lh_status lh_gicp_debug_sweep(lh_gicp* g, const float T[16], const float guess[1
   t.P = g->P; t.src = g->src; t.tgt = g->tgt; t.ws = &g->ws; t.trace = nullptr; t.slot = 0;
   memcpy(t.guess, guess ? guess : I16, sizeof(I16));
   t.count_stats = true;
+  t.stream = nullptr;
   if (!g->dbg_prepared) {  // first debug sweep after a change of clouds: cold state; later ones are warm (like align's sweeps)
     st = task_prepare(c, &t, !g->tgt->has_index);
     if (st) return st;
