@@ -130,12 +130,27 @@ LH_HD void cswap(uint64_t& a, uint64_t& b) {
 // box distance of every subtree that is pruned (so a collector can keep a lower bound on everything it never looked at).
 template <class Collector>
 LH_HD void tree_search(const TreeView& t, float qx, float qy, float qz, Collector& col) {
+  // "while-while" traversal: every lane first descends through internal nodes until it holds a leaf, then the wave
+  // scans leaves together -- the node body and the leaf body are not both replayed on every step of a divergent wave.
+  // Sort keys are 32-bit: the float bits of the (non-negative) box distance with the two low mantissa bits replaced by
+  // the child number.  The truncated distance is <= the true one, so using it for the pop-time prune test and for
+  // skip() stays conservative (exactness preserved), and a 4-key sort is ten v_min/v_max_u32.
   uint64_t stack[STACK_MAX];
   int sp = 0;
-  int lin = 0;
-  const uint64_t INVALID = ~0ull;
+  const uint32_t NONE = 0xffffffffu;
+  const uint32_t first_leaf = (uint32_t)t.first_leaf;
+  uint32_t lin = 0;
+  auto pop = [&]() -> uint32_t {
+    for (;;) {
+      if (sp == 0) return NONE;
+      uint64_t e = stack[--sp];
+      float dk = u2f((uint32_t)(e >> 32) & ~3u);
+      if (dk <= col.bound()) return (uint32_t)e;
+      col.skip(dk);
+    }
+  };
   for (;;) {
-    if (lin < t.first_leaf) {
+    while (lin < first_leaf) {
       col.count_node();
       const Node4& nd = t.nodes[lin];
       float4 lx = *reinterpret_cast<const float4*>(nd.lox), ly = *reinterpret_cast<const float4*>(nd.loy),
@@ -146,36 +161,38 @@ LH_HD void tree_search(const TreeView& t, float qx, float qy, float qz, Collecto
       float d1 = boxd2(qx, qy, qz, lx.y, ly.y, lz.y, hx.y, hy.y, hz.y);
       float d2 = boxd2(qx, qy, qz, lx.z, ly.z, lz.z, hx.z, hy.z, hz.z);
       float d3 = boxd2(qx, qy, qz, lx.w, ly.w, lz.w, hx.w, hy.w, hz.w);
-      const uint32_t c0 = 4u * (uint32_t)lin + 1u;
       const float INF = inf_f();
-      uint64_t k0 = (d0 <= bd && d0 < INF) ? (((uint64_t)f2u(d0) << 32) | (c0 + 0u)) : INVALID;
-      uint64_t k1 = (d1 <= bd && d1 < INF) ? (((uint64_t)f2u(d1) << 32) | (c0 + 1u)) : INVALID;
-      uint64_t k2 = (d2 <= bd && d2 < INF) ? (((uint64_t)f2u(d2) << 32) | (c0 + 2u)) : INVALID;
-      uint64_t k3 = (d3 <= bd && d3 < INF) ? (((uint64_t)f2u(d3) << 32) | (c0 + 3u)) : INVALID;
-      col.skip(d0 <= bd ? INF : d0); col.skip(d1 <= bd ? INF : d1); col.skip(d2 <= bd ? INF : d2); col.skip(d3 <= bd ? INF : d3);
-      cswap(k0, k1); cswap(k2, k3); cswap(k0, k2); cswap(k1, k3); cswap(k1, k2);
-      if (k3 != INVALID) stack[sp++] = k3;
-      if (k2 != INVALID) stack[sp++] = k2;
-      if (k1 != INVALID) stack[sp++] = k1;
-      if (k0 != INVALID) { lin = (int)(uint32_t)k0; continue; }
-    } else {
-      col.count_leaf();
-      const float4* p = t.pts + (size_t)(lin - t.first_leaf) * LEAF;
-#pragma unroll
-      for (int e = 0; e < LEAF; e++) {
-        float4 v = p[e];
-        col.offer(d2f(qx, qy, qz, v.x, v.y, v.z), (int)f2u(v.w));
+      bool v0 = d0 <= bd && d0 < INF, v1 = d1 <= bd && d1 < INF, v2 = d2 <= bd && d2 < INF, v3 = d3 <= bd && d3 < INF;
+      uint32_t k0 = v0 ? ((f2u(d0) & ~3u) | 0u) : NONE;
+      uint32_t k1 = v1 ? ((f2u(d1) & ~3u) | 1u) : NONE;
+      uint32_t k2 = v2 ? ((f2u(d2) & ~3u) | 2u) : NONE;
+      uint32_t k3 = v3 ? ((f2u(d3) & ~3u) | 3u) : NONE;
+      col.skip(v0 ? INF : d0); col.skip(v1 ? INF : d1); col.skip(v2 ? INF : d2); col.skip(v3 ? INF : d3);
+      uint32_t a, b;
+      a = k0 < k1 ? k0 : k1; b = k0 < k1 ? k1 : k0; k0 = a; k1 = b;
+      a = k2 < k3 ? k2 : k3; b = k2 < k3 ? k3 : k2; k2 = a; k3 = b;
+      a = k0 < k2 ? k0 : k2; b = k0 < k2 ? k2 : k0; k0 = a; k2 = b;
+      a = k1 < k3 ? k1 : k3; b = k1 < k3 ? k3 : k1; k1 = a; k3 = b;
+      a = k1 < k2 ? k1 : k2; b = k1 < k2 ? k2 : k1; k1 = a; k2 = b;
+      const uint32_t c0 = 4u * lin + 1u;
+      if (k1 != NONE) {  // valid keys sort first: k1 invalid => k2, k3 invalid
+        if (k2 != NONE) {
+          if (k3 != NONE) stack[sp++] = ((uint64_t)k3 << 32) | (c0 + (k3 & 3u));
+          stack[sp++] = ((uint64_t)k2 << 32) | (c0 + (k2 & 3u));
+        }
+        stack[sp++] = ((uint64_t)k1 << 32) | (c0 + (k1 & 3u));
       }
+      lin = (k0 != NONE) ? (c0 + (k0 & 3u)) : pop();
     }
-    uint64_t key;
-    for (;;) {
-      if (sp == 0) return;
-      key = stack[--sp];
-      float dk = u2f((uint32_t)(key >> 32));
-      if (dk <= col.bound()) break;
-      col.skip(dk);
+    if (lin == NONE) return;
+    col.count_leaf();
+    const float4* p = t.pts + (size_t)(lin - first_leaf) * LEAF;
+#pragma unroll
+    for (int e = 0; e < LEAF; e++) {
+      float4 v = p[e];
+      col.offer(d2f(qx, qy, qz, v.x, v.y, v.z), (int)f2u(v.w));
     }
-    lin = (int)(uint32_t)key;
+    lin = pop();
   }
 }
 
@@ -183,8 +200,10 @@ struct Nn1Collector {
   float bd;
   int bi;
   LH_HD float bound() const { return bd; }
-  LH_HD void offer(float d, int id) {
-    if (d < bd || (d == bd && id < bi)) { bd = d; bi = id; }
+  LH_HD void offer(float d, int id) {  // branch-free: selects instead of exec-mask branches in the 8-point leaf scan
+    bool better = (d < bd) | ((d == bd) & (id < bi));
+    bd = better ? d : bd;
+    bi = better ? id : bi;
   }
   LH_HD void skip(float) {}
   LH_HD void count_node() {}
@@ -214,15 +233,14 @@ struct Nn1CertCollector {
   int bi;
   float lb;
   LH_HD float bound() const { return bd; }
-  LH_HD void offer(float d, int id) {
-    if (id == bi) return;  // the warm-start candidate met again
-    if (d < bd || (d == bd && id < bi)) {
-      lb = fminf(lb, bd);  // the dethroned winner becomes a runner-up (bd is +inf while there is no winner yet)
-      bd = d;
-      bi = id;
-    } else {
-      lb = fminf(lb, d);
-    }
+  LH_HD void offer(float d, int id) {  // branch-free
+    bool same = id == bi;                                   // the warm-start candidate met again: no-op
+    bool better = (d < bd) | ((d == bd) & (id < bi));
+    float runner = better ? bd : d;                         // dethroned winner, or the rejected point, is a runner-up
+    lb = same ? lb : fminf(lb, runner);                     // (bd is +inf while there is no winner yet)
+    bool take = better & !same;
+    bd = take ? d : bd;
+    bi = take ? id : bi;
   }
   LH_HD void skip(float d) { lb = fminf(lb, d); }
   LH_HD void count_node() {}
