@@ -515,6 +515,8 @@ static lh_status task_prepare(lh_ctx* c, Task* t, bool rebuild_index) {
   d.src_cov_pad = src->n_pad;
   d.corr_dist2 = P.corr_dist * P.corr_dist;  // gicp.hpp:438
   d.gicp_eps = P.gicp_epsilon;
+  for (int r = 0; r < 3; r++)
+    for (int cc = 0; cc < 3; cc++) d.guess3[r * 3 + cc] = (double)t->guess[cc * 4 + r];
   HIPCHK(hipMemcpyAsync(&c->descs_dev[t->slot], &d, sizeof(PairDesc), hipMemcpyHostToDevice, ts));
   HIPCHK(hipGetLastError());
   return LH_OK;
@@ -535,9 +537,14 @@ struct Group {
 static lh_status group_launch(lh_ctx* c, Group& g) {
   hipStream_t st = g.stream;
   g.sweeps.clear(); g.moms.clear(); g.costs.clear();
-  // phase 1: sweeps (+ seed pre-pass for cold pairs)
+  // phase 1: sweeps (+ seed pre-pass for cold pairs).  Sweeps are held until every pair of the group has finished its
+  // BFGS solve (cost_mode 0 pairs need different numbers of cost passes), so they always go out as ONE wide launch.
+  bool any_cost = false;
   for (Task* t : g.active)
-    if (t->req == REQ_SWEEP) g.sweeps.push_back(t);
+    if (t->req == REQ_COST) any_cost = true;
+  if (!any_cost)
+    for (Task* t : g.active)
+      if (t->req == REQ_SWEEP) g.sweeps.push_back(t);
   for (size_t o = 0; o < g.sweeps.size(); o += MAX_JOBS) {
     SweepArgs a;
     a.njobs = (int)std::min<size_t>(MAX_JOBS, g.sweeps.size() - o);
@@ -549,7 +556,6 @@ static lh_status group_launch(lh_ctx* c, Group& g) {
       a.job[j].slot = t->slot;
       a.job[j].pad = 0;
       memcpy(a.job[j].T, t->req_T12, sizeof(t->req_T12));
-      memcpy(a.job[j].R, t->req_R9, sizeof(t->req_R9));
       max_n = std::max(max_n, t->src->n);
       bytes += 20.0 * t->src->n;  // SURVEY 8d B_nn = 20 N + 232 K_t; the K_t term is added when the count is known
       t->sweep_bytes_pending = true;
@@ -1186,12 +1192,6 @@ lh_status lh_gicp_debug_sweep(lh_gicp* g, const float T[16], const float guess[1
   SweepArgs a;
   a.njobs = 1; a.bpj = 0; a.job[0].slot = 0; a.job[0].pad = 0;
   Task::T16_to_T12(T, a.job[0].T);
-  for (int i = 0; i < 3; i++)
-    for (int j = 0; j < 3; j++) {
-      double s = 0.0;
-      for (int k = 0; k < 4; k++) s += (double)T[k * 4 + i] * (double)t.guess[j * 4 + k];
-      a.job[0].R[i * 3 + j] = s;
-    }
   { ProfScope p(c, "nn_sweep", 252.0 * g->src->n); launch_sweep(c->descs_dev, a, g->src->n, c->stream); }
   HIPCHK(hipGetLastError());
   int n = g->src->n;

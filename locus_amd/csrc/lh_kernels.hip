@@ -415,7 +415,15 @@ __global__ void __launch_bounds__(256) k_sweep(const PairDesc* __restrict__ desc
       float4 nn = d.tgt_nrm[j];
       cov_from_normal(nn.x, nn.y, nn.z, d.gicp_eps, C2);
     }
-    mahalanobis(job.R, C1, C2, M);  // gicp.hpp:488-493
+    // transform_R = double(transformation_) * double(guess), top-left 3x3 (gicp.hpp:450-460); the k = 3 term is T(i,3)*0
+    double R[9];
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int cc = 0; cc < 3; cc++)
+        R[r * 3 + cc] = (((double)job.T[r * 4 + 0] * d.guess3[0 * 3 + cc] + (double)job.T[r * 4 + 1] * d.guess3[1 * 3 + cc]) +
+                         (double)job.T[r * 4 + 2] * d.guess3[2 * 3 + cc]) + (double)job.T[r * 4 + 3] * 0.0;
+    mahalanobis(R, C1, C2, M);  // gicp.hpp:488-493
     d.maha6[(size_t)0 * d.n_pad + i] = M[0];
     d.maha6[(size_t)1 * d.n_pad + i] = M[1];
     d.maha6[(size_t)2 * d.n_pad + i] = M[2];

@@ -7,7 +7,7 @@
 
 namespace lh {
 
-constexpr int MAX_JOBS = 24;       // jobs (scan pairs) per batched launch; kernarg stays < 4 KB
+constexpr int MAX_JOBS = 32;       // jobs (scan pairs) per batched launch; kernarg stays < 4 KB (32 x 56 B)
 constexpr int COST_CHUNK = 512;    // source points per cost-kernel workgroup (fixed => deterministic sums)
 constexpr int COST_NSUM = 14;      // f, g_t[3], R[9], count
 constexpr int MOM_CHUNK = 1024;    // source points per moment-kernel workgroup
@@ -33,13 +33,13 @@ struct PairDesc {
   int src_cov_pad;  // plane stride of src_cov6
   double corr_dist2;
   double gicp_eps;
+  double guess3[9];  // top-left 3x3 of `guess` (row-major, as double): R = double(transformation_) * double(guess), gicp.hpp:450-460
 };
 
 struct SweepJob {  // dynamic per-launch part
   int slot;
   int pad;
   float T[12];     // transformation_ (row-major 3x4 float)
-  double R[9];     // (double(transformation_) * double(guess)) 3x3, row-major
 };
 struct SweepArgs {
   int njobs;
