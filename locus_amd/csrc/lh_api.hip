@@ -549,10 +549,13 @@ static lh_status group_launch(lh_ctx* c, Group& g) {
     SweepArgs a;
     a.njobs = (int)std::min<size_t>(MAX_JOBS, g.sweeps.size() - o);
     a.bpj = 0;
+    a.max_depth = 0;
+    a.pad = 0;
     int max_n = 0;
     double bytes = 0;
     for (int j = 0; j < a.njobs; j++) {
       Task* t = g.sweeps[o + j];
+      a.max_depth = std::max(a.max_depth, t->tgt->depth);
       a.job[j].slot = t->slot;
       a.job[j].pad = 0;
       memcpy(a.job[j].T, t->req_T12, sizeof(t->req_T12));
@@ -563,6 +566,8 @@ static lh_status group_launch(lh_ctx* c, Group& g) {
     {  // cold tasks (first sweep of a pair): seed pre-pass so the sweep starts warm
       SweepArgs sa;
       sa.njobs = 0;
+      sa.max_depth = a.max_depth;
+      sa.pad = 0;
       int smax = 0;
       for (int j = 0; j < a.njobs; j++) {
         Task* t = g.sweeps[o + j];
@@ -1190,7 +1195,7 @@ lh_status lh_gicp_debug_sweep(lh_gicp* g, const float T[16], const float guess[1
     g->dbg_prepared = true;
   }
   SweepArgs a;
-  a.njobs = 1; a.bpj = 0; a.job[0].slot = 0; a.job[0].pad = 0;
+  a.njobs = 1; a.bpj = 0; a.max_depth = g->tgt->depth; a.pad = 0; a.job[0].slot = 0; a.job[0].pad = 0;
   Task::T16_to_T12(T, a.job[0].T);
   { ProfScope p(c, "nn_sweep", 252.0 * g->src->n); launch_sweep(c->descs_dev, a, g->src->n, c->stream); }
   HIPCHK(hipGetLastError());

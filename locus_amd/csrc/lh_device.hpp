@@ -22,7 +22,7 @@ namespace lh {
 
 constexpr int LEAF = 8;        // points per leaf (128 B = one cache line of sorted points)
 constexpr int MAX_DEPTH = 12;  // 4^12 leaves * 8 pts = 134 M points
-constexpr int STACK_MAX = 3 * MAX_DEPTH + 1;
+constexpr int STACK_MAX = 3 * MAX_DEPTH + 1;  // entries; a kernel launch sizes its LDS stack for the deepest tree it walks
 
 struct alignas(16) Node4 {
   float lox[4], loy[4], loz[4], hix[4], hiy[4], hiz[4];
@@ -34,6 +34,11 @@ struct TreeView {
   int first_leaf;      // heap index of leaf 0 = (4^depth - 1) / 3
   int n_points;
 };
+LH_HD int tree_depth_of(int first_leaf) {  // first_leaf = (4^depth - 1) / 3
+  int d = 0;
+  while ((int)(0x55555555u & ((1u << (2 * d)) - 1u)) < first_leaf) d++;
+  return d;
+}
 
 LH_HD uint32_t f2u(float f) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -128,24 +133,35 @@ LH_HD void cswap(uint64_t& a, uint64_t& b) {
 // Collector concept: float bound() const; void offer(float d2, int id); void skip(float box_d2);
 // A subtree / leaf is visited iff box_d2 <= bound() (ties must be visited for the lowest-index rule); skip() is told the
 // box distance of every subtree that is pruned (so a collector can keep a lower bound on everything it never looked at).
+// Traversal stack: 32-bit entries kept in LDS on the device (layout [entry][thread], conflict-free), a plain array
+// on the host.  An entry does not store a node index: every stacked node is a sibling of a node on the current
+// root-to-node path, so (level, child number) identify it, and the rest of the word holds the box distance
+// truncated to 26 bits (rounded DOWN => the pop-time prune test stays conservative and exactness is preserved).
+// A private uint64 stack[37] lived in scratch: 160 MB for a full chip of waves, i.e. HBM traffic on every push/pop.
+LH_HD uint32_t level_offset_u(int k) { return 0x55555555u & ((1u << (2 * k)) - 1u); }  // (4^k - 1) / 3
+LH_HD int stack_entries_for_depth(int depth) { return 3 * depth + 1; }
+
 template <class Collector>
-LH_HD void tree_search(const TreeView& t, float qx, float qy, float qz, Collector& col) {
+LH_HD void tree_search(const TreeView& t, float qx, float qy, float qz, Collector& col, uint32_t* stack, int stride) {
   // "while-while" traversal: every lane first descends through internal nodes until it holds a leaf, then the wave
-  // scans leaves together -- the node body and the leaf body are not both replayed on every step of a divergent wave.
-  // Sort keys are 32-bit: the float bits of the (non-negative) box distance with the two low mantissa bits replaced by
-  // the child number.  The truncated distance is <= the true one, so using it for the pop-time prune test and for
-  // skip() stays conservative (exactness preserved), and a 4-key sort is ten v_min/v_max_u32.
-  uint64_t stack[STACK_MAX];
-  int sp = 0;
+  // scans leaves together.  Children are ordered with 32-bit keys: float bits of the (non-negative) box distance with
+  // the two low mantissa bits replaced by the child number -> a 4-key sort is ten v_min/v_max_u32.
+  int sp = 0, lvl = 0;
   const uint32_t NONE = 0xffffffffu;
   const uint32_t first_leaf = (uint32_t)t.first_leaf;
   uint32_t lin = 0;
   auto pop = [&]() -> uint32_t {
     for (;;) {
       if (sp == 0) return NONE;
-      uint64_t e = stack[--sp];
-      float dk = u2f((uint32_t)(e >> 32) & ~3u);
-      if (dk <= col.bound()) return (uint32_t)e;
+      uint32_t e = stack[(--sp) * stride];
+      float dk = u2f((e >> 6) << 5);
+      if (dk <= col.bound()) {
+        int le = (int)((e >> 2) & 15u);
+        uint32_t j = (lin - level_offset_u(lvl)) >> (2 * (lvl - (le - 1)));  // ancestor of the current node at level le-1
+        lin = 4u * (level_offset_u(le - 1) + j) + 1u + (e & 3u);
+        lvl = le;
+        return lin;
+      }
       col.skip(dk);
     }
   };
@@ -174,15 +190,16 @@ LH_HD void tree_search(const TreeView& t, float qx, float qy, float qz, Collecto
       a = k0 < k2 ? k0 : k2; b = k0 < k2 ? k2 : k0; k0 = a; k2 = b;
       a = k1 < k3 ? k1 : k3; b = k1 < k3 ? k3 : k1; k1 = a; k3 = b;
       a = k1 < k2 ? k1 : k2; b = k1 < k2 ? k2 : k1; k1 = a; k2 = b;
-      const uint32_t c0 = 4u * lin + 1u;
+      const uint32_t tag = (uint32_t)(lvl + 1) << 2;
       if (k1 != NONE) {  // valid keys sort first: k1 invalid => k2, k3 invalid
         if (k2 != NONE) {
-          if (k3 != NONE) stack[sp++] = ((uint64_t)k3 << 32) | (c0 + (k3 & 3u));
-          stack[sp++] = ((uint64_t)k2 << 32) | (c0 + (k2 & 3u));
+          if (k3 != NONE) { stack[sp * stride] = ((k3 >> 5) << 6) | tag | (k3 & 3u); sp++; }
+          stack[sp * stride] = ((k2 >> 5) << 6) | tag | (k2 & 3u); sp++;
         }
-        stack[sp++] = ((uint64_t)k1 << 32) | (c0 + (k1 & 3u));
+        stack[sp * stride] = ((k1 >> 5) << 6) | tag | (k1 & 3u); sp++;
       }
-      lin = (k0 != NONE) ? (c0 + (k0 & 3u)) : pop();
+      if (k0 != NONE) { lin = 4u * lin + 1u + (k0 & 3u); lvl++; }
+      else lin = pop();
     }
     if (lin == NONE) return;
     col.count_leaf();

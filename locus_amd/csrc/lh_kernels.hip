@@ -327,11 +327,13 @@ __device__ __forceinline__ bool xcd_job_map(int njobs, int bpj, int& job, int& b
   return job < njobs;
 }
 static inline int xcd_grid(int njobs, int bpj) { return njobs * bpj; }
+static inline size_t stack_lds_bytes(int depth, int threads) { return (size_t)stack_entries_for_depth(depth) * threads * sizeof(uint32_t); }
 
 // K2': seeds for a cold sweep.  One thread per group of SEED_GROUP consecutive source points runs the exact search for
 // the group's first point and hands its neighbour to the whole group as warm-start candidate (any target point is a
 // valid candidate, so exactness is untouched; consecutive lidar returns are spatial neighbours, so the bound is tight).
 __global__ void __launch_bounds__(256) k_seed(const PairDesc* __restrict__ descs, SweepArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];  // [entries][256]
   int jb, blk;
   if (!xcd_job_map(a.njobs, a.bpj, jb, blk)) return;
   const SweepJob& job = a.job[jb];
@@ -344,7 +346,7 @@ __global__ void __launch_bounds__(256) k_seed(const PairDesc* __restrict__ descs
   xform_pt(job.T, p.x, p.y, p.z, qx, qy, qz);
   TreeView tv{d.tgt_sorted, d.tgt_nodes, d.first_leaf, d.m};
   Nn1Collector col{INFINITY, 0x7fffffff};
-  tree_search(tv, qx, qy, qz, col);
+  tree_search(tv, qx, qy, qz, col, lds_stack + threadIdx.x, 256);
   int j = (col.bi == 0x7fffffff) ? -1 : col.bi;
 #pragma unroll
   for (int e = 0; e < SEED_GROUP; e++)
@@ -356,10 +358,11 @@ __global__ void __launch_bounds__(256) k_seed(const PairDesc* __restrict__ descs
 void launch_seed(const PairDesc* descs, SweepArgs& a, int max_n, hipStream_t s) {
   int groups = (max_n + SEED_GROUP - 1) / SEED_GROUP;
   a.bpj = (groups + 255) / 256;
-  hipLaunchKernelGGL(k_seed, dim3(xcd_grid(a.njobs, a.bpj)), dim3(256), 0, s, descs, a);
+  hipLaunchKernelGGL(k_seed, dim3(xcd_grid(a.njobs, a.bpj)), dim3(256), stack_lds_bytes(a.max_depth, 256), s, descs, a);
 }
 
 __global__ void __launch_bounds__(256) k_sweep(const PairDesc* __restrict__ descs, SweepArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];  // [entries][256]
   int jb, blk;
   if (!xcd_job_map(a.njobs, a.bpj, jb, blk)) return;
   const SweepJob& job = a.job[jb];
@@ -387,7 +390,7 @@ __global__ void __launch_bounds__(256) k_sweep(const PairDesc* __restrict__ desc
     if (dw * (1.0 + 1e-5) + e * (1.0 + 1e-5) + 1e-12 < lo * (1.0 - 1e-5)) need_search = false;
   }
   if (need_search) {
-    tree_search(tv, qx, qy, qz, col);
+    tree_search(tv, qx, qy, qz, col, lds_stack + threadIdx.x, 256);
     d.cert[i] = make_float4(qx, qy, qz, col.lb);
     if (d.stats) atomicAdd(&d.stats[0], 1ull);  // instrumentation only (lh_gicp_debug_sweep): contended atomics
   }
@@ -438,7 +441,7 @@ __global__ void __launch_bounds__(256) k_sweep(const PairDesc* __restrict__ desc
 
 void launch_sweep(const PairDesc* descs, SweepArgs& a, int max_n, hipStream_t s) {
   a.bpj = (max_n + 255) / 256;
-  hipLaunchKernelGGL(k_sweep, dim3(xcd_grid(a.njobs, a.bpj)), dim3(256), 0, s, descs, a);
+  hipLaunchKernelGGL(k_sweep, dim3(xcd_grid(a.njobs, a.bpj)), dim3(256), stack_lds_bytes(a.max_depth, 256), s, descs, a);
 }
 
 // ===== K5: cost / gradient reduction =======================================================================
@@ -658,24 +661,26 @@ void launch_fill_i32(int32_t* p, int n, int32_t v, hipStream_t s) {
 
 __global__ void __launch_bounds__(256) k_nn1(const float4* __restrict__ q, int nq, T12 T, int has_T, TreeView tv,
                                              int32_t* __restrict__ idx, float* __restrict__ d2) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nq) return;
   float4 p = q[i];
   float x = p.x, y = p.y, z = p.z;
   if (has_T) xform_pt(T.v, p.x, p.y, p.z, x, y, z);
   Nn1Collector col{INFINITY, 0x7fffffff};
-  tree_search(tv, x, y, z, col);
+  tree_search(tv, x, y, z, col, lds_stack + threadIdx.x, 256);
   idx[i] = (col.bi == 0x7fffffff) ? -1 : col.bi;
   d2[i] = col.bd;
 }
 void launch_nn1(const float4* q, int nq, const float* T12p, TreeView tree, int32_t* idx, float* d2, hipStream_t s) {
   T12 T;
   for (int k = 0; k < 12; k++) T.v[k] = T12p ? T12p[k] : 0.f;
-  hipLaunchKernelGGL(k_nn1, dim3((nq + 255) / 256), dim3(256), 0, s, q, nq, T, T12p ? 1 : 0, tree, idx, d2);
+  hipLaunchKernelGGL(k_nn1, dim3((nq + 255) / 256), dim3(256), stack_lds_bytes(tree_depth_of(tree.first_leaf), 256), s, q, nq, T, T12p ? 1 : 0, tree, idx, d2);
 }
 
 __global__ void __launch_bounds__(256) k_nn1_stats(const float4* __restrict__ q, int nq, T12 T, int has_T, TreeView tv,
                                                    unsigned long long* __restrict__ stats) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   int nodes = 0, leaves = 0;
   if (i < nq) {
@@ -683,7 +688,7 @@ __global__ void __launch_bounds__(256) k_nn1_stats(const float4* __restrict__ q,
     float x = p.x, y = p.y, z = p.z;
     if (has_T) xform_pt(T.v, p.x, p.y, p.z, x, y, z);
     Nn1CountCollector col{INFINITY, 0x7fffffff, 0, 0};
-    tree_search(tv, x, y, z, col);
+    tree_search(tv, x, y, z, col, lds_stack + threadIdx.x, 256);
     nodes = col.nodes; leaves = col.leaves;
   }
   int tot = nodes + leaves, mx = tot, sn = nodes, sl = leaves;
@@ -703,7 +708,7 @@ __global__ void __launch_bounds__(256) k_nn1_stats(const float4* __restrict__ q,
 void launch_nn1_stats(const float4* q, int nq, const float* T12p, TreeView tree, unsigned long long* stats, hipStream_t s) {
   T12 T;
   for (int k = 0; k < 12; k++) T.v[k] = T12p ? T12p[k] : 0.f;
-  hipLaunchKernelGGL(k_nn1_stats, dim3((nq + 255) / 256), dim3(256), 0, s, q, nq, T, T12p ? 1 : 0, tree, stats);
+  hipLaunchKernelGGL(k_nn1_stats, dim3((nq + 255) / 256), dim3(256), stack_lds_bytes(tree_depth_of(tree.first_leaf), 256), s, q, nq, T, T12p ? 1 : 0, tree, stats);
 }
 
 // double sum of floats: 1024 values per block, fixed tree
@@ -738,7 +743,8 @@ __global__ void __launch_bounds__(KNN_BLOCK) k_knn(const float4* __restrict__ q,
   if (i >= nq) return;
   float4 p = q[i];
   KnnCollector col{kd + threadIdx.x, ki + threadIdx.x, k, KNN_BLOCK, 0};
-  tree_search(tv, p.x, p.y, p.z, col);
+  uint32_t* lds_stack = reinterpret_cast<uint32_t*>(smem + (size_t)8 * k * KNN_BLOCK);
+  tree_search(tv, p.x, p.y, p.z, col, lds_stack + threadIdx.x, KNN_BLOCK);
   for (int e = 0; e < k; e++) {
     bool ok = e < col.cnt;
     idx[(size_t)i * k + e] = ok ? ki[e * KNN_BLOCK + threadIdx.x] : -1;
@@ -746,7 +752,7 @@ __global__ void __launch_bounds__(KNN_BLOCK) k_knn(const float4* __restrict__ q,
   }
 }
 void launch_knn(const float4* q, int nq, TreeView tree, int k, int32_t* idx, float* d2, hipStream_t s) {
-  size_t sh = (size_t)k * KNN_BLOCK * 8;
+  size_t sh = (size_t)k * KNN_BLOCK * 8 + stack_lds_bytes(tree_depth_of(tree.first_leaf), KNN_BLOCK);
   hipLaunchKernelGGL(k_knn, dim3((nq + KNN_BLOCK - 1) / KNN_BLOCK), dim3(KNN_BLOCK), sh, s, q, nq, tree, k, idx, d2);
 }
 
@@ -760,7 +766,8 @@ __global__ void __launch_bounds__(KNN_BLOCK) k_knn_cov(const float4* __restrict_
   if (i >= n) return;
   float4 p = xyz[i];
   KnnCollector col{kd + threadIdx.x, ki + threadIdx.x, k, KNN_BLOCK, 0};
-  tree_search(tv, p.x, p.y, p.z, col);
+  uint32_t* lds_stack = reinterpret_cast<uint32_t*>(smem + (size_t)8 * k * KNN_BLOCK);
+  tree_search(tv, p.x, p.y, p.z, col, lds_stack + threadIdx.x, KNN_BLOCK);
   double mean[3] = {0, 0, 0}, c00 = 0, c10 = 0, c11 = 0, c20 = 0, c21 = 0, c22 = 0;
   for (int e = 0; e < k; e++) {  // neighbours in ascending (d2, id) order, like the search returns them
     float4 t = xyz[ki[e * KNN_BLOCK + threadIdx.x]];
@@ -791,7 +798,7 @@ __global__ void __launch_bounds__(KNN_BLOCK) k_knn_cov(const float4* __restrict_
   cov6[(size_t)5 * n_pad + i] = 1.0 - s * u[2] * u[2];
 }
 void launch_knn_cov(const float4* xyz, int n, int n_pad, TreeView tree, int k, double eps, double* cov6, hipStream_t s) {
-  size_t sh = (size_t)k * KNN_BLOCK * 8;
+  size_t sh = (size_t)k * KNN_BLOCK * 8 + stack_lds_bytes(tree_depth_of(tree.first_leaf), KNN_BLOCK);
   hipLaunchKernelGGL(k_knn_cov, dim3((n + KNN_BLOCK - 1) / KNN_BLOCK), dim3(KNN_BLOCK), sh, s, xyz, n, n_pad, tree, k, eps, cov6);
 }
 
@@ -843,7 +850,8 @@ __global__ void __launch_bounds__(KNN_BLOCK) k_knn_normals(const float4* __restr
   if (i >= n) return;
   float4 p = xyz[i];
   KnnCollector col{kd + threadIdx.x, ki + threadIdx.x, k, KNN_BLOCK, 0};
-  tree_search(tv, p.x, p.y, p.z, col);
+  uint32_t* lds_stack = reinterpret_cast<uint32_t*>(smem + (size_t)8 * k * KNN_BLOCK);
+  tree_search(tv, p.x, p.y, p.z, col, lds_stack + threadIdx.x, KNN_BLOCK);
   const float qnan = __uint_as_float(0x7fc00000u);
   if (col.cnt < 3) {
     out[i] = make_float4(qnan, qnan, qnan, qnan);
@@ -888,7 +896,7 @@ __global__ void __launch_bounds__(KNN_BLOCK) k_knn_normals(const float4* __restr
   out[i] = make_float4(nx, ny, nz, curv);
 }
 void launch_knn_normals(const float4* xyz, int n, TreeView tree, int k, float4* out_nrm, hipStream_t s) {
-  size_t sh = (size_t)k * KNN_BLOCK * 8;
+  size_t sh = (size_t)k * KNN_BLOCK * 8 + stack_lds_bytes(tree_depth_of(tree.first_leaf), KNN_BLOCK);
   hipLaunchKernelGGL(k_knn_normals, dim3((n + KNN_BLOCK - 1) / KNN_BLOCK), dim3(KNN_BLOCK), sh, s, xyz, n, tree, k, out_nrm);
 }
 

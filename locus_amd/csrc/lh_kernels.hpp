@@ -44,6 +44,8 @@ struct SweepJob {  // dynamic per-launch part
 struct SweepArgs {
   int njobs;
   int bpj;         // workgroups per job
+  int max_depth;   // deepest target tree among the jobs (sizes the LDS traversal stack)
+  int pad;
   SweepJob job[MAX_JOBS];
 };
 

@@ -96,6 +96,7 @@ static int run_case(int n, int nq, int k, unsigned seed, bool dup) {
   HostTree t = build(pts);
   TreeView tv = t.view();
   int bad = 0;
+  std::vector<uint32_t> stk(STACK_MAX);
   std::vector<float> kd(k), bd(n);
   std::vector<int> ki(k), ord(n);
   for (int i = 0; i < nq; i++) {
@@ -105,15 +106,15 @@ static int run_case(int n, int nq, int k, unsigned seed, bool dup) {
     int kk = std::min(k, n);
     std::partial_sort(ord.begin(), ord.begin() + kk, ord.end(), [&](int a, int b) { return bd[a] < bd[b] || (bd[a] == bd[b] && a < b); });
     Nn1Collector c1{inf_f(), 0x7fffffff};
-    tree_search(tv, q.x, q.y, q.z, c1);
+    tree_search(tv, q.x, q.y, q.z, c1, stk.data(), 1);
     if (c1.bi != ord[0] || c1.bd != bd[ord[0]]) bad++;
     // warm start from an arbitrary valid candidate must give the same answer
     int w = (int)(rng() % n);
     Nn1Collector c2{bd[w], w};
-    tree_search(tv, q.x, q.y, q.z, c2);
+    tree_search(tv, q.x, q.y, q.z, c2, stk.data(), 1);
     if (c2.bi != ord[0] || c2.bd != bd[ord[0]]) bad++;
     KnnCollector ck{kd.data(), ki.data(), kk, 1, 0};
-    tree_search(tv, q.x, q.y, q.z, ck);
+    tree_search(tv, q.x, q.y, q.z, ck, stk.data(), 1);
     if (ck.cnt != kk) bad++;
     for (int e = 0; e < kk; e++)
       if (ki[e] != ord[e] || kd[e] != bd[ord[e]]) { bad++; break; }
