@@ -298,7 +298,7 @@ struct Workspace {
 
 static lh_status ctx_ensure_slots(lh_ctx* c, int n_slots, int max_n) {
   size_t per_slot = std::max<size_t>((size_t)cost_blocks(max_n) * COST_NSUM, MOM_NSUM);
-  int mom_stride = mom_blocks(max_n) * MOM_NSUM;
+  int mom_stride = ((max_n + FUSED_CHUNK - 1) / FUSED_CHUNK) * MOM_NSUM;  // one partial per 256-point workgroup of the fused sweep
   if (n_slots <= c->n_slots && per_slot <= c->partials_per_slot && mom_stride <= c->mom_stride) return LH_OK;
   (void)hipStreamSynchronize(c->stream);
   n_slots = std::max(n_slots, c->n_slots);
@@ -582,26 +582,49 @@ static lh_status group_launch(lh_ctx* c, Group& g) {
         launch_seed(c->descs_dev, sa, smax, st);
       }
     }
-    ProfScope p(c, "nn_sweep", bytes, st);
-    launch_sweep(c->descs_dev, a, max_n, st);
-  }
-  // cost_mode 1: one moment reduction per sweep replaces every per-evaluation pass of this outer iteration
-  for (Task* t : g.sweeps)
-    if (t->P.cost_mode == 1) g.moms.push_back(t);
-  for (size_t o = 0; o < g.moms.size(); o += MAX_JOBS) {
-    CostArgs a;
-    a.njobs = (int)std::min<size_t>(MAX_JOBS, g.moms.size() - o);
-    a.pad = 0;
-    int max_n = 0;
-    for (int j = 0; j < a.njobs; j++) {
-      Task* t = g.moms[o + j];
-      a.job[j].slot = t->slot;
-      a.job[j].out_offset = (int)((size_t)t->slot * c->partials_per_slot);
-      memcpy(a.job[j].T, t->req_T12, sizeof(t->req_T12));
-      max_n = std::max(max_n, t->src->n);
+    bool all_fused = true;
+    for (int j = 0; j < a.njobs; j++)
+      if (g.sweeps[o + j]->P.cost_mode != 1) all_fused = false;
+    if (all_fused) {
+      // cost_mode 1: sweep and moment reduction in ONE kernel; M and the correspondences never reach HBM
+      CostArgs ca;
+      ca.njobs = a.njobs;
+      ca.pad = 0;
+      for (int j = 0; j < a.njobs; j++) {
+        Task* t = g.sweeps[o + j];
+        ca.job[j].slot = t->slot;
+        ca.job[j].out_offset = (int)((size_t)t->slot * c->partials_per_slot);
+        memcpy(ca.job[j].T, t->req_T12, sizeof(t->req_T12));
+        g.moms.push_back(t);
+      }
+      ProfScope p(c, "nn_sweep", bytes, st);
+      launch_sweep_fused(c->descs_dev, a, max_n, c->mom_partials_dev, c->mom_stride, st);
+      launch_moments_final(c->descs_dev, ca, c->mom_partials_dev, c->mom_stride, FUSED_CHUNK, c->partials_host, st);
+    } else {
+      {
+        ProfScope p(c, "nn_sweep", bytes, st);
+        launch_sweep(c->descs_dev, a, max_n, st);
+      }
+      // mixed batch: cost_mode 1 pairs get a separate moment pass over the stored correspondences
+      CostArgs ca;
+      ca.njobs = 0;
+      ca.pad = 0;
+      int mmax = 0;
+      for (int j = 0; j < a.njobs; j++) {
+        Task* t = g.sweeps[o + j];
+        if (t->P.cost_mode != 1) continue;
+        ca.job[ca.njobs].slot = t->slot;
+        ca.job[ca.njobs].out_offset = (int)((size_t)t->slot * c->partials_per_slot);
+        memcpy(ca.job[ca.njobs].T, t->req_T12, sizeof(t->req_T12));
+        ca.njobs++;
+        mmax = std::max(mmax, t->src->n);
+        g.moms.push_back(t);
+      }
+      if (ca.njobs > 0) {
+        ProfScope p(c, "cost_moments", 0.0, st);
+        launch_moments(c->descs_dev, ca, mmax, c->mom_partials_dev, c->mom_stride, c->partials_host, st);
+      }
     }
-    ProfScope p(c, "cost_moments", 0.0, st);
-    launch_moments(c->descs_dev, a, max_n, c->mom_partials_dev, c->mom_stride, c->partials_host, st);
   }
   for (Task* t : g.sweeps)
     if (t->P.cost_mode != 1) t->resume();  // each now yields its first COST request (or DONE)

@@ -361,17 +361,18 @@ void launch_seed(const PairDesc* descs, SweepArgs& a, int max_n, hipStream_t s) 
   hipLaunchKernelGGL(k_seed, dim3(xcd_grid(a.njobs, a.bpj)), dim3(256), stack_lds_bytes(a.max_depth, 256), s, descs, a);
 }
 
-__global__ void __launch_bounds__(256) k_sweep(const PairDesc* __restrict__ descs, SweepArgs a) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];  // [entries][256]
-  int jb, blk;
-  if (!xcd_job_map(a.njobs, a.bpj, jb, blk)) return;
-  const SweepJob& job = a.job[jb];
-  const PairDesc d = descs[job.slot];
-  int i = blk * 256 + threadIdx.x;
-  if (i >= d.n) return;
-  float4 p = d.src[i];
+// one source point of a sweep: exact NN (warm start + certificate) and, if gated in, M = (R C1 R^T + C2)^-1
+struct SweepPoint {
+  float4 p;      // source point
+  float4 tgt;    // matched target point
+  double M[9];
+  int j;         // target index or -1
+  bool matched;
+};
+__device__ __forceinline__ void sweep_point(const PairDesc& d, const SweepJob& job, int i, uint32_t* stack, SweepPoint& o) {
+  o.p = d.src[i];
   float qx, qy, qz;
-  xform_pt(job.T, p.x, p.y, p.z, qx, qy, qz);  // gicp.hpp:469
+  xform_pt(job.T, o.p.x, o.p.y, o.p.z, qx, qy, qz);  // gicp.hpp:469
   TreeView tv{d.tgt_sorted, d.tgt_nodes, d.first_leaf, d.m};
   Nn1CertCollector col{INFINITY, 0x7fffffff, INFINITY};
   int w = d.prev_nn[i];
@@ -390,16 +391,17 @@ __global__ void __launch_bounds__(256) k_sweep(const PairDesc* __restrict__ desc
     if (dw * (1.0 + 1e-5) + e * (1.0 + 1e-5) + 1e-12 < lo * (1.0 - 1e-5)) need_search = false;
   }
   if (need_search) {
-    tree_search(tv, qx, qy, qz, col, lds_stack + threadIdx.x, 256);
+    tree_search(tv, qx, qy, qz, col, stack, 256);
     d.cert[i] = make_float4(qx, qy, qz, col.lb);
     if (d.stats) atomicAdd(&d.stats[0], 1ull);  // instrumentation only (lh_gicp_debug_sweep): contended atomics
   }
   if (d.stats) atomicAdd(&d.stats[1], 1ull);
   int j = (col.bi == 0x7fffffff) ? -1 : col.bi;
-  d.prev_nn[i] = j;
-  float4 c = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
-  if (j >= 0 && (double)col.bd < d.corr_dist2) {  // gicp.hpp:483
-    double C1[9], C2[9], M[9];
+  if (j != w) d.prev_nn[i] = j;
+  o.j = j;
+  o.matched = j >= 0 && (double)col.bd < d.corr_dist2;  // gicp.hpp:483
+  if (o.matched) {
+    double C1[9], C2[9];
     if (d.src_cov6) {
       double s6[6];
 #pragma unroll
@@ -426,19 +428,107 @@ __global__ void __launch_bounds__(256) k_sweep(const PairDesc* __restrict__ desc
       for (int cc = 0; cc < 3; cc++)
         R[r * 3 + cc] = (((double)job.T[r * 4 + 0] * d.guess3[0 * 3 + cc] + (double)job.T[r * 4 + 1] * d.guess3[1 * 3 + cc]) +
                          (double)job.T[r * 4 + 2] * d.guess3[2 * 3 + cc]) + (double)job.T[r * 4 + 3] * 0.0;
-    mahalanobis(R, C1, C2, M);  // gicp.hpp:488-493
-    d.maha6[(size_t)0 * d.n_pad + i] = M[0];
-    d.maha6[(size_t)1 * d.n_pad + i] = M[1];
-    d.maha6[(size_t)2 * d.n_pad + i] = M[2];
-    d.maha6[(size_t)3 * d.n_pad + i] = M[4];
-    d.maha6[(size_t)4 * d.n_pad + i] = M[5];
-    d.maha6[(size_t)5 * d.n_pad + i] = M[8];
-    float4 t = d.tgt_xyz[j];
-    c = make_float4(t.x, t.y, t.z, __int_as_float(j));
+    mahalanobis(R, C1, C2, o.M);  // gicp.hpp:488-493
+    o.tgt = d.tgt_xyz[j];
+  }
+}
+
+__global__ void __launch_bounds__(256) k_sweep(const PairDesc* __restrict__ descs, SweepArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];  // [entries][256]
+  int jb, blk;
+  if (!xcd_job_map(a.njobs, a.bpj, jb, blk)) return;
+  const SweepJob& job = a.job[jb];
+  const PairDesc d = descs[job.slot];
+  int i = blk * 256 + threadIdx.x;
+  if (i >= d.n) return;
+  SweepPoint sp;
+  sweep_point(d, job, i, lds_stack + threadIdx.x, sp);
+  float4 c = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
+  if (sp.matched) {
+    d.maha6[(size_t)0 * d.n_pad + i] = sp.M[0];
+    d.maha6[(size_t)1 * d.n_pad + i] = sp.M[1];
+    d.maha6[(size_t)2 * d.n_pad + i] = sp.M[2];
+    d.maha6[(size_t)3 * d.n_pad + i] = sp.M[4];
+    d.maha6[(size_t)4 * d.n_pad + i] = sp.M[5];
+    d.maha6[(size_t)5 * d.n_pad + i] = sp.M[8];
+    c = make_float4(sp.tgt.x, sp.tgt.y, sp.tgt.z, __int_as_float(sp.j));
   }
   d.corr[i] = c;
 }
 
+// K4 + K5' fused (cost_mode 1): the Mahalanobis matrix and the correspondence never leave registers -- each workgroup
+// reduces the 74 second-order moments of its 256 points through LDS (the traversal stack's region is reused) and writes
+// one 74-double partial.  Late GICP iterations, where certificates skip the tree walk, become a pure stream of the
+// source cloud: ~90 B/point instead of 152 B (sweep) + 80 B (moments pass).
+__device__ __forceinline__ double mom_value(int k, const double* M6, const double* Ma, double aMa, const double* pt, const double* pp) {
+  if (k == 0) return aMa;
+  if (k < 13) return Ma[(k - 1) >> 2] * pt[(k - 1) & 3];
+  if (k < 73) return M6[(k - 13) / 10] * pp[(k - 13) % 10];
+  return 1.0;
+}
+__global__ void __launch_bounds__(256) k_sweep_fused(const PairDesc* __restrict__ descs, SweepArgs a, double* __restrict__ partials,
+                                                     int partials_stride) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];  // [entries][256], later reused as double[8][256]
+  int jb, blk;
+  if (!xcd_job_map(a.njobs, a.bpj, jb, blk)) return;
+  const SweepJob& job = a.job[jb];
+  const PairDesc d = descs[job.slot];
+  if (blk * 256 >= d.n) return;  // whole workgroup out of range (uniform)
+  int i = blk * 256 + threadIdx.x;
+  SweepPoint sp;
+  sp.matched = false;
+  if (i < d.n) sweep_point(d, job, i, lds_stack + threadIdx.x, sp);
+  double M6[6] = {0, 0, 0, 0, 0, 0}, Ma[3] = {0, 0, 0}, pt[4] = {0, 0, 0, 0}, pp[10], aMa = 0.0;
+  if (sp.matched) {
+    pt[0] = (double)sp.p.x; pt[1] = (double)sp.p.y; pt[2] = (double)sp.p.z; pt[3] = 1.0;
+    double T0[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) T0[k] = (double)job.T[k];
+    double a0 = (((T0[0] * pt[0] + T0[1] * pt[1]) + T0[2] * pt[2]) + T0[3]) - (double)sp.tgt.x;
+    double a1 = (((T0[4] * pt[0] + T0[5] * pt[1]) + T0[6] * pt[2]) + T0[7]) - (double)sp.tgt.y;
+    double a2 = (((T0[8] * pt[0] + T0[9] * pt[1]) + T0[10] * pt[2]) + T0[11]) - (double)sp.tgt.z;
+    M6[0] = sp.M[0]; M6[1] = sp.M[1]; M6[2] = sp.M[2]; M6[3] = sp.M[4]; M6[4] = sp.M[5]; M6[5] = sp.M[8];
+    Ma[0] = (M6[0] * a0 + M6[1] * a1) + M6[2] * a2;
+    Ma[1] = (M6[1] * a0 + M6[3] * a1) + M6[4] * a2;
+    Ma[2] = (M6[2] * a0 + M6[4] * a1) + M6[5] * a2;
+    aMa = (a0 * Ma[0] + a1 * Ma[1]) + a2 * Ma[2];
+  }
+  {
+    int t = 0;
+#pragma unroll
+    for (int cc = 0; cc < 4; cc++)
+#pragma unroll
+      for (int ee = cc; ee < 4; ee++) pp[t++] = pt[cc] * pt[ee];
+  }
+  const double live = sp.matched ? 1.0 : 0.0;
+  double* st = reinterpret_cast<double*>(lds_stack);  // [8][256]
+  const int tid = threadIdx.x, v_of = tid >> 5, part = tid & 31;
+  double* out = partials + (size_t)job.slot * partials_stride + (size_t)blk * MOM_NSUM;
+  __syncthreads();  // every lane is done with its traversal stack
+#pragma unroll
+  for (int g = 0; g < (MOM_NSUM + 7) / 8; g++) {
+#pragma unroll
+    for (int v = 0; v < 8; v++) {
+      int k = g * 8 + v;
+      if (k < MOM_NSUM) st[v * 256 + tid] = (k == 73) ? live : mom_value(k, M6, Ma, aMa, pt, pp);
+    }
+    __syncthreads();
+    double s = 0.0;
+#pragma unroll
+    for (int jj = 0; jj < 8; jj++) s += st[v_of * 256 + jj * 32 + part];
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) s += __shfl_down(s, off, 32);
+    if (part == 0 && g * 8 + v_of < MOM_NSUM) out[g * 8 + v_of] = s;
+    __syncthreads();
+  }
+}
+
+void launch_sweep_fused(const PairDesc* descs, SweepArgs& a, int max_n, double* partials_dev, int partials_stride, hipStream_t s) {
+  a.bpj = (max_n + 255) / 256;
+  size_t lds = stack_lds_bytes(a.max_depth, 256);
+  if (lds < 8 * 256 * sizeof(double)) lds = 8 * 256 * sizeof(double);
+  hipLaunchKernelGGL(k_sweep_fused, dim3(xcd_grid(a.njobs, a.bpj)), dim3(256), lds, s, descs, a, partials_dev, partials_stride);
+}
 void launch_sweep(const PairDesc* descs, SweepArgs& a, int max_n, hipStream_t s) {
   a.bpj = (max_n + 255) / 256;
   hipLaunchKernelGGL(k_sweep, dim3(xcd_grid(a.njobs, a.bpj)), dim3(256), stack_lds_bytes(a.max_depth, 256), s, descs, a);
@@ -602,10 +692,10 @@ __global__ void __launch_bounds__(256) k_moments(const PairDesc* __restrict__ de
 }
 
 __global__ void __launch_bounds__(128) k_moments_final(const PairDesc* __restrict__ descs, CostArgs a, const double* __restrict__ partials,
-                                                       int partials_stride, double* __restrict__ out) {
+                                                       int partials_stride, int chunk, double* __restrict__ out) {
   const CostJob& job = a.job[blockIdx.x];
   int n = descs[job.slot].n;
-  int nb = (n + MOM_CHUNK - 1) / MOM_CHUNK;
+  int nb = (n + chunk - 1) / chunk;
   if (threadIdx.x < MOM_NSUM) {
     const double* p = partials + (size_t)job.slot * partials_stride + threadIdx.x;
     double s = 0.0;
@@ -625,7 +715,11 @@ __global__ void __launch_bounds__(128) k_moments_final(const PairDesc* __restric
 void launch_moments(const PairDesc* descs, const CostArgs& a, int max_n, double* partials_dev, int partials_stride, double* out,
                     hipStream_t s) {
   hipLaunchKernelGGL(k_moments, dim3(mom_blocks(max_n), a.njobs), dim3(256), 0, s, descs, a, partials_dev, partials_stride);
-  hipLaunchKernelGGL(k_moments_final, dim3(a.njobs), dim3(128), 0, s, descs, a, partials_dev, partials_stride, out);
+  hipLaunchKernelGGL(k_moments_final, dim3(a.njobs), dim3(128), 0, s, descs, a, partials_dev, partials_stride, MOM_CHUNK, out);
+}
+void launch_moments_final(const PairDesc* descs, const CostArgs& a, double* partials_dev, int partials_stride, int chunk, double* out,
+                          hipStream_t s) {
+  hipLaunchKernelGGL(k_moments_final, dim3(a.njobs), dim3(128), 0, s, descs, a, partials_dev, partials_stride, chunk, out);
 }
 
 // ===== K6 / misc ===========================================================================================

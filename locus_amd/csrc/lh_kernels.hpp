@@ -91,6 +91,11 @@ void launch_index_trees(const IndexDesc* descs, int n_clouds, int max_n_padded, 
 
 // ---- K4 / K5 ---------------------------------------------------------------------------------------
 void launch_sweep(const PairDesc* descs, SweepArgs& a, int max_n, hipStream_t s);
+// cost_mode 1: sweep + 74-moment reduction in one kernel (one partial per 256-point workgroup), then the final sum
+void launch_sweep_fused(const PairDesc* descs, SweepArgs& a, int max_n, double* partials_dev, int partials_stride, hipStream_t s);
+void launch_moments_final(const PairDesc* descs, const CostArgs& a, double* partials_dev, int partials_stride, int chunk, double* out,
+                          hipStream_t s);
+constexpr int FUSED_CHUNK = 256;
 // cold-start helper: exact NN of every 8th source point, written as the warm-start candidate of its 8-point group
 void launch_seed(const PairDesc* descs, SweepArgs& a, int max_n, hipStream_t s);
 constexpr int SEED_GROUP = 8;
