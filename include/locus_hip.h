@@ -163,9 +163,11 @@ lh_status lh_cov_knn(lh_cloud* c, int k, double gicp_epsilon, double* cov9_out);
 lh_status lh_gicp_debug_sweep(lh_gicp* g, const float T[16], const float guess[16], int32_t* tgt_idx, double* maha9);
 /* instrumentation: out[0] = source points whose sweep ran the tree traversal, out[1] = source points swept (cumulative) */
 lh_status lh_gicp_debug_stats(lh_gicp* g, uint64_t out[2], int reset);
-/* instrumentation of the tree traversal (cold 1-NN of T*q): out = {sum node visits, sum leaf visits, sum over waves of the
-   per-wave max visits, number of waves, max visits of any query} */
-lh_status lh_debug_traversal_stats(lh_cloud* target, const lh_cloud* q, const float T[16], uint64_t out[5]);
+/* instrumentation of the tree traversal (1-NN of T*q; cand = optional warm-start candidate per query, leaf_prescan = look at
+   the candidate's leaf first): out = {sum node visits, sum leaf visits, sum over waves of the per-wave max visits, number of
+   waves, max visits of any query} */
+lh_status lh_debug_traversal_stats(lh_cloud* target, const lh_cloud* q, const float T[16], const int32_t* cand, int leaf_prescan,
+                                   uint64_t out[5]);
 /* K5: one cost-functor pass fdf(x) (gicp.hpp:362-402) on the correspondences of the last sweep */
 lh_status lh_gicp_debug_cost(lh_gicp* g, const double x[6], double* f, double g6[6], double sums13[13], int* m);
 

@@ -144,7 +144,7 @@ def lib():
         L.lh_cov_knn.argtypes = [vp, i32, dbl, vp]
         L.lh_gicp_debug_sweep.argtypes = [vp, vp, vp, vp, vp]
         L.lh_gicp_debug_stats.argtypes = [vp, vp, i32]
-        L.lh_debug_traversal_stats.argtypes = [vp, vp, vp, vp]
+        L.lh_debug_traversal_stats.argtypes = [vp, vp, vp, vp, i32, vp]
         L.lh_gicp_debug_cost.argtypes = [vp, vp, C.POINTER(dbl), vp, vp, C.POINTER(i32)]
         L.lh_p2plane_information.argtypes = [vp, vp, vp, vp, vp]
         L.lh_icp_covariance.argtypes = [vp, dbl, vp, C.POINTER(dbl)]
@@ -352,10 +352,12 @@ class Cloud:
         _check(lib().lh_knn_cloud(self.h, query_cloud.h, k, _ptr(idx), _ptr(d2)), "lh_knn_cloud")
         return idx, d2
 
-    def traversal_stats(self, query_cloud, T16=None):
+    def traversal_stats(self, query_cloud, T16=None, cand=None, leaf_prescan=False):
         out = np.zeros(5, np.uint64)
         T = np.ascontiguousarray(T16, np.float32).reshape(16) if T16 is not None else None
-        _check(lib().lh_debug_traversal_stats(self.h, query_cloud.h, _ptr(T), _ptr(out)), "lh_debug_traversal_stats")
+        cd = np.ascontiguousarray(cand, np.int32) if cand is not None else None
+        _check(lib().lh_debug_traversal_stats(self.h, query_cloud.h, _ptr(T), _ptr(cd), 1 if leaf_prescan else 0, _ptr(out)),
+               "lh_debug_traversal_stats")
         n, w = len(query_cloud), int(out[3])
         return {"nodes_per_query": out[0] / n, "leaves_per_query": out[1] / n, "wave_max_visits_avg": out[2] / max(w, 1),
                 "max_visits": int(out[4])}

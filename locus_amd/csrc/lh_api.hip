@@ -130,6 +130,7 @@ struct lh_cloud {
   bool has_index = false;
   float4* sorted = nullptr;
   Node4* nodes = nullptr;
+  int32_t* pos = nullptr;      // original index -> sorted position
   int depth = 0, first_leaf = 0, n_leaves = 0, sorted_cap = 0, nodes_cap = 0;
   // k-NN covariances (6 planes of n_pad doubles), valid for (cov_k, cov_eps)
   double* cov6 = nullptr;
@@ -143,7 +144,7 @@ static int round_up(int v, int m) { return (v + m - 1) / m * m; }
 static void cloud_free(lh_cloud* c) {
   if (!c) return;
   (void)hipFree(c->xyz); (void)hipFree(c->nrm); (void)hipFree(c->intensity);
-  (void)hipFree(c->sorted); (void)hipFree(c->nodes); (void)hipFree(c->cov6);
+  (void)hipFree(c->sorted); (void)hipFree(c->nodes); (void)hipFree(c->cov6); (void)hipFree(c->pos);
   delete c;
 }
 
@@ -203,6 +204,8 @@ static lh_status build_indices(lh_ctx* x, lh_cloud* const* clouds, int n_clouds,
         (void)hipStreamSynchronize(x->stream);
         (void)hipFree(c->sorted);
         HIPCHK(hipMalloc(&c->sorted, sizeof(float4) * (size_t)n_padded));
+        (void)hipFree(c->pos);
+        HIPCHK(hipMalloc(&c->pos, sizeof(int32_t) * (size_t)n_padded));
         c->sorted_cap = n_padded;
       }
       if (n_nodes > c->nodes_cap) {
@@ -215,7 +218,7 @@ static lh_status build_indices(lh_ctx* x, lh_cloud* const* clouds, int n_clouds,
       c->n_leaves = n_leaves;
       c->first_leaf = n_nodes;
       IndexDesc& d = x->idx_descs_host[k];
-      d.xyz = c->xyz; d.sorted = c->sorted; d.nodes = c->nodes;
+      d.xyz = c->xyz; d.sorted = c->sorted; d.nodes = c->nodes; d.pos = c->pos;
       d.n = c->n; d.n_padded = n_padded; d.depth = depth; d.offset = (int)total;
       total += c->n;
       max_n = std::max(max_n, c->n);
@@ -501,6 +504,7 @@ static lh_status task_prepare(lh_ctx* c, Task* t, bool rebuild_index) {
   d.tgt_nrm = P.recompute_target_cov ? nullptr : tgt->nrm;
   d.tgt_cov6 = P.recompute_target_cov ? tgt->cov6 : nullptr;
   d.tgt_sorted = tgt->sorted;
+  d.tgt_pos = tgt->pos;
   d.tgt_nodes = tgt->nodes;
   d.prev_nn = t->ws->prev_nn;
   d.cert = t->ws->cert;
@@ -1253,20 +1257,34 @@ lh_status lh_gicp_debug_stats(lh_gicp* g, uint64_t out[2], int reset) {
   return LH_OK;
 }
 
-lh_status lh_debug_traversal_stats(lh_cloud* target, const lh_cloud* q, const float T[16], uint64_t out[5]) {
+lh_status lh_debug_traversal_stats(lh_cloud* target, const lh_cloud* q, const float T[16], const int32_t* cand, int leaf_prescan,
+                                   uint64_t out[5]) {
   if (!target || !q || !out || target->ctx != q->ctx) return LH_EINVAL;
   lh_ctx* c = target->ctx;
   HIPCHK(hipSetDevice(c->device));
   if (!target->has_index) { lh_status st = cloud_build_index(target); if (st) return st; }
   unsigned long long* d = nullptr;
-  HIPCHK(hipMalloc(&d, 40));
-  HIPCHK(hipMemsetAsync(d, 0, 40, c->stream));
+  HIPCHK(hipMalloc(&d, 8 * 24));
+  HIPCHK(hipMemsetAsync(d, 0, 8 * 24, c->stream));
   float T12[12];
   if (T) fill_T12(T, T12);
-  launch_nn1_stats(q->xyz, q->n, T ? T12 : nullptr, target->view(), d, c->stream);
+  int32_t* d_cand = nullptr;
+  if (cand) {
+    HIPCHK(hipMalloc(&d_cand, sizeof(int32_t) * (size_t)q->n));
+    HIPCHK(hipMemcpyAsync(d_cand, cand, sizeof(int32_t) * (size_t)q->n, hipMemcpyHostToDevice, c->stream));
+  }
+  launch_nn1_stats(q->xyz, q->n, T ? T12 : nullptr, target->view(), target->xyz, target->pos, d_cand, leaf_prescan, d, c->stream);
   HIPCHK(hipMemcpyAsync(out, d, 40, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
+  if (getenv("LH_STATS_LEVELS")) {
+    unsigned long long lv[24];
+    HIPCHK(hipMemcpy(lv, d, sizeof(lv), hipMemcpyDeviceToHost));
+    fprintf(stderr, "[locus_hip] node visits per query by level:");
+    for (int l = 0; l < MAX_DEPTH; l++) fprintf(stderr, " %.2f", (double)lv[8 + l] / q->n);
+    fprintf(stderr, "\n");
+  }
   (void)hipFree(d);
+  (void)hipFree(d_cand);
   return LH_OK;
 }
 

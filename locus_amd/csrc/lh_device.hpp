@@ -125,6 +125,46 @@ LH_HD uint32_t spatial_key30(float px, float py, float pz, float lx, float ly, f
   return hilbert30((uint32_t)ix, (uint32_t)iy, (uint32_t)iz);
 }
 
+// 48-bit variant: 16 bits per axis (1.2 mm cells on an 80 m scene) so that dense regions are still ordered spatially
+LH_HD uint64_t expand16(uint32_t v) {  // 16 bits -> every third bit of a 48-bit word
+  uint64_t x = v & 0xffffu;
+  x = (x | (x << 32)) & 0x00ff00000000ffffull;   // not used directly; generic spread below
+  x = v & 0xffffu;
+  x = (x | x << 16) & 0x0000ff0000ffull;
+  x = (x | x << 8) & 0x00f00f00f00full;
+  x = (x | x << 4) & 0x0c30c30c30c3ull;
+  x = (x | x << 2) & 0x249249249249ull;
+  return x;
+}
+LH_HD uint64_t hilbert48(uint32_t x0, uint32_t x1, uint32_t x2) {
+  uint32_t X[3] = {x0 & 0xffffu, x1 & 0xffffu, x2 & 0xffffu};
+  const uint32_t M = 1u << 15;
+  for (uint32_t Q = M; Q > 1; Q >>= 1) {
+    uint32_t P = Q - 1;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      if (X[i] & Q) X[0] ^= P;
+      else { uint32_t t = (X[0] ^ X[i]) & P; X[0] ^= t; X[i] ^= t; }
+    }
+  }
+  X[1] ^= X[0];
+  X[2] ^= X[1];
+  uint32_t t = 0;
+  for (uint32_t Q = M; Q > 1; Q >>= 1)
+    if (X[2] & Q) t ^= Q - 1;
+  X[0] ^= t; X[1] ^= t; X[2] ^= t;
+  return (expand16(X[0]) << 2) | (expand16(X[1]) << 1) | expand16(X[2]);
+}
+LH_HD uint64_t spatial_key48(float px, float py, float pz, float lx, float ly, float lz, float hx, float hy, float hz) {
+  float ext = fmaxf(fmaxf(hx - lx, hy - ly), fmaxf(hz - lz, 1e-30f));
+  float sc = 65535.99f / ext;
+  int ix = (int)((px - lx) * sc), iy = (int)((py - ly) * sc), iz = (int)((pz - lz) * sc);
+  ix = ix < 0 ? 0 : (ix > 65535 ? 65535 : ix);
+  iy = iy < 0 ? 0 : (iy > 65535 ? 65535 : iy);
+  iz = iz < 0 ? 0 : (iz > 65535 ? 65535 : iz);
+  return hilbert48((uint32_t)ix, (uint32_t)iy, (uint32_t)iz);
+}
+
 LH_HD void cswap(uint64_t& a, uint64_t& b) {
   uint64_t lo = a < b ? a : b, hi = a < b ? b : a;
   a = lo; b = hi;
@@ -167,7 +207,7 @@ LH_HD void tree_search(const TreeView& t, float qx, float qy, float qz, Collecto
   };
   for (;;) {
     while (lin < first_leaf) {
-      col.count_node();
+      col.count_node(lvl);
       const Node4& nd = t.nodes[lin];
       float4 lx = *reinterpret_cast<const float4*>(nd.lox), ly = *reinterpret_cast<const float4*>(nd.loy),
              lz = *reinterpret_cast<const float4*>(nd.loz), hx = *reinterpret_cast<const float4*>(nd.hix),
@@ -223,7 +263,7 @@ struct Nn1Collector {
     bi = better ? id : bi;
   }
   LH_HD void skip(float) {}
-  LH_HD void count_node() {}
+  LH_HD void count_node(int) {}
   LH_HD void count_leaf() {}
 };
 
@@ -237,7 +277,8 @@ struct Nn1CountCollector {
     if (d < bd || (d == bd && id < bi)) { bd = d; bi = id; }
   }
   LH_HD void skip(float) {}
-  LH_HD void count_node() { nodes++; }
+  int per_level[MAX_DEPTH];
+  LH_HD void count_node(int l) { nodes++; per_level[l]++; }
   LH_HD void count_leaf() { leaves++; }
 };
 
@@ -260,7 +301,7 @@ struct Nn1CertCollector {
     bi = take ? id : bi;
   }
   LH_HD void skip(float d) { lb = fminf(lb, d); }
-  LH_HD void count_node() {}
+  LH_HD void count_node(int) {}
   LH_HD void count_leaf() {}
 };
 
@@ -272,7 +313,7 @@ struct KnnCollector {
   int k, stride, cnt;
   LH_HD float bound() const { return cnt < k ? inf_f() : kd[(k - 1) * stride]; }
   LH_HD void skip(float) {}
-  LH_HD void count_node() {}
+  LH_HD void count_node(int) {}
   LH_HD void count_leaf() {}
   LH_HD void offer(float d, int id) {
     if (id == 0x7fffffff) return;  // padding point

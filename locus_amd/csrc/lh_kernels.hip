@@ -191,6 +191,7 @@ __global__ void __launch_bounds__(256) k_key_b(const IndexDesc* __restrict__ des
   if (i >= d.n) return;
   const uint32_t* bb = bbox + blockIdx.y * 8;
   float4 p = d.xyz[i];
+  // 30 bits (7.8 cm cells on an 80 m scene) are enough: 16 bits/axis (spatial_key48) leaves the visit counts unchanged
   uint32_t k = spatial_key30(p.x, p.y, p.z, dec_ordered(bb[0]), dec_ordered(bb[1]), dec_ordered(bb[2]), dec_ordered(bb[3]),
                              dec_ordered(bb[4]), dec_ordered(bb[5]));
   keys[d.offset + i] = ((uint64_t)blockIdx.y << 32) | k;
@@ -205,6 +206,7 @@ __global__ void __launch_bounds__(256) k_gather_b(const IndexDesc* __restrict__ 
     uint32_t j = vals[d.offset + i] - (uint32_t)d.offset;
     float4 p = d.xyz[j];
     o = make_float4(p.x, p.y, p.z, __uint_as_float(j));
+    d.pos[j] = i;
   } else {
     o = make_float4(INFINITY, INFINITY, INFINITY, __uint_as_float(0x7fffffffu));
   }
@@ -773,6 +775,8 @@ void launch_nn1(const float4* q, int nq, const float* T12p, TreeView tree, int32
 }
 
 __global__ void __launch_bounds__(256) k_nn1_stats(const float4* __restrict__ q, int nq, T12 T, int has_T, TreeView tv,
+                                                   const float4* __restrict__ tgt_xyz, const int32_t* __restrict__ tgt_pos,
+                                                   const int32_t* __restrict__ cand, int leaf_prescan,
                                                    unsigned long long* __restrict__ stats) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -782,8 +786,23 @@ __global__ void __launch_bounds__(256) k_nn1_stats(const float4* __restrict__ q,
     float x = p.x, y = p.y, z = p.z;
     if (has_T) xform_pt(T.v, p.x, p.y, p.z, x, y, z);
     Nn1CountCollector col{INFINITY, 0x7fffffff, 0, 0};
+    for (int l = 0; l < MAX_DEPTH; l++) col.per_level[l] = 0;
+    if (cand && cand[i] >= 0) {
+      int w = cand[i];
+      float4 t = tgt_xyz[w];
+      col.bd = d2f(x, y, z, t.x, t.y, t.z);
+      col.bi = w;
+      if (leaf_prescan) {
+        const float4* lp = tv.pts + ((size_t)(tgt_pos[w] >> 3) << 3);
+        for (int e8 = 0; e8 < LEAF; e8++) {
+          float4 v = lp[e8];
+          col.offer(d2f(x, y, z, v.x, v.y, v.z), (int)__float_as_uint(v.w));
+        }
+      }
+    }
     tree_search(tv, x, y, z, col, lds_stack + threadIdx.x, 256);
     nodes = col.nodes; leaves = col.leaves;
+    for (int l = 0; l < MAX_DEPTH; l++) atomicAdd(&stats[8 + l], (unsigned long long)col.per_level[l]);
   }
   int tot = nodes + leaves, mx = tot, sn = nodes, sl = leaves;
   for (int off = 32; off > 0; off >>= 1) {
@@ -799,10 +818,11 @@ __global__ void __launch_bounds__(256) k_nn1_stats(const float4* __restrict__ q,
     atomicMax(&stats[4], (unsigned long long)mx);
   }
 }
-void launch_nn1_stats(const float4* q, int nq, const float* T12p, TreeView tree, unsigned long long* stats, hipStream_t s) {
+void launch_nn1_stats(const float4* q, int nq, const float* T12p, TreeView tree, const float4* tgt_xyz, const int32_t* tgt_pos,
+                      const int32_t* cand, int leaf_prescan, unsigned long long* stats, hipStream_t s) {
   T12 T;
   for (int k = 0; k < 12; k++) T.v[k] = T12p ? T12p[k] : 0.f;
-  hipLaunchKernelGGL(k_nn1_stats, dim3((nq + 255) / 256), dim3(256), stack_lds_bytes(tree_depth_of(tree.first_leaf), 256), s, q, nq, T, T12p ? 1 : 0, tree, stats);
+  hipLaunchKernelGGL(k_nn1_stats, dim3((nq + 255) / 256), dim3(256), stack_lds_bytes(tree_depth_of(tree.first_leaf), 256), s, q, nq, T, T12p ? 1 : 0, tree, tgt_xyz, tgt_pos, cand, leaf_prescan, stats);
 }
 
 // double sum of floats: 1024 values per block, fixed tree

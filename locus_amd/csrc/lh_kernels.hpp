@@ -21,7 +21,8 @@ struct PairDesc {
   const float4* tgt_xyz;    // target xyz1 in ORIGINAL order                             [m]
   const float4* tgt_nrm;    // target normals or null
   const double* tgt_cov6;   // target covariances planes (stride m_pad) or null
-  const float4* tgt_sorted; // Morton-sorted target (x,y,z,id)
+  const float4* tgt_sorted; // Hilbert-sorted target (x,y,z,id)
+  const int32_t* tgt_pos;   // original index -> sorted position
   const Node4* tgt_nodes;
   int32_t* prev_nn;         // warm-start NN index per source point                      [n]
   float4* cert;             // (query x,y,z at the last full search, lower bound on the other points' d2) [n]
@@ -78,6 +79,7 @@ struct IndexDesc {
   const float4* xyz;
   float4* sorted;
   Node4* nodes;
+  int32_t* pos;   // original index -> position in `sorted` (lets a sweep start from the leaf of its candidate)
   int n, n_padded, depth, offset;  // offset = start of this cloud in the concatenated key/value arrays
 };
 constexpr int MAX_INDEX_BATCH = 64;
@@ -115,7 +117,8 @@ void launch_fill_i32(int32_t* p, int n, int32_t v, hipStream_t s);
 void launch_nn1(const float4* q, int nq, const float* T12, TreeView tree, int32_t* idx, float* d2, hipStream_t s);
 // instrumentation: per-query visit counts of a cold 1-NN search; stats[0..4] = sum nodes, sum leaves, sum over waves of
 // the per-wave max (nodes+leaves), number of waves, max (nodes+leaves) of any query
-void launch_nn1_stats(const float4* q, int nq, const float* T12, TreeView tree, unsigned long long* stats, hipStream_t s);
+void launch_nn1_stats(const float4* q, int nq, const float* T12, TreeView tree, const float4* tgt_xyz, const int32_t* tgt_pos,
+                      const int32_t* cand /*nullable: warm-start candidates*/, int leaf_prescan, unsigned long long* stats, hipStream_t s);
 // deterministic double sum of float d2 (fitness): partials[ceil(n/1024)]
 void launch_sum_f32(const float* v, int n, double* partials, hipStream_t s);
 inline int sum_blocks(int n) { return (n + 1023) / 1024; }
