@@ -301,7 +301,7 @@ struct Workspace {
 
 static lh_status ctx_ensure_slots(lh_ctx* c, int n_slots, int max_n) {
   size_t per_slot = std::max<size_t>((size_t)cost_blocks(max_n) * COST_NSUM, MOM_NSUM);
-  int mom_stride = ((max_n + FUSED_CHUNK - 1) / FUSED_CHUNK) * MOM_NSUM;  // one partial per 256-point workgroup of the fused sweep
+  int mom_stride = ((max_n + 255) / 256) * 4 * MOM_NSUM;  // one partial per wave of every 256-point workgroup of the fused sweep
   if (n_slots <= c->n_slots && per_slot <= c->partials_per_slot && mom_stride <= c->mom_stride) return LH_OK;
   (void)hipStreamSynchronize(c->stream);
   n_slots = std::max(n_slots, c->n_slots);

@@ -10,6 +10,8 @@
 //   k_nn1 / k_sum_f32                                                 K7  getFitnessScore; PointCloudLocalization.cc:327-336
 //   k_knn / k_knn_cov / k_knn_normals                                 K3  gicp.hpp:85-154; normal_computation.cc:26-59
 //   k_ap                                                              K8  PointCloudLocalization.cc:723-750
+#include <cstdlib>
+
 #include "lh_kernels.hpp"
 
 namespace lh {
@@ -387,10 +389,11 @@ __device__ __forceinline__ void sweep_point(const PairDesc& d, const SweepJob& j
     // certificate from the last full search at query position cq: every other target point was at squared distance
     // >= cq.w from cq, so it is at distance >= sqrt(cq.w) - |q - cq| from q.  If the candidate is strictly closer
     // (1e-5 relative margin >> float rounding of the d2 evaluations), the traversal cannot change the result.
+    // (float arithmetic: sqrtf is correctly rounded to ~1e-7 relative, two orders below the 1e-5 margins)
     float4 cq = d.cert[i];
-    double e = sqrt((double)d2f(qx, qy, qz, cq.x, cq.y, cq.z));
-    double dw = sqrt((double)col.bd), lo = sqrt((double)cq.w);
-    if (dw * (1.0 + 1e-5) + e * (1.0 + 1e-5) + 1e-12 < lo * (1.0 - 1e-5)) need_search = false;
+    float e = sqrtf(d2f(qx, qy, qz, cq.x, cq.y, cq.z));
+    float dw = sqrtf(col.bd), lo = sqrtf(cq.w);
+    if (dw * (1.0f + 1e-5f) + e * (1.0f + 1e-5f) + 1e-12f < lo * (1.0f - 1e-5f)) need_search = false;
   }
   if (need_search) {
     tree_search(tv, qx, qy, qz, col, stack, 256);
@@ -468,6 +471,7 @@ __device__ __forceinline__ double mom_value(int k, const double* M6, const doubl
   if (k < 73) return M6[(k - 13) / 10] * pp[(k - 13) % 10];
   return 1.0;
 }
+template <bool WAVE_REDUCE>
 __global__ void __launch_bounds__(256) k_sweep_fused(const PairDesc* __restrict__ descs, SweepArgs a, double* __restrict__ partials,
                                                      int partials_stride) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];  // [entries][256], later reused as double[8][256]
@@ -503,25 +507,60 @@ __global__ void __launch_bounds__(256) k_sweep_fused(const PairDesc* __restrict_
       for (int ee = cc; ee < 4; ee++) pp[t++] = pt[cc] * pt[ee];
   }
   const double live = sp.matched ? 1.0 : 0.0;
-  double* st = reinterpret_cast<double*>(lds_stack);  // [8][256]
-  const int tid = threadIdx.x, v_of = tid >> 5, part = tid & 31;
-  double* out = partials + (size_t)job.slot * partials_stride + (size_t)blk * MOM_NSUM;
-  __syncthreads();  // every lane is done with its traversal stack
+  const int tid = threadIdx.x;
+  if (WAVE_REDUCE) {
+    // Per-wave reduction, no workgroup barriers inside the loop: after ONE barrier (all lanes are done with their
+    // traversal stacks) each wave owns a private 4-KB slice [8 values][64 lanes] of the LDS region; a wave's DS operations
+    // execute in order, so write -> fence -> read needs no s_barrier.  64 lanes -> 8 strided partial sums -> 3 shuffles.
+    const int wave = tid >> 6, lane = tid & 63;
+    double* wst = reinterpret_cast<double*>(lds_stack) + wave * 512;
+    const int v_of = lane >> 3, part = lane & 7;
+    double* out = partials + (size_t)job.slot * partials_stride + ((size_t)blk * 4 + wave) * MOM_NSUM;
+    __syncthreads();
 #pragma unroll
-  for (int g = 0; g < (MOM_NSUM + 7) / 8; g++) {
+    for (int g = 0; g < (MOM_NSUM + 7) / 8; g++) {
 #pragma unroll
-    for (int v = 0; v < 8; v++) {
-      int k = g * 8 + v;
-      if (k < MOM_NSUM) st[v * 256 + tid] = (k == 73) ? live : mom_value(k, M6, Ma, aMa, pt, pp);
+      for (int v = 0; v < 8; v++) {
+        int k = g * 8 + v;
+        if (k < MOM_NSUM) wst[v * 64 + lane] = (k == 73) ? live : mom_value(k, M6, Ma, aMa, pt, pp);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      double s = 0.0;
+#pragma unroll
+      for (int jj = 0; jj < 8; jj++) s += wst[v_of * 64 + jj * 8 + part];
+#pragma unroll
+      for (int off = 4; off > 0; off >>= 1) s += __shfl_down(s, off, 8);
+      if (part == 0 && g * 8 + v_of < MOM_NSUM) out[g * 8 + v_of] = s;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      __builtin_amdgcn_wave_barrier();
     }
+  } else {
+    // workgroup reduction: [8][256] staging, 256 -> 32 strided partial sums -> 5 shuffles; two barriers per round;
+    // only wave 0's slot of the 4 per-workgroup partial slots is used (the others are written as zeros)
+    double* st = reinterpret_cast<double*>(lds_stack);
+    const int v_of = tid >> 5, part = tid & 31;
+    double* out = partials + (size_t)job.slot * partials_stride + (size_t)blk * 4 * MOM_NSUM;
     __syncthreads();
-    double s = 0.0;
 #pragma unroll
-    for (int jj = 0; jj < 8; jj++) s += st[v_of * 256 + jj * 32 + part];
+    for (int g = 0; g < (MOM_NSUM + 7) / 8; g++) {
 #pragma unroll
-    for (int off = 16; off > 0; off >>= 1) s += __shfl_down(s, off, 32);
-    if (part == 0 && g * 8 + v_of < MOM_NSUM) out[g * 8 + v_of] = s;
-    __syncthreads();
+      for (int v = 0; v < 8; v++) {
+        int k = g * 8 + v;
+        if (k < MOM_NSUM) st[v * 256 + tid] = (k == 73) ? live : mom_value(k, M6, Ma, aMa, pt, pp);
+      }
+      __syncthreads();
+      double s = 0.0;
+#pragma unroll
+      for (int jj = 0; jj < 8; jj++) s += st[v_of * 256 + jj * 32 + part];
+#pragma unroll
+      for (int off = 16; off > 0; off >>= 1) s += __shfl_down(s, off, 32);
+      if (part == 0 && g * 8 + v_of < MOM_NSUM) {
+        out[g * 8 + v_of] = s;
+        out[MOM_NSUM + g * 8 + v_of] = 0.0; out[2 * MOM_NSUM + g * 8 + v_of] = 0.0; out[3 * MOM_NSUM + g * 8 + v_of] = 0.0;
+      }
+      __syncthreads();
+    }
   }
 }
 
@@ -529,7 +568,11 @@ void launch_sweep_fused(const PairDesc* descs, SweepArgs& a, int max_n, double* 
   a.bpj = (max_n + 255) / 256;
   size_t lds = stack_lds_bytes(a.max_depth, 256);
   if (lds < 8 * 256 * sizeof(double)) lds = 8 * 256 * sizeof(double);
-  hipLaunchKernelGGL(k_sweep_fused, dim3(xcd_grid(a.njobs, a.bpj)), dim3(256), lds, s, descs, a, partials_dev, partials_stride);
+  static const bool wave_reduce = []() { const char* e = getenv("LH_FUSED_REDUCE"); return !(e && e[0] == 'b'); }();  // A/B switch
+  if (wave_reduce)
+    hipLaunchKernelGGL(k_sweep_fused<true>, dim3(xcd_grid(a.njobs, a.bpj)), dim3(256), lds, s, descs, a, partials_dev, partials_stride);
+  else
+    hipLaunchKernelGGL(k_sweep_fused<false>, dim3(xcd_grid(a.njobs, a.bpj)), dim3(256), lds, s, descs, a, partials_dev, partials_stride);
 }
 void launch_sweep(const PairDesc* descs, SweepArgs& a, int max_n, hipStream_t s) {
   a.bpj = (max_n + 255) / 256;
@@ -848,6 +891,35 @@ void launch_sum_f32(const float* v, int n, double* partials, hipStream_t s) {
 // ===== K3: k-NN, covariances, normals ======================================================================
 constexpr int KNN_BLOCK = 128;
 
+template <int KCAP>
+__device__ __forceinline__ int knn_search_regs(const TreeView& tv, float x, float y, float z, int k, float* kd, int* ki, uint32_t* stack) {
+  KnnRegCollector<KCAP> col;
+  col.init(k);
+  tree_search(tv, x, y, z, col, stack, KNN_BLOCK);
+  return col.dump(kd, ki, KNN_BLOCK);
+}
+// k best of one query into kd/ki ([k][KNN_BLOCK] LDS, already offset by threadIdx.x); returns the number found.
+// KCAP = register-list capacity chosen by the host (smallest of 8 / 20 / 32 that holds k; 0 = LDS insertion list for k > 32),
+// a template parameter of the kernels so that each instantiation only pays for its own registers.
+template <int KCAP>
+__device__ __forceinline__ int knn_search(const TreeView& tv, float x, float y, float z, int k, float* kd, int* ki, uint32_t* stack) {
+  if constexpr (KCAP > 0) {
+    return knn_search_regs<KCAP>(tv, x, y, z, k, kd, ki, stack);
+  } else {
+    KnnCollector col{kd, ki, k, KNN_BLOCK, 0};
+    tree_search(tv, x, y, z, col, stack, KNN_BLOCK);
+    return col.cnt;
+  }
+}
+#define LH_KNN_DISPATCH(KERNEL, k, ...)                                              \
+  do {                                                                              \
+    if ((k) <= 8) hipLaunchKernelGGL(KERNEL<8>, __VA_ARGS__);                       \
+    else if ((k) <= 20) hipLaunchKernelGGL(KERNEL<20>, __VA_ARGS__);                \
+    else if ((k) <= 32) hipLaunchKernelGGL(KERNEL<32>, __VA_ARGS__);                \
+    else hipLaunchKernelGGL(KERNEL<0>, __VA_ARGS__);                                \
+  } while (0)
+
+template <int KCAP>
 __global__ void __launch_bounds__(KNN_BLOCK) k_knn(const float4* __restrict__ q, int nq, TreeView tv, int k, int32_t* __restrict__ idx,
                                                    float* __restrict__ d2) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -856,9 +928,9 @@ __global__ void __launch_bounds__(KNN_BLOCK) k_knn(const float4* __restrict__ q,
   int i = blockIdx.x * KNN_BLOCK + threadIdx.x;
   if (i >= nq) return;
   float4 p = q[i];
-  KnnCollector col{kd + threadIdx.x, ki + threadIdx.x, k, KNN_BLOCK, 0};
   uint32_t* lds_stack = reinterpret_cast<uint32_t*>(smem + (size_t)8 * k * KNN_BLOCK);
-  tree_search(tv, p.x, p.y, p.z, col, lds_stack + threadIdx.x, KNN_BLOCK);
+  struct { int cnt; } col;
+  col.cnt = knn_search<KCAP>(tv, p.x, p.y, p.z, k, kd + threadIdx.x, ki + threadIdx.x, lds_stack + threadIdx.x);
   for (int e = 0; e < k; e++) {
     bool ok = e < col.cnt;
     idx[(size_t)i * k + e] = ok ? ki[e * KNN_BLOCK + threadIdx.x] : -1;
@@ -867,10 +939,11 @@ __global__ void __launch_bounds__(KNN_BLOCK) k_knn(const float4* __restrict__ q,
 }
 void launch_knn(const float4* q, int nq, TreeView tree, int k, int32_t* idx, float* d2, hipStream_t s) {
   size_t sh = (size_t)k * KNN_BLOCK * 8 + stack_lds_bytes(tree_depth_of(tree.first_leaf), KNN_BLOCK);
-  hipLaunchKernelGGL(k_knn, dim3((nq + KNN_BLOCK - 1) / KNN_BLOCK), dim3(KNN_BLOCK), sh, s, q, nq, tree, k, idx, d2);
+  LH_KNN_DISPATCH(k_knn, k, dim3((nq + KNN_BLOCK - 1) / KNN_BLOCK), dim3(KNN_BLOCK), sh, s, q, nq, tree, k, idx, d2);
 }
 
 // computeCovariances k-NN branch (gicp.hpp:85-154)
+template <int KCAP>
 __global__ void __launch_bounds__(KNN_BLOCK) k_knn_cov(const float4* __restrict__ xyz, int n, int n_pad, TreeView tv, int k, double eps,
                                                        double* __restrict__ cov6) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -879,9 +952,9 @@ __global__ void __launch_bounds__(KNN_BLOCK) k_knn_cov(const float4* __restrict_
   int i = blockIdx.x * KNN_BLOCK + threadIdx.x;
   if (i >= n) return;
   float4 p = xyz[i];
-  KnnCollector col{kd + threadIdx.x, ki + threadIdx.x, k, KNN_BLOCK, 0};
   uint32_t* lds_stack = reinterpret_cast<uint32_t*>(smem + (size_t)8 * k * KNN_BLOCK);
-  tree_search(tv, p.x, p.y, p.z, col, lds_stack + threadIdx.x, KNN_BLOCK);
+  struct { int cnt; } col;
+  col.cnt = knn_search<KCAP>(tv, p.x, p.y, p.z, k, kd + threadIdx.x, ki + threadIdx.x, lds_stack + threadIdx.x);
   double mean[3] = {0, 0, 0}, c00 = 0, c10 = 0, c11 = 0, c20 = 0, c21 = 0, c22 = 0;
   for (int e = 0; e < k; e++) {  // neighbours in ascending (d2, id) order, like the search returns them
     float4 t = xyz[ki[e * KNN_BLOCK + threadIdx.x]];
@@ -913,7 +986,7 @@ __global__ void __launch_bounds__(KNN_BLOCK) k_knn_cov(const float4* __restrict_
 }
 void launch_knn_cov(const float4* xyz, int n, int n_pad, TreeView tree, int k, double eps, double* cov6, hipStream_t s) {
   size_t sh = (size_t)k * KNN_BLOCK * 8 + stack_lds_bytes(tree_depth_of(tree.first_leaf), KNN_BLOCK);
-  hipLaunchKernelGGL(k_knn_cov, dim3((n + KNN_BLOCK - 1) / KNN_BLOCK), dim3(KNN_BLOCK), sh, s, xyz, n, n_pad, tree, k, eps, cov6);
+  LH_KNN_DISPATCH(k_knn_cov, k, dim3((n + KNN_BLOCK - 1) / KNN_BLOCK), dim3(KNN_BLOCK), sh, s, xyz, n, n_pad, tree, k, eps, cov6);
 }
 
 // pcl::eigen33 smallest eigenpair, float closed form (PCL 1.10 common/eigen.hpp restated)
@@ -955,6 +1028,7 @@ __device__ void roots3f(float m00, float m01, float m02, float m11, float m12, f
   if (r[0] <= 0.0f) roots2f(c2, c1, r);
 }
 
+template <int KCAP>
 __global__ void __launch_bounds__(KNN_BLOCK) k_knn_normals(const float4* __restrict__ xyz, int n, TreeView tv, int k,
                                                            float4* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -963,9 +1037,9 @@ __global__ void __launch_bounds__(KNN_BLOCK) k_knn_normals(const float4* __restr
   int i = blockIdx.x * KNN_BLOCK + threadIdx.x;
   if (i >= n) return;
   float4 p = xyz[i];
-  KnnCollector col{kd + threadIdx.x, ki + threadIdx.x, k, KNN_BLOCK, 0};
   uint32_t* lds_stack = reinterpret_cast<uint32_t*>(smem + (size_t)8 * k * KNN_BLOCK);
-  tree_search(tv, p.x, p.y, p.z, col, lds_stack + threadIdx.x, KNN_BLOCK);
+  struct { int cnt; } col;
+  col.cnt = knn_search<KCAP>(tv, p.x, p.y, p.z, k, kd + threadIdx.x, ki + threadIdx.x, lds_stack + threadIdx.x);
   const float qnan = __uint_as_float(0x7fc00000u);
   if (col.cnt < 3) {
     out[i] = make_float4(qnan, qnan, qnan, qnan);
@@ -1011,7 +1085,7 @@ __global__ void __launch_bounds__(KNN_BLOCK) k_knn_normals(const float4* __restr
 }
 void launch_knn_normals(const float4* xyz, int n, TreeView tree, int k, float4* out_nrm, hipStream_t s) {
   size_t sh = (size_t)k * KNN_BLOCK * 8 + stack_lds_bytes(tree_depth_of(tree.first_leaf), KNN_BLOCK);
-  hipLaunchKernelGGL(k_knn_normals, dim3((n + KNN_BLOCK - 1) / KNN_BLOCK), dim3(KNN_BLOCK), sh, s, xyz, n, tree, k, out_nrm);
+  LH_KNN_DISPATCH(k_knn_normals, k, dim3((n + KNN_BLOCK - 1) / KNN_BLOCK), dim3(KNN_BLOCK), sh, s, xyz, n, tree, k, out_nrm);
 }
 
 // ===== K8: point-to-plane information matrix ===============================================================

@@ -97,7 +97,7 @@ void launch_sweep(const PairDesc* descs, SweepArgs& a, int max_n, hipStream_t s)
 void launch_sweep_fused(const PairDesc* descs, SweepArgs& a, int max_n, double* partials_dev, int partials_stride, hipStream_t s);
 void launch_moments_final(const PairDesc* descs, const CostArgs& a, double* partials_dev, int partials_stride, int chunk, double* out,
                           hipStream_t s);
-constexpr int FUSED_CHUNK = 256;
+constexpr int FUSED_CHUNK = 64;   // one 74-double partial per WAVE of the fused sweep
 // cold-start helper: exact NN of every 8th source point, written as the warm-start candidate of its 8-point group
 void launch_seed(const PairDesc* descs, SweepArgs& a, int max_n, hipStream_t s);
 constexpr int SEED_GROUP = 8;

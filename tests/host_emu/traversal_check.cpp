@@ -118,6 +118,16 @@ static int run_case(int n, int nq, int k, unsigned seed, bool dup) {
     if (ck.cnt != kk) bad++;
     for (int e = 0; e < kk; e++)
       if (ki[e] != ord[e] || kd[e] != bd[ord[e]]) { bad++; break; }
+    if (kk <= 20) {  // register-resident list used by the device k-NN kernels
+      KnnRegCollector<20> cr;
+      cr.init(kk);
+      tree_search(tv, q.x, q.y, q.z, cr, stk.data(), 1);
+      std::vector<float> rd(kk);
+      std::vector<int> ri(kk);
+      if (cr.dump(rd.data(), ri.data(), 1) != kk) bad++;
+      for (int e = 0; e < kk; e++)
+        if (ri[e] != ord[e] || rd[e] != bd[ord[e]]) { bad++; break; }
+    }
   }
   printf("n=%d nq=%d k=%d dup=%d depth=%d -> %s (%d mismatches)\n", n, nq, k, (int)dup, t.depth, bad ? "FAIL" : "ok", bad);
   return bad;
