@@ -183,6 +183,9 @@ lh_status lh_icp_covariance(const double Ap[36], double icp_max_covariance, doub
    *out_count is the number of voxels (may exceed cap: then only cap are written).  LH_EINVAL on int32 index overflow. */
 lh_status lh_voxel_grid(lh_ctx* ctx, const lh_cloud_view* in, float leaf, int limit_axis, double lo, double hi,
                         float* out_xyzi, uint32_t out_capacity, uint32_t* out_count);
+/* device-resident K1: the voxelised cloud (x, y, z, intensity centroids) is created on the GPU; with lh_normals_knn_cloud and
+   lh_gicp_set_*_cloud a raw scan goes voxel grid -> normals -> GICP without crossing PCIe */
+lh_status lh_cloud_voxel_grid(const lh_cloud* in, float leaf, int limit_axis, double lo, double hi, lh_cloud** out);
 /* K3 (filter flavour): NormalComputation::filter (normal_computation.cc:26-59), k-NN, viewpoint (0,0,0).
    out = float[count][4] (nx, ny, nz, curvature) */
 lh_status lh_normals_knn(lh_ctx* ctx, const lh_cloud_view* in, int k, float* out_normals4);

@@ -1556,36 +1556,20 @@ static float dec_ordered_host(uint32_t e) {
   memcpy(&f, &u, 4);
   return f;
 }
-lh_status lh_voxel_grid(lh_ctx* c, const lh_cloud_view* in, float leaf, int limit_axis, double lo, double hi, float* out_xyzi,
-                        uint32_t out_capacity, uint32_t* out_count) {
-  if (!c || !in || !in->base || !out_count || !(leaf > 0.0f) || limit_axis > 2) return LH_EINVAL;
-  if (out_capacity > 0 && !out_xyzi) return LH_EINVAL;
-  HIPCHK(hipSetDevice(c->device));
-  *out_count = 0;
-  int n = (int)in->count;
-  if (n == 0) return LH_OK;
-  // pack x,y,z,intensity
-  std::vector<float> host((size_t)n * 4);
-  const char* base = (const char*)in->base;
-  for (int i = 0; i < n; i++) {
-    const char* p = base + (size_t)i * in->stride;
-    memcpy(&host[4 * (size_t)i], p + in->off_xyz, 12);
-    host[4 * (size_t)i + 3] = (in->off_intensity != UINT32_MAX) ? *(const float*)(p + in->off_intensity) : 0.0f;
-  }
+// device core: d_in = n x (x, y, z, intensity); on success *d_out (hipMalloc'ed, caller frees) holds *total centroids
+static lh_status voxel_grid_device(lh_ctx* c, const float4* d_in, int n, float leaf, int limit_axis, double lo, double hi,
+                                   float4** d_out, uint32_t* total_out) {
+  *d_out = nullptr;
+  *total_out = 0;
   lh_status st = ctx_ensure_scratch(c, n);
   if (st) return st;
-  float4 *d_in = nullptr, *d_out = nullptr;
   uint32_t *d_heads = nullptr, *d_rank = nullptr;
   void* d_scan_tmp = nullptr;
   size_t scan_bytes = scan_temp_bytes(n);
-  uint32_t cap = std::min<uint32_t>(out_capacity, (uint32_t)n);
-  HIPCHK(hipMalloc(&d_in, sizeof(float4) * (size_t)n));
-  HIPCHK(hipMalloc(&d_out, sizeof(float4) * (size_t)std::max<uint32_t>(cap, 1)));
   HIPCHK(hipMalloc(&d_heads, sizeof(uint32_t) * (size_t)n));
   HIPCHK(hipMalloc(&d_rank, sizeof(uint32_t) * (size_t)n));
   HIPCHK(hipMalloc(&d_scan_tmp, scan_bytes ? scan_bytes : 16));
-  auto cleanup = [&]() { (void)hipFree(d_in); (void)hipFree(d_out); (void)hipFree(d_heads); (void)hipFree(d_rank); (void)hipFree(d_scan_tmp); };
-  HIPCHK(hipMemcpyAsync(d_in, host.data(), sizeof(float) * host.size(), hipMemcpyHostToDevice, c->stream));
+  auto cleanup = [&]() { (void)hipFree(d_heads); (void)hipFree(d_rank); (void)hipFree(d_scan_tmp); };
   float flo = (float)std::max(lo, -3.0e38), fhi = (float)std::min(hi, 3.0e38);
   { ProfScope p(c, "voxel_bbox", 16.0 * n); launch_voxel_bbox(d_in, n, limit_axis, flo, fhi, c->bbox, c->stream); }
   uint32_t enc[6];
@@ -1610,15 +1594,88 @@ lh_status lh_voxel_grid(lh_ctx* c, const lh_cloud_view* in, float leaf, int limi
   { ProfScope p(c, "voxel_segments", 16.0 * n);
     launch_voxel_heads(c->keys1, n, d_heads, c->stream);
     inclusive_scan_u32(d_scan_tmp, scan_bytes, d_heads, d_rank, n, c->stream); }
-  { ProfScope p(c, "voxel_centroids", 32.0 * n); launch_voxel_centroids(d_in, c->keys1, c->vals1, d_heads, d_rank, n, d_out, cap, c->stream); }
-  HIPCHK(hipGetLastError());
   uint32_t total = 0;
   HIPCHK(hipMemcpyAsync(&total, d_rank + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
-  *out_count = total;
-  uint32_t ncopy = std::min(total, cap);
-  if (ncopy) HIPCHK(hipMemcpy(out_xyzi, d_out, sizeof(float4) * (size_t)ncopy, hipMemcpyDeviceToHost));
+  if (total > 0) {
+    HIPCHK(hipMalloc(d_out, sizeof(float4) * (size_t)total));
+    ProfScope p(c, "voxel_centroids", 32.0 * n);
+    launch_voxel_centroids(d_in, c->keys1, c->vals1, d_heads, d_rank, n, *d_out, total, c->stream);
+  }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(c->stream));
+  *total_out = total;
   cleanup();
+  return LH_OK;
+}
+
+lh_status lh_voxel_grid(lh_ctx* c, const lh_cloud_view* in, float leaf, int limit_axis, double lo, double hi, float* out_xyzi,
+                        uint32_t out_capacity, uint32_t* out_count) {
+  if (!c || !in || !in->base || !out_count || !(leaf > 0.0f) || limit_axis > 2) return LH_EINVAL;
+  if (out_capacity > 0 && !out_xyzi) return LH_EINVAL;
+  HIPCHK(hipSetDevice(c->device));
+  *out_count = 0;
+  int n = (int)in->count;
+  if (n == 0) return LH_OK;
+  std::vector<float> host((size_t)n * 4);  // pack x,y,z,intensity
+  const char* base = (const char*)in->base;
+  for (int i = 0; i < n; i++) {
+    const char* p = base + (size_t)i * in->stride;
+    memcpy(&host[4 * (size_t)i], p + in->off_xyz, 12);
+    host[4 * (size_t)i + 3] = (in->off_intensity != UINT32_MAX) ? *(const float*)(p + in->off_intensity) : 0.0f;
+  }
+  float4 *d_in = nullptr, *d_out = nullptr;
+  HIPCHK(hipMalloc(&d_in, sizeof(float4) * (size_t)n));
+  HIPCHK(hipMemcpyAsync(d_in, host.data(), sizeof(float) * host.size(), hipMemcpyHostToDevice, c->stream));
+  uint32_t total = 0;
+  lh_status st = voxel_grid_device(c, d_in, n, leaf, limit_axis, lo, hi, &d_out, &total);
+  if (!st) {
+    *out_count = total;
+    uint32_t ncopy = std::min(total, out_capacity);
+    if (ncopy && hipMemcpy(out_xyzi, d_out, sizeof(float4) * (size_t)ncopy, hipMemcpyDeviceToHost) != hipSuccess) st = LH_EDEVICE;
+  }
+  (void)hipFree(d_in);
+  (void)hipFree(d_out);
+  return st;
+}
+
+// device-resident variant: cloud in -> new cloud out (x, y, z, intensity centroids; no normals), nothing crosses PCIe
+__global__ void __launch_bounds__(256) k_pack_xyzi(const float4* __restrict__ xyz, const float* __restrict__ inten, int n, float4* __restrict__ out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float4 p = xyz[i];
+  out[i] = make_float4(p.x, p.y, p.z, inten ? inten[i] : 0.0f);
+}
+__global__ void __launch_bounds__(256) k_unpack_xyzi(const float4* __restrict__ in, int n, float4* __restrict__ xyz, float* __restrict__ inten) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float4 p = in[i];
+  xyz[i] = make_float4(p.x, p.y, p.z, 1.0f);
+  inten[i] = p.w;
+}
+lh_status lh_cloud_voxel_grid(const lh_cloud* in, float leaf, int limit_axis, double lo, double hi, lh_cloud** out) {
+  if (!in || !out || !(leaf > 0.0f) || limit_axis > 2 || in->n <= 0) return LH_EINVAL;
+  lh_ctx* c = in->ctx;
+  HIPCHK(hipSetDevice(c->device));
+  float4 *d_in = nullptr, *d_out = nullptr;
+  HIPCHK(hipMalloc(&d_in, sizeof(float4) * (size_t)in->n));
+  hipLaunchKernelGGL(k_pack_xyzi, dim3((in->n + 255) / 256), dim3(256), 0, c->stream, in->xyz, in->intensity, in->n, d_in);
+  uint32_t total = 0;
+  lh_status st = voxel_grid_device(c, d_in, in->n, leaf, limit_axis, lo, hi, &d_out, &total);
+  (void)hipFree(d_in);
+  if (st) { (void)hipFree(d_out); return st; }
+  if (total == 0) { (void)hipFree(d_out); return LH_EINVAL; }  // every point was filtered out: no cloud to return
+  lh_cloud* o = new lh_cloud();
+  o->ctx = c;
+  o->n = (int)total;
+  o->n_pad = round_up(o->n, 256);
+  HIPCHK(hipMalloc(&o->xyz, sizeof(float4) * (size_t)o->n_pad));
+  HIPCHK(hipMalloc(&o->intensity, sizeof(float) * (size_t)o->n_pad));
+  hipLaunchKernelGGL(k_unpack_xyzi, dim3((o->n + 255) / 256), dim3(256), 0, c->stream, d_out, o->n, o->xyz, o->intensity);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(c->stream));
+  (void)hipFree(d_out);
+  *out = o;
   return LH_OK;
 }
 

@@ -1160,18 +1160,21 @@ __global__ void __launch_bounds__(256) k_voxel_bbox(const float4* __restrict__ x
       hi[a] = fmaxf(hi[a], __shfl_down(hi[a], off, 64));
     }
   }
+  __shared__ float sm[4][6];
   if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-    for (int a = 0; a < 3; a++) {
-      atomicMin(&bbox[a], enc_ordered(lo[a]));
-      atomicMax(&bbox[3 + a], enc_ordered(hi[a]));
-    }
+    for (int a = 0; a < 3; a++) { sm[threadIdx.x >> 6][a] = lo[a]; sm[threadIdx.x >> 6][3 + a] = hi[a]; }
   }
+  __syncthreads();
+  if (threadIdx.x < 3)
+    atomicMin(&bbox[threadIdx.x], enc_ordered(fminf(fminf(sm[0][threadIdx.x], sm[1][threadIdx.x]), fminf(sm[2][threadIdx.x], sm[3][threadIdx.x]))));
+  else if (threadIdx.x < 6)
+    atomicMax(&bbox[threadIdx.x], enc_ordered(fmaxf(fmaxf(sm[0][threadIdx.x], sm[1][threadIdx.x]), fmaxf(sm[2][threadIdx.x], sm[3][threadIdx.x]))));
 }
 void launch_voxel_bbox(const float4* xyzi, int n, int limit_axis, float lo, float hi, uint32_t* bbox, hipStream_t s) {
   hipLaunchKernelGGL(k_bbox_init, dim3(1), dim3(64), 0, s, bbox);
   int blocks = (n + 255) / 256;
-  if (blocks > 1024) blocks = 1024;
+  if (blocks > 128) blocks = 128;
   hipLaunchKernelGGL(k_voxel_bbox, dim3(blocks), dim3(256), 0, s, xyzi, n, limit_axis, lo, hi, bbox);
 }
 

@@ -75,7 +75,11 @@ def test_config5_merged_1M_full_pipeline(ctx, capi, oracle):
     ref = oracle.voxel_grid(np.concatenate([crop, np.zeros((crop.shape[0], 1), np.float32)], 1), 0.1, 2, -100.0, 100.0)
     got, _ = ctx.voxel_grid(capi.make_pointxyzi(crop), 0.1, 2, -100.0, 100.0)
     assert (got == ref).all()
-    c0, c1 = capi.Cloud(ctx, v0), capi.Cloud(ctx, v1)
+    # device-resident pipeline (raw cloud -> voxel grid -> normals -> GICP without leaving the GPU) == host-buffer filter
+    c0 = capi.Cloud(ctx, capi.make_pointxyzi(f0)).voxel_grid(0.1, 2, -100.0, 100.0)
+    c1 = capi.Cloud(ctx, capi.make_pointxyzi(f1)).voxel_grid(0.1, 2, -100.0, 100.0)
+    d0 = c0.download()
+    assert len(c0) == v0.shape[0] and (np.stack([d0["x"], d0["y"], d0["z"]], 1) == v0).all()
     c0.normals_knn(20)
     c1.normals_knn(20)
     P = capi.default_params(max_iterations=20, corr_dist=1.0, transformation_epsilon=1e-3)
