@@ -198,6 +198,26 @@ def main():
                 T[0].drop_index()
                 g.align(want_trace=False)
             result["single_pair_latency_ms"] = round(1e3 * (time.perf_counter() - t1) / 5, 3)
+        if world == 1 and args.cost_mode == 1:
+            # the same workload in the reference-arithmetic mode (one device pass per BFGS evaluation, float T*p): the strict
+            # parity mode (<= 1e-4 m vs the CPU path); reported next to the headline, never as `value`
+            P0 = capi.default_params(max_iterations=20, max_inner_iterations=20, corr_dist=1.0, transformation_epsilon=1e-12,
+                                     rotation_epsilon=1e-12, cost_mode=0)
+
+            def step0():
+                for t in T:
+                    t.drop_index()
+                return capi.align_batch(ctx, P0, S, T, max_in_flight=args.in_flight)
+
+            step0()
+            ctx.synchronize()
+            t1 = time.perf_counter()
+            out0 = step0()
+            ctx.synchronize()
+            dt0 = time.perf_counter() - t1
+            result["cost_mode0"] = {"value": round(args.pairs / dt0, 2), "unit": "scan-pairs/s",
+                                    "max_abs_pose_diff_vs_mode1": float(max(np.abs(np.asarray(a["T"]) - np.asarray(b["T"])).max()
+                                                                            for a, b in zip(out0, out)))}
         if world == 1 and not args.no_cpu_baseline:
             cb, poses = cpu_baseline(S, T, host, P)
             # parity of the timed GPU work against the CPU path on the sampled pairs (reported, asserted in tests/)

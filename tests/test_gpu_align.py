@@ -11,8 +11,10 @@ TOL_T, TOL_R = 1e-4, 1e-4
 # cost_mode 1 evaluates T*p in double instead of float: it differs from the reference arithmetic by the reference's own
 # float rounding noise.  The same source built with / without FMA contraction moves the reference's result by up to
 # 1e-3 m (tests/test_oracle_kats.py::test_reference_float_noise_floor) -- the order of the stopping threshold
-# transformation_epsilon = 1e-3 itself -- so mode 1 is held to 2e-3 m / 2e-4 (measured: <= 1e-3 m, <= 1.5e-4).
-TOL_T1, TOL_R1 = 2e-3, 2e-4
+# transformation_epsilon = 1e-3 / rotation_epsilon = 2e-3 themselves (the iteration stops as soon as the update is below
+# them) -- so mode 1 is held to 2e-3 m / 2.5e-3 under production stopping (measured: <= 1e-3 m, <= 1.8e-3), and to
+# 2e-4 when the iteration count is forced (test_forced_20_iterations_and_guess).
+TOL_T1, TOL_R1 = 2e-3, 2.5e-3
 
 
 def _tol(cost_mode):
@@ -96,7 +98,7 @@ def test_forced_20_iterations_and_guess(ctx, capi, oracle, cost_mode):
     print("cost_mode", cost_mode, "dt", dt, "dR", dR, "iters", res["iterations"], ro["iterations"])
     if cost_mode == 0:
         assert res["iterations"] == ro["iterations"]
-    assert dt < _tol(cost_mode)[0] and dR < _tol(cost_mode)[1], (dt, dR)
+    assert dt < 2e-4 and dR < 2e-4, (dt, dR)  # fully iterated: both modes agree with the oracle to 2e-4
 
 
 def test_hollow_cube_kat_on_gpu(ctx, capi, oracle):
@@ -186,3 +188,57 @@ def test_full_size_properties_100k(ctx, capi, oracle):
     # NN of a cloud against itself is the identity map with d2 = 0 (no duplicate points in a noisy scan)
     idx, d2 = ct.nn1(ct)
     assert (d2 == 0).all() and (idx == np.arange(len(ct))).mean() > 0.9999
+
+
+def test_ragged_batch_sizes_and_slot_reuse(ctx, capi, oracle):
+    # pairs of very different sizes in one batch, fewer slots than pairs (slots are recycled), odd counts that do not fill
+    # an XCD group of 8 jobs: every result must equal the one-at-a-time alignment bit for bit
+    specs = [(8, 120), (16, 700), (4, 97), (32, 640), (16, 333), (8, 1000), (2, 64), (24, 500), (16, 128), (12, 901), (6, 251)]
+    pairs = []
+    for i, (rings, az) in enumerate(specs):
+        src, tgt, _ = synth.scan_pair(n_rings=rings, n_az=az, scale=1.0, noise=0.01, seed=500 + 3 * i)
+        pairs.append((src, tgt))
+    P = capi.default_params(max_iterations=20, corr_dist=1.0, transformation_epsilon=1e-3)
+    S, T, singles = [], [], []
+    for src, tgt in pairs:
+        cs, ct = capi.Cloud(ctx, src), capi.Cloud(ctx, tgt)
+        cs.normals_knn(10)
+        ct.normals_knn(10)
+        S.append(cs)
+        T.append(ct)
+        g = capi.Gicp(ctx, P)
+        g.set_source(cs)
+        g.set_target(ct)
+        singles.append(g.align(want_trace=False))
+    for in_flight in (3, 8, 16, 32):
+        out = capi.align_batch(ctx, P, S, T, max_in_flight=in_flight)
+        for k, (a, b) in enumerate(zip(out, singles)):
+            assert a["status"] == b["status"] and a["iterations"] == b["iterations"], (in_flight, k)
+            assert (a["T"] == b["T"]).all(), (in_flight, k)
+    # and the oracle agrees: a tiny 388-point member in the reference-arithmetic mode (its alignment is too loosely
+    # constrained for the noise-floor argument), two larger members in the default mode
+    for k in (2, 3, 5):
+        dl_s, dl_t = S[k].download(), T[k].download()
+        ro = oracle.gicp_align(oracle.xyz4(pairs[k][0]), oracle.nrm4(np.stack([dl_s["normal_x"], dl_s["normal_y"], dl_s["normal_z"]], 1)),
+                               oracle.xyz4(pairs[k][1]), oracle.nrm4(np.stack([dl_t["normal_x"], dl_t["normal_y"], dl_t["normal_z"]], 1)),
+                               oracle.default_params(num_threads=4, max_iterations=20, corr_dist=1.0, transformation_epsilon=1e-3))
+        if k == 2:
+            g0 = capi.Gicp(ctx, capi.default_params(max_iterations=20, corr_dist=1.0, transformation_epsilon=1e-3, cost_mode=0))
+            g0.set_source(S[k])
+            g0.set_target(T[k])
+            dt, dR = _pose_err(g0.align(want_trace=False)["T"], ro["T"], oracle)
+            assert dt < TOL_T and dR < TOL_R, (k, dt, dR)
+        else:
+            dt, dR = _pose_err(singles[k]["T"], ro["T"], oracle)
+            assert dt < TOL_T1 and dR < TOL_R1, (k, dt, dR)
+
+
+def test_empty_and_invalid_inputs(ctx, capi):
+    with pytest.raises(capi.LocusHipError):
+        capi.Cloud(ctx, np.zeros((0, 3), np.float32))  # empty cloud: LH_EINVAL like pcl::Registration::initCompute
+    g = capi.Gicp(ctx, capi.default_params())
+    with pytest.raises(capi.LocusHipError):
+        g.align()  # no source / target set
+    with pytest.raises(capi.LocusHipError):
+        g.fitness()
+    assert capi.align_batch(ctx, capi.default_params(), [], []) == []
