@@ -191,6 +191,10 @@ lh_status lh_cloud_voxel_grid(const lh_cloud* in, float leaf, int limit_axis, do
 lh_status lh_normals_knn(lh_ctx* ctx, const lh_cloud_view* in, int k, float* out_normals4);
 lh_status lh_normals_knn_cloud(lh_cloud* c, int k); /* in place: fills the cloud's normals on the device */
 
+/* SURVEY 8f-1 (next row): IPointCloudMapper::ApproxNearestNeighbors (Locus.cc:479-483) -- for every point of `query` (already in
+   the map frame) its nearest map point, copied with normal and intensity into a new cloud of query-size (exact search) */
+lh_status lh_cloud_nearest_neighbors(lh_cloud* map, const lh_cloud* query, lh_cloud** out);
+
 /* ---- instrumentation (enableTimingOutput analogue) ------------------------- */
 typedef struct {
   char name[32];

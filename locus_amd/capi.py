@@ -91,7 +91,7 @@ EXPORTS = [
     "lh_gicp_set_source", "lh_gicp_set_target", "lh_gicp_set_source_cloud", "lh_gicp_set_target_cloud",
     "lh_gicp_promote_source_to_target", "lh_gicp_align", "lh_gicp_fitness", "lh_nn1", "lh_nn1_cloud", "lh_knn_cloud",
     "lh_gicp_align_batch", "lh_cov_knn", "lh_gicp_debug_sweep", "lh_gicp_debug_stats", "lh_debug_traversal_stats", "lh_gicp_debug_cost", "lh_p2plane_information",
-    "lh_icp_covariance", "lh_voxel_grid", "lh_cloud_voxel_grid", "lh_normals_knn", "lh_normals_knn_cloud", "lh_profile_enable",
+    "lh_icp_covariance", "lh_voxel_grid", "lh_cloud_voxel_grid", "lh_cloud_nearest_neighbors", "lh_normals_knn", "lh_normals_knn_cloud", "lh_profile_enable",
     "lh_profile_reset", "lh_profile_get",
 ]
 
@@ -150,6 +150,7 @@ def lib():
         L.lh_icp_covariance.argtypes = [vp, dbl, vp, C.POINTER(dbl)]
         L.lh_voxel_grid.argtypes = [vp, C.POINTER(CloudView), C.c_float, i32, dbl, dbl, vp, u32, C.POINTER(u32)]
         L.lh_cloud_voxel_grid.argtypes = [vp, C.c_float, i32, dbl, dbl, C.POINTER(vp)]
+        L.lh_cloud_nearest_neighbors.argtypes = [vp, vp, C.POINTER(vp)]
         L.lh_normals_knn.argtypes = [vp, C.POINTER(CloudView), i32, vp]
         L.lh_normals_knn_cloud.argtypes = [vp, i32]
         L.lh_profile_enable.argtypes = [vp, i32]
@@ -343,6 +344,12 @@ class Cloud:
         out = C.c_void_p()
         _check(lib().lh_cloud_voxel_grid(self.h, leaf, limit_axis, float(max(lo, -3e38)), float(min(hi, 3e38)), C.byref(out)),
                "lh_cloud_voxel_grid")
+        return Cloud(self.ctx, None, _handle=out)
+
+    def nearest_neighbors(self, query_cloud):
+        """mapper ApproxNearestNeighbors analogue: cloud of this (map) cloud's points nearest to each query point"""
+        out = C.c_void_p()
+        _check(lib().lh_cloud_nearest_neighbors(self.h, query_cloud.h, C.byref(out)), "lh_cloud_nearest_neighbors")
         return Cloud(self.ctx, None, _handle=out)
 
     def nn1(self, query_cloud):

@@ -1679,6 +1679,44 @@ lh_status lh_cloud_voxel_grid(const lh_cloud* in, float leaf, int limit_axis, do
   return LH_OK;
 }
 
+// ---- next-row helper: mapper_->ApproxNearestNeighbors (Locus.cc:479-483) ------------------------------
+// for every query point the nearest map point is copied (xyz, normal, intensity) into a new cloud; the reference uses an
+// approximate octree search, this is the exact search (never farther than the reference's answer)
+__global__ void __launch_bounds__(256) k_gather_cloud(const float4* __restrict__ xyz, const float4* __restrict__ nrm, const float* __restrict__ inten,
+                                                     const int32_t* __restrict__ idx, int n, float4* __restrict__ oxyz, float4* __restrict__ onrm,
+                                                     float* __restrict__ ointen) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int j = idx[i];
+  oxyz[i] = xyz[j];
+  if (nrm && onrm) onrm[i] = nrm[j];
+  if (inten && ointen) ointen[i] = inten[j];
+}
+lh_status lh_cloud_nearest_neighbors(lh_cloud* map, const lh_cloud* query, lh_cloud** out) {
+  if (!map || !query || !out || map->ctx != query->ctx || map->n <= 0 || query->n <= 0) return LH_EINVAL;
+  lh_ctx* c = map->ctx;
+  HIPCHK(hipSetDevice(c->device));
+  if (!map->has_index) { lh_status st = cloud_build_index(map); if (st) return st; }
+  int n = query->n;
+  int32_t* d_idx = nullptr;
+  float* d_d2 = nullptr;
+  HIPCHK(hipMalloc(&d_idx, sizeof(int32_t) * (size_t)n));
+  HIPCHK(hipMalloc(&d_d2, sizeof(float) * (size_t)n));
+  { ProfScope p(c, "nn1", 24.0 * n); launch_nn1(query->xyz, n, nullptr, map->view(), d_idx, d_d2, c->stream); }
+  lh_cloud* o = new lh_cloud();
+  o->ctx = c; o->n = n; o->n_pad = round_up(n, 256);
+  HIPCHK(hipMalloc(&o->xyz, sizeof(float4) * (size_t)o->n_pad));
+  if (map->nrm) HIPCHK(hipMalloc(&o->nrm, sizeof(float4) * (size_t)o->n_pad));
+  if (map->intensity) HIPCHK(hipMalloc(&o->intensity, sizeof(float) * (size_t)o->n_pad));
+  hipLaunchKernelGGL(k_gather_cloud, dim3((n + 255) / 256), dim3(256), 0, c->stream, map->xyz, map->nrm, map->intensity, d_idx, n, o->xyz, o->nrm,
+                     o->intensity);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(c->stream));
+  (void)hipFree(d_idx); (void)hipFree(d_d2);
+  *out = o;
+  return LH_OK;
+}
+
 // ---- instrumentation -------------------------------------------------------------------------------------------
 lh_status lh_profile_enable(lh_ctx* c, int on) {
   if (!c) return LH_EINVAL;

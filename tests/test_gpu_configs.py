@@ -37,6 +37,22 @@ def test_config3_scan_to_submap_2M(ctx, capi, oracle):
     idx, d2 = cmap.nn1(capi.Cloud(ctx, qs))
     io, do = oracle.Tree(oracle.xyz4(mpts)).nn1(oracle.xyz4(qs), threads=8)
     assert (idx == io).all() and (d2 == do).all()
+    # the LOCUS flow (Locus.cc:474-489): scan -> fixed frame -> mapper neighbours (one map point per scan point) -> sensor
+    # frame -> MeasurementUpdate against those neighbours
+    G16 = oracle.mat_to_T(guess)
+    in_fixed = cq.transform(G16, with_normals=True)
+    neigh = cmap.nearest_neighbors(in_fixed)
+    assert len(neigh) == len(cq)
+    nd = neigh.download()
+    nidx, _ = cmap.nn1(in_fixed)
+    assert (np.stack([nd["x"], nd["y"], nd["z"]], 1) == mpts[nidx]).all()
+    neigh_s = neigh.transform(oracle.mat_to_T(np.linalg.inv(guess)), with_normals=True)
+    gl = capi.Gicp(ctx, capi.default_params(max_iterations=20, max_inner_iterations=50, corr_dist=0.2, transformation_epsilon=1e-5))
+    gl.set_source(cq)
+    gl.set_target(neigh_s)
+    rl = gl.align()
+    Tl = guess @ oracle.T_to_mat(rl["T"])  # pose correction composed with the prior
+    assert rl["status"] == 0 and np.abs(Tl[:3, 3] - true_pose[:3, 3]).max() < 0.05
     # MeasurementUpdate-style alignment: corr_dist 0.2, inner 50, tf_eps 1e-5 (point_cloud_localization yaml)
     P = capi.default_params(max_iterations=20, max_inner_iterations=50, corr_dist=0.2, transformation_epsilon=1e-5)
     g = capi.Gicp(ctx, P)
