@@ -76,8 +76,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--pairs", type=int, default=32, help="scan pairs per GPU per step")
-    ap.add_argument("--in-flight", type=int, default=32)
+    ap.add_argument("--pairs", type=int, default=64, help="scan pairs per GPU per step")
+    ap.add_argument("--in-flight", type=int, default=64)
     ap.add_argument("--rings", type=int, default=64)
     ap.add_argument("--azimuths", type=int, default=1563)  # 64 x 1563 = 100 032 points / scan
     ap.add_argument("--scale", type=float, default=2.0)

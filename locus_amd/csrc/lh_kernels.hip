@@ -342,8 +342,9 @@ __global__ void __launch_bounds__(256) k_seed(const PairDesc* __restrict__ descs
   if (!xcd_job_map(a.njobs, a.bpj, jb, blk)) return;
   const SweepJob& job = a.job[jb];
   const PairDesc d = descs[job.slot];
+  const int group = a.pad;  // seed group size (runtime so it can be tuned)
   int g = blk * 256 + threadIdx.x;
-  int i = g * SEED_GROUP;
+  int i = g * group;
   if (i >= d.n) return;
   float4 p = d.src[i];
   float qx, qy, qz;
@@ -352,15 +353,16 @@ __global__ void __launch_bounds__(256) k_seed(const PairDesc* __restrict__ descs
   Nn1Collector col{INFINITY, 0x7fffffff};
   tree_search(tv, qx, qy, qz, col, lds_stack + threadIdx.x, 256);
   int j = (col.bi == 0x7fffffff) ? -1 : col.bi;
-#pragma unroll
-  for (int e = 0; e < SEED_GROUP; e++)
+  for (int e = 0; e < group; e++)
     if (i + e < d.n) {
       d.prev_nn[i + e] = j;
       d.cert[i + e] = make_float4(0.f, 0.f, 0.f, 0.f);  // lower bound 0 => the certificate can never skip the search
     }
 }
 void launch_seed(const PairDesc* descs, SweepArgs& a, int max_n, hipStream_t s) {
-  int groups = (max_n + SEED_GROUP - 1) / SEED_GROUP;
+  static const int seed_group = []() { const char* e = getenv("LH_SEED_GROUP"); int v = e ? atoi(e) : SEED_GROUP; return v < 1 ? 1 : v; }();
+  a.pad = seed_group;
+  int groups = (max_n + seed_group - 1) / seed_group;
   a.bpj = (groups + 255) / 256;
   hipLaunchKernelGGL(k_seed, dim3(xcd_grid(a.njobs, a.bpj)), dim3(256), stack_lds_bytes(a.max_depth, 256), s, descs, a);
 }

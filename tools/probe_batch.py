@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from locus_amd import capi, synth
 ctx = capi.Context(0)
 S, T = [], []
-for p in range(32):
+for p in range(32):  # = one scheduler group of the default bench (64 in flight = 2 groups of 32)
     src, tgt, _ = synth.scan_pair(n_rings=64, n_az=1563, scale=2.0, noise=0.02, seed=10 + 2 * p)
     cs, ct = capi.Cloud(ctx, src), capi.Cloud(ctx, tgt)
     cs.normals_knn(20); ct.normals_knn(20); ct.drop_index()
