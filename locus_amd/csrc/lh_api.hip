@@ -10,6 +10,11 @@
 #include <ucontext.h>
 
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -38,8 +43,69 @@ static const float I16[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
 struct ProfEntry { std::string name; uint64_t launches = 0; double ms = 0, bytes = 0; };
 struct ProfPending { int entry; hipEvent_t a, b; };
 
+// Small persistent host thread pool: in cost_mode 1 every pair runs its whole BFGS solve (~30 evaluations of the 12x12
+// moment model per outer iteration) on the host between two sweeps; with 32 pairs per scheduler group that is ~0.2 ms of
+// serial host work per round -- as long as the GPU time of the round.  The solves are independent, so they are spread
+// over a few workers (LH_HOST_THREADS, default 8; the calling thread takes part).
+struct HostPool {
+  std::vector<std::thread> workers;
+  std::mutex m;
+  std::condition_variable cv_work, cv_done;
+  std::function<void(int)> fn;
+  int n_items = 0, pending = 0;
+  std::atomic<int> next{0};
+  uint64_t generation = 0;
+  bool stop = false;
+  explicit HostPool(int n_workers) {
+    for (int i = 0; i < n_workers; i++) workers.emplace_back([this] { loop(); });
+  }
+  ~HostPool() {
+    { std::lock_guard<std::mutex> l(m); stop = true; }
+    cv_work.notify_all();
+    for (auto& t : workers) t.join();
+  }
+  void drain() {
+    for (;;) {
+      int i = next.fetch_add(1);
+      if (i >= n_items) break;
+      fn(i);
+      std::lock_guard<std::mutex> l(m);
+      if (--pending == 0) cv_done.notify_all();
+    }
+  }
+  void loop() {
+    uint64_t seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> l(m);
+        cv_work.wait(l, [&] { return stop || generation != seen; });
+        if (stop) return;
+        seen = generation;
+      }
+      drain();
+    }
+  }
+  void parallel_for(int n, std::function<void(int)> f) {
+    if (n <= 0) return;
+    if (workers.empty() || n == 1) { for (int i = 0; i < n; i++) f(i); return; }
+    {
+      std::lock_guard<std::mutex> l(m);
+      fn = std::move(f);
+      n_items = n;
+      pending = n;
+      next.store(0);
+      generation++;
+    }
+    cv_work.notify_all();
+    drain();
+    std::unique_lock<std::mutex> l(m);
+    cv_done.wait(l, [&] { return pending == 0; });
+  }
+};
+
 struct lh_ctx {
   int device = 0;
+  HostPool* pool = nullptr;
   hipStream_t stream = nullptr, stream2 = nullptr;  // stream2: second half-batch of the pipelined scheduler
   // index-build scratch (shared by all clouds of the context; builds are serial on the stream)
   uint32_t *keys0 = nullptr, *keys1 = nullptr, *vals0 = nullptr, *vals1 = nullptr, *bbox = nullptr;
@@ -679,12 +745,19 @@ static lh_status group_collect(lh_ctx* c, Group& g) {
     for (int r = 0; r < 3; r++)
       for (int cc = 0; cc < 4; cc++) t->mom.T0[cc * 4 + r] = t->req_T12[r * 4 + cc];
     t->mom.T0[3] = t->mom.T0[7] = t->mom.T0[11] = 0.f; t->mom.T0[15] = 1.f;
-    if (c->prof) {
-      c->prof_entries[c->prof_entry("cost_moments")].bytes += 108.0 * S[73];
-      c->prof_entries[c->prof_entry("nn_sweep")].bytes += 232.0 * S[73];
-    }
+    t->mom.prepare();
+    if (c->prof)  // fused K4+K5': algorithmic bytes B_nn + one B_fdf = 20 N + (232 + 108) K_t
+      c->prof_entries[c->prof_entry("nn_sweep")].bytes += 340.0 * S[73];
     t->sweep_bytes_pending = false;
-    t->resume();
+  }
+  if (!g.moms.empty()) {  // the BFGS solves of the group's pairs are independent: run them on the host pool
+    if (!c->pool) {
+      const char* e = getenv("LH_HOST_THREADS");
+      int nt = e ? atoi(e) : 8;
+      c->pool = new HostPool(std::max(0, nt - 1));
+    }
+    std::vector<Task*>& moms = g.moms;
+    c->pool->parallel_for((int)moms.size(), [&moms](int i) { moms[i]->resume(); });
   }
   g.costs.clear(); g.moms.clear(); g.sweeps.clear();
   for (size_t i = 0; i < g.active.size();) {  // retire finished pairs
@@ -874,6 +947,8 @@ void lh_destroy(lh_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
+  delete c->pool;
+  c->pool = nullptr;
   c->prof_flush();
   for (auto e : c->ev_pool) (void)hipEventDestroy(e);
   (void)hipFree(c->keys0); (void)hipFree(c->keys1); (void)hipFree(c->vals0); (void)hipFree(c->vals1);

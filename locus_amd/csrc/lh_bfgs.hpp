@@ -102,25 +102,31 @@ struct CostFn {
 // Device side: k_moments (lh_kernels.hip).  S = c0, B[3][4], H[6][10], count; T0 = transformation_ at sweep time.
 struct MomentModel {
   double S[74];
-  float T0[16];  // column-major
+  float T0[16];    // column-major
+  double H12[144]; // expanded symmetric 12x12 form of H, row (r,c) = 4r+c, filled by prepare()
   static int sym3(int r, int s) { static const int m[3][3] = {{0, 1, 2}, {1, 3, 4}, {2, 4, 5}}; return m[r][s]; }
   static int sym4(int c, int e) { static const int m[4][4] = {{0, 1, 2, 3}, {1, 4, 5, 6}, {2, 5, 7, 8}, {3, 6, 8, 9}}; return m[c][e]; }
   double count() const { return S[73]; }
+  void prepare() {  // once per sweep; the ~600 evaluations of a pair's BFGS solves then cost one 12x12 mat-vec each
+    const double* H = S + 13;
+    for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 4; c++)
+        for (int s = 0; s < 3; s++)
+          for (int e = 0; e < 4; e++) H12[(4 * r + c) * 12 + 4 * s + e] = H[sym3(r, s) * 10 + sym4(c, e)];
+  }
   // the 13 sums of gicp.hpp:388-396 at T (column-major float matrix from applyState)
   void sums(const float* T16, double* sums13) const {
     double d[12];
     for (int r = 0; r < 3; r++)
       for (int c = 0; c < 4; c++) d[4 * r + c] = (double)T16[c * 4 + r] - (double)T0[c * 4 + r];
     const double* B = S + 1;
-    const double* H = S + 13;
     double G[12], f = S[0];
-    for (int r = 0; r < 3; r++)
-      for (int c = 0; c < 4; c++) {
-        double g = 0.0;
-        for (int s = 0; s < 3; s++)
-          for (int e = 0; e < 4; e++) g += H[sym3(r, s) * 10 + sym4(c, e)] * d[4 * s + e];
-        G[4 * r + c] = B[4 * r + c] + g;
-      }
+    for (int i = 0; i < 12; i++) {
+      const double* row = H12 + 12 * i;
+      double g = 0.0;
+      for (int k = 0; k < 12; k++) g += row[k] * d[k];  // same summation order (s outer, e inner) as the sym-indexed form
+      G[i] = B[i] + g;
+    }
     for (int k = 0; k < 12; k++) f += d[k] * (B[k] + G[k]);
     sums13[0] = f;
     sums13[1] = G[3]; sums13[2] = G[7]; sums13[3] = G[11];

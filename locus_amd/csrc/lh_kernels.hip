@@ -738,35 +738,47 @@ __global__ void __launch_bounds__(256) k_moments(const PairDesc* __restrict__ de
   }
 }
 
-__global__ void __launch_bounds__(128) k_moments_final(const PairDesc* __restrict__ descs, CostArgs a, const double* __restrict__ partials,
-                                                       int partials_stride, int chunk, double* __restrict__ out) {
+// final sum of a job's per-wave / per-workgroup partials: 8 chunks x 74 values per job, each thread adds its chunk in
+// block order (16 independent loads in flight), then the 8 chunk sums are combined in chunk order => bitwise reproducible
+constexpr int FINAL_CHUNKS = 8;
+__global__ void __launch_bounds__(FINAL_CHUNKS * MOM_NSUM) k_moments_final(const PairDesc* __restrict__ descs, CostArgs a, const double* __restrict__ partials,
+                                                                         int partials_stride, int chunk, double* __restrict__ out) {
   const CostJob& job = a.job[blockIdx.x];
   int n = descs[job.slot].n;
   int nb = (n + chunk - 1) / chunk;
-  if (threadIdx.x < MOM_NSUM) {
-    const double* p = partials + (size_t)job.slot * partials_stride + threadIdx.x;
-    double s = 0.0;
-    int b = 0;
-    for (; b + 16 <= nb; b += 16) {  // 16 independent loads in flight, summed in block order => bitwise reproducible
-      double v[16];
+  int v = threadIdx.x % MOM_NSUM, c = threadIdx.x / MOM_NSUM;
+  int per = (nb + FINAL_CHUNKS - 1) / FINAL_CHUNKS;
+  int b0 = c * per, b1 = min(nb, b0 + per);
+  const double* p = partials + (size_t)job.slot * partials_stride + v;
+  double s = 0.0;
+  int b = b0;
+  for (; b + 16 <= b1; b += 16) {
+    double t[16];
 #pragma unroll
-      for (int k = 0; k < 16; k++) v[k] = p[(size_t)(b + k) * MOM_NSUM];
+    for (int k = 0; k < 16; k++) t[k] = p[(size_t)(b + k) * MOM_NSUM];
 #pragma unroll
-      for (int k = 0; k < 16; k++) s += v[k];
-    }
-    for (; b < nb; b++) s += p[(size_t)b * MOM_NSUM];
-    out[job.out_offset + threadIdx.x] = s;
+    for (int k = 0; k < 16; k++) s += t[k];
+  }
+  for (; b < b1; b++) s += p[(size_t)b * MOM_NSUM];
+  __shared__ double sm[FINAL_CHUNKS][MOM_NSUM];
+  sm[c][v] = s;
+  __syncthreads();
+  if (c == 0) {
+    double tot = 0.0;
+#pragma unroll
+    for (int k = 0; k < FINAL_CHUNKS; k++) tot += sm[k][v];
+    out[job.out_offset + v] = tot;
   }
 }
 
 void launch_moments(const PairDesc* descs, const CostArgs& a, int max_n, double* partials_dev, int partials_stride, double* out,
                     hipStream_t s) {
   hipLaunchKernelGGL(k_moments, dim3(mom_blocks(max_n), a.njobs), dim3(256), 0, s, descs, a, partials_dev, partials_stride);
-  hipLaunchKernelGGL(k_moments_final, dim3(a.njobs), dim3(128), 0, s, descs, a, partials_dev, partials_stride, MOM_CHUNK, out);
+  hipLaunchKernelGGL(k_moments_final, dim3(a.njobs), dim3(FINAL_CHUNKS * MOM_NSUM), 0, s, descs, a, partials_dev, partials_stride, MOM_CHUNK, out);
 }
 void launch_moments_final(const PairDesc* descs, const CostArgs& a, double* partials_dev, int partials_stride, int chunk, double* out,
                           hipStream_t s) {
-  hipLaunchKernelGGL(k_moments_final, dim3(a.njobs), dim3(128), 0, s, descs, a, partials_dev, partials_stride, chunk, out);
+  hipLaunchKernelGGL(k_moments_final, dim3(a.njobs), dim3(FINAL_CHUNKS * MOM_NSUM), 0, s, descs, a, partials_dev, partials_stride, chunk, out);
 }
 
 // ===== K6 / misc ===========================================================================================
