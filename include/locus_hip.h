@@ -190,6 +190,13 @@ lh_status lh_cloud_voxel_grid(const lh_cloud* in, float leaf, int limit_axis, do
    out = float[count][4] (nx, ny, nz, curvature) */
 lh_status lh_normals_knn(lh_ctx* ctx, const lh_cloud_view* in, int k, float* out_normals4);
 lh_status lh_normals_knn_cloud(lh_cloud* c, int k); /* in place: fills the cloud's normals on the device */
+/* radius mode of the same nodelet (normal_search_method = radius, normal_computation.cc:71-74; default radius 0.3): every
+   neighbour with d2 < radius^2 enters the covariance; fewer than 3 neighbours -> NaN normal and curvature.  The nodelet then
+   drops those points (pcl::removeNaNNormalsFromPointCloud, normal_computation.cc:52-56): lh_cloud_remove_nan_normals is
+   that order-preserving compaction on the device (new cloud; LH_EINVAL if nothing survives). */
+lh_status lh_normals_radius(lh_ctx* ctx, const lh_cloud_view* in, float radius, float* out_normals4);
+lh_status lh_normals_radius_cloud(lh_cloud* c, float radius);
+lh_status lh_cloud_remove_nan_normals(const lh_cloud* in, lh_cloud** out);
 
 /* SURVEY 8f-1 (next row): IPointCloudMapper::ApproxNearestNeighbors (Locus.cc:479-483) -- for every point of `query` (already in
    the map frame) its nearest map point, copied with normal and intensity into a new cloud of query-size (exact search) */

@@ -91,7 +91,8 @@ EXPORTS = [
     "lh_gicp_set_source", "lh_gicp_set_target", "lh_gicp_set_source_cloud", "lh_gicp_set_target_cloud",
     "lh_gicp_promote_source_to_target", "lh_gicp_align", "lh_gicp_fitness", "lh_nn1", "lh_nn1_cloud", "lh_knn_cloud",
     "lh_gicp_align_batch", "lh_cov_knn", "lh_gicp_debug_sweep", "lh_gicp_debug_stats", "lh_debug_traversal_stats", "lh_gicp_debug_cost", "lh_p2plane_information",
-    "lh_icp_covariance", "lh_voxel_grid", "lh_cloud_voxel_grid", "lh_cloud_nearest_neighbors", "lh_normals_knn", "lh_normals_knn_cloud", "lh_profile_enable",
+    "lh_icp_covariance", "lh_voxel_grid", "lh_cloud_voxel_grid", "lh_cloud_nearest_neighbors", "lh_normals_knn", "lh_normals_knn_cloud",
+    "lh_normals_radius", "lh_normals_radius_cloud", "lh_cloud_remove_nan_normals", "lh_profile_enable",
     "lh_profile_reset", "lh_profile_get",
 ]
 
@@ -153,6 +154,9 @@ def lib():
         L.lh_cloud_nearest_neighbors.argtypes = [vp, vp, C.POINTER(vp)]
         L.lh_normals_knn.argtypes = [vp, C.POINTER(CloudView), i32, vp]
         L.lh_normals_knn_cloud.argtypes = [vp, i32]
+        L.lh_normals_radius.argtypes = [vp, C.POINTER(CloudView), C.c_float, vp]
+        L.lh_normals_radius_cloud.argtypes = [vp, C.c_float]
+        L.lh_cloud_remove_nan_normals.argtypes = [vp, C.POINTER(vp)]
         L.lh_profile_enable.argtypes = [vp, i32]
         L.lh_profile_reset.argtypes = [vp]
         L.lh_profile_get.argtypes = [vp, C.POINTER(KernelStat), i32]
@@ -279,6 +283,12 @@ class Context:
         _check(lib().lh_normals_knn(self.h, C.byref(v), k, _ptr(out)), "lh_normals_knn")
         return out
 
+    def normals_radius(self, points, radius=0.3):
+        v, keep = view_of(points)
+        out = np.empty((v.count, 4), np.float32)
+        _check(lib().lh_normals_radius(self.h, C.byref(v), radius, _ptr(out)), "lh_normals_radius")
+        return out
+
     def p2plane_information(self, query, reference, corr):
         corr = np.ascontiguousarray(corr, np.int64)
         Ap = np.empty((6, 6), np.float64)
@@ -383,6 +393,15 @@ class Cloud:
 
     def normals_knn(self, k=20):
         _check(lib().lh_normals_knn_cloud(self.h, k), "lh_normals_knn_cloud")
+
+    def normals_radius(self, radius=0.3):
+        _check(lib().lh_normals_radius_cloud(self.h, radius), "lh_normals_radius_cloud")
+
+    def remove_nan_normals(self):
+        """pcl::removeNaNNormalsFromPointCloud (normal_computation.cc:52-56): new cloud without the NaN-normal points"""
+        out = C.c_void_p()
+        _check(lib().lh_cloud_remove_nan_normals(self.h, C.byref(out)), "lh_cloud_remove_nan_normals")
+        return Cloud(self.ctx, None, _handle=out)
 
 
 def _result_dict(r, trace=None):

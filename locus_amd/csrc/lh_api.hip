@@ -1608,6 +1608,68 @@ lh_status lh_normals_knn_cloud(lh_cloud* c, int k) {
   HIPCHK(hipGetLastError());
   return LH_OK;
 }
+// radius mode (normal_computation.cc:71-74): NaN normals where fewer than 3 neighbours lie within `radius`
+lh_status lh_normals_radius_cloud(lh_cloud* c, float radius) {
+  if (!c || !(radius > 0.0f)) return LH_EINVAL;
+  lh_ctx* x = c->ctx;
+  HIPCHK(hipSetDevice(x->device));
+  if (!c->has_index) { lh_status st = cloud_build_index(c); if (st) return st; }
+  if (!c->nrm) HIPCHK(hipMalloc(&c->nrm, sizeof(float4) * (size_t)c->n_pad));
+  { ProfScope p(x, "radius_normals", 32.0 * c->n); launch_radius_normals(c->xyz, c->n, c->view(), radius, c->nrm, x->stream); }
+  HIPCHK(hipGetLastError());
+  return LH_OK;
+}
+lh_status lh_normals_radius(lh_ctx* ctx, const lh_cloud_view* in, float radius, float* out_normals4) {
+  if (!ctx || !in || !out_normals4) return LH_EINVAL;
+  lh_cloud* c = nullptr;
+  lh_status st = upload_view(ctx, in, &c);
+  if (st) return st;
+  st = lh_normals_radius_cloud(c, radius);
+  if (!st) {
+    hipError_t e = hipMemcpyAsync(out_normals4, c->nrm, sizeof(float4) * (size_t)c->n, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) st = LH_EDEVICE;
+  }
+  (void)hipStreamSynchronize(ctx->stream);
+  cloud_free(c);
+  return st;
+}
+// pcl::removeNaNNormalsFromPointCloud (normal_computation.cc:52-56) on the device: order-preserving compaction into a new cloud
+lh_status lh_cloud_remove_nan_normals(const lh_cloud* in, lh_cloud** out) {
+  if (!in || !out || !in->nrm || in->n <= 0) return LH_EINVAL;
+  lh_ctx* c = in->ctx;
+  HIPCHK(hipSetDevice(c->device));
+  int n = in->n;
+  uint32_t *d_flags = nullptr, *d_incl = nullptr;
+  void* d_tmp = nullptr;
+  size_t tmp_bytes = scan_temp_bytes(n);
+  HIPCHK(hipMalloc(&d_flags, sizeof(uint32_t) * (size_t)n));
+  HIPCHK(hipMalloc(&d_incl, sizeof(uint32_t) * (size_t)n));
+  HIPCHK(hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 16));
+  launch_finite_normal_flags(in->nrm, n, d_flags, c->stream);
+  inclusive_scan_u32(d_tmp, tmp_bytes, d_flags, d_incl, n, c->stream);
+  uint32_t total = 0;
+  hipError_t e = hipMemcpyAsync(&total, d_incl + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  lh_status st = e == hipSuccess ? LH_OK : LH_EDEVICE;
+  lh_cloud* o = nullptr;
+  if (!st && total == 0) st = LH_EINVAL;  // nothing survives: no cloud to return
+  if (!st) {
+    o = new lh_cloud();
+    o->ctx = c; o->n = (int)total; o->n_pad = round_up(o->n, 256);
+    if (hipMalloc(&o->xyz, sizeof(float4) * (size_t)o->n_pad) != hipSuccess || hipMalloc(&o->nrm, sizeof(float4) * (size_t)o->n_pad) != hipSuccess ||
+        (in->intensity && hipMalloc(&o->intensity, sizeof(float) * (size_t)o->n_pad) != hipSuccess))
+      st = LH_ENOMEM;
+  }
+  if (!st) {
+    launch_compact(d_incl, n, in->xyz, in->nrm, in->intensity, o->xyz, o->nrm, o->intensity, c->stream);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) st = LH_EDEVICE;
+  }
+  (void)hipFree(d_flags); (void)hipFree(d_incl); (void)hipFree(d_tmp);
+  if (st) { cloud_free(o); return st; }
+  *out = o;
+  return LH_OK;
+}
 lh_status lh_normals_knn(lh_ctx* ctx, const lh_cloud_view* in, int k, float* out_normals4) {
   if (!ctx || !in || !out_normals4) return LH_EINVAL;
   lh_cloud* c = nullptr;

@@ -171,6 +171,7 @@ LH_HD void cswap(uint64_t& a, uint64_t& b) {
 }
 
 // Collector concept: float bound() const; void offer(float d2, int id); void skip(float box_d2);
+// (a collector with kXyz = true is offered the point itself instead of its id: offer_xyz(d2, x, y, z))
 // A subtree / leaf is visited iff box_d2 <= bound() (ties must be visited for the lowest-index rule); skip() is told the
 // box distance of every subtree that is pruned (so a collector can keep a lower bound on everything it never looked at).
 // Traversal stack: 32-bit entries kept in LDS on the device (layout [entry][thread], conflict-free), a plain array
@@ -247,7 +248,8 @@ LH_HD void tree_search(const TreeView& t, float qx, float qy, float qz, Collecto
 #pragma unroll
     for (int e = 0; e < LEAF; e++) {
       float4 v = p[e];
-      col.offer(d2f(qx, qy, qz, v.x, v.y, v.z), (int)f2u(v.w));
+      if constexpr (Collector::kXyz) col.offer_xyz(d2f(qx, qy, qz, v.x, v.y, v.z), v.x, v.y, v.z);
+      else col.offer(d2f(qx, qy, qz, v.x, v.y, v.z), (int)f2u(v.w));
     }
     lin = pop();
   }
@@ -256,6 +258,7 @@ LH_HD void tree_search(const TreeView& t, float qx, float qy, float qz, Collecto
 struct Nn1Collector {
   float bd;
   int bi;
+  static constexpr bool kXyz = false;
   LH_HD float bound() const { return bd; }
   LH_HD void offer(float d, int id) {  // branch-free: selects instead of exec-mask branches in the 8-point leaf scan
     bool better = (d < bd) | ((d == bd) & (id < bi));
@@ -272,6 +275,7 @@ struct Nn1CountCollector {
   float bd;
   int bi;
   int nodes, leaves;
+  static constexpr bool kXyz = false;
   LH_HD float bound() const { return bd; }
   LH_HD void offer(float d, int id) {
     if (d < bd || (d == bd && id < bi)) { bd = d; bi = id; }
@@ -290,6 +294,7 @@ struct Nn1CertCollector {
   float bd;
   int bi;
   float lb;
+  static constexpr bool kXyz = false;
   LH_HD float bound() const { return bd; }
   LH_HD void offer(float d, int id) {  // branch-free
     bool same = id == bi;                                   // the warm-start candidate met again: no-op
@@ -305,12 +310,34 @@ struct Nn1CertCollector {
   LH_HD void count_leaf() {}
 };
 
+// radius search for the normal filter's radius mode (normal_computation.cc:71-74): every point with d2 < r2 feeds the
+// nine float moment accumulators of computeMeanAndCovarianceMatrix directly (no neighbour list: the count is unbounded).
+struct RadiusMomentCollector {
+  float r2;
+  int cnt;
+  float a[9];
+  static constexpr bool kXyz = true;
+  LH_HD float bound() const { return r2; }
+  LH_HD void offer_xyz(float d, float x, float y, float z) {
+    if (d < r2) {  // FLANN RadiusResultSet: strict
+      cnt++;
+      a[0] += x * x; a[1] += x * y; a[2] += x * z;
+      a[3] += y * y; a[4] += y * z; a[5] += z * z;
+      a[6] += x; a[7] += y; a[8] += z;
+    }
+  }
+  LH_HD void skip(float) {}
+  LH_HD void count_node(int) {}
+  LH_HD void count_leaf() {}
+};
+
 // k best (d2, id) ascending, lexicographic; storage strided so that a workgroup can keep the lists in LDS
 // as [element][thread] (conflict-free) -- stride 1 on the host.
 struct KnnCollector {
   float* kd;
   int* ki;
   int k, stride, cnt;
+  static constexpr bool kXyz = false;
   LH_HD float bound() const { return cnt < k ? inf_f() : kd[(k - 1) * stride]; }
   LH_HD void skip(float) {}
   LH_HD void count_node(int) {}
@@ -354,6 +381,7 @@ struct KnnRegCollector {
     kd = inf_f();
     ki = 0x7fffffff;
   }
+  static constexpr bool kXyz = false;
   LH_HD float bound() const { return kd; }
   LH_HD void skip(float) {}
   LH_HD void count_node(int) {}

@@ -1042,31 +1042,10 @@ __device__ void roots3f(float m00, float m01, float m02, float m11, float m12, f
   if (r[0] <= 0.0f) roots2f(c2, c1, r);
 }
 
-template <int KCAP>
-__global__ void __launch_bounds__(KNN_BLOCK) k_knn_normals(const float4* __restrict__ xyz, int n, TreeView tv, int k,
-                                                           float4* __restrict__ out) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* kd = reinterpret_cast<float*>(smem);
-  int* ki = reinterpret_cast<int*>(smem + sizeof(float) * (size_t)k * KNN_BLOCK);
-  int i = blockIdx.x * KNN_BLOCK + threadIdx.x;
-  if (i >= n) return;
-  float4 p = xyz[i];
-  uint32_t* lds_stack = reinterpret_cast<uint32_t*>(smem + (size_t)8 * k * KNN_BLOCK);
-  struct { int cnt; } col;
-  col.cnt = knn_search<KCAP>(tv, p.x, p.y, p.z, k, kd + threadIdx.x, ki + threadIdx.x, lds_stack + threadIdx.x);
-  const float qnan = __uint_as_float(0x7fc00000u);
-  if (col.cnt < 3) {
-    out[i] = make_float4(qnan, qnan, qnan, qnan);
-    return;
-  }
-  float a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, a6 = 0, a7 = 0, a8 = 0;
-  for (int e = 0; e < col.cnt; e++) {  // computeMeanAndCovarianceMatrix, float accumulators (PCL 1.10)
-    float4 t = xyz[ki[e * KNN_BLOCK + threadIdx.x]];
-    a0 += t.x * t.x; a1 += t.x * t.y; a2 += t.x * t.z;
-    a3 += t.y * t.y; a4 += t.y * t.z; a5 += t.z * t.z;
-    a6 += t.x; a7 += t.y; a8 += t.z;
-  }
-  float c = (float)col.cnt;
+// solvePlaneParameters + flipNormalTowardsViewpoint on the nine raw moment sums of `cnt` neighbours (PCL 1.10)
+__device__ float4 normal_from_moments(float a0, float a1, float a2, float a3, float a4, float a5, float a6, float a7, float a8, int cnt,
+                                      float4 p) {
+  float c = (float)cnt;
   a0 /= c; a1 /= c; a2 /= c; a3 /= c; a4 /= c; a5 /= c; a6 /= c; a7 /= c; a8 /= c;
   float m00 = a0 - a6 * a6, m01 = a1 - a6 * a7, m02 = a2 - a6 * a8, m11 = a3 - a7 * a7, m12 = a4 - a7 * a8, m22 = a5 - a8 * a8;
   // pcl::eigen33(mat, eigenvalue, eigenvector)
@@ -1095,11 +1074,89 @@ __global__ void __launch_bounds__(KNN_BLOCK) k_knn_normals(const float4* __restr
   float vx = 0.0f - p.x, vy = 0.0f - p.y, vz = 0.0f - p.z;  // flipNormalTowardsViewpoint, vp = 0
   float cos_theta = (vx * nx + vy * ny) + vz * nz;
   if (cos_theta < 0) { nx = -nx; ny = -ny; nz = -nz; }
-  out[i] = make_float4(nx, ny, nz, curv);
+  return make_float4(nx, ny, nz, curv);
+}
+
+template <int KCAP>
+__global__ void __launch_bounds__(KNN_BLOCK) k_knn_normals(const float4* __restrict__ xyz, int n, TreeView tv, int k,
+                                                           float4* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* kd = reinterpret_cast<float*>(smem);
+  int* ki = reinterpret_cast<int*>(smem + sizeof(float) * (size_t)k * KNN_BLOCK);
+  int i = blockIdx.x * KNN_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  float4 p = xyz[i];
+  uint32_t* lds_stack = reinterpret_cast<uint32_t*>(smem + (size_t)8 * k * KNN_BLOCK);
+  struct { int cnt; } col;
+  col.cnt = knn_search<KCAP>(tv, p.x, p.y, p.z, k, kd + threadIdx.x, ki + threadIdx.x, lds_stack + threadIdx.x);
+  const float qnan = __uint_as_float(0x7fc00000u);
+  if (col.cnt < 3) {
+    out[i] = make_float4(qnan, qnan, qnan, qnan);
+    return;
+  }
+  float a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, a6 = 0, a7 = 0, a8 = 0;
+  for (int e = 0; e < col.cnt; e++) {  // computeMeanAndCovarianceMatrix, float accumulators (PCL 1.10)
+    float4 t = xyz[ki[e * KNN_BLOCK + threadIdx.x]];
+    a0 += t.x * t.x; a1 += t.x * t.y; a2 += t.x * t.z;
+    a3 += t.y * t.y; a4 += t.y * t.z; a5 += t.z * t.z;
+    a6 += t.x; a7 += t.y; a8 += t.z;
+  }
+  out[i] = normal_from_moments(a0, a1, a2, a3, a4, a5, a6, a7, a8, col.cnt, p);
 }
 void launch_knn_normals(const float4* xyz, int n, TreeView tree, int k, float4* out_nrm, hipStream_t s) {
   size_t sh = (size_t)k * KNN_BLOCK * 8 + stack_lds_bytes(tree_depth_of(tree.first_leaf), KNN_BLOCK);
   LH_KNN_DISPATCH(k_knn_normals, k, dim3((n + KNN_BLOCK - 1) / KNN_BLOCK), dim3(KNN_BLOCK), sh, s, xyz, n, tree, k, out_nrm);
+}
+
+// radius mode of the normal filter (normal_computation.cc:71-74): moments of all points with d2 < r2, < 3 neighbours -> NaN
+__global__ void __launch_bounds__(KNN_BLOCK) k_radius_normals(const float4* __restrict__ xyz, int n, TreeView tv, float r2,
+                                                              float4* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int i = blockIdx.x * KNN_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  float4 p = xyz[i];
+  uint32_t* lds_stack = reinterpret_cast<uint32_t*>(smem);
+  RadiusMomentCollector col;
+  col.r2 = r2; col.cnt = 0;
+#pragma unroll
+  for (int e = 0; e < 9; e++) col.a[e] = 0.0f;
+  tree_search(tv, p.x, p.y, p.z, col, lds_stack + threadIdx.x, KNN_BLOCK);
+  const float qnan = __uint_as_float(0x7fc00000u);
+  if (col.cnt < 3) {
+    out[i] = make_float4(qnan, qnan, qnan, qnan);
+    return;
+  }
+  out[i] = normal_from_moments(col.a[0], col.a[1], col.a[2], col.a[3], col.a[4], col.a[5], col.a[6], col.a[7], col.a[8], col.cnt, p);
+}
+void launch_radius_normals(const float4* xyz, int n, TreeView tree, float radius, float4* out_nrm, hipStream_t s) {
+  size_t sh = stack_lds_bytes(tree_depth_of(tree.first_leaf), KNN_BLOCK);
+  hipLaunchKernelGGL(k_radius_normals, dim3((n + KNN_BLOCK - 1) / KNN_BLOCK), dim3(KNN_BLOCK), sh, s, xyz, n, tree, radius * radius, out_nrm);
+}
+
+// removeNaNNormalsFromPointCloud (normal_computation.cc:52-56): order-preserving compaction of points with finite normals
+__global__ void __launch_bounds__(256) k_finite_normal_flags(const float4* __restrict__ nrm, int n, uint32_t* __restrict__ flags) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float4 v = nrm[i];
+  flags[i] = (isfinite(v.x) && isfinite(v.y) && isfinite(v.z)) ? 1u : 0u;
+}
+__global__ void __launch_bounds__(256) k_compact(const uint32_t* __restrict__ incl, int n, const float4* __restrict__ xyz,
+                                                 const float4* __restrict__ nrm, const float* __restrict__ inten, float4* __restrict__ oxyz,
+                                                 float4* __restrict__ onrm, float* __restrict__ ointen) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  uint32_t here = incl[i], before = i ? incl[i - 1] : 0u;
+  if (here == before) return;
+  oxyz[before] = xyz[i];
+  onrm[before] = nrm[i];
+  if (inten) ointen[before] = inten[i];
+}
+void launch_finite_normal_flags(const float4* nrm, int n, uint32_t* flags, hipStream_t s) {
+  hipLaunchKernelGGL(k_finite_normal_flags, dim3((n + 255) / 256), dim3(256), 0, s, nrm, n, flags);
+}
+void launch_compact(const uint32_t* incl, int n, const float4* xyz, const float4* nrm, const float* inten, float4* oxyz, float4* onrm,
+                    float* ointen, hipStream_t s) {
+  hipLaunchKernelGGL(k_compact, dim3((n + 255) / 256), dim3(256), 0, s, incl, n, xyz, nrm, inten, oxyz, onrm, ointen);
 }
 
 // ===== K8: point-to-plane information matrix ===============================================================

@@ -129,6 +129,10 @@ void launch_knn(const float4* q, int nq, TreeView tree, int k, int32_t* idx, flo
 void launch_knn_cov(const float4* xyz, int n, int n_pad, TreeView tree, int k, double eps, double* cov6, hipStream_t s);
 // NormalEstimationOMP k-NN restated (normal_computation.cc:26-59): out = (nx,ny,nz,curvature)
 void launch_knn_normals(const float4* xyz, int n, TreeView tree, int k, float4* out_nrm, hipStream_t s);
+void launch_radius_normals(const float4* xyz, int n, TreeView tree, float radius, float4* out_nrm, hipStream_t s);
+void launch_finite_normal_flags(const float4* nrm, int n, uint32_t* flags, hipStream_t s);
+void launch_compact(const uint32_t* incl, int n, const float4* xyz, const float4* nrm, const float* inten, float4* oxyz, float4* onrm,
+                    float* ointen, hipStream_t s);
 
 // ---- K8 ----------------------------------------------------------------------------------------------
 // stage 1: per-block partial sums (x,y,z float-in-double) for the centroid; stage 2 etc. are in lh_api.hip

@@ -1415,6 +1415,39 @@ static void eigen33_smallest(const float* mat, float* eval, float* evec) {
   evec[0] = v[0] / s; evec[1] = v[1] / s; evec[2] = v[2] / s;
 }
 
+/* NormalEstimation::computeFeature body for one point, given its neighbour list in search order
+ * (pcl/features/normal_3d.h computePointNormal -> computeMeanAndCovarianceMatrix (float accumulators) ->
+ * solvePlaneParameters (eigen33) -> flipNormalTowardsViewpoint, vp = 0) */
+static void normal_from_neighbours(const float* xyz4, const int* idx, int cnt, const float* q, float* o) {
+  if (cnt < 3) { o[0] = o[1] = o[2] = o[3] = NAN; return; }
+  float acc[9] = {0};
+  for (int j = 0; j < cnt; j++) {
+    const float* p = xyz4 + 4 * (size_t)idx[j];
+    acc[0] += p[0] * p[0]; acc[1] += p[0] * p[1]; acc[2] += p[0] * p[2];
+    acc[3] += p[1] * p[1]; acc[4] += p[1] * p[2]; acc[5] += p[2] * p[2];
+    acc[6] += p[0]; acc[7] += p[1]; acc[8] += p[2];
+  }
+  float c = (float)cnt;
+  for (int a = 0; a < 9; a++) acc[a] /= c;
+  float cov[9];
+  cov[0] = acc[0] - acc[6] * acc[6];
+  cov[1] = acc[1] - acc[6] * acc[7];
+  cov[2] = acc[2] - acc[6] * acc[8];
+  cov[4] = acc[3] - acc[7] * acc[7];
+  cov[5] = acc[4] - acc[7] * acc[8];
+  cov[8] = acc[5] - acc[8] * acc[8];
+  cov[3] = cov[1]; cov[6] = cov[2]; cov[7] = cov[5];
+  float ev, nv[3];
+  eigen33_smallest(cov, &ev, nv);
+  float eig_sum = cov[0] + cov[4] + cov[8];
+  float curv = (eig_sum != 0.0f) ? fabsf(ev / eig_sum) : 0.0f;
+  /* flipNormalTowardsViewpoint, vp = (0,0,0) */
+  float vx = 0.0f - q[0], vy = 0.0f - q[1], vz = 0.0f - q[2];
+  float cos_theta = (vx * nv[0] + vy * nv[1]) + vz * nv[2];
+  if (cos_theta < 0) { nv[0] = -nv[0]; nv[1] = -nv[1]; nv[2] = -nv[2]; }
+  o[0] = nv[0]; o[1] = nv[1]; o[2] = nv[2]; o[3] = curv;
+}
+
 void lo_normals_knn(const float* xyz4, int n, const lo_tree* t, int k, float* out, int threads) {
   if (threads < 1) threads = 1;
   if (k > 64) k = 64;
@@ -1427,33 +1460,55 @@ void lo_normals_knn(const float* xyz4, int n, const lo_tree* t, int k, float* ou
     float* o = out + 4 * (size_t)i;
     if (!isfinite(q[0]) || !isfinite(q[1]) || !isfinite(q[2])) { o[0] = o[1] = o[2] = o[3] = NAN; continue; }
     knn_rec(t, 0, q, &L);
-    if (L.cnt < 3) { o[0] = o[1] = o[2] = o[3] = NAN; continue; }
-    float acc[9] = {0};
-    for (int j = 0; j < L.cnt; j++) {
-      const float* p = xyz4 + 4 * (size_t)idx[j];
-      acc[0] += p[0] * p[0]; acc[1] += p[0] * p[1]; acc[2] += p[0] * p[2];
-      acc[3] += p[1] * p[1]; acc[4] += p[1] * p[2]; acc[5] += p[2] * p[2];
-      acc[6] += p[0]; acc[7] += p[1]; acc[8] += p[2];
+    normal_from_neighbours(xyz4, idx, L.cnt, q, o);
+  }
+}
+
+/* radius search (normal_computation.cc:71-74 -> setRadiusSearch; FLANN RadiusResultSet keeps dist < r^2, PCL returns the
+ * neighbours sorted by distance); ties ordered by index here ("parity unpinned", see the NN index note) */
+typedef struct { float d; int i; } rad_hit;
+typedef struct { rad_hit* h; int cnt, cap; } rad_list;
+static void radius_rec(const lo_tree* t, int node, const float* q, float r2, rad_list* L) {
+  const lo_node* nd = &t->nodes[node];
+  if (boxd2(q, nd->lo, nd->hi) >= r2) return;
+  if (nd->left < 0) {
+    for (int i = nd->begin; i < nd->end; i++) {
+      float d = d2f(q, t->pts + 3 * i);
+      if (d < r2) {
+        if (L->cnt == L->cap) { L->cap = L->cap ? 2 * L->cap : 64; L->h = (rad_hit*)realloc(L->h, sizeof(rad_hit) * L->cap); }
+        L->h[L->cnt].d = d; L->h[L->cnt].i = t->idx[i]; L->cnt++;
+      }
     }
-    float c = (float)L.cnt;
-    for (int a = 0; a < 9; a++) acc[a] /= c;
-    float cov[9];
-    cov[0] = acc[0] - acc[6] * acc[6];
-    cov[1] = acc[1] - acc[6] * acc[7];
-    cov[2] = acc[2] - acc[6] * acc[8];
-    cov[4] = acc[3] - acc[7] * acc[7];
-    cov[5] = acc[4] - acc[7] * acc[8];
-    cov[8] = acc[5] - acc[8] * acc[8];
-    cov[3] = cov[1]; cov[6] = cov[2]; cov[7] = cov[5];
-    float ev, nv[3];
-    eigen33_smallest(cov, &ev, nv);
-    float eig_sum = cov[0] + cov[4] + cov[8];
-    float curv = (eig_sum != 0.0f) ? fabsf(ev / eig_sum) : 0.0f;
-    /* flipNormalTowardsViewpoint, vp = (0,0,0) */
-    float vx = 0.0f - q[0], vy = 0.0f - q[1], vz = 0.0f - q[2];
-    float cos_theta = (vx * nv[0] + vy * nv[1]) + vz * nv[2];
-    if (cos_theta < 0) { nv[0] = -nv[0]; nv[1] = -nv[1]; nv[2] = -nv[2]; }
-    o[0] = nv[0]; o[1] = nv[1]; o[2] = nv[2]; o[3] = curv;
+    return;
+  }
+  radius_rec(t, nd->left, q, r2, L);
+  radius_rec(t, nd->right, q, r2, L);
+}
+static int rad_cmp(const void* a, const void* b) {
+  const rad_hit *x = (const rad_hit*)a, *y = (const rad_hit*)b;
+  if (x->d != y->d) return x->d < y->d ? -1 : 1;
+  return (x->i > y->i) - (x->i < y->i);
+}
+void lo_normals_radius(const float* xyz4, int n, const lo_tree* t, float radius, float* out, int threads) {
+  if (threads < 1) threads = 1;
+  float r2 = radius * radius;
+#pragma omp parallel num_threads(threads) if (threads > 1)
+  {
+    rad_list L = {NULL, 0, 0};
+    int* idx = NULL; int idx_cap = 0;
+#pragma omp for schedule(dynamic, 16)
+    for (int i = 0; i < n; i++) {
+      const float* q = xyz4 + 4 * (size_t)i;
+      float* o = out + 4 * (size_t)i;
+      if (!isfinite(q[0]) || !isfinite(q[1]) || !isfinite(q[2])) { o[0] = o[1] = o[2] = o[3] = NAN; continue; }
+      L.cnt = 0;
+      if (t->n > 0) radius_rec(t, 0, q, r2, &L);
+      qsort(L.h, L.cnt, sizeof(rad_hit), rad_cmp);
+      if (L.cnt > idx_cap) { idx_cap = 2 * L.cnt; idx = (int*)realloc(idx, sizeof(int) * idx_cap); }
+      for (int j = 0; j < L.cnt; j++) idx[j] = L.h[j].i;
+      normal_from_neighbours(xyz4, idx, L.cnt, q, o);
+    }
+    free(L.h); free(idx);
   }
 }
 

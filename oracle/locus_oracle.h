@@ -129,6 +129,9 @@ int lo_voxel_grid(const float* xyzi, int n, float leaf, int limit_axis, double l
 /* K3 (filter flavour): pcl::NormalEstimationOMP k-NN (normal_computation.cc:26-59), viewpoint (0,0,0).
    out_nrm4 = nx,ny,nz,curvature. */
 void lo_normals_knn(const float* xyz4, int n, const lo_tree* t, int k, float* out_nrm4, int threads);
+/* radius flavour (normal_computation.cc:71-74): all neighbours with d2 < radius^2, sorted by distance; < 3 neighbours -> NaN
+   (the nodelet then drops those points, normal_computation.cc:52-56) */
+void lo_normals_radius(const float* xyz4, int n, const lo_tree* t, float radius, float* out_nrm4, int threads);
 
 /* PCD v0.7 binary/ascii reader for the reference's own fixtures (x y z intensity). returns n or <0 */
 int lo_read_pcd_xyzi(const char* path, float* out_xyzi, int cap);

@@ -102,6 +102,7 @@ def lib():
         L.lo_eig_sym.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.lo_voxel_grid.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_int]
         L.lo_normals_knn.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.lo_normals_radius.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_void_p, C.c_int]
         L.lo_read_pcd_xyzi.argtypes = [C.c_char_p, C.c_void_p, C.c_int]
         L.lo_default_params.argtypes = [C.POINTER(LoParams)]
     return _lib
@@ -342,6 +343,14 @@ def normals_knn(pts4, k=20, threads=1, tree=None):
     tree = tree or Tree(pts4)
     out = np.empty_like(pts4)
     lib().lo_normals_knn(_p(pts4), pts4.shape[0], tree.h, k, _p(out), threads)
+    return out
+
+
+def normals_radius(pts4, radius=0.3, threads=1, tree=None):
+    pts4 = _f4(pts4)
+    tree = tree or Tree(pts4)
+    out = np.empty_like(pts4)
+    lib().lo_normals_radius(_p(pts4), pts4.shape[0], tree.h, radius, _p(out), threads)
     return out
 
 

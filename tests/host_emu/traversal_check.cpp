@@ -118,6 +118,18 @@ static int run_case(int n, int nq, int k, unsigned seed, bool dup) {
     if (ck.cnt != kk) bad++;
     for (int e = 0; e < kk; e++)
       if (ki[e] != ord[e] || kd[e] != bd[ord[e]]) { bad++; break; }
+    {  // radius collector: the exact set of points with d2 < r2 (count) and their coordinate sum
+      float r2 = (i % 3 == 0) ? 0.25f : (i % 3 == 1 ? 4.0f : bd[ord[std::min(n - 1, 5)]]);  // third flavour: r2 equal to a point distance
+      RadiusMomentCollector rc;
+      rc.r2 = r2; rc.cnt = 0;
+      for (int e = 0; e < 9; e++) rc.a[e] = 0.f;
+      tree_search(tv, q.x, q.y, q.z, rc, stk.data(), 1);
+      int cnt = 0;
+      double sx = 0;
+      for (int j = 0; j < n; j++)
+        if (bd[j] < r2) { cnt++; sx += pts[j].x; }
+      if (rc.cnt != cnt || fabs(rc.a[6] - sx) > 1e-3 * (1.0 + fabs(sx))) bad++;
+    }
     if (kk <= 20) {  // register-resident list used by the device k-NN kernels
       KnnRegCollector<20> cr;
       cr.init(kk);

@@ -152,6 +152,37 @@ def test_normals_match_oracle(ctx, capi, oracle):
     assert np.allclose(np.linalg.norm(out[:, :3], axis=1), 1.0, atol=1e-5)
 
 
+def test_radius_normals_match_oracle_and_nan_compaction(ctx, capi, oracle):
+    # normal_search_method = radius (normal_computation.cc:71-74, radius 0.3) on a voxelised VLP-16-style scan: far, sparse
+    # returns have < 3 neighbours -> NaN normal, and the nodelet drops them (normal_computation.cc:52-56)
+    pts = synth.scan(rings=16, azimuths=900, scale=1.0, seed=21)
+    far = np.array([[300.0, 0.0, 0.0], [0.0, 300.0, 1.0], [301.0, 0.1, 0.0]], np.float32)  # isolated: 1-2 neighbours only
+    pts = np.concatenate([pts[:4000], far, pts[4000:]], 0)
+    out = ctx.normals_radius(pts, 0.3)
+    ref = oracle.normals_radius(oracle.xyz4(pts), 0.3, threads=4)
+    nan_g, nan_o = np.isnan(out[:, 0]), np.isnan(ref[:, 0])
+    assert (nan_g == nan_o).all() and nan_g[4000:4003].all()   # the neighbour SET (d2 < r2, float) is exact
+    ok = ~nan_o
+    assert ok.sum() > 0.5 * len(pts)
+    # same float moments, but the device adds them in traversal order and PCL/the oracle in distance order: the one-pass
+    # float covariance (E[xx] - E[x]E[x]) is ill-conditioned by |p|^2 / r^2, so parity is an angle tolerance, not bit-exact
+    cosang = np.abs((out[ok, :3] * ref[ok, :3]).sum(1))
+    assert np.quantile(cosang, 0.05) > 1 - 1e-3, np.quantile(cosang, [0.01, 0.05, 0.5])
+    assert np.median(cosang) > 1 - 1e-5
+    assert np.allclose(np.linalg.norm(out[ok, :3], axis=1), 1.0, atol=1e-5)
+    # device-resident flavour + compaction
+    c = capi.Cloud(ctx, capi.make_pointxyzi(pts, np.arange(len(pts), dtype=np.float32)))
+    c.normals_radius(0.3)
+    full = c.download()
+    assert (np.isnan(full["normal_x"]) == nan_o).all()
+    kept = c.remove_nan_normals()
+    assert len(kept) == int(ok.sum())
+    k = kept.download()
+    assert (k["intensity"] == np.arange(len(pts), dtype=np.float32)[ok]).all()       # order preserved, same survivors
+    assert (np.stack([k["x"], k["y"], k["z"]], 1) == pts[ok]).all()
+    assert np.array_equal(k["normal_x"], full["normal_x"][ok])
+
+
 def test_p2plane_information_kat_and_oracle(ctx, capi, oracle):
     pts, nrm = synth.plane_grid(10, 10, 0.1)
     c = capi.Cloud(ctx, capi.make_pointf(pts, nrm))

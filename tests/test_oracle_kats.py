@@ -219,3 +219,17 @@ def test_reference_float_noise_floor(oracle):
         worst_r = max(worst_r, np.abs(A[:3, :3] - B[:3, :3]).max())
     print("FMA vs non-FMA reference builds differ by up to |dt| = %.2e m, |dR| = %.2e" % (worst_t, worst_r))
     assert 1e-6 < worst_t < 5e-3  # noise floor is real (not bit-stable) and of order 1e-4..1e-3 m
+
+
+def test_radius_normals_plane_and_sparse(oracle):
+    """radius flavour of the normal filter (normal_computation.cc:71-74): plane normal (0,0,1) like the Ap KATs' planes
+    (test_point_cloud_localization.cpp:296); isolated points get NaN (then dropped, normal_computation.cc:52-56)"""
+    pts, _ = synth.plane_grid(20, 20, 0.1)
+    pts = pts + np.array([0.5, 0.3, -2.0], np.float32)   # below the sensor: viewpoint flip -> +z
+    pts = np.concatenate([pts, np.array([[50, 50, 50], [50.2, 50, 50]], np.float32)], 0)
+    out = oracle.normals_radius(oracle.xyz4(pts), 0.3, threads=2)
+    assert np.isnan(out[-2:]).all()
+    assert np.allclose(out[:-2, :3], [0, 0, 1], atol=1e-3)
+    # k-NN flavour agrees where the 0.3 m ball holds the same evidence (interior of the grid)
+    knn = oracle.normals_knn(oracle.xyz4(pts[:-2]), 20)
+    assert np.allclose(knn[:, :3], out[:-2, :3], atol=2e-3)
