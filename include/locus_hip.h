@@ -121,6 +121,11 @@ lh_status lh_cloud_download(const lh_cloud* c, void* out_base, uint32_t stride, 
    with_normals != 0 also rotates normals (transformPointCloudWithNormals, PointCloudLocalization.cc:197,218,325).
    out may alias in. */
 lh_status lh_cloud_transform(const lh_cloud* in, const float T[16], int with_normals, lh_cloud** out);
+/* points [first, first+count) as a new cloud, device to device: a rank's source shard (lh_set_allreduce below) */
+lh_status lh_cloud_slice(const lh_cloud* in, uint32_t first, uint32_t count, lh_cloud** out);
+/* multi-lidar merge (PointCloudMerger.cc:158-159, `*merged = *a + *b`): the inputs' points in order, device to device;
+   normals / intensity are kept only if every input has them */
+lh_status lh_cloud_concat(lh_cloud* const* parts, int n_parts, lh_cloud** out);
 
 /* ---- registration object (MultithreadedGeneralizedIterativeClosestPoint) ---------------------- */
 lh_status lh_gicp_create(lh_ctx* ctx, const lh_gicp_params* p, lh_gicp** out);
@@ -142,6 +147,16 @@ lh_status lh_gicp_align(lh_gicp* g, const float guess[16], lh_gicp_result* out, 
                         void* aligned_out, uint32_t stride, uint32_t off_xyz);
 /* getFitnessScore(max_range = DBL_MAX) of the last alignment (K7) */
 lh_status lh_gicp_fitness(lh_gicp* g, double* fitness);
+
+/* One huge pair sharded by SOURCE points over several GPUs: every rank holds the whole target
+   (+ index) and a disjoint slice of the source (with its normals / covariances), sets this hook and makes the same
+   lh_gicp_align / lh_gicp_fitness calls.  The hook sums `n` doubles in place over the ranks (RCCL/gloo all-reduce in the
+   caller's runtime); it is called once per outer iteration with the 74 moment sums (cost_mode 1) or once per cost
+   evaluation with the 13 sums + count of the functor (cost_mode 0, gicp.hpp:291-402), and every rank then runs the same
+   BFGS on the same numbers, so all ranks return the same transform.  NULL removes the hook.  Non-zero return -> LH_EDEVICE.
+   Not for lh_gicp_align_batch (ranks hold different pairs there: no exchange step at all). */
+typedef int (*lh_allreduce_fn)(double* sums, int n, void* user);
+lh_status lh_set_allreduce(lh_ctx* ctx, lh_allreduce_fn fn, void* user);
 /* getSearchMethodTarget()->nearestKSearch(pt, 1, ...) for every point of q (PointCloudLocalization.cc:327-336) */
 lh_status lh_nn1(lh_gicp* g, const lh_cloud_view* q, int32_t* idx, float* d2);
 lh_status lh_nn1_cloud(lh_cloud* target, const lh_cloud* q, int32_t* idx, float* d2);

@@ -83,13 +83,16 @@ class KernelStat(C.Structure):
     _fields_ = [("name", C.c_char * 32), ("launches", C.c_uint64), ("total_ms", C.c_double), ("bytes", C.c_double)]
 
 
+# lh_allreduce_fn: int (*)(double* sums, int n, void* user)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_int, C.c_void_p)
+
 # every symbol include/locus_hip.h declares (tests check the library exports all of them)
 EXPORTS = [
     "lh_abi_version", "lh_status_string", "lh_create", "lh_destroy", "lh_synchronize", "lh_default_gicp_params",
     "lh_cloud_create", "lh_cloud_destroy", "lh_cloud_size", "lh_cloud_build_index", "lh_cloud_drop_index",
-    "lh_cloud_download", "lh_cloud_transform", "lh_gicp_create", "lh_gicp_destroy", "lh_gicp_set_params",
+    "lh_cloud_download", "lh_cloud_transform", "lh_cloud_slice", "lh_cloud_concat", "lh_gicp_create", "lh_gicp_destroy", "lh_gicp_set_params",
     "lh_gicp_set_source", "lh_gicp_set_target", "lh_gicp_set_source_cloud", "lh_gicp_set_target_cloud",
-    "lh_gicp_promote_source_to_target", "lh_gicp_align", "lh_gicp_fitness", "lh_nn1", "lh_nn1_cloud", "lh_knn_cloud",
+    "lh_gicp_promote_source_to_target", "lh_gicp_align", "lh_gicp_fitness", "lh_set_allreduce", "lh_nn1", "lh_nn1_cloud", "lh_knn_cloud",
     "lh_gicp_align_batch", "lh_cov_knn", "lh_gicp_debug_sweep", "lh_gicp_debug_stats", "lh_debug_traversal_stats", "lh_gicp_debug_cost", "lh_p2plane_information",
     "lh_icp_covariance", "lh_voxel_grid", "lh_cloud_voxel_grid", "lh_cloud_nearest_neighbors", "lh_normals_knn", "lh_normals_knn_cloud",
     "lh_normals_radius", "lh_normals_radius_cloud", "lh_cloud_remove_nan_normals", "lh_profile_enable",
@@ -154,6 +157,9 @@ def lib():
         L.lh_cloud_nearest_neighbors.argtypes = [vp, vp, C.POINTER(vp)]
         L.lh_normals_knn.argtypes = [vp, C.POINTER(CloudView), i32, vp]
         L.lh_normals_knn_cloud.argtypes = [vp, i32]
+        L.lh_cloud_slice.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(vp)]
+        L.lh_cloud_concat.argtypes = [C.POINTER(vp), i32, C.POINTER(vp)]
+        L.lh_set_allreduce.argtypes = [vp, ALLREDUCE_FN, vp]
         L.lh_normals_radius.argtypes = [vp, C.POINTER(CloudView), C.c_float, vp]
         L.lh_normals_radius_cloud.argtypes = [vp, C.c_float]
         L.lh_cloud_remove_nan_normals.argtypes = [vp, C.POINTER(vp)]
@@ -256,6 +262,22 @@ class Context:
     def synchronize(self):
         _check(lib().lh_synchronize(self.h), "lh_synchronize")
 
+    def set_allreduce(self, fn):
+        """source-sharded single pair: fn(numpy float64 view) sums in place over the ranks; None removes it"""
+        if fn is None:
+            self._reduce_cb = C.cast(None, ALLREDUCE_FN)
+        else:
+            def _cb(ptr, n, _user):
+                try:
+                    fn(np.ctypeslib.as_array(ptr, shape=(n,)))
+                    return 0
+                except Exception:  # an exception must not unwind through the C frames
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+            self._reduce_cb = ALLREDUCE_FN(_cb)  # keep alive as long as the context uses it
+        _check(lib().lh_set_allreduce(self.h, self._reduce_cb, None), "lh_set_allreduce")
+
     def profile(self, on=True):
         _check(lib().lh_profile_enable(self.h, 1 if on else 0), "lh_profile_enable")
 
@@ -349,6 +371,19 @@ class Cloud:
         out = C.c_void_p()
         _check(lib().lh_cloud_transform(self.h, _ptr(T), 1 if with_normals else 0, C.byref(out)), "lh_cloud_transform")
         return Cloud(self.ctx, None, _handle=out)
+
+    def slice(self, first, count):
+        out = C.c_void_p()
+        _check(lib().lh_cloud_slice(self.h, first, count, C.byref(out)), "lh_cloud_slice")
+        return Cloud(self.ctx, None, _handle=out)
+
+    @staticmethod
+    def concat(parts):
+        """PointCloudMerger.cc:158-159 (`*merged = *a + *b`) on the device"""
+        arr = (C.c_void_p * len(parts))(*[p.h for p in parts])
+        out = C.c_void_p()
+        _check(lib().lh_cloud_concat(arr, len(parts), C.byref(out)), "lh_cloud_concat")
+        return Cloud(parts[0].ctx, None, _handle=out)
 
     def voxel_grid(self, leaf, limit_axis=-1, lo=-np.inf, hi=np.inf):
         out = C.c_void_p()

@@ -131,6 +131,9 @@ struct lh_ctx {
   // misc pinned scratch for small downloads
   double* small_host = nullptr;
   size_t small_host_doubles = 0;
+  // source-sharded single pair: in-place sum of the cost/moment sums over the ranks that hold the other shards
+  lh_allreduce_fn reduce_fn = nullptr;
+  void* reduce_user = nullptr;
   // profiling
   bool prof = false;
   std::vector<ProfEntry> prof_entries;
@@ -731,6 +734,7 @@ static lh_status group_collect(lh_ctx* c, Group& g) {
     for (int k = 0; k < COST_NSUM; k++) S[k] = 0.0;
     for (int b = 0; b < nb; b++)  // fixed order => bitwise reproducible
       for (int k = 0; k < COST_NSUM; k++) S[k] += part[(size_t)b * COST_NSUM + k];
+    if (c->reduce_fn && c->reduce_fn(S, COST_NSUM, c->reduce_user) != 0) return LH_EDEVICE;
     memcpy(t->res_sums, S, sizeof(S));
     if (c->prof) {  // algorithmic bytes with the measured K_t: B_fdf = 108 K_t, B_nn += 232 K_t
       c->prof_entries[c->prof_entry("cost_fdf")].bytes += 108.0 * S[13];
@@ -742,6 +746,7 @@ static lh_status group_collect(lh_ctx* c, Group& g) {
   for (Task* t : g.moms) {  // deliver the moments; the task then runs its whole BFGS solve on the host
     const double* S = c->partials_host + (size_t)t->slot * c->partials_per_slot;
     memcpy(t->mom.S, S, sizeof(double) * MOM_NSUM);
+    if (c->reduce_fn && c->reduce_fn(t->mom.S, MOM_NSUM, c->reduce_user) != 0) return LH_EDEVICE;
     for (int r = 0; r < 3; r++)
       for (int cc = 0; cc < 4; cc++) t->mom.T0[cc * 4 + r] = t->req_T12[r * 4 + cc];
     t->mom.T0[3] = t->mom.T0[7] = t->mom.T0[11] = 0.f; t->mom.T0[15] = 1.f;
@@ -1049,6 +1054,62 @@ lh_status lh_cloud_transform(const lh_cloud* in, const float T[16], int with_nor
   return LH_OK;
 }
 
+// points [first, first+count) as a new cloud (device-to-device): the source shard of a rank, and the pieces
+// PointCloudMerger concatenates (lh_cloud_concat)
+lh_status lh_cloud_slice(const lh_cloud* in, uint32_t first, uint32_t count, lh_cloud** out) {
+  if (!in || !out || count == 0 || (uint64_t)first + count > (uint64_t)in->n) return LH_EINVAL;
+  lh_ctx* c = in->ctx;
+  HIPCHK(hipSetDevice(c->device));
+  lh_cloud* o = new lh_cloud();
+  o->ctx = c; o->n = (int)count; o->n_pad = round_up(o->n, 256);
+  hipError_t e = hipMalloc(&o->xyz, sizeof(float4) * (size_t)o->n_pad);
+  if (e == hipSuccess && in->nrm) e = hipMalloc(&o->nrm, sizeof(float4) * (size_t)o->n_pad);
+  if (e == hipSuccess && in->intensity) e = hipMalloc(&o->intensity, sizeof(float) * (size_t)o->n_pad);
+  if (e != hipSuccess) { cloud_free(o); return LH_ENOMEM; }
+  e = hipMemcpyAsync(o->xyz, in->xyz + first, sizeof(float4) * (size_t)count, hipMemcpyDeviceToDevice, c->stream);
+  if (e == hipSuccess && in->nrm) e = hipMemcpyAsync(o->nrm, in->nrm + first, sizeof(float4) * (size_t)count, hipMemcpyDeviceToDevice, c->stream);
+  if (e == hipSuccess && in->intensity) e = hipMemcpyAsync(o->intensity, in->intensity + first, sizeof(float) * (size_t)count, hipMemcpyDeviceToDevice, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  if (e != hipSuccess) { cloud_free(o); return LH_EDEVICE; }
+  *out = o;
+  return LH_OK;
+}
+// PointCloudMerger concatenation (PointCloudMerger.cc:158-159, `*merged = *a + *b`): points of the inputs in order; normals /
+// intensity are kept only if every input has them
+lh_status lh_cloud_concat(lh_cloud* const* parts, int n_parts, lh_cloud** out) {
+  if (!parts || n_parts < 1 || !out || !parts[0]) return LH_EINVAL;
+  lh_ctx* c = parts[0]->ctx;
+  uint64_t total = 0;
+  bool nrm = true, inten = true;
+  for (int i = 0; i < n_parts; i++) {
+    if (!parts[i] || parts[i]->ctx != c) return LH_EINVAL;
+    total += (uint64_t)parts[i]->n;
+    nrm = nrm && parts[i]->nrm;
+    inten = inten && parts[i]->intensity;
+  }
+  if (total == 0 || total > 0x7fffff00ull) return LH_EINVAL;
+  HIPCHK(hipSetDevice(c->device));
+  lh_cloud* o = new lh_cloud();
+  o->ctx = c; o->n = (int)total; o->n_pad = round_up(o->n, 256);
+  hipError_t e = hipMalloc(&o->xyz, sizeof(float4) * (size_t)o->n_pad);
+  if (e == hipSuccess && nrm) e = hipMalloc(&o->nrm, sizeof(float4) * (size_t)o->n_pad);
+  if (e == hipSuccess && inten) e = hipMalloc(&o->intensity, sizeof(float) * (size_t)o->n_pad);
+  if (e != hipSuccess) { cloud_free(o); return LH_ENOMEM; }
+  size_t at = 0;
+  for (int i = 0; i < n_parts && e == hipSuccess; i++) {
+    size_t k = (size_t)parts[i]->n;
+    if (!k) continue;
+    e = hipMemcpyAsync(o->xyz + at, parts[i]->xyz, sizeof(float4) * k, hipMemcpyDeviceToDevice, c->stream);
+    if (e == hipSuccess && nrm) e = hipMemcpyAsync(o->nrm + at, parts[i]->nrm, sizeof(float4) * k, hipMemcpyDeviceToDevice, c->stream);
+    if (e == hipSuccess && inten) e = hipMemcpyAsync(o->intensity + at, parts[i]->intensity, sizeof(float) * k, hipMemcpyDeviceToDevice, c->stream);
+    at += k;
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  if (e != hipSuccess) { cloud_free(o); return LH_EDEVICE; }
+  *out = o;
+  return LH_OK;
+}
+
 // ---- registration object ----------------------------------------------------------------------------------
 lh_status lh_gicp_create(lh_ctx* ctx, const lh_gicp_params* p, lh_gicp** out) {
   if (!ctx || !out) return LH_EINVAL;
@@ -1190,13 +1251,22 @@ static lh_status nn1_device(lh_ctx* c, lh_cloud* target, const float4* q, int nq
   return rc;
 }
 
+lh_status lh_set_allreduce(lh_ctx* ctx, lh_allreduce_fn fn, void* user) {
+  if (!ctx) return LH_EINVAL;
+  ctx->reduce_fn = fn;
+  ctx->reduce_user = user;
+  return LH_OK;
+}
+
 lh_status lh_gicp_fitness(lh_gicp* g, double* fitness) {
   if (!g || !fitness || !g->src || !g->tgt || !g->have_result) return LH_EINVAL;
   HIPCHK(hipSetDevice(g->ctx->device));
   double s = 0;
   lh_status st = nn1_device(g->ctx, g->tgt, g->src->xyz, g->src->n, g->last_T, nullptr, nullptr, &s);
   if (st) return st;
-  *fitness = s / (double)g->src->n;  // every query finds a neighbour (max_range = DBL_MAX)
+  double sn[2] = {s, (double)g->src->n};
+  if (g->ctx->reduce_fn && g->ctx->reduce_fn(sn, 2, g->ctx->reduce_user) != 0) return LH_EDEVICE;
+  *fitness = sn[0] / sn[1];  // every query finds a neighbour (max_range = DBL_MAX)
   return LH_OK;
 }
 

@@ -1,6 +1,7 @@
 """Multi-GPU plumbing of the hot path: independent scan pairs are sharded over ranks (one process per GPU) with NO
 data-path collective; the only exchanges are an all_gather of the 16-float poses and a MAX all-reduce of the elapsed time
-(SURVEY.md 8e).  Backend "nccl" is RCCL over xGMI on the GPU box; the same code runs under "gloo" on CPU in the tests."""
+(SURVEY.md 8e).  The single-huge-pair case (config 5) shards SOURCE points instead and has one real exchange step, the
+SUM all-reduce of make_sum_hook.  Backend "nccl" is RCCL over xGMI on the GPU box; the same code runs under "gloo" on CPU in the tests."""
 import numpy as np
 
 
@@ -40,6 +41,32 @@ def max_over_ranks(value, world, device=None):
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def make_sum_hook(world, device=None):
+    """The one real exchange step of the path (one huge pair sharded by source points): in-place SUM
+    all-reduce of the 74 moment sums (or 14 cost sums) every rank computed over its own slice of the source cloud.
+    Returns fn(float64 numpy view) for Context.set_allreduce.  gloo reduces the host buffer directly; under nccl (RCCL)
+    the 592 bytes take a round trip through a small device tensor."""
+    import torch
+    import torch.distributed as dist
+    if world == 1:
+        return lambda buf: None
+    staging = {}
+
+    def hook(buf):
+        if device is None:
+            t = torch.from_numpy(buf)     # shares memory with the C buffer
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        else:
+            n = buf.shape[0]
+            t = staging.get(n)
+            if t is None:
+                t = staging[n] = torch.zeros(n, dtype=torch.float64, device=device)
+            t.copy_(torch.from_numpy(buf))
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            buf[:] = t.cpu().numpy()
+    return hook
 
 
 def chain_poses(poses16):

@@ -112,3 +112,18 @@ def plane_grid(nx=10, ny=10, step=0.1, z=0.0):
     pts = np.stack([ix.ravel() * step, iy.ravel() * step, np.full(ix.size, z)], -1).astype(np.float32)
     nrm = np.tile(np.array([0, 0, 1], np.float32), (pts.shape[0], 1))
     return pts, nrm
+
+
+def husky_extrinsics():
+    """body -> sensor extrinsics of a three-lidar platform (top / front tilted down / rear tilted, husky4_sensors.yaml style)"""
+    return [pose_matrix(0, 0, 0.3), pose_matrix(0.4, 0, 0.0, pitch=0.35), pose_matrix(-0.4, 0, 0.0, pitch=-0.35, yaw=np.pi)]
+
+
+def multi_lidar_parts(body_pose, extrinsics, rings=128, azimuths=2604, seed=0, scale=2.0, noise=0.02):
+    """SURVEY 8d config 5: one scan per sensor, each expressed in the BODY frame (what point_cloud_merger receives);
+    3 x 128 x 2604 ~ 1.0 M points"""
+    parts = []
+    for k, e in enumerate(extrinsics):
+        pts = scan(body_pose @ e, rings, azimuths, (-25.0, 15.0), scale, noise, seed=seed + k)
+        parts.append((pts.astype(np.float64) @ e[:3, :3].T + e[:3, 3]).astype(np.float32))
+    return parts

@@ -65,3 +65,47 @@ def test_two_rank_gather_over_gloo(n_pairs):
     traj = ldist.chain_poses(res[0][1])
     assert traj.shape == (n_pairs + 1, 4, 4)
     assert np.allclose(traj[-1][:3, :3] @ traj[-1][:3, :3].T, np.eye(3), atol=1e-5)
+
+
+def _hook_worker(rank, world, port, q):
+    import ctypes as C
+    import torch.distributed as dist
+    from locus_amd import capi
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    hook = ldist.make_sum_hook(world)
+    # drive it exactly the way the C side does: through the lh_allreduce_fn C callback on a raw double buffer
+    def _cb(ptr, n, _user):
+        hook(np.ctypeslib.as_array(ptr, shape=(n,)))
+        return 0
+    cb = capi.ALLREDUCE_FN(_cb)
+    out = []
+    for n in (74, 14, 2):   # moment sums, cost sums + count, fitness (sum, n)
+        buf = (C.c_double * n)(*[(rank + 1) * (i + 0.5) for i in range(n)])
+        assert cb(C.cast(buf, C.POINTER(C.c_double)), n, None) == 0
+        out.append(np.array(buf[:]))
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, out))
+
+
+def test_source_shard_sum_hook_over_gloo():
+    """the exchange step of the source-sharded single pair (lh_set_allreduce): every rank ends with the same sums"""
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_hook_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, out in res:
+        for n, got in zip((74, 14, 2), out):
+            assert np.array_equal(got, np.array([3.0 * (i + 0.5) for i in range(n)]))  # (1 + 2) * (i + 0.5), exact

@@ -183,6 +183,28 @@ def test_radius_normals_match_oracle_and_nan_compaction(ctx, capi, oracle):
     assert np.array_equal(k["normal_x"], full["normal_x"][ok])
 
 
+def test_cloud_slice_and_concat(ctx, capi):
+    # lh_cloud_concat = PointCloudMerger.cc:158-159 (`*merged = *a + *b`); lh_cloud_slice = a rank's source shard
+    rng = np.random.default_rng(5)
+    a = capi.make_pointf(rng.normal(size=(1000, 3)).astype(np.float32), rng.normal(size=(1000, 3)).astype(np.float32))
+    b = capi.make_pointf(rng.normal(size=(37, 3)).astype(np.float32), rng.normal(size=(37, 3)).astype(np.float32))
+    a["intensity"] = np.arange(1000)
+    b["intensity"] = 5000 + np.arange(37)
+    ca, cb = capi.Cloud(ctx, a), capi.Cloud(ctx, b)
+    m = capi.Cloud.concat([ca, cb, ca]).download()
+    for f in ("x", "y", "z", "normal_x", "normal_y", "normal_z", "intensity"):
+        assert np.array_equal(m[f], np.concatenate([a[f], b[f], a[f]]))
+    sl = ca.slice(123, 456).download()
+    for f in ("x", "y", "z", "normal_x", "normal_y", "normal_z", "intensity"):
+        assert np.array_equal(sl[f], a[f][123:123 + 456])
+    with pytest.raises(capi.LocusHipError):
+        ca.slice(900, 200)
+    # a cloud without normals in the mix: the merged cloud has none either (zeros on download)
+    cx = capi.Cloud(ctx, capi.make_pointxyzi(rng.normal(size=(10, 3)).astype(np.float32)))
+    mm = capi.Cloud.concat([ca, cx]).download()
+    assert len(mm) == 1010 and np.array_equal(mm["x"][:1000], a["x"])
+
+
 def test_p2plane_information_kat_and_oracle(ctx, capi, oracle):
     pts, nrm = synth.plane_grid(10, 10, 0.1)
     c = capi.Cloud(ctx, capi.make_pointf(pts, nrm))
