@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "liblocus_hip.so")
+LIB_PATH = os.environ.get("LH_LIB") or os.path.join(_HERE, "csrc", "liblocus_hip.so")  # LH_LIB: A/B a second build of the same ABI
 LH_MAX_TRACE = 256
 UINT32_MAX = 0xFFFFFFFF
 

@@ -117,6 +117,9 @@ struct lh_ctx {
   uint32_t *v32a = nullptr, *v32b = nullptr, *idx_bbox = nullptr;
   void* sort64_temp = nullptr;
   size_t sort64_temp_bytes = 0;
+  char* tree_tmp = nullptr;        // TreeScratch arrays (TREE_SCRATCH_BYTES_PER_POINT per point)
+  void* scan_tmp = nullptr;
+  size_t scan_tmp_bytes = 0;
   int idx_cap = 0;
   IndexDesc *idx_descs_dev = nullptr, *idx_descs_host = nullptr;
   hipEvent_t idx_copy_done = nullptr, idx_build_done = nullptr;
@@ -161,6 +164,8 @@ struct lh_ctx {
       (void)hipEventSynchronize(p.b);
       (void)hipEventElapsedTime(&ms, p.a, p.b);
       prof_entries[p.entry].ms += ms;
+      static FILE* plog = []() { const char* e = getenv("LH_PROF_LOG"); return e ? fopen(e, "a") : (FILE*)nullptr; }();  // per-launch trace (debug)
+      if (plog) { fprintf(plog, "%s %.4f\n", prof_entries[p.entry].name.c_str(), ms); fflush(plog); }
       ev_pool.push_back(p.a);
       ev_pool.push_back(p.b);
     }
@@ -197,15 +202,17 @@ struct lh_cloud {
   float* intensity = nullptr;  // null if none
   // NN index
   bool has_index = false;
-  float4* sorted = nullptr;
-  Node4* nodes = nullptr;
+  float4* sorted = nullptr;    // [n + LEAF_CAP]
+  NodeX* node_buf = nullptr;   // element 0 holds the TreeHeader, the nodes start at element 1
   int32_t* pos = nullptr;      // original index -> sorted position
-  int depth = 0, first_leaf = 0, n_leaves = 0, sorted_cap = 0, nodes_cap = 0;
+  int index_cap = 0;           // points the index buffers were allocated for
+  NodeX* nodes() const { return node_buf ? node_buf + 1 : nullptr; }
+  TreeHeader* hdr() const { return reinterpret_cast<TreeHeader*>(node_buf); }
   // k-NN covariances (6 planes of n_pad doubles), valid for (cov_k, cov_eps)
   double* cov6 = nullptr;
   int cov_k = 0;
   double cov_eps = 0;
-  TreeView view() const { return TreeView{sorted, nodes, first_leaf, n}; }
+  TreeView view() const { return TreeView{sorted, nodes(), hdr(), n}; }
 };
 
 static int round_up(int v, int m) { return (v + m - 1) / m * m; }
@@ -213,7 +220,7 @@ static int round_up(int v, int m) { return (v + m - 1) / m * m; }
 static void cloud_free(lh_cloud* c) {
   if (!c) return;
   (void)hipFree(c->xyz); (void)hipFree(c->nrm); (void)hipFree(c->intensity);
-  (void)hipFree(c->sorted); (void)hipFree(c->nodes); (void)hipFree(c->cov6); (void)hipFree(c->pos);
+  (void)hipFree(c->sorted); (void)hipFree(c->node_buf); (void)hipFree(c->cov6); (void)hipFree(c->pos);
   delete c;
 }
 
@@ -242,15 +249,15 @@ static lh_status ctx_ensure_small(lh_ctx* c, size_t doubles) {
   return LH_OK;
 }
 
-// K2: Hilbert sort + implicit 4-ary box tree (replaces tree_->setInputCloud of pcl::Registration::initCompute).
-// All clouds of a batch are built by the same launches and one radix sort (see lh_kernels.hpp "K2 batched").
+// K2: Hilbert sort + cell-aligned radix tree with 4-ary nodes (replaces tree_->setInputCloud of pcl::Registration::initCompute).
+// All clouds of a batch are built by the same launches, one radix sort and one scan (see lh_kernels.hpp "K2 batched").
 static lh_status build_indices(lh_ctx* x, lh_cloud* const* clouds, int n_clouds, hipStream_t s_in = nullptr) {
   if (n_clouds <= 0) return LH_OK;
   hipStream_t s = s_in ? s_in : x->stream;
   for (int o = 0; o < n_clouds; o += MAX_INDEX_BATCH) {
     int nb = std::min(MAX_INDEX_BATCH, n_clouds - o);
     long total = 0;
-    int max_n = 0, max_np = 0, max_depth = 0;
+    int max_n = 0;
     if (!x->idx_descs_dev) {
       HIPCHK(hipMalloc(&x->idx_descs_dev, sizeof(IndexDesc) * MAX_INDEX_BATCH));
       HIPCHK(hipHostMalloc(&x->idx_descs_host, sizeof(IndexDesc) * MAX_INDEX_BATCH, hipHostMallocDefault));
@@ -263,41 +270,29 @@ static lh_status build_indices(lh_ctx* x, lh_cloud* const* clouds, int n_clouds,
     for (int k = 0; k < nb; k++) {
       lh_cloud* c = clouds[o + k];
       if (!c || c->n <= 0 || c->ctx != x) return LH_EINVAL;
-      int n_leaves = (c->n + LEAF - 1) / LEAF;
-      int depth = 0;
-      while ((1ll << (2 * depth)) < n_leaves) depth++;
-      if (depth > MAX_DEPTH) return LH_EINVAL;
-      int n_padded = n_leaves * LEAF;
-      int n_nodes = (int)(((1ll << (2 * depth)) - 1) / 3);
-      if (n_padded > c->sorted_cap) {
+      if (c->n > (1 << 27)) return LH_EINVAL;  // leaf references keep 27 bits of sorted position
+      if (c->n > c->index_cap) {
         (void)hipStreamSynchronize(x->stream);
-        (void)hipFree(c->sorted);
-        HIPCHK(hipMalloc(&c->sorted, sizeof(float4) * (size_t)n_padded));
-        (void)hipFree(c->pos);
-        HIPCHK(hipMalloc(&c->pos, sizeof(int32_t) * (size_t)n_padded));
-        c->sorted_cap = n_padded;
+        if (x->stream2) (void)hipStreamSynchronize(x->stream2);
+        (void)hipFree(c->sorted); (void)hipFree(c->pos); (void)hipFree(c->node_buf);
+        c->sorted = nullptr; c->pos = nullptr; c->node_buf = nullptr; c->index_cap = 0;
+        HIPCHK(hipMalloc(&c->sorted, sizeof(float4) * ((size_t)c->n + LEAF_CAP)));
+        HIPCHK(hipMalloc(&c->pos, sizeof(int32_t) * (size_t)c->n));
+        HIPCHK(hipMalloc(&c->node_buf, sizeof(NodeX) * ((size_t)c->n + 1)));  // worst case: every point its own leaf
+        c->index_cap = c->n;
       }
-      if (n_nodes > c->nodes_cap) {
-        (void)hipStreamSynchronize(x->stream);
-        (void)hipFree(c->nodes);
-        HIPCHK(hipMalloc(&c->nodes, sizeof(Node4) * (size_t)std::max(n_nodes, 1)));
-        c->nodes_cap = n_nodes;
-      }
-      c->depth = depth;
-      c->n_leaves = n_leaves;
-      c->first_leaf = n_nodes;
       IndexDesc& d = x->idx_descs_host[k];
-      d.xyz = c->xyz; d.sorted = c->sorted; d.nodes = c->nodes; d.pos = c->pos;
-      d.n = c->n; d.n_padded = n_padded; d.depth = depth; d.offset = (int)total;
+      d.xyz = c->xyz; d.sorted = c->sorted; d.nodes = c->nodes(); d.hdr = c->hdr(); d.pos = c->pos;
+      d.n = c->n; d.offset = (int)total;
       total += c->n;
       max_n = std::max(max_n, c->n);
-      max_np = std::max(max_np, n_padded);
-      max_depth = std::max(max_depth, depth);
     }
-    if (total > 0x7fffffffL) return LH_EINVAL;
+    if (total > 0x7ffffff0L) return LH_EINVAL;
     if ((int)total > x->idx_cap) {
       (void)hipStreamSynchronize(x->stream);
+      if (x->stream2) (void)hipStreamSynchronize(x->stream2);
       (void)hipFree(x->k64a); (void)hipFree(x->k64b); (void)hipFree(x->v32a); (void)hipFree(x->v32b); (void)hipFree(x->sort64_temp);
+      (void)hipFree(x->tree_tmp); (void)hipFree(x->scan_tmp);
       int cap = round_up((int)std::min<long>(total + total / 4, 0x7fffff00L), 1024);
       HIPCHK(hipMalloc(&x->k64a, sizeof(uint64_t) * (size_t)cap));
       HIPCHK(hipMalloc(&x->k64b, sizeof(uint64_t) * (size_t)cap));
@@ -305,7 +300,26 @@ static lh_status build_indices(lh_ctx* x, lh_cloud* const* clouds, int n_clouds,
       HIPCHK(hipMalloc(&x->v32b, sizeof(uint32_t) * (size_t)cap));
       x->sort64_temp_bytes = sort64_temp_bytes(cap);
       HIPCHK(hipMalloc(&x->sort64_temp, x->sort64_temp_bytes ? x->sort64_temp_bytes : 16));
+      HIPCHK(hipMalloc(&x->tree_tmp, TREE_SCRATCH_BYTES_PER_POINT * ((size_t)cap + 16) + 4096));
+      x->scan_tmp_bytes = scan_temp_bytes(cap);
+      HIPCHK(hipMalloc(&x->scan_tmp, x->scan_tmp_bytes ? x->scan_tmp_bytes : 16));
       x->idx_cap = cap;
+    }
+    TreeScratch ts;
+    {
+      size_t cap = (size_t)x->idx_cap + 16;
+      char* p = x->tree_tmp;
+      ts.lkey = reinterpret_cast<uint64_t*>(p); p += 8 * cap;       // 16-byte aligned arrays first (cap is a multiple of 16)
+      ts.lbox = reinterpret_cast<float4*>(p); p += 32 * cap;
+      ts.a1box = reinterpret_cast<float4*>(p); p += 32 * (cap / 32 + 16);
+      ts.a2box = reinterpret_cast<float4*>(p); p += 32 * (cap / 1024 + 16);
+      ts.ichild = reinterpret_cast<int32_t*>(p); p += 8 * cap;
+      ts.irange = reinterpret_cast<int32_t*>(p); p += 8 * cap;
+      ts.flag = reinterpret_cast<uint32_t*>(p); p += 4 * cap;
+      ts.lid = reinterpret_cast<uint32_t*>(p); p += 4 * cap;
+      ts.lstart = reinterpret_cast<uint32_t*>(p); p += 4 * cap;
+      ts.keys = x->k64b;
+      ts.total = (int)total;
     }
     HIPCHK(hipStreamWaitEvent(s, x->idx_build_done, 0));  // the shared build scratch may still be in use on the other stream
     HIPCHK(hipMemcpyAsync(x->idx_descs_dev, x->idx_descs_host, sizeof(IndexDesc) * nb, hipMemcpyHostToDevice, s));
@@ -315,7 +329,10 @@ static lh_status build_indices(lh_ctx* x, lh_cloud* const* clouds, int n_clouds,
     { ProfScope p(x, "index_bbox_keys", 16.0 * total * 2, s); launch_index_keys(x->idx_descs_dev, nb, max_n, x->idx_bbox, x->k64a, x->v32a, s); }
     { ProfScope p(x, "index_radix_sort", 12.0 * total * 2 * 4, s);
       sort_pairs_u64(x->sort64_temp, x->sort64_temp_bytes, x->k64a, x->k64b, x->v32a, x->v32b, (int)total, 32 + id_bits, s); }
-    { ProfScope p(x, "index_gather_boxes", 32.0 * total, s); launch_index_trees(x->idx_descs_dev, nb, max_np, max_depth, x->v32b, s); }
+    { ProfScope p(x, "index_leaves_scan", 8.0 * total * 3, s);
+      launch_index_leaves(ts, s);
+      inclusive_scan_u32(x->scan_tmp, x->scan_tmp_bytes, ts.flag, ts.lid, (int)total, s); }
+    { ProfScope p(x, "index_tree", 32.0 * total + 128.0 * total / 4, s); launch_index_trees(x->idx_descs_dev, nb, max_n, ts, x->v32b, s); }
     HIPCHK(hipEventRecord(x->idx_build_done, s));
     HIPCHK(hipGetLastError());
     for (int k = 0; k < nb; k++) clouds[o + k]->has_index = true;
@@ -573,8 +590,8 @@ static lh_status task_prepare(lh_ctx* c, Task* t, bool rebuild_index) {
   d.tgt_nrm = P.recompute_target_cov ? nullptr : tgt->nrm;
   d.tgt_cov6 = P.recompute_target_cov ? tgt->cov6 : nullptr;
   d.tgt_sorted = tgt->sorted;
-  d.tgt_pos = tgt->pos;
-  d.tgt_nodes = tgt->nodes;
+  d.tgt_nodes = tgt->nodes();
+  d.tgt_hdr = tgt->hdr();
   d.prev_nn = t->ws->prev_nn;
   d.cert = t->ws->cert;
   d.stats = t->count_stats ? t->ws->stats : nullptr;
@@ -584,7 +601,7 @@ static lh_status task_prepare(lh_ctx* c, Task* t, bool rebuild_index) {
   d.n_pad = t->ws->n_pad;
   d.m = tgt->n;
   d.m_pad = tgt->n_pad;
-  d.first_leaf = tgt->first_leaf;
+  d.reserved0 = 0;
   d.src_cov_pad = src->n_pad;
   d.corr_dist2 = P.corr_dist * P.corr_dist;  // gicp.hpp:438
   d.gicp_eps = P.gicp_epsilon;
@@ -628,7 +645,6 @@ static lh_status group_launch(lh_ctx* c, Group& g) {
     double bytes = 0;
     for (int j = 0; j < a.njobs; j++) {
       Task* t = g.sweeps[o + j];
-      a.max_depth = std::max(a.max_depth, t->tgt->depth);
       a.job[j].slot = t->slot;
       a.job[j].pad = 0;
       memcpy(a.job[j].T, t->req_T12, sizeof(t->req_T12));
@@ -958,6 +974,7 @@ void lh_destroy(lh_ctx* c) {
   for (auto e : c->ev_pool) (void)hipEventDestroy(e);
   (void)hipFree(c->keys0); (void)hipFree(c->keys1); (void)hipFree(c->vals0); (void)hipFree(c->vals1);
   (void)hipFree(c->k64a); (void)hipFree(c->k64b); (void)hipFree(c->v32a); (void)hipFree(c->v32b); (void)hipFree(c->sort64_temp);
+  (void)hipFree(c->tree_tmp); (void)hipFree(c->scan_tmp);
   (void)hipFree(c->idx_bbox); (void)hipFree(c->idx_descs_dev);
   if (c->idx_descs_host) (void)hipHostFree(c->idx_descs_host);
   if (c->idx_copy_done) (void)hipEventDestroy(c->idx_copy_done);
@@ -1367,7 +1384,7 @@ lh_status lh_gicp_debug_sweep(lh_gicp* g, const float T[16], const float guess[1
     g->dbg_prepared = true;
   }
   SweepArgs a;
-  a.njobs = 1; a.bpj = 0; a.max_depth = g->tgt->depth; a.pad = 0; a.job[0].slot = 0; a.job[0].pad = 0;
+  a.njobs = 1; a.bpj = 0; a.max_depth = 0; a.pad = 0; a.job[0].slot = 0; a.job[0].pad = 0;
   Task::T16_to_T12(T, a.job[0].T);
   { ProfScope p(c, "nn_sweep", 252.0 * g->src->n); launch_sweep(c->descs_dev, a, g->src->n, c->stream); }
   HIPCHK(hipGetLastError());
@@ -1418,7 +1435,8 @@ lh_status lh_debug_traversal_stats(lh_cloud* target, const lh_cloud* q, const fl
     HIPCHK(hipMalloc(&d_cand, sizeof(int32_t) * (size_t)q->n));
     HIPCHK(hipMemcpyAsync(d_cand, cand, sizeof(int32_t) * (size_t)q->n, hipMemcpyHostToDevice, c->stream));
   }
-  launch_nn1_stats(q->xyz, q->n, T ? T12 : nullptr, target->view(), target->xyz, target->pos, d_cand, leaf_prescan, d, c->stream);
+  launch_nn1_stats(q->xyz, q->n, T ? T12 : nullptr, target->view(), target->xyz, d_cand, d, c->stream);
+  (void)leaf_prescan;  // an experiment of the implicit-tree layout; ignored
   HIPCHK(hipMemcpyAsync(out, d, 40, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   if (getenv("LH_STATS_LEVELS")) {

@@ -4,9 +4,14 @@
 // the CPU against brute force; the product only ever calls them from HIP kernels (lh_kernels.hip).
 //
 // NN index ("K2", replaces the FLANN kd-tree built by tree_->setInputCloud in pcl::Registration::initCompute):
-//   * target points are sorted by a 30-bit Hilbert-curve index; leaf L owns sorted points [8L, 8L+8)
-//   * an implicit complete 4-ary tree sits on the leaves (heap numbering: children of node i are 4i+1..4i+4);
-//     an internal node stores the float AABBs of its 4 children as SoA (96 B = six float4 loads)
+//   * target points are sorted by a 30-bit Hilbert-curve index (10 bits per axis of a cubic grid over the cloud's box)
+//   * LEAVES are cells of that grid hierarchy: the largest key-prefix cell around a point that holds <= LEAF_CAP points
+//     (runs of > LEAF_CAP identical keys are cut into chunks).  A key prefix is an aligned box, so leaves are DISJOINT in
+//     space; equal-count runs of the curve (the previous layout) overlap their neighbours at every level and cost 2-3x
+//     the node visits per query (measured: 17.8 -> 10.2 dependent steps warm, 31.8 -> 10.4 cold)
+//   * a binary radix tree over the leaves' keys (Karras 2012: one thread per internal node, no scans) gives the
+//     hierarchy; every internal node adopts its GRANDCHILDREN, so the walk sees 4-ary nodes (NodeX, 128 B = one cache
+//     line: the float AABBs of <= 4 children as SoA + their references) and half the dependent steps of the binary tree
 //   * sorted point = float4(x, y, z, bitcast(original index)) so one 16-B load yields position + id
 // Exactness: distances are float ((dx*dx+dy*dy)+dz*dz), no FMA contraction (the TU is compiled with
 // -ffp-contract=off).  The box distance uses the same operation order, and float rounding is monotone, so
@@ -20,25 +25,31 @@
 
 namespace lh {
 
-constexpr int LEAF = 8;        // points per leaf (128 B = one cache line of sorted points)
-constexpr int MAX_DEPTH = 12;  // 4^12 leaves * 8 pts = 134 M points
-constexpr int STACK_MAX = 3 * MAX_DEPTH + 1;  // entries; a kernel launch sizes its LDS stack for the deepest tree it walks
+constexpr int LEAF_CAP = 8;     // max points per leaf (128 B = one cache line of sorted points)
+constexpr int LDS_STACK = 12;   // traversal-stack entries (64-bit) a thread keeps in LDS; deeper entries spill to private memory
+constexpr int SPILL_MAX = 80;   // structural bound: binary depth <= 30 key bits + 28 tie-break bits => 4-ary depth <= 29,
+                                // at most 3 pushes per level + 1 => 88 <= LDS_STACK + SPILL_MAX entries for any cloud < 2^31 points
+constexpr int MAX_DEPTH = 12;   // (size of the instrumentation histogram; only slot 0 is used by the explicit tree)
 
-struct alignas(16) Node4 {
-  float lox[4], loy[4], loz[4], hix[4], hiy[4], hiz[4];
+// child reference: >= 0 internal node index (cloud-local); < 0 leaf: ~ref = (first sorted position << 4) | (count - 1)
+struct alignas(16) NodeX {
+  float lox[4], loy[4], loz[4], hix[4], hiy[4], hiz[4];  // absent child: lo = +inf, hi = -inf (box distance = +inf)
+  int32_t child[4];
+  int32_t pad[4];
 };
-
+static_assert(sizeof(NodeX) == 128, "NodeX is one 128-B line");
+struct TreeHeader {
+  int32_t root;       // child reference of the root (a leaf reference for clouds of <= LEAF_CAP points)
+  int32_t n_leaves;
+  int32_t pad[2];
+};
 struct TreeView {
-  const float4* pts;   // sorted points, padded to n_leaves*LEAF with +inf / id INT_MAX
-  const Node4* nodes;  // internal nodes, heap order
-  int first_leaf;      // heap index of leaf 0 = (4^depth - 1) / 3
+  const float4* pts;        // sorted points (+ LEAF_CAP padding entries of +inf / id INT_MAX)
+  const NodeX* nodes;       // internal nodes, cloud-local indices
+  const TreeHeader* hdr;    // written by the build kernels (device memory)
   int n_points;
 };
-LH_HD int tree_depth_of(int first_leaf) {  // first_leaf = (4^depth - 1) / 3
-  int d = 0;
-  while ((int)(0x55555555u & ((1u << (2 * d)) - 1u)) < first_leaf) d++;
-  return d;
-}
+LH_HD int32_t leaf_ref(uint32_t first_pos, int count) { return ~(int32_t)((first_pos << 4) | (uint32_t)(count - 1)); }
 
 LH_HD uint32_t f2u(float f) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -125,46 +136,6 @@ LH_HD uint32_t spatial_key30(float px, float py, float pz, float lx, float ly, f
   return hilbert30((uint32_t)ix, (uint32_t)iy, (uint32_t)iz);
 }
 
-// 48-bit variant: 16 bits per axis (1.2 mm cells on an 80 m scene) so that dense regions are still ordered spatially
-LH_HD uint64_t expand16(uint32_t v) {  // 16 bits -> every third bit of a 48-bit word
-  uint64_t x = v & 0xffffu;
-  x = (x | (x << 32)) & 0x00ff00000000ffffull;   // not used directly; generic spread below
-  x = v & 0xffffu;
-  x = (x | x << 16) & 0x0000ff0000ffull;
-  x = (x | x << 8) & 0x00f00f00f00full;
-  x = (x | x << 4) & 0x0c30c30c30c3ull;
-  x = (x | x << 2) & 0x249249249249ull;
-  return x;
-}
-LH_HD uint64_t hilbert48(uint32_t x0, uint32_t x1, uint32_t x2) {
-  uint32_t X[3] = {x0 & 0xffffu, x1 & 0xffffu, x2 & 0xffffu};
-  const uint32_t M = 1u << 15;
-  for (uint32_t Q = M; Q > 1; Q >>= 1) {
-    uint32_t P = Q - 1;
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
-      if (X[i] & Q) X[0] ^= P;
-      else { uint32_t t = (X[0] ^ X[i]) & P; X[0] ^= t; X[i] ^= t; }
-    }
-  }
-  X[1] ^= X[0];
-  X[2] ^= X[1];
-  uint32_t t = 0;
-  for (uint32_t Q = M; Q > 1; Q >>= 1)
-    if (X[2] & Q) t ^= Q - 1;
-  X[0] ^= t; X[1] ^= t; X[2] ^= t;
-  return (expand16(X[0]) << 2) | (expand16(X[1]) << 1) | expand16(X[2]);
-}
-LH_HD uint64_t spatial_key48(float px, float py, float pz, float lx, float ly, float lz, float hx, float hy, float hz) {
-  float ext = fmaxf(fmaxf(hx - lx, hy - ly), fmaxf(hz - lz, 1e-30f));
-  float sc = 65535.99f / ext;
-  int ix = (int)((px - lx) * sc), iy = (int)((py - ly) * sc), iz = (int)((pz - lz) * sc);
-  ix = ix < 0 ? 0 : (ix > 65535 ? 65535 : ix);
-  iy = iy < 0 ? 0 : (iy > 65535 ? 65535 : iy);
-  iz = iz < 0 ? 0 : (iz > 65535 ? 65535 : iz);
-  return hilbert48((uint32_t)ix, (uint32_t)iy, (uint32_t)iz);
-}
-
 LH_HD void cswap(uint64_t& a, uint64_t& b) {
   uint64_t lo = a < b ? a : b, hi = a < b ? b : a;
   a = lo; b = hi;
@@ -174,52 +145,105 @@ LH_HD void cswap(uint64_t& a, uint64_t& b) {
 // (a collector with kXyz = true is offered the point itself instead of its id: offer_xyz(d2, x, y, z))
 // A subtree / leaf is visited iff box_d2 <= bound() (ties must be visited for the lowest-index rule); skip() is told the
 // box distance of every subtree that is pruned (so a collector can keep a lower bound on everything it never looked at).
-// Traversal stack: 32-bit entries kept in LDS on the device (layout [entry][thread], conflict-free), a plain array
-// on the host.  An entry does not store a node index: every stacked node is a sibling of a node on the current
-// root-to-node path, so (level, child number) identify it, and the rest of the word holds the box distance
-// truncated to 26 bits (rounded DOWN => the pop-time prune test stays conservative and exactness is preserved).
-// A private uint64 stack[37] lived in scratch: 160 MB for a full chip of waves, i.e. HBM traffic on every push/pop.
-LH_HD uint32_t level_offset_u(int k) { return 0x55555555u & ((1u << (2 * k)) - 1u); }  // (4^k - 1) / 3
-LH_HD int stack_entries_for_depth(int depth) { return 3 * depth + 1; }
+// kGreedy collectors (1-NN: re-offering a point is harmless) that start without a bound first walk straight down to the
+// nearest leaf, so that the real traversal starts with a finite bound and stacks only what can still matter.
+// Traversal stack: 64-bit entries (float bits of the box distance | child reference); the first LDS_STACK entries of a
+// thread live in LDS (layout [entry][thread], conflict-free; a plain array on the host), deeper ones in private memory --
+// a warm-started walk (GICP sweeps) never gets that deep (measured max 5..17), a cold k-NN walk occasionally does.
+LH_HD int clz64(uint64_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return x ? __clzll((long long)x) : 64;
+#else
+  return x ? __builtin_clzll(x) : 64;
+#endif
+}
+LH_HD int clz32(uint32_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return x ? __clz((int)x) : 32;
+#else
+  return x ? __builtin_clz(x) : 32;
+#endif
+}
 
 template <class Collector>
-LH_HD void tree_search(const TreeView& t, float qx, float qy, float qz, Collector& col, uint32_t* stack, int stride) {
-  // "while-while" traversal: every lane first descends through internal nodes until it holds a leaf, then the wave
-  // scans leaves together.  Children are ordered with 32-bit keys: float bits of the (non-negative) box distance with
-  // the two low mantissa bits replaced by the child number -> a 4-key sort is ten v_min/v_max_u32.
-  int sp = 0, lvl = 0;
+LH_HD void scan_leaf(const TreeView& t, int32_t ref, float qx, float qy, float qz, Collector& col) {
+  col.count_leaf();
+  const uint32_t u = (uint32_t)~ref;
+  const int cnt = (int)(u & 15u) + 1;
+  const float4* p = t.pts + (u >> 4);
+#pragma unroll
+  for (int e = 0; e < LEAF_CAP; e++) {
+    float4 v = p[e];  // the array is padded by LEAF_CAP entries, so the load is always in bounds
+    if (e < cnt) {
+      if constexpr (Collector::kXyz) col.offer_xyz(d2f(qx, qy, qz, v.x, v.y, v.z), v.x, v.y, v.z);
+      else col.offer(d2f(qx, qy, qz, v.x, v.y, v.z), (int)f2u(v.w));
+    }
+  }
+}
+
+template <class Collector>
+LH_HD void tree_search(const TreeView& t, float qx, float qy, float qz, Collector& col, uint64_t* stack, int stride) {
   const uint32_t NONE = 0xffffffffu;
-  const uint32_t first_leaf = (uint32_t)t.first_leaf;
-  uint32_t lin = 0;
-  auto pop = [&]() -> uint32_t {
-    for (;;) {
-      if (sp == 0) return NONE;
-      uint32_t e = stack[(--sp) * stride];
-      float dk = u2f((e >> 6) << 5);
-      if (dk <= col.bound()) {
-        int le = (int)((e >> 2) & 15u);
-        uint32_t j = (lin - level_offset_u(lvl)) >> (2 * (lvl - (le - 1)));  // ancestor of the current node at level le-1
-        lin = 4u * (level_offset_u(le - 1) + j) + 1u + (e & 3u);
-        lvl = le;
-        return lin;
+  const float INF = inf_f();
+  const int32_t root = t.hdr->root;
+  if constexpr (Collector::kGreedy) {
+    if (!(col.bound() < INF)) {  // cold start: nearest-child descent to one leaf, nothing stacked, nothing pruned
+      int32_t r = root;
+      while (r >= 0) {
+        const NodeX& nd = t.nodes[r];
+        float4 lx = *reinterpret_cast<const float4*>(nd.lox), ly = *reinterpret_cast<const float4*>(nd.loy),
+               lz = *reinterpret_cast<const float4*>(nd.loz), hx = *reinterpret_cast<const float4*>(nd.hix),
+               hy = *reinterpret_cast<const float4*>(nd.hiy), hz = *reinterpret_cast<const float4*>(nd.hiz);
+        int4 ch = *reinterpret_cast<const int4*>(nd.child);
+        float d0 = boxd2(qx, qy, qz, lx.x, ly.x, lz.x, hx.x, hy.x, hz.x);
+        float d1 = boxd2(qx, qy, qz, lx.y, ly.y, lz.y, hx.y, hy.y, hz.y);
+        float d2 = boxd2(qx, qy, qz, lx.z, ly.z, lz.z, hx.z, hy.z, hz.z);
+        float d3 = boxd2(qx, qy, qz, lx.w, ly.w, lz.w, hx.w, hy.w, hz.w);
+        float dm = d0; int32_t rm = ch.x;          // child 0 always exists
+        if (d1 < dm) { dm = d1; rm = ch.y; }
+        if (d2 < dm) { dm = d2; rm = ch.z; }
+        if (d3 < dm) { dm = d3; rm = ch.w; }
+        r = rm;
       }
+      scan_leaf(t, r, qx, qy, qz, col);
+    }
+  }
+  int sp = 0;
+  uint64_t spill[SPILL_MAX];
+  auto push = [&](uint32_t key, int32_t ref) {
+    uint64_t e = ((uint64_t)key << 32) | (uint32_t)ref;
+    if (sp < LDS_STACK) stack[sp * stride] = e;
+    else spill[sp - LDS_STACK] = e;
+    sp++;
+  };
+  const int32_t DONE = 0x7fffffff;  // never a valid reference (internal indices are < 2^31 - 1)
+  auto pop = [&]() -> int32_t {
+    for (;;) {
+      if (sp == 0) return DONE;
+      --sp;
+      uint64_t e = (sp < LDS_STACK) ? stack[sp * stride] : spill[sp - LDS_STACK];
+      float dk = u2f((uint32_t)(e >> 32) & ~3u);  // key = distance bits with the child slot in the two low mantissa bits (rounded DOWN)
+      if (dk <= col.bound()) return (int32_t)(uint32_t)e;
       col.skip(dk);
     }
   };
+  int32_t ref = root;
   for (;;) {
-    while (lin < first_leaf) {
-      col.count_node(lvl);
-      const Node4& nd = t.nodes[lin];
+    while (ref >= 0 && ref != DONE) {
+      col.count_node(0);
+      const NodeX& nd = t.nodes[ref];
       float4 lx = *reinterpret_cast<const float4*>(nd.lox), ly = *reinterpret_cast<const float4*>(nd.loy),
              lz = *reinterpret_cast<const float4*>(nd.loz), hx = *reinterpret_cast<const float4*>(nd.hix),
              hy = *reinterpret_cast<const float4*>(nd.hiy), hz = *reinterpret_cast<const float4*>(nd.hiz);
+      int4 ch = *reinterpret_cast<const int4*>(nd.child);
       float bd = col.bound();
       float d0 = boxd2(qx, qy, qz, lx.x, ly.x, lz.x, hx.x, hy.x, hz.x);
       float d1 = boxd2(qx, qy, qz, lx.y, ly.y, lz.y, hx.y, hy.y, hz.y);
       float d2 = boxd2(qx, qy, qz, lx.z, ly.z, lz.z, hx.z, hy.z, hz.z);
       float d3 = boxd2(qx, qy, qz, lx.w, ly.w, lz.w, hx.w, hy.w, hz.w);
-      const float INF = inf_f();
       bool v0 = d0 <= bd && d0 < INF, v1 = d1 <= bd && d1 < INF, v2 = d2 <= bd && d2 < INF, v3 = d3 <= bd && d3 < INF;
+      // 32-bit sort keys: float bits of the (non-negative) box distance with the two low mantissa bits replaced by the
+      // child slot -> a 4-key sort is ten v_min/v_max_u32
       uint32_t k0 = v0 ? ((f2u(d0) & ~3u) | 0u) : NONE;
       uint32_t k1 = v1 ? ((f2u(d1) & ~3u) | 1u) : NONE;
       uint32_t k2 = v2 ? ((f2u(d2) & ~3u) | 2u) : NONE;
@@ -231,34 +255,89 @@ LH_HD void tree_search(const TreeView& t, float qx, float qy, float qz, Collecto
       a = k0 < k2 ? k0 : k2; b = k0 < k2 ? k2 : k0; k0 = a; k2 = b;
       a = k1 < k3 ? k1 : k3; b = k1 < k3 ? k3 : k1; k1 = a; k3 = b;
       a = k1 < k2 ? k1 : k2; b = k1 < k2 ? k2 : k1; k1 = a; k2 = b;
-      const uint32_t tag = (uint32_t)(lvl + 1) << 2;
+      auto child_of = [&](uint32_t k) -> int32_t {
+        uint32_t sl = k & 3u;
+        return sl == 0 ? ch.x : (sl == 1 ? ch.y : (sl == 2 ? ch.z : ch.w));
+      };
       if (k1 != NONE) {  // valid keys sort first: k1 invalid => k2, k3 invalid
         if (k2 != NONE) {
-          if (k3 != NONE) { stack[sp * stride] = ((k3 >> 5) << 6) | tag | (k3 & 3u); sp++; }
-          stack[sp * stride] = ((k2 >> 5) << 6) | tag | (k2 & 3u); sp++;
+          if (k3 != NONE) push(k3, child_of(k3));
+          push(k2, child_of(k2));
         }
-        stack[sp * stride] = ((k1 >> 5) << 6) | tag | (k1 & 3u); sp++;
+        push(k1, child_of(k1));
       }
-      if (k0 != NONE) { lin = 4u * lin + 1u + (k0 & 3u); lvl++; }
-      else lin = pop();
+      ref = (k0 != NONE) ? child_of(k0) : pop();
     }
-    if (lin == NONE) return;
-    col.count_leaf();
-    const float4* p = t.pts + (size_t)(lin - first_leaf) * LEAF;
-#pragma unroll
-    for (int e = 0; e < LEAF; e++) {
-      float4 v = p[e];
-      if constexpr (Collector::kXyz) col.offer_xyz(d2f(qx, qy, qz, v.x, v.y, v.z), v.x, v.y, v.z);
-      else col.offer(d2f(qx, qy, qz, v.x, v.y, v.z), (int)f2u(v.w));
-    }
-    lin = pop();
+    if (ref == DONE) return;
+    scan_leaf(t, ref, qx, qy, qz, col);
+    ref = pop();
   }
+}
+
+// ---- index build, per-element steps shared by the build kernels and the host-side check ---------------------------------
+// sorted keys: (cloud id << 32) | 30-bit Hilbert key, so a batch of clouds is one sorted array and no cell spans two clouds
+constexpr int KEY_PREFIX_MIN = 34;  // 64 - 30: shortest prefix that still pins the cloud id (and the two unused bits)
+
+// does sorted position g start a leaf?  Leaf = the largest prefix cell around g with <= LEAF_CAP points.
+LH_HD uint32_t leafcell_flag(const uint64_t* __restrict__ keys, int64_t total, int64_t g) {
+  if (g == 0) return 1u;
+  const uint64_t K = keys[g];
+  int L[LEAF_CAP], R[LEAF_CAP];
+#pragma unroll
+  for (int k = 1; k <= LEAF_CAP; k++) {
+    L[k - 1] = (g - k >= 0) ? clz64(K ^ keys[g - k]) : 0;
+    R[k - 1] = (g + k < total) ? clz64(K ^ keys[g + k]) : 0;
+  }
+  auto fits = [&](int p) {  // the cell of prefix length p around g holds <= LEAF_CAP points
+    int c = 1;
+#pragma unroll
+    for (int k = 0; k < LEAF_CAP; k++) c += (L[k] >= p ? 1 : 0) + (R[k] >= p ? 1 : 0);
+    return c <= LEAF_CAP;
+  };
+  const int c_prev = L[0];
+  if (!fits(64)) return (c_prev < 64 || (g % LEAF_CAP) == 0) ? 1u : 0u;  // > LEAF_CAP identical keys: fixed-size chunks
+  int lo = KEY_PREFIX_MIN, hi = 64;  // smallest p in [lo, hi] that fits (fits is monotone in p, fits(64) holds)
+  while (lo < hi) {
+    int mid = (lo + hi) >> 1;
+    if (fits(mid)) hi = mid; else lo = mid + 1;
+  }
+  return c_prev < lo ? 1u : 0u;
+}
+
+// Karras' binary radix tree over the n_leaves leaf keys: internal node i in [0, n_leaves - 1)
+LH_HD int radix_delta(const uint64_t* __restrict__ lkey, int n_leaves, int i, int j) {
+  if (j < 0 || j >= n_leaves) return -1;
+  uint64_t x = lkey[i] ^ lkey[j];
+  return x ? clz64(x) : 64 + clz32((uint32_t)i ^ (uint32_t)j);
+}
+// children are returned as binary-tree references: >= 0 internal node, < 0 leaf ~index; [lo, hi] = leaf range covered
+LH_HD void radix_node(const uint64_t* __restrict__ lkey, int n_leaves, int i, int& left, int& right, int& lo, int& hi) {
+  int d = (radix_delta(lkey, n_leaves, i, i + 1) - radix_delta(lkey, n_leaves, i, i - 1)) >= 0 ? 1 : -1;
+  int dmin = radix_delta(lkey, n_leaves, i, i - d);
+  int lmax = 2;
+  while (radix_delta(lkey, n_leaves, i, i + lmax * d) > dmin) lmax <<= 1;
+  int l = 0;
+  for (int t = lmax >> 1; t >= 1; t >>= 1)
+    if (radix_delta(lkey, n_leaves, i, i + (l + t) * d) > dmin) l += t;
+  int j = i + l * d;
+  int dnode = radix_delta(lkey, n_leaves, i, j);
+  int s = 0;
+  for (int t = (l + 1) >> 1;; t = (t + 1) >> 1) {
+    if (radix_delta(lkey, n_leaves, i, i + (s + t) * d) > dnode) s += t;
+    if (t == 1) break;
+  }
+  int gamma = i + s * d + (d < 0 ? -1 : 0);
+  lo = i < j ? i : j;
+  hi = i < j ? j : i;
+  left = (lo == gamma) ? ~gamma : gamma;
+  right = (hi == gamma + 1) ? ~(gamma + 1) : gamma + 1;
 }
 
 struct Nn1Collector {
   float bd;
   int bi;
   static constexpr bool kXyz = false;
+  static constexpr bool kGreedy = true;
   LH_HD float bound() const { return bd; }
   LH_HD void offer(float d, int id) {  // branch-free: selects instead of exec-mask branches in the 8-point leaf scan
     bool better = (d < bd) | ((d == bd) & (id < bi));
@@ -276,6 +355,7 @@ struct Nn1CountCollector {
   int bi;
   int nodes, leaves;
   static constexpr bool kXyz = false;
+  static constexpr bool kGreedy = true;
   LH_HD float bound() const { return bd; }
   LH_HD void offer(float d, int id) {
     if (d < bd || (d == bd && id < bi)) { bd = d; bi = id; }
@@ -295,6 +375,7 @@ struct Nn1CertCollector {
   int bi;
   float lb;
   static constexpr bool kXyz = false;
+  static constexpr bool kGreedy = true;
   LH_HD float bound() const { return bd; }
   LH_HD void offer(float d, int id) {  // branch-free
     bool same = id == bi;                                   // the warm-start candidate met again: no-op
@@ -317,6 +398,7 @@ struct RadiusMomentCollector {
   int cnt;
   float a[9];
   static constexpr bool kXyz = true;
+  static constexpr bool kGreedy = false;
   LH_HD float bound() const { return r2; }
   LH_HD void offer_xyz(float d, float x, float y, float z) {
     if (d < r2) {  // FLANN RadiusResultSet: strict
@@ -338,6 +420,7 @@ struct KnnCollector {
   int* ki;
   int k, stride, cnt;
   static constexpr bool kXyz = false;
+  static constexpr bool kGreedy = false;
   LH_HD float bound() const { return cnt < k ? inf_f() : kd[(k - 1) * stride]; }
   LH_HD void skip(float) {}
   LH_HD void count_node(int) {}
@@ -382,6 +465,7 @@ struct KnnRegCollector {
     ki = 0x7fffffff;
   }
   static constexpr bool kXyz = false;
+  static constexpr bool kGreedy = false;
   LH_HD float bound() const { return kd; }
   LH_HD void skip(float) {}
   LH_HD void count_node(int) {}

@@ -26,130 +26,6 @@ __device__ __forceinline__ float dec_ordered(uint32_t e) {
   return __uint_as_float(u);
 }
 
-__global__ void __launch_bounds__(256) k_bbox_init(uint32_t* bbox) {
-  if (threadIdx.x < 3) bbox[threadIdx.x] = 0xffffffffu;       // min slots
-  else if (threadIdx.x < 6) bbox[threadIdx.x] = 0u;           // max slots
-}
-
-__global__ void __launch_bounds__(256) k_bbox(const float4* __restrict__ xyz, int n, uint32_t* bbox) {
-  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    float4 p = xyz[i];
-    lo[0] = fminf(lo[0], p.x); hi[0] = fmaxf(hi[0], p.x);
-    lo[1] = fminf(lo[1], p.y); hi[1] = fmaxf(hi[1], p.y);
-    lo[2] = fminf(lo[2], p.z); hi[2] = fmaxf(hi[2], p.z);
-  }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-#pragma unroll
-    for (int a = 0; a < 3; a++) {
-      lo[a] = fminf(lo[a], __shfl_down(lo[a], off, 64));
-      hi[a] = fmaxf(hi[a], __shfl_down(hi[a], off, 64));
-    }
-  }
-  __shared__ float sm[4][6];
-  if ((threadIdx.x & 63) == 0) {
-#pragma unroll
-    for (int a = 0; a < 3; a++) { sm[threadIdx.x >> 6][a] = lo[a]; sm[threadIdx.x >> 6][3 + a] = hi[a]; }
-  }
-  __syncthreads();
-  if (threadIdx.x < 3)
-    atomicMin(&bbox[threadIdx.x], enc_ordered(fminf(fminf(sm[0][threadIdx.x], sm[1][threadIdx.x]), fminf(sm[2][threadIdx.x], sm[3][threadIdx.x]))));
-  else if (threadIdx.x < 6)
-    atomicMax(&bbox[threadIdx.x], enc_ordered(fmaxf(fmaxf(sm[0][threadIdx.x], sm[1][threadIdx.x]), fmaxf(sm[2][threadIdx.x], sm[3][threadIdx.x]))));
-}
-
-__global__ void __launch_bounds__(256) k_morton(const float4* __restrict__ xyz, int n, const uint32_t* __restrict__ bbox,
-                                                uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float lx = dec_ordered(bbox[0]), ly = dec_ordered(bbox[1]), lz = dec_ordered(bbox[2]);
-  float hx = dec_ordered(bbox[3]), hy = dec_ordered(bbox[4]), hz = dec_ordered(bbox[5]);
-  float4 p = xyz[i];
-  keys[i] = spatial_key30(p.x, p.y, p.z, lx, ly, lz, hx, hy, hz);
-  vals[i] = (uint32_t)i;
-}
-
-__global__ void __launch_bounds__(256) k_gather_sorted(const float4* __restrict__ xyz, const uint32_t* __restrict__ vals, int n,
-                                                       int n_padded, float4* __restrict__ sorted) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_padded) return;
-  float4 o;
-  if (i < n) {
-    uint32_t j = vals[i];
-    float4 p = xyz[j];
-    o = make_float4(p.x, p.y, p.z, __uint_as_float(j));
-  } else {
-    o = make_float4(INFINITY, INFINITY, INFINITY, __uint_as_float(0x7fffffffu));
-  }
-  sorted[i] = o;
-}
-
-__device__ __forceinline__ int level_offset(int l) { return (int)(((1ll << (2 * l)) - 1) / 3); }
-
-// one thread per leaf slot: box of its (<= 8) points -> child slot of the last internal level
-__global__ void __launch_bounds__(256) k_leaf_level(const float4* __restrict__ sorted, int n, int depth, Node4* __restrict__ nodes) {
-  int L = blockIdx.x * blockDim.x + threadIdx.x;
-  int slots = 1 << (2 * depth);
-  if (L >= slots) return;
-  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-  int base = L * LEAF;
-#pragma unroll
-  for (int e = 0; e < LEAF; e++) {
-    if (base + e < n) {
-      float4 p = sorted[base + e];
-      lo[0] = fminf(lo[0], p.x); hi[0] = fmaxf(hi[0], p.x);
-      lo[1] = fminf(lo[1], p.y); hi[1] = fmaxf(hi[1], p.y);
-      lo[2] = fminf(lo[2], p.z); hi[2] = fmaxf(hi[2], p.z);
-    }
-  }
-  Node4& nd = nodes[level_offset(depth - 1) + (L >> 2)];
-  int c = L & 3;
-  nd.lox[c] = lo[0]; nd.loy[c] = lo[1]; nd.loz[c] = lo[2];
-  nd.hix[c] = hi[0]; nd.hiy[c] = hi[1]; nd.hiz[c] = hi[2];
-}
-
-// one thread per (node of level l, child c): union of the child's four boxes
-__global__ void __launch_bounds__(256) k_level_up(int l, Node4* __restrict__ nodes) {
-  int t = blockIdx.x * blockDim.x + threadIdx.x;
-  int cnt = 1 << (2 * l + 2);
-  if (t >= cnt) return;
-  int j = t >> 2, c = t & 3;
-  const Node4& ch = nodes[level_offset(l + 1) + 4 * j + c];
-  float lx = fminf(fminf(ch.lox[0], ch.lox[1]), fminf(ch.lox[2], ch.lox[3]));
-  float ly = fminf(fminf(ch.loy[0], ch.loy[1]), fminf(ch.loy[2], ch.loy[3]));
-  float lz = fminf(fminf(ch.loz[0], ch.loz[1]), fminf(ch.loz[2], ch.loz[3]));
-  float hx = fmaxf(fmaxf(ch.hix[0], ch.hix[1]), fmaxf(ch.hix[2], ch.hix[3]));
-  float hy = fmaxf(fmaxf(ch.hiy[0], ch.hiy[1]), fmaxf(ch.hiy[2], ch.hiy[3]));
-  float hz = fmaxf(fmaxf(ch.hiz[0], ch.hiz[1]), fmaxf(ch.hiz[2], ch.hiz[3]));
-  Node4& nd = nodes[level_offset(l) + j];
-  nd.lox[c] = lx; nd.loy[c] = ly; nd.loz[c] = lz;
-  nd.hix[c] = hx; nd.hiy[c] = hy; nd.hiz[c] = hz;
-}
-
-// levels l_top .. 0 in ONE workgroup (level l has 4^(l+1) <= 1024 (node, child) slots for l <= 4)
-__global__ void __launch_bounds__(1024) k_levels_top(int l_top, Node4* __restrict__ nodes) {
-  for (int l = l_top; l >= 0; l--) {
-    int cnt = 1 << (2 * l + 2);
-    int t = threadIdx.x;
-    if (t < cnt) {
-      int j = t >> 2, c = t & 3;
-      const Node4& ch = nodes[level_offset(l + 1) + 4 * j + c];
-      float lx = fminf(fminf(ch.lox[0], ch.lox[1]), fminf(ch.lox[2], ch.lox[3]));
-      float ly = fminf(fminf(ch.loy[0], ch.loy[1]), fminf(ch.loy[2], ch.loy[3]));
-      float lz = fminf(fminf(ch.loz[0], ch.loz[1]), fminf(ch.loz[2], ch.loz[3]));
-      float hx = fmaxf(fmaxf(ch.hix[0], ch.hix[1]), fmaxf(ch.hix[2], ch.hix[3]));
-      float hy = fmaxf(fmaxf(ch.hiy[0], ch.hiy[1]), fmaxf(ch.hiy[2], ch.hiy[3]));
-      float hz = fmaxf(fmaxf(ch.hiz[0], ch.hiz[1]), fmaxf(ch.hiz[2], ch.hiz[3]));
-      Node4& nd = nodes[level_offset(l) + j];
-      nd.lox[c] = lx; nd.loy[c] = ly; nd.loz[c] = lz;
-      nd.hix[c] = hx; nd.hiy[c] = hy; nd.hiz[c] = hz;
-    }
-    __threadfence_block();
-    __syncthreads();  // same workgroup wrote the level it reads next
-  }
-}
-
 // ----- batched index build -----------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_bbox_init_b(uint32_t* bbox, int n_clouds) {
   int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -202,7 +78,7 @@ __global__ void __launch_bounds__(256) k_key_b(const IndexDesc* __restrict__ des
 __global__ void __launch_bounds__(256) k_gather_b(const IndexDesc* __restrict__ descs, const uint32_t* __restrict__ vals) {
   const IndexDesc d = descs[blockIdx.y];
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= d.n_padded) return;
+  if (i >= d.n + LEAF_CAP) return;
   float4 o;
   if (i < d.n) {
     uint32_t j = vals[d.offset + i] - (uint32_t)d.offset;
@@ -210,101 +86,179 @@ __global__ void __launch_bounds__(256) k_gather_b(const IndexDesc* __restrict__ 
     o = make_float4(p.x, p.y, p.z, __uint_as_float(j));
     d.pos[j] = i;
   } else {
-    o = make_float4(INFINITY, INFINITY, INFINITY, __uint_as_float(0x7fffffffu));
+    o = make_float4(INFINITY, INFINITY, INFINITY, __uint_as_float(0x7fffffffu));  // padding behind the last leaf (scan_leaf loads 8)
   }
   d.sorted[i] = o;
 }
-__global__ void __launch_bounds__(256) k_leaf_level_b(const IndexDesc* __restrict__ descs) {
-  const IndexDesc d = descs[blockIdx.y];
-  if (d.depth <= 0) return;
+
+// --- leaves: the largest key-prefix cell around every sorted position with <= LEAF_CAP points --------------------------
+__global__ void __launch_bounds__(256) k_leafcell_b(TreeScratch t) {
+  int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= t.total) return;
+  t.flag[g] = leafcell_flag(t.keys, t.total, g);
+}
+// after the inclusive scan lid[] of the flags: leaf L = lid[g] - 1 starts at the flagged position g
+__global__ void __launch_bounds__(256) k_leafrec_b(TreeScratch t) {
+  int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= t.total) return;
+  if (t.flag[g]) {
+    uint32_t L = t.lid[g] - 1u;
+    t.lkey[L] = t.keys[g];
+    t.lstart[L] = (uint32_t)g;
+  }
+  if (g == t.total - 1) {  // sentinel: leaf L's points are [lstart[L], lstart[L+1])
+    uint32_t Lt = t.lid[g];
+    t.lstart[Lt] = (uint32_t)t.total;
+    t.lkey[Lt] = ~0ull;
+  }
+}
+// --- Karras' binary radix tree over the leaf keys of the WHOLE batch (nodes that join two clouds are never used) -------
+__global__ void __launch_bounds__(256) k_radix_b(TreeScratch t) {
+  const int n_leaves = (int)t.lid[t.total - 1];
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_leaves - 1) return;
+  int left, right, lo, hi;
+  radix_node(t.lkey, n_leaves, i, left, right, lo, hi);
+  t.ichild[2 * i] = left;
+  t.ichild[2 * i + 1] = right;
+  t.irange[2 * i] = lo;
+  t.irange[2 * i + 1] = hi;
+}
+// --- boxes WITHOUT a bottom-up pass.  A node's box is the min/max over a contiguous range of leaves, so it can be read
+// off three tables: lbox (one box per leaf), a1box (per 32 consecutive leaves), a2box (per 1024).  Every thread works
+// alone on data written by earlier launches: no arrival counters, no agent-scope fences (a __threadfence() per tree level
+// costs ~3.5 us on this chip because the per-XCD L2s are not coherent: the climbing version took 3.5 ms per batch).
+struct Box6 { float lx, ly, lz, hx, hy, hz; };
+__device__ __forceinline__ Box6 box_empty() { return Box6{INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY}; }
+__device__ __forceinline__ void box_merge(Box6& b, const float4* __restrict__ tab, int idx) {  // table entry = 2 x float4
+  float4 lo = tab[2 * (size_t)idx], hi = tab[2 * (size_t)idx + 1];
+  b.lx = fminf(b.lx, lo.x); b.ly = fminf(b.ly, lo.y); b.lz = fminf(b.lz, lo.z);
+  b.hx = fmaxf(b.hx, hi.x); b.hy = fmaxf(b.hy, hi.y); b.hz = fmaxf(b.hz, hi.z);
+}
+__device__ __forceinline__ void box_store(float4* tab, int idx, const Box6& b) {
+  tab[2 * (size_t)idx] = make_float4(b.lx, b.ly, b.lz, 0.f);
+  tab[2 * (size_t)idx + 1] = make_float4(b.hx, b.hy, b.hz, 0.f);
+}
+__global__ void __launch_bounds__(256) k_leafbox_b(const IndexDesc* __restrict__ descs, TreeScratch t) {
+  const int n_leaves = (int)t.lid[t.total - 1];
   int L = blockIdx.x * blockDim.x + threadIdx.x;
-  int slots = 1 << (2 * d.depth);
-  if (L >= slots) return;
-  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-  int base = L * LEAF;
+  if (L >= n_leaves) return;
+  const int cloud = (int)(t.lkey[L] >> 32);
+  const IndexDesc d = descs[cloud];
+  const uint32_t s0 = t.lstart[L], s1 = t.lstart[L + 1];
+  Box6 b = box_empty();
+  for (uint32_t g = s0; g < s1; g++) {
+    float4 p = d.sorted[g - (uint32_t)d.offset];
+    b.lx = fminf(b.lx, p.x); b.ly = fminf(b.ly, p.y); b.lz = fminf(b.lz, p.z);
+    b.hx = fmaxf(b.hx, p.x); b.hy = fmaxf(b.hy, p.y); b.hz = fmaxf(b.hz, p.z);
+  }
+  box_store(t.lbox, L, b);
+  const int a_c = (int)t.lid[d.offset] - 1, b_c = (int)t.lid[d.offset + d.n - 1] - 1;
+  if (a_c == b_c) {  // the whole cloud is one leaf: no internal node will write the header
+    d.hdr->root = leaf_ref(0u, d.n);
+    d.hdr->n_leaves = 1;
+  }
+}
+// chunk tables: dst[c] = union of src[32c .. 32c+31] (entries past n_src are skipped)
+__global__ void __launch_bounds__(256) k_chunkbox_b(TreeScratch t, int level) {
+  const int n_leaves = (int)t.lid[t.total - 1];
+  const int n_src = level == 1 ? n_leaves : (n_leaves + 31) / 32;
+  const float4* src = level == 1 ? t.lbox : t.a1box;
+  float4* dst = level == 1 ? t.a1box : t.a2box;
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c * 32 >= n_src) return;
+  Box6 b = box_empty();
+  int e = min(n_src, c * 32 + 32);
+  for (int k = c * 32; k < e; k++) box_merge(b, src, k);
+  box_store(dst, c, b);
+}
+// box of the leaves [a, e)
+__device__ __forceinline__ Box6 range_box(const TreeScratch& t, int a, int e) {
+  Box6 b = box_empty();
+  if (e - a <= 64) {
+    for (int l = a; l < e; l++) box_merge(b, t.lbox, l);
+    return b;
+  }
+  int a1 = (a + 31) & ~31, e1 = e & ~31;
+  for (int l = a; l < a1; l++) box_merge(b, t.lbox, l);
+  for (int l = e1; l < e; l++) box_merge(b, t.lbox, l);
+  int c0 = a1 >> 5, c1 = e1 >> 5;
+  if (c1 - c0 <= 64) {
+    for (int c = c0; c < c1; c++) box_merge(b, t.a1box, c);
+    return b;
+  }
+  int c0a = (c0 + 31) & ~31, c1a = c1 & ~31;
+  for (int c = c0; c < c0a; c++) box_merge(b, t.a1box, c);
+  for (int c = c1a; c < c1; c++) box_merge(b, t.a1box, c);
+  for (int c = c0a >> 5; c < (c1a >> 5); c++) box_merge(b, t.a2box, c);
+  return b;
+}
+// --- 4-ary nodes: every binary node of a cloud adopts its grandchildren (a leaf child stays a child) -------------------
+__global__ void __launch_bounds__(256) k_nodex_b(const IndexDesc* __restrict__ descs, TreeScratch t) {
+  const int n_leaves = (int)t.lid[t.total - 1];
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_leaves - 1) return;
+  const int lo = t.irange[2 * i], hi = t.irange[2 * i + 1];
+  const int cloud = (int)(t.lkey[lo] >> 32);
+  if (cloud != (int)(t.lkey[hi] >> 32)) return;  // joins two clouds: not part of any cloud's tree
+  const IndexDesc d = descs[cloud];
+  const int a_c = (int)t.lid[d.offset] - 1, b_c = (int)t.lid[d.offset + d.n - 1] - 1;
+  NodeX nd;
 #pragma unroll
-  for (int e = 0; e < LEAF; e++) {
-    if (base + e < d.n) {
-      float4 p = d.sorted[base + e];
-      lo[0] = fminf(lo[0], p.x); hi[0] = fmaxf(hi[0], p.x);
-      lo[1] = fminf(lo[1], p.y); hi[1] = fmaxf(hi[1], p.y);
-      lo[2] = fminf(lo[2], p.z); hi[2] = fmaxf(hi[2], p.z);
+  for (int k = 0; k < 4; k++) {
+    nd.lox[k] = nd.loy[k] = nd.loz[k] = INFINITY;
+    nd.hix[k] = nd.hiy[k] = nd.hiz[k] = -INFINITY;
+    nd.child[k] = 0x7fffffff;
+    nd.pad[k] = 0;
+  }
+  int cnt = 0;
+  auto emit = [&](int ref) {
+    Box6 bx;
+    int32_t cref;
+    if (ref < 0) {
+      int L = ~ref;
+      bx = range_box(t, L, L + 1);
+      cref = leaf_ref(t.lstart[L] - (uint32_t)d.offset, (int)(t.lstart[L + 1] - t.lstart[L]));
+    } else {
+      bx = range_box(t, t.irange[2 * ref], t.irange[2 * ref + 1] + 1);
+      cref = ref - a_c;
     }
+    nd.lox[cnt] = bx.lx; nd.loy[cnt] = bx.ly; nd.loz[cnt] = bx.lz;
+    nd.hix[cnt] = bx.hx; nd.hiy[cnt] = bx.hy; nd.hiz[cnt] = bx.hz;
+    nd.child[cnt] = cref;
+    cnt++;
+  };
+#pragma unroll
+  for (int side = 0; side < 2; side++) {
+    int c = t.ichild[2 * i + side];
+    if (c < 0) emit(c);
+    else { emit(t.ichild[2 * c]); emit(t.ichild[2 * c + 1]); }
   }
-  Node4& nd = d.nodes[level_offset(d.depth - 1) + (L >> 2)];
-  int c = L & 3;
-  nd.lox[c] = lo[0]; nd.loy[c] = lo[1]; nd.loz[c] = lo[2];
-  nd.hix[c] = hi[0]; nd.hiy[c] = hi[1]; nd.hiz[c] = hi[2];
-}
-__device__ __forceinline__ void level_up_slot(Node4* nodes, int l, int t) {
-  int j = t >> 2, c = t & 3;
-  const Node4& ch = nodes[level_offset(l + 1) + 4 * j + c];
-  float lx = fminf(fminf(ch.lox[0], ch.lox[1]), fminf(ch.lox[2], ch.lox[3]));
-  float ly = fminf(fminf(ch.loy[0], ch.loy[1]), fminf(ch.loy[2], ch.loy[3]));
-  float lz = fminf(fminf(ch.loz[0], ch.loz[1]), fminf(ch.loz[2], ch.loz[3]));
-  float hx = fmaxf(fmaxf(ch.hix[0], ch.hix[1]), fmaxf(ch.hix[2], ch.hix[3]));
-  float hy = fmaxf(fmaxf(ch.hiy[0], ch.hiy[1]), fmaxf(ch.hiy[2], ch.hiy[3]));
-  float hz = fmaxf(fmaxf(ch.hiz[0], ch.hiz[1]), fmaxf(ch.hiz[2], ch.hiz[3]));
-  Node4& nd = nodes[level_offset(l) + j];
-  nd.lox[c] = lx; nd.loy[c] = ly; nd.loz[c] = lz;
-  nd.hix[c] = hx; nd.hiy[c] = hy; nd.hiz[c] = hz;
-}
-__global__ void __launch_bounds__(256) k_level_up_b(const IndexDesc* __restrict__ descs, int l) {
-  const IndexDesc d = descs[blockIdx.y];
-  if (l > d.depth - 2) return;
-  int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= (1 << (2 * l + 2))) return;
-  level_up_slot(d.nodes, l, t);
-}
-__global__ void __launch_bounds__(1024) k_levels_top_b(const IndexDesc* __restrict__ descs) {
-  const IndexDesc d = descs[blockIdx.x];
-  int l_top = min(d.depth - 2, 4);
-  for (int l = l_top; l >= 0; l--) {
-    if ((int)threadIdx.x < (1 << (2 * l + 2))) level_up_slot(d.nodes, l, threadIdx.x);
-    __threadfence_block();
-    __syncthreads();
+  d.nodes[i - a_c] = nd;
+  if (lo == a_c && hi == b_c) {
+    d.hdr->root = i - a_c;
+    d.hdr->n_leaves = b_c - a_c + 1;
   }
 }
+
 void launch_index_keys(const IndexDesc* descs, int n_clouds, int max_n, uint32_t* bbox, uint64_t* keys, uint32_t* vals, hipStream_t s) {
   hipLaunchKernelGGL(k_bbox_init_b, dim3((n_clouds * 8 + 255) / 256), dim3(256), 0, s, bbox, n_clouds);
   int blocks = (max_n + 255) / 256;
   hipLaunchKernelGGL(k_bbox_b, dim3(blocks > 128 ? 128 : blocks, n_clouds), dim3(256), 0, s, descs, bbox);
   hipLaunchKernelGGL(k_key_b, dim3(blocks, n_clouds), dim3(256), 0, s, descs, bbox, keys, vals);
 }
-void launch_index_trees(const IndexDesc* descs, int n_clouds, int max_n_padded, int max_depth, const uint32_t* vals_sorted, hipStream_t s) {
-  hipLaunchKernelGGL(k_gather_b, dim3((max_n_padded + 255) / 256, n_clouds), dim3(256), 0, s, descs, vals_sorted);
-  if (max_depth <= 0) return;
-  int slots = 1 << (2 * max_depth);
-  hipLaunchKernelGGL(k_leaf_level_b, dim3((slots + 255) / 256, n_clouds), dim3(256), 0, s, descs);
-  for (int l = max_depth - 2; l > 4; l--) {
-    int cnt = 1 << (2 * l + 2);
-    hipLaunchKernelGGL(k_level_up_b, dim3((cnt + 255) / 256, n_clouds), dim3(256), 0, s, descs, l);
-  }
-  if (max_depth >= 2) hipLaunchKernelGGL(k_levels_top_b, dim3(n_clouds), dim3(1024), 0, s, descs);
+void launch_index_leaves(const TreeScratch& t, hipStream_t s) {
+  hipLaunchKernelGGL(k_leafcell_b, dim3((t.total + 255) / 256), dim3(256), 0, s, t);
 }
-
-void launch_bbox(const float4* xyz, int n, uint32_t* bbox, hipStream_t s) {
-  hipLaunchKernelGGL(k_bbox_init, dim3(1), dim3(64), 0, s, bbox);
-  int blocks = (n + 255) / 256;
-  if (blocks > 128) blocks = 128;  // few contended atomics: one per block and component
-  hipLaunchKernelGGL(k_bbox, dim3(blocks), dim3(256), 0, s, xyz, n, bbox);
-}
-void launch_morton(const float4* xyz, int n, const uint32_t* bbox, uint32_t* keys, uint32_t* vals, hipStream_t s) {
-  hipLaunchKernelGGL(k_morton, dim3((n + 255) / 256), dim3(256), 0, s, xyz, n, bbox, keys, vals);
-}
-void launch_gather_sorted(const float4* xyz, const uint32_t* vals, int n, int n_padded, float4* sorted, hipStream_t s) {
-  hipLaunchKernelGGL(k_gather_sorted, dim3((n_padded + 255) / 256), dim3(256), 0, s, xyz, vals, n, n_padded, sorted);
-}
-void launch_build_nodes(const float4* sorted, int n, int depth, Node4* nodes, hipStream_t s) {
-  if (depth <= 0) return;
-  int slots = 1 << (2 * depth);
-  hipLaunchKernelGGL(k_leaf_level, dim3((slots + 255) / 256), dim3(256), 0, s, sorted, n, depth, nodes);
-  int l = depth - 2;
-  for (; l > 4; l--) {
-    int cnt = 1 << (2 * l + 2);
-    hipLaunchKernelGGL(k_level_up, dim3((cnt + 255) / 256), dim3(256), 0, s, l, nodes);
-  }
-  if (l >= 0) hipLaunchKernelGGL(k_levels_top, dim3(1), dim3(1024), 0, s, l, nodes);
+void launch_index_trees(const IndexDesc* descs, int n_clouds, int max_n, const TreeScratch& t, const uint32_t* vals_sorted, hipStream_t s) {
+  hipLaunchKernelGGL(k_gather_b, dim3((max_n + LEAF_CAP + 255) / 256, n_clouds), dim3(256), 0, s, descs, vals_sorted);
+  int blocks = (t.total + 255) / 256;  // upper bound of the leaf count; the kernels read the real one from lid[total-1]
+  hipLaunchKernelGGL(k_leafrec_b, dim3(blocks), dim3(256), 0, s, t);
+  hipLaunchKernelGGL(k_radix_b, dim3(blocks), dim3(256), 0, s, t);
+  hipLaunchKernelGGL(k_leafbox_b, dim3(blocks), dim3(256), 0, s, descs, t);
+  hipLaunchKernelGGL(k_chunkbox_b, dim3((blocks + 31) / 32), dim3(256), 0, s, t, 1);
+  hipLaunchKernelGGL(k_chunkbox_b, dim3((blocks + 1023) / 1024), dim3(256), 0, s, t, 2);
+  hipLaunchKernelGGL(k_nodex_b, dim3(blocks), dim3(256), 0, s, descs, t);
 }
 
 // ===== K4: NN + Mahalanobis sweep ==========================================================================
@@ -331,13 +285,13 @@ __device__ __forceinline__ bool xcd_job_map(int njobs, int bpj, int& job, int& b
   return job < njobs;
 }
 static inline int xcd_grid(int njobs, int bpj) { return njobs * bpj; }
-static inline size_t stack_lds_bytes(int depth, int threads) { return (size_t)stack_entries_for_depth(depth) * threads * sizeof(uint32_t); }
+static inline size_t stack_lds_bytes(int /*depth*/, int threads) { return (size_t)LDS_STACK * threads * sizeof(uint64_t); }
 
 // K2': seeds for a cold sweep.  One thread per group of SEED_GROUP consecutive source points runs the exact search for
 // the group's first point and hands its neighbour to the whole group as warm-start candidate (any target point is a
 // valid candidate, so exactness is untouched; consecutive lidar returns are spatial neighbours, so the bound is tight).
 __global__ void __launch_bounds__(256) k_seed(const PairDesc* __restrict__ descs, SweepArgs a) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];  // [entries][256]
+  extern __shared__ __attribute__((aligned(16))) uint64_t lds_stack[];  // [entries][256]
   int jb, blk;
   if (!xcd_job_map(a.njobs, a.bpj, jb, blk)) return;
   const SweepJob& job = a.job[jb];
@@ -349,7 +303,7 @@ __global__ void __launch_bounds__(256) k_seed(const PairDesc* __restrict__ descs
   float4 p = d.src[i];
   float qx, qy, qz;
   xform_pt(job.T, p.x, p.y, p.z, qx, qy, qz);
-  TreeView tv{d.tgt_sorted, d.tgt_nodes, d.first_leaf, d.m};
+  TreeView tv{d.tgt_sorted, d.tgt_nodes, d.tgt_hdr, d.m};
   Nn1Collector col{INFINITY, 0x7fffffff};
   tree_search(tv, qx, qy, qz, col, lds_stack + threadIdx.x, 256);
   int j = (col.bi == 0x7fffffff) ? -1 : col.bi;
@@ -375,11 +329,11 @@ struct SweepPoint {
   int j;         // target index or -1
   bool matched;
 };
-__device__ __forceinline__ void sweep_point(const PairDesc& d, const SweepJob& job, int i, uint32_t* stack, SweepPoint& o) {
+__device__ __forceinline__ void sweep_point(const PairDesc& d, const SweepJob& job, int i, uint64_t* stack, SweepPoint& o) {
   o.p = d.src[i];
   float qx, qy, qz;
   xform_pt(job.T, o.p.x, o.p.y, o.p.z, qx, qy, qz);  // gicp.hpp:469
-  TreeView tv{d.tgt_sorted, d.tgt_nodes, d.first_leaf, d.m};
+  TreeView tv{d.tgt_sorted, d.tgt_nodes, d.tgt_hdr, d.m};
   Nn1CertCollector col{INFINITY, 0x7fffffff, INFINITY};
   int w = d.prev_nn[i];
   bool need_search = true;
@@ -441,7 +395,7 @@ __device__ __forceinline__ void sweep_point(const PairDesc& d, const SweepJob& j
 }
 
 __global__ void __launch_bounds__(256) k_sweep(const PairDesc* __restrict__ descs, SweepArgs a) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];  // [entries][256]
+  extern __shared__ __attribute__((aligned(16))) uint64_t lds_stack[];  // [entries][256]
   int jb, blk;
   if (!xcd_job_map(a.njobs, a.bpj, jb, blk)) return;
   const SweepJob& job = a.job[jb];
@@ -476,7 +430,7 @@ __device__ __forceinline__ double mom_value(int k, const double* M6, const doubl
 template <bool WAVE_REDUCE>
 __global__ void __launch_bounds__(256) k_sweep_fused(const PairDesc* __restrict__ descs, SweepArgs a, double* __restrict__ partials,
                                                      int partials_stride) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];  // [entries][256], later reused as double[8][256]
+  extern __shared__ __attribute__((aligned(16))) uint64_t lds_stack[];  // [entries][256], later reused as double[8][256]
   int jb, blk;
   if (!xcd_job_map(a.njobs, a.bpj, jb, blk)) return;
   const SweepJob& job = a.job[jb];
@@ -814,7 +768,7 @@ void launch_fill_i32(int32_t* p, int n, int32_t v, hipStream_t s) {
 
 __global__ void __launch_bounds__(256) k_nn1(const float4* __restrict__ q, int nq, T12 T, int has_T, TreeView tv,
                                              int32_t* __restrict__ idx, float* __restrict__ d2) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
+  extern __shared__ __attribute__((aligned(16))) uint64_t lds_stack[];
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nq) return;
   float4 p = q[i];
@@ -828,14 +782,13 @@ __global__ void __launch_bounds__(256) k_nn1(const float4* __restrict__ q, int n
 void launch_nn1(const float4* q, int nq, const float* T12p, TreeView tree, int32_t* idx, float* d2, hipStream_t s) {
   T12 T;
   for (int k = 0; k < 12; k++) T.v[k] = T12p ? T12p[k] : 0.f;
-  hipLaunchKernelGGL(k_nn1, dim3((nq + 255) / 256), dim3(256), stack_lds_bytes(tree_depth_of(tree.first_leaf), 256), s, q, nq, T, T12p ? 1 : 0, tree, idx, d2);
+  hipLaunchKernelGGL(k_nn1, dim3((nq + 255) / 256), dim3(256), stack_lds_bytes(0, 256), s, q, nq, T, T12p ? 1 : 0, tree, idx, d2);
 }
 
 __global__ void __launch_bounds__(256) k_nn1_stats(const float4* __restrict__ q, int nq, T12 T, int has_T, TreeView tv,
-                                                   const float4* __restrict__ tgt_xyz, const int32_t* __restrict__ tgt_pos,
-                                                   const int32_t* __restrict__ cand, int leaf_prescan,
+                                                   const float4* __restrict__ tgt_xyz, const int32_t* __restrict__ cand,
                                                    unsigned long long* __restrict__ stats) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
+  extern __shared__ __attribute__((aligned(16))) uint64_t lds_stack[];
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   int nodes = 0, leaves = 0;
   if (i < nq) {
@@ -849,13 +802,6 @@ __global__ void __launch_bounds__(256) k_nn1_stats(const float4* __restrict__ q,
       float4 t = tgt_xyz[w];
       col.bd = d2f(x, y, z, t.x, t.y, t.z);
       col.bi = w;
-      if (leaf_prescan) {
-        const float4* lp = tv.pts + ((size_t)(tgt_pos[w] >> 3) << 3);
-        for (int e8 = 0; e8 < LEAF; e8++) {
-          float4 v = lp[e8];
-          col.offer(d2f(x, y, z, v.x, v.y, v.z), (int)__float_as_uint(v.w));
-        }
-      }
     }
     tree_search(tv, x, y, z, col, lds_stack + threadIdx.x, 256);
     nodes = col.nodes; leaves = col.leaves;
@@ -875,11 +821,11 @@ __global__ void __launch_bounds__(256) k_nn1_stats(const float4* __restrict__ q,
     atomicMax(&stats[4], (unsigned long long)mx);
   }
 }
-void launch_nn1_stats(const float4* q, int nq, const float* T12p, TreeView tree, const float4* tgt_xyz, const int32_t* tgt_pos,
-                      const int32_t* cand, int leaf_prescan, unsigned long long* stats, hipStream_t s) {
+void launch_nn1_stats(const float4* q, int nq, const float* T12p, TreeView tree, const float4* tgt_xyz, const int32_t* cand,
+                      unsigned long long* stats, hipStream_t s) {
   T12 T;
   for (int k = 0; k < 12; k++) T.v[k] = T12p ? T12p[k] : 0.f;
-  hipLaunchKernelGGL(k_nn1_stats, dim3((nq + 255) / 256), dim3(256), stack_lds_bytes(tree_depth_of(tree.first_leaf), 256), s, q, nq, T, T12p ? 1 : 0, tree, tgt_xyz, tgt_pos, cand, leaf_prescan, stats);
+  hipLaunchKernelGGL(k_nn1_stats, dim3((nq + 255) / 256), dim3(256), stack_lds_bytes(0, 256), s, q, nq, T, T12p ? 1 : 0, tree, tgt_xyz, cand, stats);
 }
 
 // double sum of floats: 1024 values per block, fixed tree
@@ -906,7 +852,7 @@ void launch_sum_f32(const float* v, int n, double* partials, hipStream_t s) {
 constexpr int KNN_BLOCK = 128;
 
 template <int KCAP>
-__device__ __forceinline__ int knn_search_regs(const TreeView& tv, float x, float y, float z, int k, float* kd, int* ki, uint32_t* stack) {
+__device__ __forceinline__ int knn_search_regs(const TreeView& tv, float x, float y, float z, int k, float* kd, int* ki, uint64_t* stack) {
   KnnRegCollector<KCAP> col;
   col.init(k);
   tree_search(tv, x, y, z, col, stack, KNN_BLOCK);
@@ -916,7 +862,7 @@ __device__ __forceinline__ int knn_search_regs(const TreeView& tv, float x, floa
 // KCAP = register-list capacity chosen by the host (smallest of 8 / 20 / 32 that holds k; 0 = LDS insertion list for k > 32),
 // a template parameter of the kernels so that each instantiation only pays for its own registers.
 template <int KCAP>
-__device__ __forceinline__ int knn_search(const TreeView& tv, float x, float y, float z, int k, float* kd, int* ki, uint32_t* stack) {
+__device__ __forceinline__ int knn_search(const TreeView& tv, float x, float y, float z, int k, float* kd, int* ki, uint64_t* stack) {
   if constexpr (KCAP > 0) {
     return knn_search_regs<KCAP>(tv, x, y, z, k, kd, ki, stack);
   } else {
@@ -942,7 +888,7 @@ __global__ void __launch_bounds__(KNN_BLOCK) k_knn(const float4* __restrict__ q,
   int i = blockIdx.x * KNN_BLOCK + threadIdx.x;
   if (i >= nq) return;
   float4 p = q[i];
-  uint32_t* lds_stack = reinterpret_cast<uint32_t*>(smem + (size_t)8 * k * KNN_BLOCK);
+  uint64_t* lds_stack = reinterpret_cast<uint64_t*>(smem + (size_t)8 * k * KNN_BLOCK);
   struct { int cnt; } col;
   col.cnt = knn_search<KCAP>(tv, p.x, p.y, p.z, k, kd + threadIdx.x, ki + threadIdx.x, lds_stack + threadIdx.x);
   for (int e = 0; e < k; e++) {
@@ -952,7 +898,7 @@ __global__ void __launch_bounds__(KNN_BLOCK) k_knn(const float4* __restrict__ q,
   }
 }
 void launch_knn(const float4* q, int nq, TreeView tree, int k, int32_t* idx, float* d2, hipStream_t s) {
-  size_t sh = (size_t)k * KNN_BLOCK * 8 + stack_lds_bytes(tree_depth_of(tree.first_leaf), KNN_BLOCK);
+  size_t sh = (size_t)k * KNN_BLOCK * 8 + stack_lds_bytes(0, KNN_BLOCK);
   LH_KNN_DISPATCH(k_knn, k, dim3((nq + KNN_BLOCK - 1) / KNN_BLOCK), dim3(KNN_BLOCK), sh, s, q, nq, tree, k, idx, d2);
 }
 
@@ -966,7 +912,7 @@ __global__ void __launch_bounds__(KNN_BLOCK) k_knn_cov(const float4* __restrict_
   int i = blockIdx.x * KNN_BLOCK + threadIdx.x;
   if (i >= n) return;
   float4 p = xyz[i];
-  uint32_t* lds_stack = reinterpret_cast<uint32_t*>(smem + (size_t)8 * k * KNN_BLOCK);
+  uint64_t* lds_stack = reinterpret_cast<uint64_t*>(smem + (size_t)8 * k * KNN_BLOCK);
   struct { int cnt; } col;
   col.cnt = knn_search<KCAP>(tv, p.x, p.y, p.z, k, kd + threadIdx.x, ki + threadIdx.x, lds_stack + threadIdx.x);
   double mean[3] = {0, 0, 0}, c00 = 0, c10 = 0, c11 = 0, c20 = 0, c21 = 0, c22 = 0;
@@ -999,7 +945,7 @@ __global__ void __launch_bounds__(KNN_BLOCK) k_knn_cov(const float4* __restrict_
   cov6[(size_t)5 * n_pad + i] = 1.0 - s * u[2] * u[2];
 }
 void launch_knn_cov(const float4* xyz, int n, int n_pad, TreeView tree, int k, double eps, double* cov6, hipStream_t s) {
-  size_t sh = (size_t)k * KNN_BLOCK * 8 + stack_lds_bytes(tree_depth_of(tree.first_leaf), KNN_BLOCK);
+  size_t sh = (size_t)k * KNN_BLOCK * 8 + stack_lds_bytes(0, KNN_BLOCK);
   LH_KNN_DISPATCH(k_knn_cov, k, dim3((n + KNN_BLOCK - 1) / KNN_BLOCK), dim3(KNN_BLOCK), sh, s, xyz, n, n_pad, tree, k, eps, cov6);
 }
 
@@ -1086,7 +1032,7 @@ __global__ void __launch_bounds__(KNN_BLOCK) k_knn_normals(const float4* __restr
   int i = blockIdx.x * KNN_BLOCK + threadIdx.x;
   if (i >= n) return;
   float4 p = xyz[i];
-  uint32_t* lds_stack = reinterpret_cast<uint32_t*>(smem + (size_t)8 * k * KNN_BLOCK);
+  uint64_t* lds_stack = reinterpret_cast<uint64_t*>(smem + (size_t)8 * k * KNN_BLOCK);
   struct { int cnt; } col;
   col.cnt = knn_search<KCAP>(tv, p.x, p.y, p.z, k, kd + threadIdx.x, ki + threadIdx.x, lds_stack + threadIdx.x);
   const float qnan = __uint_as_float(0x7fc00000u);
@@ -1104,7 +1050,7 @@ __global__ void __launch_bounds__(KNN_BLOCK) k_knn_normals(const float4* __restr
   out[i] = normal_from_moments(a0, a1, a2, a3, a4, a5, a6, a7, a8, col.cnt, p);
 }
 void launch_knn_normals(const float4* xyz, int n, TreeView tree, int k, float4* out_nrm, hipStream_t s) {
-  size_t sh = (size_t)k * KNN_BLOCK * 8 + stack_lds_bytes(tree_depth_of(tree.first_leaf), KNN_BLOCK);
+  size_t sh = (size_t)k * KNN_BLOCK * 8 + stack_lds_bytes(0, KNN_BLOCK);
   LH_KNN_DISPATCH(k_knn_normals, k, dim3((n + KNN_BLOCK - 1) / KNN_BLOCK), dim3(KNN_BLOCK), sh, s, xyz, n, tree, k, out_nrm);
 }
 
@@ -1115,7 +1061,7 @@ __global__ void __launch_bounds__(KNN_BLOCK) k_radius_normals(const float4* __re
   int i = blockIdx.x * KNN_BLOCK + threadIdx.x;
   if (i >= n) return;
   float4 p = xyz[i];
-  uint32_t* lds_stack = reinterpret_cast<uint32_t*>(smem);
+  uint64_t* lds_stack = reinterpret_cast<uint64_t*>(smem);
   RadiusMomentCollector col;
   col.r2 = r2; col.cnt = 0;
 #pragma unroll
@@ -1129,7 +1075,7 @@ __global__ void __launch_bounds__(KNN_BLOCK) k_radius_normals(const float4* __re
   out[i] = normal_from_moments(col.a[0], col.a[1], col.a[2], col.a[3], col.a[4], col.a[5], col.a[6], col.a[7], col.a[8], col.cnt, p);
 }
 void launch_radius_normals(const float4* xyz, int n, TreeView tree, float radius, float4* out_nrm, hipStream_t s) {
-  size_t sh = stack_lds_bytes(tree_depth_of(tree.first_leaf), KNN_BLOCK);
+  size_t sh = stack_lds_bytes(0, KNN_BLOCK);
   hipLaunchKernelGGL(k_radius_normals, dim3((n + KNN_BLOCK - 1) / KNN_BLOCK), dim3(KNN_BLOCK), sh, s, xyz, n, tree, radius * radius, out_nrm);
 }
 
@@ -1243,7 +1189,7 @@ __global__ void __launch_bounds__(256) k_voxel_bbox(const float4* __restrict__ x
     atomicMax(&bbox[threadIdx.x], enc_ordered(fmaxf(fmaxf(sm[0][threadIdx.x], sm[1][threadIdx.x]), fmaxf(sm[2][threadIdx.x], sm[3][threadIdx.x]))));
 }
 void launch_voxel_bbox(const float4* xyzi, int n, int limit_axis, float lo, float hi, uint32_t* bbox, hipStream_t s) {
-  hipLaunchKernelGGL(k_bbox_init, dim3(1), dim3(64), 0, s, bbox);
+  hipLaunchKernelGGL(k_bbox_init_b, dim3(1), dim3(64), 0, s, bbox, 1);  // slots 0-2 = min, 3-5 = max (6, 7 unused)
   int blocks = (n + 255) / 256;
   if (blocks > 128) blocks = 128;
   hipLaunchKernelGGL(k_voxel_bbox, dim3(blocks), dim3(256), 0, s, xyzi, n, limit_axis, lo, hi, bbox);

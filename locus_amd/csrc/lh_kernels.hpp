@@ -22,15 +22,15 @@ struct PairDesc {
   const float4* tgt_nrm;    // target normals or null
   const double* tgt_cov6;   // target covariances planes (stride m_pad) or null
   const float4* tgt_sorted; // Hilbert-sorted target (x,y,z,id)
-  const int32_t* tgt_pos;   // original index -> sorted position
-  const Node4* tgt_nodes;
+  const NodeX* tgt_nodes;
+  const TreeHeader* tgt_hdr;
   int32_t* prev_nn;         // warm-start NN index per source point                      [n]
   float4* cert;             // (query x,y,z at the last full search, lower bound on the other points' d2) [n]
   unsigned long long* stats; // [0] += queries that ran the tree traversal, [1] += queries (instrumentation)
   float4* corr;             // per source point: (tgt x, y, z, bitcast tgt idx | -1)     [n]
   double* maha6;            // 6 planes of n_pad doubles: M00 M01 M02 M11 M12 M22
   int n, n_pad, m, m_pad;
-  int first_leaf;
+  int reserved0;
   int src_cov_pad;  // plane stride of src_cov6
   double corr_dist2;
   double gicp_eps;
@@ -67,29 +67,41 @@ size_t sort_temp_bytes(int n);
 void sort_pairs_u32(void* temp, size_t temp_bytes, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in,
                     uint32_t* vals_out, int n, int end_bit, hipStream_t s);
 
-void launch_bbox(const float4* xyz, int n, uint32_t* bbox_enc /*6, ordered-uint*/, hipStream_t s);
-void launch_morton(const float4* xyz, int n, const uint32_t* bbox_enc, uint32_t* keys, uint32_t* vals, hipStream_t s);
-void launch_gather_sorted(const float4* xyz, const uint32_t* vals, int n, int n_padded, float4* sorted, hipStream_t s);
-// builds all internal levels; depth = number of internal levels (4^depth >= n_leaves)
-void launch_build_nodes(const float4* sorted, int n, int depth, Node4* nodes, hipStream_t s);
-
 // ---- K2 batched: the indexes of several clouds are built by the same launches (grid.y = cloud) and ONE radix sort of
 // the concatenated 64-bit keys (cloud id << 32 | 30-bit Hilbert index); the per-pair build was launch-bound.
 struct IndexDesc {
   const float4* xyz;
-  float4* sorted;
-  Node4* nodes;
-  int32_t* pos;   // original index -> position in `sorted` (lets a sweep start from the leaf of its candidate)
-  int n, n_padded, depth, offset;  // offset = start of this cloud in the concatenated key/value arrays
+  float4* sorted;     // [n + LEAF_CAP]
+  NodeX* nodes;       // [n] worst case (one internal node per leaf, one leaf per point)
+  TreeHeader* hdr;
+  int32_t* pos;       // original index -> position in `sorted`
+  int n, offset;      // offset = start of this cloud in the concatenated key/value arrays
 };
+// build scratch shared by the clouds of a batch (capacity = total points of the batch + 1)
+struct TreeScratch {
+  const uint64_t* keys;   // sorted (cloud id << 32 | Hilbert key)      [total]
+  uint32_t* flag;         // leaf-start flags                           [total]
+  uint32_t* lid;          // inclusive scan of the flags                [total]
+  uint64_t* lkey;         // key of a leaf's first point (+ sentinel)   [leaves + 1]
+  uint32_t* lstart;       // first sorted position of a leaf (+ sentinel)
+  float4* lbox;           // leaf boxes, 2 x float4 (lo, hi) per leaf
+  float4* a1box;          // boxes of 32 consecutive leaves
+  float4* a2box;          // boxes of 1024 consecutive leaves
+  int32_t* ichild;        // binary children of internal node i [2]: >= 0 internal, < 0 leaf ~index
+  int32_t* irange;        // covered leaf range [2]
+  int total;
+};
+constexpr size_t TREE_SCRATCH_BYTES_PER_POINT = 4 + 4 + 8 + 4 + 32 + 2 + 8 + 8;  // flag lid lkey lstart lbox a1+a2 ichild irange
 constexpr int MAX_INDEX_BATCH = 64;
 size_t sort64_temp_bytes(int n);
 void sort_pairs_u64(void* temp, size_t temp_bytes, const uint64_t* keys_in, uint64_t* keys_out, const uint32_t* vals_in,
                     uint32_t* vals_out, int n, int end_bit, hipStream_t s);
 void launch_index_keys(const IndexDesc* descs, int n_clouds, int max_n, uint32_t* bbox_enc /*[n_clouds][8]*/, uint64_t* keys,
                        uint32_t* vals, hipStream_t s);
-void launch_index_trees(const IndexDesc* descs, int n_clouds, int max_n_padded, int max_depth, const uint32_t* vals_sorted,
-                        hipStream_t s);
+// flags of the leaf starts (then the caller scans them into t.lid) ...
+void launch_index_leaves(const TreeScratch& t, hipStream_t s);
+// ... and everything after the scan: sorted points, leaf records, radix tree, boxes, 4-ary nodes, headers
+void launch_index_trees(const IndexDesc* descs, int n_clouds, int max_n, const TreeScratch& t, const uint32_t* vals_sorted, hipStream_t s);
 
 // ---- K4 / K5 ---------------------------------------------------------------------------------------
 void launch_sweep(const PairDesc* descs, SweepArgs& a, int max_n, hipStream_t s);
@@ -117,8 +129,8 @@ void launch_fill_i32(int32_t* p, int n, int32_t v, hipStream_t s);
 void launch_nn1(const float4* q, int nq, const float* T12, TreeView tree, int32_t* idx, float* d2, hipStream_t s);
 // instrumentation: per-query visit counts of a cold 1-NN search; stats[0..4] = sum nodes, sum leaves, sum over waves of
 // the per-wave max (nodes+leaves), number of waves, max (nodes+leaves) of any query
-void launch_nn1_stats(const float4* q, int nq, const float* T12, TreeView tree, const float4* tgt_xyz, const int32_t* tgt_pos,
-                      const int32_t* cand /*nullable: warm-start candidates*/, int leaf_prescan, unsigned long long* stats, hipStream_t s);
+void launch_nn1_stats(const float4* q, int nq, const float* T12, TreeView tree, const float4* tgt_xyz,
+                      const int32_t* cand /*nullable: warm-start candidates*/, unsigned long long* stats, hipStream_t s);
 // deterministic double sum of float d2 (fitness): partials[ceil(n/1024)]
 void launch_sum_f32(const float* v, int n, double* partials, hipStream_t s);
 inline int sum_blocks(int n) { return (n + 1023) / 1024; }

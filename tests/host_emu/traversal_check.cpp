@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <functional>
 #include <random>
 #include <vector>
 
@@ -14,14 +15,15 @@ using namespace lh;
 
 struct HostTree {
   std::vector<float4> sorted;
-  std::vector<Node4> nodes;
-  int depth = 0, first_leaf = 0, n = 0;
-  TreeView view() const { return TreeView{sorted.data(), nodes.data(), first_leaf, n}; }
+  std::vector<NodeX> nodes;
+  TreeHeader hdr;
+  int n = 0, n_leaves = 0, depth = 0;
+  TreeView view() const { return TreeView{sorted.data(), nodes.data(), &hdr, n}; }
 };
 
-static int level_offset(int l) { return (int)(((1ll << (2 * l)) - 1) / 3); }
-
-static HostTree build(const std::vector<float4>& pts) {
+// serial restatement of the build kernels (k_key_b / k_leafcell_b / scan / k_leafrec_b / k_radix_b / k_boxes_b / k_nodex_b)
+// with the SAME per-element functions (leafcell_flag, radix_node, leaf_ref) the kernels call
+static HostTree build(const std::vector<float4>& pts, uint64_t cloud_id = 3) {
   HostTree t;
   int n = (int)pts.size();
   t.n = n;
@@ -31,61 +33,92 @@ static HostTree build(const std::vector<float4>& pts) {
     lo[1] = fminf(lo[1], p.y); hi[1] = fmaxf(hi[1], p.y);
     lo[2] = fminf(lo[2], p.z); hi[2] = fmaxf(hi[2], p.z);
   }
-  std::vector<std::pair<uint32_t, uint32_t>> kv(n);
-  for (int i = 0; i < n; i++) kv[i] = {spatial_key30(pts[i].x, pts[i].y, pts[i].z, lo[0], lo[1], lo[2], hi[0], hi[1], hi[2]), (uint32_t)i};
+  std::vector<std::pair<uint64_t, uint32_t>> kv(n);
+  for (int i = 0; i < n; i++)
+    kv[i] = {(cloud_id << 32) | spatial_key30(pts[i].x, pts[i].y, pts[i].z, lo[0], lo[1], lo[2], hi[0], hi[1], hi[2]), (uint32_t)i};
   std::stable_sort(kv.begin(), kv.end(), [](auto& a, auto& b) { return a.first < b.first; });
-  int n_leaves = (n + LEAF - 1) / LEAF;
-  int depth = 0;
-  while ((1ll << (2 * depth)) < n_leaves) depth++;
-  t.depth = depth;
-  t.first_leaf = level_offset(depth);
-  t.sorted.resize((size_t)n_leaves * LEAF);
-  for (int i = 0; i < n_leaves * LEAF; i++) {
+  std::vector<uint64_t> keys(n);
+  t.sorted.resize((size_t)n + LEAF_CAP);
+  for (int i = 0; i < n + LEAF_CAP; i++) {
     if (i < n) {
       uint32_t j = kv[i].second;
+      keys[i] = kv[i].first;
       t.sorted[i] = make_float4(pts[j].x, pts[j].y, pts[j].z, u2f(j));
     } else
       t.sorted[i] = make_float4(INFINITY, INFINITY, INFINITY, u2f(0x7fffffffu));
   }
-  t.nodes.resize(std::max(1, t.first_leaf));
-  if (depth > 0) {
-    int slots = 1 << (2 * depth);
-    for (int L = 0; L < slots; L++) {
-      float l3[3] = {INFINITY, INFINITY, INFINITY}, h3[3] = {-INFINITY, -INFINITY, -INFINITY};
-      for (int e = 0; e < LEAF; e++)
-        if (L * LEAF + e < n) {
-          float4 p = t.sorted[L * LEAF + e];
-          l3[0] = fminf(l3[0], p.x); h3[0] = fmaxf(h3[0], p.x);
-          l3[1] = fminf(l3[1], p.y); h3[1] = fmaxf(h3[1], p.y);
-          l3[2] = fminf(l3[2], p.z); h3[2] = fmaxf(h3[2], p.z);
-        }
-      Node4& nd = t.nodes[level_offset(depth - 1) + (L >> 2)];
-      int c = L & 3;
-      nd.lox[c] = l3[0]; nd.loy[c] = l3[1]; nd.loz[c] = l3[2];
-      nd.hix[c] = h3[0]; nd.hiy[c] = h3[1]; nd.hiz[c] = h3[2];
+  std::vector<uint64_t> lkey;
+  std::vector<uint32_t> lstart;
+  for (int g = 0; g < n; g++)
+    if (leafcell_flag(keys.data(), n, g)) { lkey.push_back(keys[g]); lstart.push_back((uint32_t)g); }
+  int L = (int)lkey.size();
+  lstart.push_back((uint32_t)n);
+  lkey.push_back(~0ull);
+  t.n_leaves = L;
+  struct B6 { float v[6]; };
+  auto leaf_box = [&](int l) {
+    B6 b{{INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY}};
+    for (uint32_t g = lstart[l]; g < lstart[l + 1]; g++) {
+      float4 p = t.sorted[g];
+      b.v[0] = fminf(b.v[0], p.x); b.v[1] = fminf(b.v[1], p.y); b.v[2] = fminf(b.v[2], p.z);
+      b.v[3] = fmaxf(b.v[3], p.x); b.v[4] = fmaxf(b.v[4], p.y); b.v[5] = fmaxf(b.v[5], p.z);
     }
-    for (int l = depth - 2; l >= 0; l--)
-      for (int tt = 0; tt < (1 << (2 * l + 2)); tt++) {
-        int j = tt >> 2, c = tt & 3;
-        const Node4& ch = t.nodes[level_offset(l + 1) + 4 * j + c];
-        Node4& nd = t.nodes[level_offset(l) + j];
-        nd.lox[c] = fminf(fminf(ch.lox[0], ch.lox[1]), fminf(ch.lox[2], ch.lox[3]));
-        nd.loy[c] = fminf(fminf(ch.loy[0], ch.loy[1]), fminf(ch.loy[2], ch.loy[3]));
-        nd.loz[c] = fminf(fminf(ch.loz[0], ch.loz[1]), fminf(ch.loz[2], ch.loz[3]));
-        nd.hix[c] = fmaxf(fmaxf(ch.hix[0], ch.hix[1]), fmaxf(ch.hix[2], ch.hix[3]));
-        nd.hiy[c] = fmaxf(fmaxf(ch.hiy[0], ch.hiy[1]), fmaxf(ch.hiy[2], ch.hiy[3]));
-        nd.hiz[c] = fmaxf(fmaxf(ch.hiz[0], ch.hiz[1]), fmaxf(ch.hiz[2], ch.hiz[3]));
-      }
+    return b;
+  };
+  for (int l = 0; l < L; l++)
+    if ((int)(lstart[l + 1] - lstart[l]) > LEAF_CAP || lstart[l + 1] <= lstart[l]) { printf("bad leaf size\n"); exit(2); }
+  if (L == 1) {
+    t.hdr.root = leaf_ref(0u, n);
+    t.hdr.n_leaves = 1;
+    t.nodes.resize(1);
+    return t;
   }
+  std::vector<int> ich(2 * (L - 1)), irg(2 * (L - 1));
+  for (int i = 0; i < L - 1; i++) radix_node(lkey.data(), L, i, ich[2 * i], ich[2 * i + 1], irg[2 * i], irg[2 * i + 1]);
+  // boxes by recursion from the root (the kernels climb from the leaves with arrival counters; same result)
+  std::vector<B6> ibox(L - 1);
+  std::vector<int> idepth(L - 1, 0);
+  std::function<B6(int, int)> boxof = [&](int ref, int dep) -> B6 {
+    if (ref < 0) return leaf_box(~ref);
+    B6 a = boxof(ich[2 * ref], dep + 1), b = boxof(ich[2 * ref + 1], dep + 1), m;
+    for (int k = 0; k < 3; k++) { m.v[k] = fminf(a.v[k], b.v[k]); m.v[3 + k] = fmaxf(a.v[3 + k], b.v[3 + k]); }
+    ibox[ref] = m;
+    idepth[ref] = dep;
+    t.depth = std::max(t.depth, dep);
+    return m;
+  };
+  boxof(0, 0);
+  if (irg[0] != 0 || irg[1] != L - 1) { printf("root range wrong\n"); exit(2); }
+  t.nodes.resize(L);
+  for (int i = 0; i < L - 1; i++) {
+    NodeX nd;
+    for (int k = 0; k < 4; k++) { nd.lox[k] = nd.loy[k] = nd.loz[k] = INFINITY; nd.hix[k] = nd.hiy[k] = nd.hiz[k] = -INFINITY; nd.child[k] = 0x7fffffff; nd.pad[k] = 0; }
+    int cnt = 0;
+    auto emit = [&](int ref) {
+      B6 b = ref < 0 ? leaf_box(~ref) : ibox[ref];
+      nd.lox[cnt] = b.v[0]; nd.loy[cnt] = b.v[1]; nd.loz[cnt] = b.v[2]; nd.hix[cnt] = b.v[3]; nd.hiy[cnt] = b.v[4]; nd.hiz[cnt] = b.v[5];
+      nd.child[cnt] = ref < 0 ? leaf_ref(lstart[~ref], (int)(lstart[~ref + 1] - lstart[~ref])) : ref;
+      cnt++;
+    };
+    for (int side = 0; side < 2; side++) {
+      int c = ich[2 * i + side];
+      if (c < 0) emit(c);
+      else { emit(ich[2 * c]); emit(ich[2 * c + 1]); }
+    }
+    t.nodes[i] = nd;
+  }
+  t.hdr.root = 0;  // Karras: node 0 covers every leaf
+  t.hdr.n_leaves = L;
   return t;
 }
 
-static int run_case(int n, int nq, int k, unsigned seed, bool dup) {
+static int run_case(int n, int nq, int k, unsigned seed, int dup) {
   std::mt19937 rng(seed);
   std::normal_distribution<float> g(0.f, 1.f);
   std::vector<float4> pts(n), qs(nq);
   for (int i = 0; i < n; i++) {
-    if (dup && i > 0 && (i % 3) == 0) { pts[i] = pts[i - 1]; continue; }  // exact duplicates exercise the tie rule
+    if (dup == 1 && i > 0 && (i % 3) == 0) { pts[i] = pts[i - 1]; continue; }  // exact duplicates exercise the tie rule
+    if (dup == 2 && i > 0 && (i % 50) != 0) { pts[i] = pts[i - 1]; continue; }  // runs of 50 identical points: chunked leaves, index tie-breaks in the radix tree
     float cx = (float)((i % 7) * 3), cy = (float)((i % 5) * 2);
     pts[i] = make_float4(cx + g(rng), cy + g(rng), 0.2f * g(rng), 1.f);
   }
@@ -96,7 +129,7 @@ static int run_case(int n, int nq, int k, unsigned seed, bool dup) {
   HostTree t = build(pts);
   TreeView tv = t.view();
   int bad = 0;
-  std::vector<uint32_t> stk(STACK_MAX);
+  std::vector<uint64_t> stk(LDS_STACK);
   std::vector<float> kd(k), bd(n);
   std::vector<int> ki(k), ord(n);
   for (int i = 0; i < nq; i++) {
@@ -141,7 +174,7 @@ static int run_case(int n, int nq, int k, unsigned seed, bool dup) {
         if (ri[e] != ord[e] || rd[e] != bd[ord[e]]) { bad++; break; }
     }
   }
-  printf("n=%d nq=%d k=%d dup=%d depth=%d -> %s (%d mismatches)\n", n, nq, k, (int)dup, t.depth, bad ? "FAIL" : "ok", bad);
+  printf("n=%d nq=%d k=%d dup=%d leaves=%d binary depth=%d -> %s (%d mismatches)\n", n, nq, k, (int)dup, t.n_leaves, t.depth, bad ? "FAIL" : "ok", bad);
   return bad;
 }
 
@@ -155,6 +188,8 @@ int main() {
   bad += run_case(1000, 500, 20, 6, true);
   bad += run_case(20000, 800, 20, 7, false);
   bad += run_case(20000, 400, 20, 8, true);
+  bad += run_case(3000, 300, 20, 9, 2);
+  bad += run_case(70, 100, 8, 10, 2);
   printf(bad ? "TRAVERSAL_CHECK_FAILED\n" : "TRAVERSAL_CHECK_OK\n");
   return bad ? 1 : 0;
 }

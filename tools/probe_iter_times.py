@@ -1,0 +1,30 @@
+"""per-launch sweep times of one 32-pair group (profiling mode: one scheduler group, HIP events per launch) -> which outer
+iterations cost what.  LH_PROF_LOG must point at a file."""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+log = os.environ.setdefault("LH_PROF_LOG", "/tmp/lh_prof.log")
+if os.path.exists(log):
+    os.remove(log)
+from locus_amd import capi, synth
+ctx = capi.Context(0)
+P = capi.default_params(max_iterations=20, max_inner_iterations=20, corr_dist=1.0, transformation_epsilon=1e-12, rotation_epsilon=1e-12)
+S, T = [], []
+for p in range(32):
+    src, tgt, _ = synth.scan_pair(n_rings=64, n_az=1563, scale=2.0, noise=0.02, seed=10 + 2 * p)
+    cs, ct = capi.Cloud(ctx, src), capi.Cloud(ctx, tgt)
+    cs.normals_knn(20); ct.normals_knn(20); ct.drop_index()
+    S.append(cs); T.append(ct)
+capi.align_batch(ctx, P, S, T, max_in_flight=32)   # warm-up
+for t in T:
+    t.drop_index()
+ctx.profile(True); ctx.profile_reset()
+capi.align_batch(ctx, P, S, T, max_in_flight=32)
+st = ctx.profile_get()
+ctx.profile(False)
+rows = [l.split() for l in open(log)]
+sw = [float(v) for k, v in rows if k == "nn_sweep"]
+seed = [float(v) for k, v in rows if k == "nn_seed" or k == "seed"]
+print("compact =", os.environ.get("LH_COMPACT", "1"), "launches", len(sw), "total ms %.3f" % sum(sw))
+print("per-iteration sweep us:", " ".join("%.0f" % (1e3 * v) for v in sw))
+print("other entries:", {k: round(v["ms"], 3) for k, v in st.items()})
