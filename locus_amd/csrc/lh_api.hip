@@ -332,7 +332,10 @@ static lh_status build_indices(lh_ctx* x, lh_cloud* const* clouds, int n_clouds,
     { ProfScope p(x, "index_leaves_scan", 8.0 * total * 3, s);
       launch_index_leaves(ts, s);
       inclusive_scan_u32(x->scan_tmp, x->scan_tmp_bytes, ts.flag, ts.lid, (int)total, s); }
-    { ProfScope p(x, "index_tree", 32.0 * total + 128.0 * total / 4, s); launch_index_trees(x->idx_descs_dev, nb, max_n, ts, x->v32b, s); }
+    { ProfScope p(x, "index_gather_leaves", 48.0 * total, s); launch_index_trees(x->idx_descs_dev, nb, max_n, ts, x->v32b, s, 0); }
+    { ProfScope p(x, "index_radix_tree", 8.0 * total, s); launch_index_trees(x->idx_descs_dev, nb, max_n, ts, x->v32b, s, 1); }
+    { ProfScope p(x, "index_box_tables", 24.0 * total, s); launch_index_trees(x->idx_descs_dev, nb, max_n, ts, x->v32b, s, 2); }
+    { ProfScope p(x, "index_nodes", 32.0 * total, s); launch_index_trees(x->idx_descs_dev, nb, max_n, ts, x->v32b, s, 3); }
     HIPCHK(hipEventRecord(x->idx_build_done, s));
     HIPCHK(hipGetLastError());
     for (int k = 0; k < nb; k++) clouds[o + k]->has_index = true;
@@ -386,8 +389,8 @@ struct Workspace {
 };
 
 static lh_status ctx_ensure_slots(lh_ctx* c, int n_slots, int max_n) {
-  size_t per_slot = std::max<size_t>((size_t)cost_blocks(max_n) * COST_NSUM, MOM_NSUM);
-  int mom_stride = ((max_n + 255) / 256) * 4 * MOM_NSUM;  // one partial per wave of every 256-point workgroup of the fused sweep
+  size_t per_slot = std::max<size_t>((size_t)cost_blocks(max_n) * COST_NSUM, (size_t)FINAL_CHUNKS * MOM_ROW);
+  int mom_stride = ((max_n + 255) / 256) * 4 * MOM_ROW;  // one partial row per wave of every 256-point workgroup of the fused sweep
   if (n_slots <= c->n_slots && per_slot <= c->partials_per_slot && mom_stride <= c->mom_stride) return LH_OK;
   (void)hipStreamSynchronize(c->stream);
   n_slots = std::max(n_slots, c->n_slots);
@@ -435,6 +438,7 @@ struct Task : public CostFn {
   bool sweep_bytes_pending = false;
   bool count_stats = false;  // debug sweeps only
   bool first_sweep = true;   // cold: gets a seed pre-pass
+  long last_walks = -1;      // tree walks of the previous fused sweep (instrumentation: how many certificates failed)
   // outputs
   lh_gicp_result result;
 
@@ -688,7 +692,7 @@ static lh_status group_launch(lh_ctx* c, Group& g) {
       }
       ProfScope p(c, "nn_sweep", bytes, st);
       launch_sweep_fused(c->descs_dev, a, max_n, c->mom_partials_dev, c->mom_stride, st);
-      launch_moments_final(c->descs_dev, ca, c->mom_partials_dev, c->mom_stride, FUSED_CHUNK, c->partials_host, st);
+      launch_moments_final(c->descs_dev, ca, c->mom_partials_dev, c->mom_stride, c->partials_host, st);
     } else {
       {
         ProfScope p(c, "nn_sweep", bytes, st);
@@ -760,8 +764,15 @@ static lh_status group_collect(lh_ctx* c, Group& g) {
     t->resume();
   }
   for (Task* t : g.moms) {  // deliver the moments; the task then runs its whole BFGS solve on the host
-    const double* S = c->partials_host + (size_t)t->slot * c->partials_per_slot;
-    memcpy(t->mom.S, S, sizeof(double) * MOM_NSUM);
+    const double* part = c->partials_host + (size_t)t->slot * c->partials_per_slot;  // FINAL_CHUNKS x 74 chunk sums
+    double* S = t->mom.S;
+    for (int k = 0; k < MOM_NSUM; k++) S[k] = 0.0;
+    double walks = 0.0;
+    for (int ch = 0; ch < FINAL_CHUNKS; ch++) {  // fixed order => bitwise reproducible
+      for (int k = 0; k < MOM_NSUM; k++) S[k] += part[ch * MOM_ROW + k];
+      walks += part[ch * MOM_ROW + MOM_NSUM];
+    }
+    t->last_walks = (long)walks;
     if (c->reduce_fn && c->reduce_fn(t->mom.S, MOM_NSUM, c->reduce_user) != 0) return LH_EDEVICE;
     for (int r = 0; r < 3; r++)
       for (int cc = 0; cc < 4; cc++) t->mom.T0[cc * 4 + r] = t->req_T12[r * 4 + cc];

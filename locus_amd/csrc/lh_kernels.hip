@@ -250,15 +250,20 @@ void launch_index_keys(const IndexDesc* descs, int n_clouds, int max_n, uint32_t
 void launch_index_leaves(const TreeScratch& t, hipStream_t s) {
   hipLaunchKernelGGL(k_leafcell_b, dim3((t.total + 255) / 256), dim3(256), 0, s, t);
 }
-void launch_index_trees(const IndexDesc* descs, int n_clouds, int max_n, const TreeScratch& t, const uint32_t* vals_sorted, hipStream_t s) {
-  hipLaunchKernelGGL(k_gather_b, dim3((max_n + LEAF_CAP + 255) / 256, n_clouds), dim3(256), 0, s, descs, vals_sorted);
+void launch_index_trees(const IndexDesc* descs, int n_clouds, int max_n, const TreeScratch& t, const uint32_t* vals_sorted, hipStream_t s, int stage) {
   int blocks = (t.total + 255) / 256;  // upper bound of the leaf count; the kernels read the real one from lid[total-1]
-  hipLaunchKernelGGL(k_leafrec_b, dim3(blocks), dim3(256), 0, s, t);
-  hipLaunchKernelGGL(k_radix_b, dim3(blocks), dim3(256), 0, s, t);
-  hipLaunchKernelGGL(k_leafbox_b, dim3(blocks), dim3(256), 0, s, descs, t);
-  hipLaunchKernelGGL(k_chunkbox_b, dim3((blocks + 31) / 32), dim3(256), 0, s, t, 1);
-  hipLaunchKernelGGL(k_chunkbox_b, dim3((blocks + 1023) / 1024), dim3(256), 0, s, t, 2);
-  hipLaunchKernelGGL(k_nodex_b, dim3(blocks), dim3(256), 0, s, descs, t);
+  if (stage == 0) {        // sorted points + leaf records
+    hipLaunchKernelGGL(k_gather_b, dim3((max_n + LEAF_CAP + 255) / 256, n_clouds), dim3(256), 0, s, descs, vals_sorted);
+    hipLaunchKernelGGL(k_leafrec_b, dim3(blocks), dim3(256), 0, s, t);
+  } else if (stage == 1) { // hierarchy
+    hipLaunchKernelGGL(k_radix_b, dim3(blocks), dim3(256), 0, s, t);
+  } else if (stage == 2) { // box tables
+    hipLaunchKernelGGL(k_leafbox_b, dim3(blocks), dim3(256), 0, s, descs, t);
+    hipLaunchKernelGGL(k_chunkbox_b, dim3((blocks + 31) / 32), dim3(256), 0, s, t, 1);
+    hipLaunchKernelGGL(k_chunkbox_b, dim3((blocks + 1023) / 1024), dim3(256), 0, s, t, 2);
+  } else {                 // 4-ary nodes + headers
+    hipLaunchKernelGGL(k_nodex_b, dim3(blocks), dim3(256), 0, s, descs, t);
+  }
 }
 
 // ===== K4: NN + Mahalanobis sweep ==========================================================================
@@ -328,6 +333,7 @@ struct SweepPoint {
   double M[9];
   int j;         // target index or -1
   bool matched;
+  bool searched; // the certificate did not cover this query: the tree was walked
 };
 __device__ __forceinline__ void sweep_point(const PairDesc& d, const SweepJob& job, int i, uint64_t* stack, SweepPoint& o) {
   o.p = d.src[i];
@@ -351,6 +357,7 @@ __device__ __forceinline__ void sweep_point(const PairDesc& d, const SweepJob& j
     float dw = sqrtf(col.bd), lo = sqrtf(cq.w);
     if (dw * (1.0f + 1e-5f) + e * (1.0f + 1e-5f) + 1e-12f < lo * (1.0f - 1e-5f)) need_search = false;
   }
+  o.searched = need_search;
   if (need_search) {
     tree_search(tv, qx, qy, qz, col, stack, 256);
     d.cert[i] = make_float4(qx, qy, qz, col.lb);
@@ -427,7 +434,66 @@ __device__ __forceinline__ double mom_value(int k, const double* M6, const doubl
   if (k < 73) return M6[(k - 13) / 10] * pp[(k - 13) % 10];
   return 1.0;
 }
-template <bool WAVE_REDUCE>
+// the moment contributions of one matched point, added to acc[0..73] (acc must be zero-initialised by the caller)
+__device__ __forceinline__ void moments_of_point(const SweepJob& job, const SweepPoint& sp, double* M6, double* Ma, double& aMa, double* pt, double* pp) {
+  pt[0] = (double)sp.p.x; pt[1] = (double)sp.p.y; pt[2] = (double)sp.p.z; pt[3] = 1.0;
+  double T0[12];
+#pragma unroll
+  for (int k = 0; k < 12; k++) T0[k] = (double)job.T[k];
+  double a0 = (((T0[0] * pt[0] + T0[1] * pt[1]) + T0[2] * pt[2]) + T0[3]) - (double)sp.tgt.x;
+  double a1 = (((T0[4] * pt[0] + T0[5] * pt[1]) + T0[6] * pt[2]) + T0[7]) - (double)sp.tgt.y;
+  double a2 = (((T0[8] * pt[0] + T0[9] * pt[1]) + T0[10] * pt[2]) + T0[11]) - (double)sp.tgt.z;
+  M6[0] = sp.M[0]; M6[1] = sp.M[1]; M6[2] = sp.M[2]; M6[3] = sp.M[4]; M6[4] = sp.M[5]; M6[5] = sp.M[8];
+  Ma[0] = (M6[0] * a0 + M6[1] * a1) + M6[2] * a2;
+  Ma[1] = (M6[1] * a0 + M6[3] * a1) + M6[4] * a2;
+  Ma[2] = (M6[2] * a0 + M6[4] * a1) + M6[5] * a2;
+  aMa = (a0 * Ma[0] + a1 * Ma[1]) + a2 * Ma[2];
+  int t = 0;
+#pragma unroll
+  for (int cc = 0; cc < 4; cc++)
+#pragma unroll
+    for (int ee = cc; ee < 4; ee++) pp[t++] = pt[cc] * pt[ee];
+}
+
+// Per-wave reduction of 74 per-lane values, no workgroup barriers inside the loop: after ONE barrier (all lanes are done
+// with their traversal stacks) each wave owns a private 4-KB slice [8 values][64 lanes] of the LDS region; a wave's DS
+// operations execute in order, so write -> fence -> read needs no s_barrier.  64 lanes -> 8 strided partial sums -> 3
+// shuffles.  `value(k)` yields the lane's k-th value.  The row gets two more entries: the number of tree walks of the
+// wave's points (feedback for the scheduler's choice of sweep kernel) and a zero.
+template <class F>
+__device__ __forceinline__ void wave_reduce_row(uint64_t* lds_base, double* out, int walks, F value) {
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  // row stride 72 doubles (not 64): the 16 lanes the LDS serves per cycle read two 64-B pieces of two DIFFERENT rows, and
+  // 576-B rows put those on complementary bank halves; with 512-B rows they collided (SQ_LDS_BANK_CONFLICT = 26 % of the
+  // LDS-active cycles, and the LDS pipe was busy for 78 % of a late sweep)
+  constexpr int RS = 72;
+  double* wst = reinterpret_cast<double*>(lds_base) + wave * (8 * RS);
+  const int v_of = lane >> 3, part = lane & 7;
+  __syncthreads();
+#pragma unroll
+  for (int g = 0; g < (MOM_NSUM + 7) / 8; g++) {
+#pragma unroll
+    for (int v = 0; v < 8; v++) {
+      int k = g * 8 + v;
+      if (k < MOM_NSUM) wst[v * RS + lane] = value(k);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    double s = 0.0;
+#pragma unroll
+    for (int jj = 0; jj < 8; jj++) s += wst[v_of * RS + jj * 8 + part];
+#pragma unroll
+    for (int off = 4; off > 0; off >>= 1) s += __shfl_down(s, off, 8);
+    if (part == 0 && g * 8 + v_of < MOM_NSUM) out[g * 8 + v_of] = s;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (lane == 0) { out[MOM_NSUM] = (double)walks; out[MOM_NSUM + 1] = 0.0; }
+}
+
+// one point per thread (78 VGPRs, 6 waves per SIMD).  A variant with 4 points per thread and the 74 moments accumulated in
+// registers (239 VGPRs, 2 waves per SIMD) pays the reduction once per 4 points but was slower even on certificate-only
+// sweeps (142 vs 128 us): with so few waves the dependent src -> neighbour gathers are no longer hidden.
 __global__ void __launch_bounds__(256) k_sweep_fused(const PairDesc* __restrict__ descs, SweepArgs a, double* __restrict__ partials,
                                                      int partials_stride) {
   extern __shared__ __attribute__((aligned(16))) uint64_t lds_stack[];  // [entries][256], later reused as double[8][256]
@@ -439,96 +505,21 @@ __global__ void __launch_bounds__(256) k_sweep_fused(const PairDesc* __restrict_
   int i = blk * 256 + threadIdx.x;
   SweepPoint sp;
   sp.matched = false;
+  sp.searched = false;
   if (i < d.n) sweep_point(d, job, i, lds_stack + threadIdx.x, sp);
-  double M6[6] = {0, 0, 0, 0, 0, 0}, Ma[3] = {0, 0, 0}, pt[4] = {0, 0, 0, 0}, pp[10], aMa = 0.0;
-  if (sp.matched) {
-    pt[0] = (double)sp.p.x; pt[1] = (double)sp.p.y; pt[2] = (double)sp.p.z; pt[3] = 1.0;
-    double T0[12];
-#pragma unroll
-    for (int k = 0; k < 12; k++) T0[k] = (double)job.T[k];
-    double a0 = (((T0[0] * pt[0] + T0[1] * pt[1]) + T0[2] * pt[2]) + T0[3]) - (double)sp.tgt.x;
-    double a1 = (((T0[4] * pt[0] + T0[5] * pt[1]) + T0[6] * pt[2]) + T0[7]) - (double)sp.tgt.y;
-    double a2 = (((T0[8] * pt[0] + T0[9] * pt[1]) + T0[10] * pt[2]) + T0[11]) - (double)sp.tgt.z;
-    M6[0] = sp.M[0]; M6[1] = sp.M[1]; M6[2] = sp.M[2]; M6[3] = sp.M[4]; M6[4] = sp.M[5]; M6[5] = sp.M[8];
-    Ma[0] = (M6[0] * a0 + M6[1] * a1) + M6[2] * a2;
-    Ma[1] = (M6[1] * a0 + M6[3] * a1) + M6[4] * a2;
-    Ma[2] = (M6[2] * a0 + M6[4] * a1) + M6[5] * a2;
-    aMa = (a0 * Ma[0] + a1 * Ma[1]) + a2 * Ma[2];
-  }
-  {
-    int t = 0;
-#pragma unroll
-    for (int cc = 0; cc < 4; cc++)
-#pragma unroll
-      for (int ee = cc; ee < 4; ee++) pp[t++] = pt[cc] * pt[ee];
-  }
+  double M6[6] = {0, 0, 0, 0, 0, 0}, Ma[3] = {0, 0, 0}, pt[4] = {0, 0, 0, 0}, pp[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, aMa = 0.0;
+  if (sp.matched) moments_of_point(job, sp, M6, Ma, aMa, pt, pp);
   const double live = sp.matched ? 1.0 : 0.0;
-  const int tid = threadIdx.x;
-  if (WAVE_REDUCE) {
-    // Per-wave reduction, no workgroup barriers inside the loop: after ONE barrier (all lanes are done with their
-    // traversal stacks) each wave owns a private 4-KB slice [8 values][64 lanes] of the LDS region; a wave's DS operations
-    // execute in order, so write -> fence -> read needs no s_barrier.  64 lanes -> 8 strided partial sums -> 3 shuffles.
-    const int wave = tid >> 6, lane = tid & 63;
-    double* wst = reinterpret_cast<double*>(lds_stack) + wave * 512;
-    const int v_of = lane >> 3, part = lane & 7;
-    double* out = partials + (size_t)job.slot * partials_stride + ((size_t)blk * 4 + wave) * MOM_NSUM;
-    __syncthreads();
-#pragma unroll
-    for (int g = 0; g < (MOM_NSUM + 7) / 8; g++) {
-#pragma unroll
-      for (int v = 0; v < 8; v++) {
-        int k = g * 8 + v;
-        if (k < MOM_NSUM) wst[v * 64 + lane] = (k == 73) ? live : mom_value(k, M6, Ma, aMa, pt, pp);
-      }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-      __builtin_amdgcn_wave_barrier();
-      double s = 0.0;
-#pragma unroll
-      for (int jj = 0; jj < 8; jj++) s += wst[v_of * 64 + jj * 8 + part];
-#pragma unroll
-      for (int off = 4; off > 0; off >>= 1) s += __shfl_down(s, off, 8);
-      if (part == 0 && g * 8 + v_of < MOM_NSUM) out[g * 8 + v_of] = s;
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-      __builtin_amdgcn_wave_barrier();
-    }
-  } else {
-    // workgroup reduction: [8][256] staging, 256 -> 32 strided partial sums -> 5 shuffles; two barriers per round;
-    // only wave 0's slot of the 4 per-workgroup partial slots is used (the others are written as zeros)
-    double* st = reinterpret_cast<double*>(lds_stack);
-    const int v_of = tid >> 5, part = tid & 31;
-    double* out = partials + (size_t)job.slot * partials_stride + (size_t)blk * 4 * MOM_NSUM;
-    __syncthreads();
-#pragma unroll
-    for (int g = 0; g < (MOM_NSUM + 7) / 8; g++) {
-#pragma unroll
-      for (int v = 0; v < 8; v++) {
-        int k = g * 8 + v;
-        if (k < MOM_NSUM) st[v * 256 + tid] = (k == 73) ? live : mom_value(k, M6, Ma, aMa, pt, pp);
-      }
-      __syncthreads();
-      double s = 0.0;
-#pragma unroll
-      for (int jj = 0; jj < 8; jj++) s += st[v_of * 256 + jj * 32 + part];
-#pragma unroll
-      for (int off = 16; off > 0; off >>= 1) s += __shfl_down(s, off, 32);
-      if (part == 0 && g * 8 + v_of < MOM_NSUM) {
-        out[g * 8 + v_of] = s;
-        out[MOM_NSUM + g * 8 + v_of] = 0.0; out[2 * MOM_NSUM + g * 8 + v_of] = 0.0; out[3 * MOM_NSUM + g * 8 + v_of] = 0.0;
-      }
-      __syncthreads();
-    }
-  }
+  const int walks = __popcll(__ballot(sp.searched));
+  double* out = partials + (size_t)job.slot * partials_stride + ((size_t)blk * 4 + (threadIdx.x >> 6)) * MOM_ROW;
+  wave_reduce_row(lds_stack, out, walks, [&](int k) { return (k == 73) ? live : mom_value(k, M6, Ma, aMa, pt, pp); });
 }
 
 void launch_sweep_fused(const PairDesc* descs, SweepArgs& a, int max_n, double* partials_dev, int partials_stride, hipStream_t s) {
-  a.bpj = (max_n + 255) / 256;
   size_t lds = stack_lds_bytes(a.max_depth, 256);
-  if (lds < 8 * 256 * sizeof(double)) lds = 8 * 256 * sizeof(double);
-  static const bool wave_reduce = []() { const char* e = getenv("LH_FUSED_REDUCE"); return !(e && e[0] == 'b'); }();  // A/B switch
-  if (wave_reduce)
-    hipLaunchKernelGGL(k_sweep_fused<true>, dim3(xcd_grid(a.njobs, a.bpj)), dim3(256), lds, s, descs, a, partials_dev, partials_stride);
-  else
-    hipLaunchKernelGGL(k_sweep_fused<false>, dim3(xcd_grid(a.njobs, a.bpj)), dim3(256), lds, s, descs, a, partials_dev, partials_stride);
+  if (lds < 4 * 8 * 72 * sizeof(double)) lds = 4 * 8 * 72 * sizeof(double);
+  a.bpj = (max_n + 255) / 256;
+  hipLaunchKernelGGL(k_sweep_fused, dim3(xcd_grid(a.njobs, a.bpj)), dim3(256), lds, s, descs, a, partials_dev, partials_stride);
 }
 void launch_sweep(const PairDesc* descs, SweepArgs& a, int max_n, hipStream_t s) {
   a.bpj = (max_n + 255) / 256;
@@ -686,53 +677,57 @@ __global__ void __launch_bounds__(256) k_moments(const PairDesc* __restrict__ de
       double s = 0.0;
 #pragma unroll
       for (int j = 0; j < 16; j++) s += st2[tid][j];
-      partials[(size_t)job.slot * partials_stride + (size_t)blockIdx.x * MOM_NSUM + g * 16 + tid] = s;
+      partials[(size_t)job.slot * partials_stride + (size_t)blockIdx.x * MOM_ROW + g * 16 + tid] = s;
     }
     __syncthreads();
   }
+  if (tid < MOM_ROW - MOM_NSUM) partials[(size_t)job.slot * partials_stride + (size_t)blockIdx.x * MOM_ROW + MOM_NSUM + tid] = 0.0;
 }
 
-// final sum of a job's per-wave / per-workgroup partials: 8 chunks x 74 values per job, each thread adds its chunk in
-// block order (16 independent loads in flight), then the 8 chunk sums are combined in chunk order => bitwise reproducible
-constexpr int FINAL_CHUNKS = 8;
-__global__ void __launch_bounds__(FINAL_CHUNKS * MOM_NSUM) k_moments_final(const PairDesc* __restrict__ descs, CostArgs a, const double* __restrict__ partials,
-                                                                         int partials_stride, int chunk, double* __restrict__ out) {
-  const CostJob& job = a.job[blockIdx.x];
+// final sum of a job's per-wave / per-workgroup partial rows (MOM_ROW doubles each), in two fixed-order stages: workgroup
+// (chunk c, job) adds the rows of chunk c (4 strided sub-sums per column, combined in sub order) and writes MOM_ROW chunk
+// sums into the job's slot of the pinned host buffer; the host adds the FINAL_CHUNKS chunk sums in chunk order => bitwise
+// reproducible.  (One workgroup per job took 23 us per sweep -- 15 % of a late sweep: 32 workgroups cannot pull 30 MB quickly.)
+// rows of a job = ceil(n / ppb) * rpb  (ppb points per workgroup of the producing kernel, rpb rows per workgroup)
+constexpr int FINAL_SUB = 4;
+__global__ void __launch_bounds__(FINAL_SUB * MOM_ROW) k_moments_final(const PairDesc* __restrict__ descs, CostArgs a, const double* __restrict__ partials,
+                                                                      int partials_stride, int ppb, int rpb, double* __restrict__ out) {
+  const CostJob& job = a.job[blockIdx.y];
+  const int c = blockIdx.x;
   int n = descs[job.slot].n;
-  int nb = (n + chunk - 1) / chunk;
-  int v = threadIdx.x % MOM_NSUM, c = threadIdx.x / MOM_NSUM;
+  int nb = ((n + ppb - 1) / ppb) * rpb;
+  int v = threadIdx.x % MOM_ROW, sub = threadIdx.x / MOM_ROW;
   int per = (nb + FINAL_CHUNKS - 1) / FINAL_CHUNKS;
   int b0 = c * per, b1 = min(nb, b0 + per);
   const double* p = partials + (size_t)job.slot * partials_stride + v;
   double s = 0.0;
-  int b = b0;
-  for (; b + 16 <= b1; b += 16) {
-    double t[16];
+  int b = b0 + sub;
+  for (; b + 7 * FINAL_SUB < b1; b += 8 * FINAL_SUB) {
+    double t[8];
 #pragma unroll
-    for (int k = 0; k < 16; k++) t[k] = p[(size_t)(b + k) * MOM_NSUM];
+    for (int k = 0; k < 8; k++) t[k] = p[(size_t)(b + k * FINAL_SUB) * MOM_ROW];
 #pragma unroll
-    for (int k = 0; k < 16; k++) s += t[k];
+    for (int k = 0; k < 8; k++) s += t[k];
   }
-  for (; b < b1; b++) s += p[(size_t)b * MOM_NSUM];
-  __shared__ double sm[FINAL_CHUNKS][MOM_NSUM];
-  sm[c][v] = s;
+  for (; b < b1; b += FINAL_SUB) s += p[(size_t)b * MOM_ROW];
+  __shared__ double sm[FINAL_SUB][MOM_ROW];
+  sm[sub][v] = s;
   __syncthreads();
-  if (c == 0) {
+  if (sub == 0) {
     double tot = 0.0;
 #pragma unroll
-    for (int k = 0; k < FINAL_CHUNKS; k++) tot += sm[k][v];
-    out[job.out_offset + v] = tot;
+    for (int k = 0; k < FINAL_SUB; k++) tot += sm[k][v];
+    out[job.out_offset + c * MOM_ROW + v] = tot;
   }
 }
 
 void launch_moments(const PairDesc* descs, const CostArgs& a, int max_n, double* partials_dev, int partials_stride, double* out,
                     hipStream_t s) {
   hipLaunchKernelGGL(k_moments, dim3(mom_blocks(max_n), a.njobs), dim3(256), 0, s, descs, a, partials_dev, partials_stride);
-  hipLaunchKernelGGL(k_moments_final, dim3(a.njobs), dim3(FINAL_CHUNKS * MOM_NSUM), 0, s, descs, a, partials_dev, partials_stride, MOM_CHUNK, out);
+  hipLaunchKernelGGL(k_moments_final, dim3(FINAL_CHUNKS, a.njobs), dim3(FINAL_SUB * MOM_ROW), 0, s, descs, a, partials_dev, partials_stride, MOM_CHUNK, 1, out);
 }
-void launch_moments_final(const PairDesc* descs, const CostArgs& a, double* partials_dev, int partials_stride, int chunk, double* out,
-                          hipStream_t s) {
-  hipLaunchKernelGGL(k_moments_final, dim3(a.njobs), dim3(FINAL_CHUNKS * MOM_NSUM), 0, s, descs, a, partials_dev, partials_stride, chunk, out);
+void launch_moments_final(const PairDesc* descs, const CostArgs& a, double* partials_dev, int partials_stride, double* out, hipStream_t s) {
+  hipLaunchKernelGGL(k_moments_final, dim3(FINAL_CHUNKS, a.njobs), dim3(FINAL_SUB * MOM_ROW), 0, s, descs, a, partials_dev, partials_stride, 256, 4, out);
 }
 
 // ===== K6 / misc ===========================================================================================

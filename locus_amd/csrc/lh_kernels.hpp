@@ -12,6 +12,7 @@ constexpr int COST_CHUNK = 512;    // source points per cost-kernel workgroup (f
 constexpr int COST_NSUM = 14;      // f, g_t[3], R[9], count
 constexpr int MOM_CHUNK = 1024;    // source points per moment-kernel workgroup
 constexpr int MOM_NSUM = 74;       // c0, B[3][4], H[6][10], count
+constexpr int MOM_ROW = 76;        // a partial row on the device: the 74 sums, the number of tree walks, one pad
 
 // static description of one scan pair's device buffers (lives in device memory, indexed by slot)
 struct PairDesc {
@@ -101,15 +102,16 @@ void launch_index_keys(const IndexDesc* descs, int n_clouds, int max_n, uint32_t
 // flags of the leaf starts (then the caller scans them into t.lid) ...
 void launch_index_leaves(const TreeScratch& t, hipStream_t s);
 // ... and everything after the scan: sorted points, leaf records, radix tree, boxes, 4-ary nodes, headers
-void launch_index_trees(const IndexDesc* descs, int n_clouds, int max_n, const TreeScratch& t, const uint32_t* vals_sorted, hipStream_t s);
+// stage 0: sorted points + leaf records, 1: radix hierarchy, 2: box tables, 3: 4-ary nodes + headers (separate so they can be timed)
+void launch_index_trees(const IndexDesc* descs, int n_clouds, int max_n, const TreeScratch& t, const uint32_t* vals_sorted, hipStream_t s, int stage);
 
 // ---- K4 / K5 ---------------------------------------------------------------------------------------
 void launch_sweep(const PairDesc* descs, SweepArgs& a, int max_n, hipStream_t s);
 // cost_mode 1: sweep + 74-moment reduction in one kernel (one partial per 256-point workgroup), then the final sum
 void launch_sweep_fused(const PairDesc* descs, SweepArgs& a, int max_n, double* partials_dev, int partials_stride, hipStream_t s);
-void launch_moments_final(const PairDesc* descs, const CostArgs& a, double* partials_dev, int partials_stride, int chunk, double* out,
-                          hipStream_t s);
+void launch_moments_final(const PairDesc* descs, const CostArgs& a, double* partials_dev, int partials_stride, double* out, hipStream_t s);
 constexpr int FUSED_CHUNK = 64;   // one 74-double partial per WAVE of the fused sweep
+constexpr int FINAL_CHUNKS = 8;   // the final sum leaves FINAL_CHUNKS x 74 chunk sums per job for the host to add (in chunk order)
 // cold-start helper: exact NN of every 8th source point, written as the warm-start candidate of its 8-point group
 void launch_seed(const PairDesc* descs, SweepArgs& a, int max_n, hipStream_t s);
 constexpr int SEED_GROUP = 8;
