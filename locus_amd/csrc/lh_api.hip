@@ -605,12 +605,14 @@ static lh_status task_prepare(lh_ctx* c, Task* t, bool rebuild_index) {
   d.n_pad = t->ws->n_pad;
   d.m = tgt->n;
   d.m_pad = tgt->n_pad;
-  d.reserved0 = 0;
   d.src_cov_pad = src->n_pad;
   d.corr_dist2 = P.corr_dist * P.corr_dist;  // gicp.hpp:438
   d.gicp_eps = P.gicp_epsilon;
   for (int r = 0; r < 3; r++)
     for (int cc = 0; cc < 3; cc++) d.guess3[r * 3 + cc] = (double)t->guess[cc * 4 + r];
+  d.guess_identity = 1;
+  for (int k = 0; k < 9; k++)
+    if (d.guess3[k] != ((k % 4 == 0) ? 1.0 : 0.0)) d.guess_identity = 0;
   HIPCHK(hipMemcpyAsync(&c->descs_dev[t->slot], &d, sizeof(PairDesc), hipMemcpyHostToDevice, ts));
   HIPCHK(hipGetLastError());
   return LH_OK;

@@ -390,12 +390,19 @@ __device__ __forceinline__ void sweep_point(const PairDesc& d, const SweepJob& j
     }
     // transform_R = double(transformation_) * double(guess), top-left 3x3 (gicp.hpp:450-460); the k = 3 term is T(i,3)*0
     double R[9];
+    if (d.guess_identity) {  // T * I: every product with an off-diagonal 0 vanishes and x * 1.0 + 0.0 = x exactly
 #pragma unroll
-    for (int r = 0; r < 3; r++)
+      for (int r = 0; r < 3; r++)
 #pragma unroll
-      for (int cc = 0; cc < 3; cc++)
-        R[r * 3 + cc] = (((double)job.T[r * 4 + 0] * d.guess3[0 * 3 + cc] + (double)job.T[r * 4 + 1] * d.guess3[1 * 3 + cc]) +
-                         (double)job.T[r * 4 + 2] * d.guess3[2 * 3 + cc]) + (double)job.T[r * 4 + 3] * 0.0;
+        for (int cc = 0; cc < 3; cc++) R[r * 3 + cc] = (double)job.T[r * 4 + cc];
+    } else {
+#pragma unroll
+      for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int cc = 0; cc < 3; cc++)
+          R[r * 3 + cc] = (((double)job.T[r * 4 + 0] * d.guess3[0 * 3 + cc] + (double)job.T[r * 4 + 1] * d.guess3[1 * 3 + cc]) +
+                           (double)job.T[r * 4 + 2] * d.guess3[2 * 3 + cc]) + (double)job.T[r * 4 + 3] * 0.0;
+    }
     mahalanobis(R, C1, C2, o.M);  // gicp.hpp:488-493
     o.tgt = d.tgt_xyz[j];
   }

@@ -31,7 +31,7 @@ struct PairDesc {
   float4* corr;             // per source point: (tgt x, y, z, bitcast tgt idx | -1)     [n]
   double* maha6;            // 6 planes of n_pad doubles: M00 M01 M02 M11 M12 M22
   int n, n_pad, m, m_pad;
-  int reserved0;
+  int guess_identity;  // guess3 = I (the usual case): R = double(transformation_) without the 3x3 product
   int src_cov_pad;  // plane stride of src_cov6
   double corr_dist2;
   double gicp_eps;

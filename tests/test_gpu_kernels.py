@@ -29,6 +29,47 @@ def test_nn1_bit_exact(ctx, capi, oracle, n):
     assert (d2 == do).all()  # float distances bit-identical (same operation order, no FMA)
 
 
+def test_index_heavy_duplicates_and_degenerate_clouds(ctx, capi, oracle):
+    # runs of 50 identical points (more than a leaf holds: the finest key cell is cut into fixed chunks and the radix tree
+    # breaks ties by leaf index), a cloud on a line, a cloud of one repeated point, and far outliers stretching the key grid
+    rng = np.random.default_rng(7)
+    base = (rng.normal(size=(200, 3)) * [5, 3, 1]).astype(np.float32)
+    clouds = {
+        "dup50": np.repeat(base, 50, axis=0),
+        "line": np.stack([np.linspace(-30, 30, 5000), np.zeros(5000), np.zeros(5000)], 1).astype(np.float32),
+        "one_point": np.repeat(np.array([[1.5, -2.0, 0.25]], np.float32), 300, axis=0),
+        "outliers": np.concatenate([base, np.array([[4000.0, 0, 0], [0, -4000.0, 10.0]], np.float32)]),
+    }
+    q = np.concatenate([rng.normal(size=(2000, 3)) * [6, 4, 2], base[:100]]).astype(np.float32)
+    qc = capi.Cloud(ctx, q)
+    for name, pts in clouds.items():
+        tgt = capi.Cloud(ctx, pts)
+        idx, d2 = tgt.nn1(qc)
+        io, do = oracle.nn1_brute(oracle.xyz4(pts), oracle.xyz4(q))
+        assert (idx == io).all() and (d2 == do).all(), name
+        k = 20
+        ki, kd = tgt.knn(qc, k)
+        ko, kdo = oracle.knn_brute(oracle.xyz4(pts), oracle.xyz4(q), k)
+        assert (ki == ko).all() and (kd == kdo).all(), name
+
+
+def test_batched_index_build_mixed_sizes(ctx, capi, oracle):
+    # one batched build (one key sort, one leaf scan, one radix tree over all clouds' leaves) for clouds of very different
+    # sizes, including single-leaf clouds between big ones: every cloud must get exactly its own tree
+    rng = np.random.default_rng(8)
+    sizes = [30000, 3, 8, 9, 12000, 1, 700, 64]
+    tg = [(_cloud_pts(20 + i, max(n, 8), dup=n > 100)[:n] + np.float32(3.0 * i)) for i, n in enumerate(sizes)]
+    src = [(t[: min(len(t), 400)] + rng.normal(scale=0.05, size=(min(len(t), 400), 3))).astype(np.float32) for t in tg]
+    S = [capi.Cloud(ctx, capi.make_pointf(s, np.tile([0, 0, 1.0], (len(s), 1)).astype(np.float32))) for s in src]
+    T = [capi.Cloud(ctx, capi.make_pointf(t, np.tile([0, 0, 1.0], (len(t), 1)).astype(np.float32))) for t in tg]
+    P = capi.default_params(max_iterations=2, corr_dist=5.0)
+    capi.align_batch(ctx, P, S, T, max_in_flight=8)   # builds the 8 target indexes in one batch
+    for t_cloud, t_pts, s_pts in zip(T, tg, src):
+        idx, d2 = t_cloud.nn1(capi.Cloud(ctx, s_pts))  # reuses the batch-built index
+        io, do = oracle.nn1_brute(oracle.xyz4(t_pts), oracle.xyz4(s_pts))
+        assert (idx == io).all() and (d2 == do).all(), len(t_pts)
+
+
 @pytest.mark.parametrize("k", [1, 5, 20])
 def test_knn_bit_exact(ctx, capi, oracle, k):
     pts = _cloud_pts(3, 8000)

@@ -21,7 +21,7 @@ def mean(ds):
     return out
 if not order:
     print("no dispatches match", pat); sys.exit()
-first, last = mean(order[:1]), mean(order[-k:])
+first, last, allm = mean(order[:1]), mean(order[-k:]), mean(order)
 print("kernel ~", pat, "dispatches", len(order))
 for c in sorted(last):
-    print("  %-28s first %14.0f   last-%d mean %14.0f" % (c, first[c], k, last[c]))
+    print("  %-28s first %14.0f   last-%d mean %14.0f   all mean %14.0f" % (c, first[c], k, last[c], allm[c]))
