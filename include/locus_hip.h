@@ -217,6 +217,24 @@ lh_status lh_cloud_remove_nan_normals(const lh_cloud* in, lh_cloud** out);
    the map frame) its nearest map point, copied with normal and intensity into a new cloud of query-size (exact search) */
 lh_status lh_cloud_nearest_neighbors(lh_cloud* map, const lh_cloud* query, lh_cloud** out);
 
+/* The local map itself, device resident: IPointCloudMapper::InsertPoints / Refresh (Locus.cc:464-465, 531-538).
+   point_cloud_mapper is un-vendored ("parity unpinned"); restated from its BLAM lineage: a point enters the map iff the
+   octree voxel of edge `octree_resolution` it falls into is still empty, so the map keeps the FIRST point offered per voxel,
+   in input order.  Voxel = floor(double(p) / resolution).  Non-finite points are never inserted.
+     lh_map_insert   appends the accepted points of `points` (already in the fixed frame; normals / intensity travel along,
+                     zeros if a later cloud lacks them); *n_inserted = how many (the reference's incremental_points size)
+     lh_map_refresh  keeps the points with |p - center|_inf <= half_extent (mapper_->Refresh with box_filter_size,
+                     lo_settings.yaml:58), order preserved
+     lh_map_cloud    the map as a cloud handle (borrowed; NULL while empty): target of lh_gicp_set_target_cloud, first
+                     argument of lh_cloud_nearest_neighbors; its NN index is rebuilt lazily after the map changed */
+typedef struct lh_map lh_map;
+lh_status lh_map_create(lh_ctx* ctx, double octree_resolution, lh_map** out);
+void lh_map_destroy(lh_map* m);
+lh_status lh_map_insert(lh_map* m, const lh_cloud* points, uint32_t* n_inserted);
+lh_status lh_map_refresh(lh_map* m, const float center[3], float half_extent);
+lh_cloud* lh_map_cloud(lh_map* m);
+uint32_t lh_map_size(const lh_map* m);
+
 /* ---- instrumentation (enableTimingOutput analogue) ------------------------- */
 typedef struct {
   char name[32];

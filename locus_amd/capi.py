@@ -94,7 +94,7 @@ EXPORTS = [
     "lh_gicp_set_source", "lh_gicp_set_target", "lh_gicp_set_source_cloud", "lh_gicp_set_target_cloud",
     "lh_gicp_promote_source_to_target", "lh_gicp_align", "lh_gicp_fitness", "lh_set_allreduce", "lh_nn1", "lh_nn1_cloud", "lh_knn_cloud",
     "lh_gicp_align_batch", "lh_cov_knn", "lh_gicp_debug_sweep", "lh_gicp_debug_stats", "lh_debug_traversal_stats", "lh_gicp_debug_cost", "lh_p2plane_information",
-    "lh_icp_covariance", "lh_voxel_grid", "lh_cloud_voxel_grid", "lh_cloud_nearest_neighbors", "lh_normals_knn", "lh_normals_knn_cloud",
+    "lh_icp_covariance", "lh_voxel_grid", "lh_cloud_voxel_grid", "lh_cloud_nearest_neighbors", "lh_map_create", "lh_map_destroy", "lh_map_insert", "lh_map_refresh", "lh_map_cloud", "lh_map_size", "lh_normals_knn", "lh_normals_knn_cloud",
     "lh_normals_radius", "lh_normals_radius_cloud", "lh_cloud_remove_nan_normals", "lh_profile_enable",
     "lh_profile_reset", "lh_profile_get",
 ]
@@ -159,6 +159,15 @@ def lib():
         L.lh_normals_knn_cloud.argtypes = [vp, i32]
         L.lh_cloud_slice.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(vp)]
         L.lh_cloud_concat.argtypes = [C.POINTER(vp), i32, C.POINTER(vp)]
+        L.lh_map_create.argtypes = [vp, dbl, C.POINTER(vp)]
+        L.lh_map_destroy.argtypes = [vp]
+        L.lh_map_destroy.restype = None
+        L.lh_map_insert.argtypes = [vp, vp, C.POINTER(u32)]
+        L.lh_map_refresh.argtypes = [vp, vp, C.c_float]
+        L.lh_map_cloud.argtypes = [vp]
+        L.lh_map_cloud.restype = vp
+        L.lh_map_size.argtypes = [vp]
+        L.lh_map_size.restype = u32
         L.lh_set_allreduce.argtypes = [vp, ALLREDUCE_FN, vp]
         L.lh_normals_radius.argtypes = [vp, C.POINTER(CloudView), C.c_float, vp]
         L.lh_normals_radius_cloud.argtypes = [vp, C.c_float]
@@ -329,8 +338,10 @@ def icp_covariance(Ap, icp_max_covariance=0.01):
 class Cloud:
     """lh_cloud: device-resident cloud."""
 
-    def __init__(self, ctx, points, _handle=None):
+    def __init__(self, ctx, points, _handle=None, _borrowed=False, _owner=None):
         self.ctx = ctx
+        self._borrowed = _borrowed   # a handle owned by another object (lh_map_cloud): never destroyed from here
+        self._owner = _owner
         if _handle is not None:
             self.h = _handle
             return
@@ -343,7 +354,8 @@ class Cloud:
 
     def close(self):
         if getattr(self, "h", None):
-            lib().lh_cloud_destroy(self.h)
+            if not getattr(self, "_borrowed", False):
+                lib().lh_cloud_destroy(self.h)
             self.h = C.c_void_p()
 
     def __del__(self):
@@ -437,6 +449,46 @@ class Cloud:
         out = C.c_void_p()
         _check(lib().lh_cloud_remove_nan_normals(self.h, C.byref(out)), "lh_cloud_remove_nan_normals")
         return Cloud(self.ctx, None, _handle=out)
+
+
+class Map:
+    """lh_map: the device-resident local map behind mapper_->InsertPoints / ApproxNearestNeighbors / Refresh."""
+
+    def __init__(self, ctx, octree_resolution):
+        self.ctx = ctx
+        self.h = C.c_void_p()
+        _check(lib().lh_map_create(ctx.h, float(octree_resolution), C.byref(self.h)), "lh_map_create")
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().lh_map_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            if self.ctx.h:
+                self.close()
+        except Exception:
+            pass
+
+    def __len__(self):
+        return int(lib().lh_map_size(self.h))
+
+    def insert(self, cloud):
+        n = C.c_uint32()
+        _check(lib().lh_map_insert(self.h, cloud.h, C.byref(n)), "lh_map_insert")
+        return n.value
+
+    def refresh(self, center, half_extent):
+        c = np.ascontiguousarray(center, np.float32).reshape(3)
+        _check(lib().lh_map_refresh(self.h, _ptr(c), float(half_extent)), "lh_map_refresh")
+
+    def cloud(self):
+        """the map as a (borrowed) Cloud: GICP target / nearest_neighbors source; None while the map is empty"""
+        h = lib().lh_map_cloud(self.h)
+        if not h:
+            return None
+        return Cloud(self.ctx, None, _handle=C.c_void_p(h), _borrowed=True, _owner=self)
 
 
 def _result_dict(r, trace=None):

@@ -1917,6 +1917,178 @@ lh_status lh_cloud_voxel_grid(const lh_cloud* in, float leaf, int limit_axis, do
   return LH_OK;
 }
 
+// ---- local map: the state behind mapper_->InsertPoints / ApproxNearestNeighbors / Refresh (Locus.cc:464-465,
+// 479-483, 531-538), device resident.  point_cloud_mapper is un-vendored ("parity unpinned"); restated from its BLAM lineage:
+// a point enters the map iff the octree voxel it falls into is still empty, so the map holds one point per voxel of edge
+// `resolution` (the first one offered, in input order).  Voxel = floor(double(p) / resolution) here (PCL's octree anchors its
+// lattice at a bounding box that grows with the data; the lattice phase is the unpinned part).
+struct lh_map {
+  lh_ctx* ctx = nullptr;
+  double res = 0.0;
+  lh_cloud* cloud = nullptr;   // n = points in the map; buffers hold `cap` points
+  int cap = 0;
+  uint64_t* keys = nullptr;    // sorted occupancy keys, one per map point
+};
+
+static lh_status map_reserve(lh_map* m, int need, bool with_nrm, bool with_inten) {
+  lh_cloud* c = m->cloud;
+  if (need <= m->cap && (!with_nrm || c->nrm) && (!with_inten || c->intensity)) return LH_OK;
+  lh_ctx* x = m->ctx;
+  int cap = std::max(need, m->cap);
+  if (need > m->cap) cap = round_up(std::max(need + need / 2, 4096), 256);
+  float4 *xyz = nullptr, *nrm = nullptr;
+  float* inten = nullptr;
+  uint64_t* keys = nullptr;
+  bool want_n = with_nrm || c->nrm, want_i = with_inten || c->intensity;
+  hipError_t e = hipMalloc(&xyz, sizeof(float4) * (size_t)cap);
+  if (e == hipSuccess && want_n) e = hipMalloc(&nrm, sizeof(float4) * (size_t)cap);
+  if (e == hipSuccess && want_i) e = hipMalloc(&inten, sizeof(float) * (size_t)cap);
+  if (e == hipSuccess) e = hipMalloc(&keys, sizeof(uint64_t) * (size_t)cap);
+  if (e == hipSuccess && want_n) e = hipMemsetAsync(nrm, 0, sizeof(float4) * (size_t)cap, x->stream);
+  if (e == hipSuccess && want_i) e = hipMemsetAsync(inten, 0, sizeof(float) * (size_t)cap, x->stream);
+  if (e == hipSuccess && c->n > 0) {
+    e = hipMemcpyAsync(xyz, c->xyz, sizeof(float4) * (size_t)c->n, hipMemcpyDeviceToDevice, x->stream);
+    if (e == hipSuccess && c->nrm) e = hipMemcpyAsync(nrm, c->nrm, sizeof(float4) * (size_t)c->n, hipMemcpyDeviceToDevice, x->stream);
+    if (e == hipSuccess && c->intensity) e = hipMemcpyAsync(inten, c->intensity, sizeof(float) * (size_t)c->n, hipMemcpyDeviceToDevice, x->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(keys, m->keys, sizeof(uint64_t) * (size_t)c->n, hipMemcpyDeviceToDevice, x->stream);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(x->stream);
+  if (e != hipSuccess) { (void)hipFree(xyz); (void)hipFree(nrm); (void)hipFree(inten); (void)hipFree(keys); return e == hipErrorOutOfMemory ? LH_ENOMEM : LH_EDEVICE; }
+  (void)hipFree(c->xyz); (void)hipFree(c->nrm); (void)hipFree(c->intensity); (void)hipFree(m->keys); (void)hipFree(c->cov6);
+  c->xyz = xyz; c->nrm = nrm; c->intensity = inten; m->keys = keys; c->cov6 = nullptr; c->cov_k = 0;
+  c->n_pad = cap;
+  m->cap = cap;
+  return LH_OK;
+}
+
+lh_status lh_map_create(lh_ctx* ctx, double octree_resolution, lh_map** out) {
+  if (!ctx || !out || !(octree_resolution > 0.0)) return LH_EINVAL;
+  lh_map* m = new lh_map();
+  m->ctx = ctx;
+  m->res = octree_resolution;
+  m->cloud = new lh_cloud();
+  m->cloud->ctx = ctx;
+  *out = m;
+  return LH_OK;
+}
+void lh_map_destroy(lh_map* m) {
+  if (!m) return;
+  (void)hipSetDevice(m->ctx->device);
+  (void)hipStreamSynchronize(m->ctx->stream);
+  (void)hipFree(m->keys);
+  cloud_free(m->cloud);
+  delete m;
+}
+uint32_t lh_map_size(const lh_map* m) { return m ? (uint32_t)m->cloud->n : 0; }
+lh_cloud* lh_map_cloud(lh_map* m) { return (m && m->cloud->n > 0) ? m->cloud : nullptr; }
+
+// sort `n` keys of the map in place (through a temporary)
+static lh_status map_sort_keys(lh_map* m, int n) {
+  if (n <= 1) return LH_OK;
+  lh_ctx* x = m->ctx;
+  uint64_t* tmp = nullptr;
+  void* st = nullptr;
+  size_t sb = sort_keys64_temp_bytes(n);
+  hipError_t e = hipMalloc(&tmp, sizeof(uint64_t) * (size_t)n);
+  if (e == hipSuccess) e = hipMalloc(&st, sb ? sb : 16);
+  if (e == hipSuccess) {
+    sort_keys_u64(st, sb, m->keys, tmp, n, x->stream);
+    e = hipMemcpyAsync(m->keys, tmp, sizeof(uint64_t) * (size_t)n, hipMemcpyDeviceToDevice, x->stream);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(x->stream);
+  (void)hipFree(tmp); (void)hipFree(st);
+  return e == hipSuccess ? LH_OK : LH_EDEVICE;
+}
+
+lh_status lh_map_insert(lh_map* m, const lh_cloud* pts, uint32_t* n_inserted) {
+  if (!m || !pts || pts->ctx != m->ctx || pts->n <= 0) return LH_EINVAL;
+  lh_ctx* x = m->ctx;
+  HIPCHK(hipSetDevice(x->device));
+  const int n = pts->n, m0 = m->cloud->n;
+  const double inv_res = 1.0 / m->res;
+  uint64_t *k0 = nullptr, *k1 = nullptr;
+  uint32_t *v0 = nullptr, *v1 = nullptr, *acc = nullptr, *incl = nullptr;
+  void *st = nullptr, *sc = nullptr;
+  size_t sb = sort64_temp_bytes(n), cb = scan_temp_bytes(n);
+  auto cleanup = [&]() { (void)hipFree(k0); (void)hipFree(k1); (void)hipFree(v0); (void)hipFree(v1); (void)hipFree(acc); (void)hipFree(incl); (void)hipFree(st); (void)hipFree(sc); };
+  hipError_t e = hipMalloc(&k0, 8 * (size_t)n);
+  if (e == hipSuccess) e = hipMalloc(&k1, 8 * (size_t)n);
+  if (e == hipSuccess) e = hipMalloc(&v0, 4 * (size_t)n);
+  if (e == hipSuccess) e = hipMalloc(&v1, 4 * (size_t)n);
+  if (e == hipSuccess) e = hipMalloc(&acc, 4 * (size_t)n);
+  if (e == hipSuccess) e = hipMalloc(&incl, 4 * (size_t)n);
+  if (e == hipSuccess) e = hipMalloc(&st, sb ? sb : 16);
+  if (e == hipSuccess) e = hipMalloc(&sc, cb ? cb : 16);
+  if (e != hipSuccess) { cleanup(); return LH_ENOMEM; }
+  uint32_t total = 0;
+  {
+    ProfScope p(x, "map_insert", 48.0 * n);
+    launch_map_keys(pts->xyz, n, inv_res, k0, v0, x->stream);
+    sort_pairs_u64(st, sb, k0, k1, v0, v1, n, 64, x->stream);   // stable: equal voxels keep input order
+    launch_map_accept(k1, v1, n, m->keys, m0, acc, x->stream);
+    inclusive_scan_u32(sc, cb, acc, incl, n, x->stream);
+  }
+  e = hipMemcpyAsync(&total, incl + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, x->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(x->stream);
+  if (e != hipSuccess) { cleanup(); return LH_EDEVICE; }
+  lh_status stt = LH_OK;
+  if (total > 0) {
+    stt = map_reserve(m, m0 + (int)total, pts->nrm != nullptr, pts->intensity != nullptr);
+    if (!stt) {
+      lh_cloud* c = m->cloud;
+      launch_map_compact(incl, n, pts->xyz, pts->nrm, pts->intensity, inv_res, m0, c->xyz, c->nrm, c->intensity, m->keys, x->stream);
+      if (hipGetLastError() != hipSuccess) stt = LH_EDEVICE;
+      if (!stt) stt = map_sort_keys(m, m0 + (int)total);
+      if (!stt) { c->n = m0 + (int)total; c->has_index = false; c->cov_k = 0; }
+    }
+  }
+  (void)hipStreamSynchronize(x->stream);
+  cleanup();
+  if (!stt && n_inserted) *n_inserted = total;
+  return stt;
+}
+
+// mapper_->Refresh(current_pose) with box_filter_size (lo_settings.yaml:58): the sliding-window crop of the local map
+lh_status lh_map_refresh(lh_map* m, const float center[3], float half_extent) {
+  if (!m || !center || !(half_extent > 0.0f)) return LH_EINVAL;
+  lh_ctx* x = m->ctx;
+  lh_cloud* c = m->cloud;
+  const int n = c->n;
+  if (n == 0) return LH_OK;
+  HIPCHK(hipSetDevice(x->device));
+  uint32_t *flags = nullptr, *incl = nullptr;
+  void* sc = nullptr;
+  size_t cb = scan_temp_bytes(n);
+  float4 *xyz = nullptr, *nrm = nullptr;
+  float* inten = nullptr;
+  uint64_t* keys = nullptr;
+  auto cleanup = [&]() { (void)hipFree(flags); (void)hipFree(incl); (void)hipFree(sc); (void)hipFree(xyz); (void)hipFree(nrm); (void)hipFree(inten); (void)hipFree(keys); };
+  hipError_t e = hipMalloc(&flags, 4 * (size_t)n);
+  if (e == hipSuccess) e = hipMalloc(&incl, 4 * (size_t)n);
+  if (e == hipSuccess) e = hipMalloc(&sc, cb ? cb : 16);
+  if (e == hipSuccess) e = hipMalloc(&xyz, sizeof(float4) * (size_t)m->cap);
+  if (e == hipSuccess && c->nrm) e = hipMalloc(&nrm, sizeof(float4) * (size_t)m->cap);
+  if (e == hipSuccess && c->intensity) e = hipMalloc(&inten, sizeof(float) * (size_t)m->cap);
+  if (e == hipSuccess) e = hipMalloc(&keys, sizeof(uint64_t) * (size_t)m->cap);
+  if (e != hipSuccess) { cleanup(); return LH_ENOMEM; }
+  uint32_t total = 0;
+  {
+    ProfScope p(x, "map_refresh", 64.0 * n);
+    launch_box_flags(c->xyz, n, center[0], center[1], center[2], half_extent, flags, x->stream);
+    inclusive_scan_u32(sc, cb, flags, incl, n, x->stream);
+    launch_map_compact(incl, n, c->xyz, c->nrm, c->intensity, 1.0 / m->res, 0, xyz, nrm, inten, keys, x->stream);
+  }
+  e = hipMemcpyAsync(&total, incl + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, x->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(x->stream);
+  if (e != hipSuccess) { cleanup(); return LH_EDEVICE; }
+  std::swap(c->xyz, xyz); std::swap(c->nrm, nrm); std::swap(c->intensity, inten); std::swap(m->keys, keys);
+  c->n = (int)total;
+  c->has_index = false;
+  c->cov_k = 0;
+  cleanup();  // frees the old buffers (now in the temporaries)
+  return map_sort_keys(m, (int)total);
+}
+
 // ---- next-row helper: mapper_->ApproxNearestNeighbors (Locus.cc:479-483) ------------------------------
 // for every query point the nearest map point is copied (xyz, normal, intensity) into a new cloud; the reference uses an
 // approximate octree search, this is the exact search (never farther than the reference's answer)

@@ -1107,6 +1107,79 @@ void launch_compact(const uint32_t* incl, int n, const float4* xyz, const float4
   hipLaunchKernelGGL(k_compact, dim3((n + 255) / 256), dim3(256), 0, s, incl, n, xyz, nrm, inten, oxyz, onrm, ointen);
 }
 
+// ===== local map: PointCloudMapper::InsertPoints / Refresh on the device =======================================
+// occupancy key of a point = its voxel floor(p / resolution) packed 21 bits per axis (offset 2^20); ~0 = rejected
+__device__ __forceinline__ uint64_t map_voxel_key(float4 p, double inv_res) {
+  if (!(isfinite(p.x) && isfinite(p.y) && isfinite(p.z))) return ~0ull;
+  double fx = floor((double)p.x * inv_res), fy = floor((double)p.y * inv_res), fz = floor((double)p.z * inv_res);
+  const double lim = 1048575.0;
+  if (fx < -lim || fx > lim || fy < -lim || fy > lim || fz < -lim || fz > lim) return ~0ull;
+  uint64_t ix = (uint64_t)((long long)fx + 1048576), iy = (uint64_t)((long long)fy + 1048576), iz = (uint64_t)((long long)fz + 1048576);
+  return (ix << 42) | (iy << 21) | iz;
+}
+__global__ void __launch_bounds__(256) k_map_keys(const float4* __restrict__ xyz, int n, double inv_res, uint64_t* __restrict__ keys,
+                                                  uint32_t* __restrict__ vals) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  keys[i] = map_voxel_key(xyz[i], inv_res);
+  if (vals) vals[i] = (uint32_t)i;
+}
+// sorted (key, input index) pairs -> accept[input index] = 1 for the FIRST point (lowest input index: the sort is stable) of
+// every voxel that the map does not occupy yet (binary search in the map's sorted keys)
+__global__ void __launch_bounds__(256) k_map_accept(const uint64_t* __restrict__ skeys, const uint32_t* __restrict__ svals, int n,
+                                                    const uint64_t* __restrict__ map_keys, int m, uint32_t* __restrict__ accept) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  uint64_t k = skeys[i];
+  uint32_t ok = 0;
+  if (k != ~0ull && (i == 0 || skeys[i - 1] != k)) {
+    int lo = 0, hi = m;
+    while (lo < hi) {
+      int mid = (lo + hi) >> 1;
+      if (map_keys[mid] < k) lo = mid + 1; else hi = mid;
+    }
+    ok = (lo < m && map_keys[lo] == k) ? 0u : 1u;
+  }
+  accept[svals[i]] = ok;
+}
+// Refresh (box filter around the current pose): keep points with |p - c|_inf <= half (pcl::CropBox bounds are inclusive)
+__global__ void __launch_bounds__(256) k_box_flags(const float4* __restrict__ xyz, int n, float cx, float cy, float cz, float half,
+                                                   uint32_t* __restrict__ flags) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float4 p = xyz[i];
+  flags[i] = (p.x >= cx - half && p.x <= cx + half && p.y >= cy - half && p.y <= cy + half && p.z >= cz - half && p.z <= cz + half) ? 1u : 0u;
+}
+// order-preserving compaction of (xyz, nrm, intensity) into dst arrays starting at dst_off; also emits the kept points' keys
+__global__ void __launch_bounds__(256) k_map_compact(const uint32_t* __restrict__ incl, int n, const float4* __restrict__ xyz,
+                                                     const float4* __restrict__ nrm, const float* __restrict__ inten, double inv_res, int dst_off,
+                                                     float4* __restrict__ oxyz, float4* __restrict__ onrm, float* __restrict__ ointen,
+                                                     uint64_t* __restrict__ okeys) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  uint32_t here = incl[i], before = i ? incl[i - 1] : 0u;
+  if (here == before) return;
+  float4 p = xyz[i];
+  int o = dst_off + (int)before;
+  oxyz[o] = make_float4(p.x, p.y, p.z, 1.0f);
+  if (onrm) onrm[o] = nrm ? nrm[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+  if (ointen) ointen[o] = inten ? inten[i] : 0.0f;
+  if (okeys) okeys[o] = map_voxel_key(p, inv_res);
+}
+void launch_map_keys(const float4* xyz, int n, double inv_res, uint64_t* keys, uint32_t* vals, hipStream_t s) {
+  hipLaunchKernelGGL(k_map_keys, dim3((n + 255) / 256), dim3(256), 0, s, xyz, n, inv_res, keys, vals);
+}
+void launch_map_accept(const uint64_t* skeys, const uint32_t* svals, int n, const uint64_t* map_keys, int m, uint32_t* accept, hipStream_t s) {
+  hipLaunchKernelGGL(k_map_accept, dim3((n + 255) / 256), dim3(256), 0, s, skeys, svals, n, map_keys, m, accept);
+}
+void launch_box_flags(const float4* xyz, int n, float cx, float cy, float cz, float half, uint32_t* flags, hipStream_t s) {
+  hipLaunchKernelGGL(k_box_flags, dim3((n + 255) / 256), dim3(256), 0, s, xyz, n, cx, cy, cz, half, flags);
+}
+void launch_map_compact(const uint32_t* incl, int n, const float4* xyz, const float4* nrm, const float* inten, double inv_res, int dst_off,
+                        float4* oxyz, float4* onrm, float* ointen, uint64_t* okeys, hipStream_t s) {
+  hipLaunchKernelGGL(k_map_compact, dim3((n + 255) / 256), dim3(256), 0, s, incl, n, xyz, nrm, inten, inv_res, dst_off, oxyz, onrm, ointen, okeys);
+}
+
 // ===== K8: point-to-plane information matrix ===============================================================
 // Ap = sum H^T H, H = [a x n, n]; 21 unique entries per block of 1024 points, fixed reduction shape
 __global__ void __launch_bounds__(256) k_ap(const float4* __restrict__ qn, int n, const float4* __restrict__ ref_nrm,

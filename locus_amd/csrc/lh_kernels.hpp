@@ -148,6 +148,13 @@ void launch_finite_normal_flags(const float4* nrm, int n, uint32_t* flags, hipSt
 void launch_compact(const uint32_t* incl, int n, const float4* xyz, const float4* nrm, const float* inten, float4* oxyz, float4* onrm,
                     float* ointen, hipStream_t s);
 
+// ---- local map ------------------------------------------------------------------------------
+void launch_map_keys(const float4* xyz, int n, double inv_res, uint64_t* keys, uint32_t* vals /*nullable*/, hipStream_t s);
+void launch_map_accept(const uint64_t* skeys, const uint32_t* svals, int n, const uint64_t* map_keys, int m, uint32_t* accept, hipStream_t s);
+void launch_box_flags(const float4* xyz, int n, float cx, float cy, float cz, float half, uint32_t* flags, hipStream_t s);
+void launch_map_compact(const uint32_t* incl, int n, const float4* xyz, const float4* nrm, const float* inten, double inv_res, int dst_off,
+                        float4* oxyz, float4* onrm, float* ointen, uint64_t* okeys, hipStream_t s);
+
 // ---- K8 ----------------------------------------------------------------------------------------------
 // stage 1: per-block partial sums (x,y,z float-in-double) for the centroid; stage 2 etc. are in lh_api.hip
 void launch_ap(const float4* qnorm, int n, const float4* ref_nrm, const int64_t* corr, double* partials /*blocks*21*/, hipStream_t s);
@@ -164,6 +171,8 @@ void launch_voxel_heads(const uint32_t* keys, int n, uint32_t* heads, hipStream_
 // one thread per voxel head: sequential float centroid of the segment in sorted (= input) order
 void launch_voxel_centroids(const float4* xyzi, const uint32_t* keys, const uint32_t* vals, const uint32_t* heads,
                             const uint32_t* rank_incl, int n, float4* out, uint32_t out_cap, hipStream_t s);
+size_t sort_keys64_temp_bytes(int n);
+void sort_keys_u64(void* temp, size_t temp_bytes, const uint64_t* keys_in, uint64_t* keys_out, int n, hipStream_t s);
 size_t scan_temp_bytes(int n);
 void inclusive_scan_u32(void* temp, size_t temp_bytes, const uint32_t* in, uint32_t* out, int n, hipStream_t s);
 

@@ -31,6 +31,15 @@ void sort_pairs_u64(void* temp, size_t temp_bytes, const uint64_t* keys_in, uint
   (void)rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0, (unsigned)end_bit, s);
 }
 
+size_t sort_keys64_temp_bytes(int n) {
+  size_t bytes = 0;
+  (void)rocprim::radix_sort_keys(nullptr, bytes, (const uint64_t*)nullptr, (uint64_t*)nullptr, (size_t)n, 0, 64, (hipStream_t)0);
+  return bytes;
+}
+void sort_keys_u64(void* temp, size_t temp_bytes, const uint64_t* keys_in, uint64_t* keys_out, int n, hipStream_t s) {
+  (void)rocprim::radix_sort_keys(temp, temp_bytes, keys_in, keys_out, (size_t)n, 0, 64, s);
+}
+
 size_t scan_temp_bytes(int n) {
   size_t bytes = 0;
   (void)rocprim::inclusive_scan(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)n, rocprim::plus<uint32_t>(),

@@ -5,6 +5,7 @@
 #include <numeric>
 
 #include "PointCloudLocalization.hpp"
+#include "PointCloudMapperHip.hpp"
 #include "PointCloudOdometry.hpp"
 
 using namespace locus_hip;
@@ -154,6 +155,37 @@ int main() {
     pcl_.GetLatestDeltaCovariance(dc);
     EXPECT_NEAR(dc[0], 0.01, epsilion);
     EXPECT(pcl_.MotionUpdate(gu::Transform3()));
+  }
+
+  {  // mapper_ call order of Locus.cc:462-489 / 531-538 on the device-resident map (no reference test exists: the mapper is un-vendored)
+    PointCloudMapperHip mapper(ctx);
+    EXPECT(mapper.Initialize(0.05));
+    mapper.SetBoxFilterSize(1);
+    auto box = GenerateHollowCubic(ctx);
+    PointCloudF inc;
+    EXPECT(mapper.InsertPoints(*box, &inc));
+    EXPECT(inc.size() == mapper.Size() && inc.size() > 0 && inc.size() <= box->size());
+    size_t first = mapper.Size();
+    EXPECT(mapper.InsertPoints(*box, &inc));          // the same points again: every voxel is taken
+    EXPECT(inc.size() == 0 && mapper.Size() == first);
+    PointCloudF shifted = *box, nb;
+    for (auto& p : shifted.points) p.x += 0.004f;     // stays inside the 5-cm voxels' neighbourhood
+    EXPECT(mapper.ApproxNearestNeighbors(shifted, &nb));
+    EXPECT(nb.size() == shifted.size());
+    double worst = 0;
+    for (size_t i = 0; i < nb.size(); i++) {
+      double dx = nb.points[i].x - shifted.points[i].x, dy = nb.points[i].y - shifted.points[i].y, dz = nb.points[i].z - shifted.points[i].z;
+      worst = std::max(worst, dx * dx + dy * dy + dz * dz);
+    }
+    EXPECT(worst < 0.11 * 0.11);                      // a map point within one grid step (0.1 m) of every query
+    gu::Transform3 pose;                              // identity: the cube spans [0, 0.9]^3, so a 1-m box keeps all of it
+    mapper.UpdateCurrentPose(pose);
+    mapper.Refresh(pose);
+    EXPECT(mapper.Size() == first);
+    pose.translation = gu::Vec3(5.0, 0.0, 0.0);
+    mapper.Refresh(pose);                             // window moved away: nothing left
+    EXPECT(mapper.Size() == 0);
+    EXPECT(!mapper.ApproxNearestNeighbors(shifted, &nb));
   }
 
   lh_destroy(ctx);

@@ -360,3 +360,43 @@ def read_pcd_xyzi(path, cap=1 << 22):
     if n < 0:
         raise IOError("cannot read %s (%d)" % (path, n))
     return buf[:n].copy()
+
+
+# ---- local map, restated sequentially.  point_cloud_mapper is un-vendored: "parity unpinned"; semantics from its
+# BLAM lineage (InsertPoints: a point is added iff its octree voxel is still empty; Refresh: box crop around the pose).
+def map_voxel(p, resolution):
+    """voxel of a float32 point: floor(double(p) / resolution) per axis"""
+    return tuple(int(np.floor(float(c) * (1.0 / float(resolution)))) for c in p[:3])
+
+
+class MapOracle:
+    """pure-Python restatement (small cases only): occupancy set + points in insertion order"""
+
+    def __init__(self, resolution):
+        self.res = float(resolution)
+        self.occ = set()
+        self.pts = []      # rows: index into the concatenation of everything ever offered (for order checks) is not kept; xyz only
+        self.extra = []    # per-point payload (e.g. intensity)
+
+    def insert(self, pts, payload=None):
+        added = []
+        for i, p in enumerate(np.asarray(pts, np.float32)):
+            if not np.all(np.isfinite(p[:3])):
+                continue
+            v = map_voxel(p, self.res)
+            if v in self.occ:
+                continue
+            self.occ.add(v)
+            self.pts.append(p[:3].copy())
+            self.extra.append(None if payload is None else payload[i])
+            added.append(i)
+        return added
+
+    def refresh(self, center, half):
+        c = np.asarray(center, np.float32)
+        h = np.float32(half)
+        keep = [k for k, p in enumerate(self.pts) if np.all(p >= c - h) and np.all(p <= c + h)]
+        self.pts = [self.pts[k] for k in keep]
+        self.extra = [self.extra[k] for k in keep]
+        self.occ = {map_voxel(p, self.res) for p in self.pts}
+        return keep

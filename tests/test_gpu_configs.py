@@ -166,3 +166,66 @@ def test_batched_odometry_stream_chain_ate(ctx, capi, oracle):
           % (ate(chains[1], gt), a0, a1, floor))
     assert a0 < max(1.0 * floor, 1e-3)    # same arithmetic; only the summation order differs (may flip a line-search branch)
     assert a1 < max(3.0 * floor, 2e-2)    # different but equally valid rounding: held to the reference's own noise floor
+
+
+def test_local_map_insert_refresh_and_scan_to_map(ctx, capi, oracle):
+    # the mapper behind Locus.cc:464-465 / 479-483 / 531-538, device resident.  Insert / Refresh are integer
+    # (voxel occupancy) work: accepted points, their order and payload must be IDENTICAL to the sequential restatement.
+    rng = np.random.default_rng(31)
+    res = 0.25
+    m, mo = capi.Map(ctx, res), oracle.MapOracle(res)
+    assert len(m) == 0 and m.cloud() is None
+    offered = []
+    for k in range(4):
+        pts = (rng.normal(size=(3000, 3)) * [6, 4, 1.5] + [2.0 * k, 0, 0]).astype(np.float32)
+        pts[::97] = pts[1]                       # repeated points inside one call
+        if k == 2:
+            pts[5] = [np.nan, 0, 0]              # never inserted
+        inten = (1000 * k + np.arange(len(pts))).astype(np.float32)
+        n_add = m.insert(capi.Cloud(ctx, capi.make_pointxyzi(pts, inten)))
+        added = mo.insert(pts, inten)
+        assert n_add == len(added)
+        offered.append(pts)
+    d = m.cloud().download()
+    assert len(m) == len(mo.pts) == len(d)
+    assert np.array_equal(np.stack([d["x"], d["y"], d["z"]], 1), np.stack(mo.pts))          # same points, same order
+    assert np.array_equal(d["intensity"], np.array(mo.extra, np.float32))
+    # one point per voxel, and re-offering everything adds nothing
+    vox = {oracle.map_voxel(p, res) for p in mo.pts}
+    assert len(vox) == len(mo.pts)
+    assert m.insert(capi.Cloud(ctx, np.concatenate(offered)[np.isfinite(np.concatenate(offered)[:, 0])])) == 0
+    # ApproxNearestNeighbors (exact here) through the map handle
+    q = (rng.normal(size=(500, 3)) * [5, 3, 1]).astype(np.float32)
+    nb = m.cloud().nearest_neighbors(capi.Cloud(ctx, q)).download()
+    io, _ = oracle.nn1_brute(oracle.xyz4(np.stack(mo.pts)), oracle.xyz4(q))
+    assert np.array_equal(np.stack([nb["x"], nb["y"], nb["z"]], 1), np.stack(mo.pts)[io])
+    # Refresh = sliding-window crop (box_filter_size), order preserved; the freed voxels accept points again
+    center, half = np.array([3.0, 0.5, 0.0], np.float32), 4.0
+    m.refresh(center, half)
+    mo.refresh(center, half)
+    d = m.cloud().download()
+    assert np.array_equal(np.stack([d["x"], d["y"], d["z"]], 1), np.stack(mo.pts))
+    far = np.array([[20.0, 0, 0], [20.01, 0, 0], [-20.0, 1, 0]], np.float32)
+    assert m.insert(capi.Cloud(ctx, far)) == len(mo.insert(far)) == 2
+
+    # scan-to-map in the reference's order of calls: first scan builds the map, the next scan is registered against its
+    # nearest map neighbours (Locus.cc:462-489) and then inserted
+    pose1 = synth.pose_matrix(0.3, -0.1, 0.0, 0, 0, 0.03)
+    s0, n0 = synth.scan(np.eye(4), 32, 900, (-25.0, 15.0), 2.0, 0.02, seed=71, with_normals=True)
+    s1, n1 = synth.scan(pose1, 32, 900, (-25.0, 15.0), 2.0, 0.02, seed=72, with_normals=True)
+    lm = capi.Map(ctx, 0.05)
+    assert lm.insert(capi.Cloud(ctx, capi.make_pointf(s0, n0))) > 0.9 * len(s0)
+    guess = synth.pose_matrix(0.25, -0.05, 0.0, 0, 0, 0.02)             # odometry prior: scan 1 in the fixed frame, roughly
+    c1 = capi.Cloud(ctx, capi.make_pointf(s1, n1))
+    c1_fixed = c1.transform(oracle.mat_to_T(guess.astype(np.float32)), with_normals=True)
+    neigh = lm.cloud().nearest_neighbors(c1_fixed)
+    P = capi.default_params(max_iterations=20, max_inner_iterations=50, corr_dist=0.5, transformation_epsilon=1e-5)
+    g = capi.Gicp(ctx, P)
+    g.set_source(c1_fixed)
+    g.set_target(neigh)
+    r = g.align()
+    T = oracle.T_to_mat(r["T"]).astype(np.float64) @ guess
+    assert r["status"] == 0 and np.abs(T[:3, 3] - pose1[:3, 3]).max() < 0.03 and np.abs(T[:3, :3] - pose1[:3, :3]).max() < 3e-3
+    before = len(lm)
+    added = lm.insert(c1.transform(oracle.mat_to_T(T.astype(np.float32)), with_normals=True))
+    assert 0 < added < len(s1) and len(lm) == before + added

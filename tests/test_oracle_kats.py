@@ -233,3 +233,16 @@ def test_radius_normals_plane_and_sparse(oracle):
     # k-NN flavour agrees where the 0.3 m ball holds the same evidence (interior of the grid)
     knn = oracle.normals_knn(oracle.xyz4(pts[:-2]), 20)
     assert np.allclose(knn[:, :3], out[:-2, :3], atol=2e-3)
+
+
+def test_map_oracle_first_point_per_voxel(oracle):
+    """local-map restatement (the mapper is un-vendored, semantics from Locus.cc:464-465 / 531-538 + BLAM):
+    one point per octree voxel, the first one offered; Refresh is an inclusive box crop that frees the voxels it drops"""
+    m = oracle.MapOracle(0.5)
+    pts = np.array([[0.1, 0.1, 0.1], [0.4, 0.2, 0.3], [0.6, 0.1, 0.1], [-0.1, 0.1, 0.1], [np.nan, 0, 0], [0.1, 0.1, 0.1]], np.float32)
+    assert m.insert(pts) == [0, 2, 3]            # 1 and 5 share voxel (0,0,0) with 0; 3 is voxel (-1,0,0): floor, not truncation
+    assert m.insert(pts) == []
+    assert oracle.map_voxel(np.array([-0.1, 0.1, 0.1], np.float32), 0.5) == (-1, 0, 0)
+    kept = m.refresh([0.0, 0.0, 0.0], 0.5)
+    assert kept == [0, 2] and len(m.pts) == 2    # |x| <= 0.5 keeps 0.1 and -0.1; 0.6 goes
+    assert m.insert(pts) == [2]                  # its voxel is free again
