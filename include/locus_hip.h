@@ -213,6 +213,13 @@ lh_status lh_normals_radius(lh_ctx* ctx, const lh_cloud_view* in, float radius, 
 lh_status lh_normals_radius_cloud(lh_cloud* c, float radius);
 lh_status lh_cloud_remove_nan_normals(const lh_cloud* in, lh_cloud** out);
 
+/* SURVEY 8f-2 (next row): BodyFilter (body_filter.cc:27-52) = pcl::CropBox with min/max corners, a box yaw (setRotation(0, 0,
+   rotation)) and setNegative(true): the points INSIDE the robot's body box are removed.  negative = 0 keeps the inside
+   instead.  Order preserved, non-finite points dropped, normals / intensity travel along; LH_EINVAL if nothing survives.
+   (The point is rotated into the box frame with cosf/sinf(yaw) in float; PCL inverts an Affine3f -- "parity unpinned" for
+   points within rounding of a box face.) */
+lh_status lh_cloud_crop_box(const lh_cloud* in, const float min_pt[3], const float max_pt[3], float yaw, int negative, lh_cloud** out);
+
 /* SURVEY 8f-1 (next row): IPointCloudMapper::ApproxNearestNeighbors (Locus.cc:479-483) -- for every point of `query` (already in
    the map frame) its nearest map point, copied with normal and intensity into a new cloud of query-size (exact search) */
 lh_status lh_cloud_nearest_neighbors(lh_cloud* map, const lh_cloud* query, lh_cloud** out);

@@ -94,7 +94,7 @@ EXPORTS = [
     "lh_gicp_set_source", "lh_gicp_set_target", "lh_gicp_set_source_cloud", "lh_gicp_set_target_cloud",
     "lh_gicp_promote_source_to_target", "lh_gicp_align", "lh_gicp_fitness", "lh_set_allreduce", "lh_nn1", "lh_nn1_cloud", "lh_knn_cloud",
     "lh_gicp_align_batch", "lh_cov_knn", "lh_gicp_debug_sweep", "lh_gicp_debug_stats", "lh_debug_traversal_stats", "lh_gicp_debug_cost", "lh_p2plane_information",
-    "lh_icp_covariance", "lh_voxel_grid", "lh_cloud_voxel_grid", "lh_cloud_nearest_neighbors", "lh_map_create", "lh_map_destroy", "lh_map_insert", "lh_map_refresh", "lh_map_cloud", "lh_map_size", "lh_normals_knn", "lh_normals_knn_cloud",
+    "lh_icp_covariance", "lh_voxel_grid", "lh_cloud_voxel_grid", "lh_cloud_nearest_neighbors", "lh_cloud_crop_box", "lh_map_create", "lh_map_destroy", "lh_map_insert", "lh_map_refresh", "lh_map_cloud", "lh_map_size", "lh_normals_knn", "lh_normals_knn_cloud",
     "lh_normals_radius", "lh_normals_radius_cloud", "lh_cloud_remove_nan_normals", "lh_profile_enable",
     "lh_profile_reset", "lh_profile_get",
 ]
@@ -159,6 +159,7 @@ def lib():
         L.lh_normals_knn_cloud.argtypes = [vp, i32]
         L.lh_cloud_slice.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(vp)]
         L.lh_cloud_concat.argtypes = [C.POINTER(vp), i32, C.POINTER(vp)]
+        L.lh_cloud_crop_box.argtypes = [vp, vp, vp, C.c_float, i32, C.POINTER(vp)]
         L.lh_map_create.argtypes = [vp, dbl, C.POINTER(vp)]
         L.lh_map_destroy.argtypes = [vp]
         L.lh_map_destroy.restype = None
@@ -401,6 +402,14 @@ class Cloud:
         out = C.c_void_p()
         _check(lib().lh_cloud_voxel_grid(self.h, leaf, limit_axis, float(max(lo, -3e38)), float(min(hi, 3e38)), C.byref(out)),
                "lh_cloud_voxel_grid")
+        return Cloud(self.ctx, None, _handle=out)
+
+    def crop_box(self, min_pt, max_pt, yaw=0.0, negative=True):
+        """BodyFilter (body_filter.cc:27-52): pcl::CropBox, negative=True removes the inside of the box"""
+        mn = np.ascontiguousarray(min_pt, np.float32).reshape(3)
+        mx = np.ascontiguousarray(max_pt, np.float32).reshape(3)
+        out = C.c_void_p()
+        _check(lib().lh_cloud_crop_box(self.h, _ptr(mn), _ptr(mx), float(yaw), 1 if negative else 0, C.byref(out)), "lh_cloud_crop_box")
         return Cloud(self.ctx, None, _handle=out)
 
     def nearest_neighbors(self, query_cloud):

@@ -1917,6 +1917,52 @@ lh_status lh_cloud_voxel_grid(const lh_cloud* in, float leaf, int limit_axis, do
   return LH_OK;
 }
 
+// ---- BodyFilter (body_filter.cc:27-52): CropBox, order-preserving, on the device ---------------------------------------------
+static lh_status compact_cloud(const lh_cloud* in, uint32_t* d_flags, lh_cloud** out) {  // flags -> scan -> new cloud
+  lh_ctx* c = in->ctx;
+  const int n = in->n;
+  uint32_t* d_incl = nullptr;
+  void* d_tmp = nullptr;
+  size_t tmp_bytes = scan_temp_bytes(n);
+  hipError_t e = hipMalloc(&d_incl, sizeof(uint32_t) * (size_t)n);
+  if (e == hipSuccess) e = hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 16);
+  if (e != hipSuccess) { (void)hipFree(d_incl); (void)hipFree(d_tmp); return LH_ENOMEM; }
+  inclusive_scan_u32(d_tmp, tmp_bytes, d_flags, d_incl, n, c->stream);
+  uint32_t total = 0;
+  e = hipMemcpyAsync(&total, d_incl + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  lh_status st = e == hipSuccess ? LH_OK : LH_EDEVICE;
+  lh_cloud* o = nullptr;
+  if (!st && total == 0) st = LH_EINVAL;  // nothing survives: no cloud to return
+  if (!st) {
+    o = new lh_cloud();
+    o->ctx = c; o->n = (int)total; o->n_pad = round_up(o->n, 256);
+    if (hipMalloc(&o->xyz, sizeof(float4) * (size_t)o->n_pad) != hipSuccess ||
+        (in->nrm && hipMalloc(&o->nrm, sizeof(float4) * (size_t)o->n_pad) != hipSuccess) ||
+        (in->intensity && hipMalloc(&o->intensity, sizeof(float) * (size_t)o->n_pad) != hipSuccess))
+      st = LH_ENOMEM;
+  }
+  if (!st) {
+    launch_map_compact(d_incl, n, in->xyz, in->nrm, in->intensity, 1.0, 0, o->xyz, o->nrm, o->intensity, nullptr, c->stream);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) st = LH_EDEVICE;
+  }
+  (void)hipFree(d_incl); (void)hipFree(d_tmp);
+  if (st) { cloud_free(o); return st; }
+  *out = o;
+  return LH_OK;
+}
+lh_status lh_cloud_crop_box(const lh_cloud* in, const float min_pt[3], const float max_pt[3], float yaw, int negative, lh_cloud** out) {
+  if (!in || !min_pt || !max_pt || !out || in->n <= 0) return LH_EINVAL;
+  lh_ctx* c = in->ctx;
+  HIPCHK(hipSetDevice(c->device));
+  uint32_t* d_flags = nullptr;
+  HIPCHK(hipMalloc(&d_flags, sizeof(uint32_t) * (size_t)in->n));
+  { ProfScope p(c, "crop_box", 20.0 * in->n); launch_crop_flags(in->xyz, in->n, min_pt, max_pt, cosf(yaw), sinf(yaw), negative, d_flags, c->stream); }
+  lh_status st = compact_cloud(in, d_flags, out);
+  (void)hipFree(d_flags);
+  return st;
+}
+
 // ---- local map: the state behind mapper_->InsertPoints / ApproxNearestNeighbors / Refresh (Locus.cc:464-465,
 // 479-483, 531-538), device resident.  point_cloud_mapper is un-vendored ("parity unpinned"); restated from its BLAM lineage:
 // a point enters the map iff the octree voxel it falls into is still empty, so the map holds one point per voxel of edge

@@ -1107,6 +1107,25 @@ void launch_compact(const uint32_t* incl, int n, const float4* xyz, const float4
   hipLaunchKernelGGL(k_compact, dim3((n + 255) / 256), dim3(256), 0, s, incl, n, xyz, nrm, inten, oxyz, onrm, ointen);
 }
 
+// ===== BodyFilter (body_filter.cc:27-52): pcl::CropBox with a yaw-rotated box, negative = keep what is OUTSIDE ================
+// flags[i] = 1 if point i survives.  Non-finite points are dropped (CropBox skips them when keep_organized is off).
+__global__ void __launch_bounds__(256) k_crop_flags(const float4* __restrict__ xyz, int n, float minx, float miny, float minz, float maxx,
+                                                    float maxy, float maxz, float c, float s, int negative, uint32_t* __restrict__ flags) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float4 p = xyz[i];
+  uint32_t keep = 0;
+  if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) {
+    float lx = c * p.x + s * p.y, ly = c * p.y - s * p.x, lz = p.z;  // inverse of the box pose Rz(yaw)
+    bool outside = lx < minx || ly < miny || lz < minz || lx > maxx || ly > maxy || lz > maxz;
+    keep = (outside == (negative != 0)) ? 1u : 0u;
+  }
+  flags[i] = keep;
+}
+void launch_crop_flags(const float4* xyz, int n, const float* mn, const float* mx, float c, float s, int negative, uint32_t* flags, hipStream_t st) {
+  hipLaunchKernelGGL(k_crop_flags, dim3((n + 255) / 256), dim3(256), 0, st, xyz, n, mn[0], mn[1], mn[2], mx[0], mx[1], mx[2], c, s, negative, flags);
+}
+
 // ===== local map: PointCloudMapper::InsertPoints / Refresh on the device =======================================
 // occupancy key of a point = its voxel floor(p / resolution) packed 21 bits per axis (offset 2^20); ~0 = rejected
 __device__ __forceinline__ uint64_t map_voxel_key(float4 p, double inv_res) {

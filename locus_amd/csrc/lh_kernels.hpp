@@ -148,6 +148,8 @@ void launch_finite_normal_flags(const float4* nrm, int n, uint32_t* flags, hipSt
 void launch_compact(const uint32_t* incl, int n, const float4* xyz, const float4* nrm, const float* inten, float4* oxyz, float4* onrm,
                     float* ointen, hipStream_t s);
 
+void launch_crop_flags(const float4* xyz, int n, const float* mn, const float* mx, float c, float s, int negative, uint32_t* flags, hipStream_t st);
+
 // ---- local map ------------------------------------------------------------------------------
 void launch_map_keys(const float4* xyz, int n, double inv_res, uint64_t* keys, uint32_t* vals /*nullable*/, hipStream_t s);
 void launch_map_accept(const uint64_t* skeys, const uint32_t* svals, int n, const uint64_t* map_keys, int m, uint32_t* accept, hipStream_t s);

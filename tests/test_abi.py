@@ -98,3 +98,29 @@ def test_traversal_device_functions_on_host():
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "TRAVERSAL_CHECK_OK" in out.stdout
+
+
+def test_adaptive_voxelization_controller_on_host():
+    """Locus::ApplyAdaptiveInputVoxelization (Locus.cc:780-810) restated in locus_amd/host/AdaptiveVoxelization.hpp: plain C++"""
+    exe = "/tmp/lh_controller_check"
+    src = os.path.join(ROOT, "tests", "host_emu", "controller_check.cpp")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", src, "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and "CONTROLLER_CHECK_OK" in out.stdout, out.stdout + out.stderr
+
+
+def test_pcd_io_and_pointcloud2_mapping_on_host(oracle):
+    """PCD v0.7 reader/writer (Locus.cc:749-751; the GICP test's fixtures) and the sensor_msgs/PointCloud2 <->
+    lh_cloud_view mapping of the filter nodelets' boundary; the reader must agree with the oracle's independent reader"""
+    import numpy as np
+    exe = "/tmp/lh_io_check"
+    src = os.path.join(ROOT, "tests", "host_emu", "io_check.cpp")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", src, "-o", exe])
+    for name, n in (("query_82_garage.pcd", 811), ("reference_82_garage.pcd", 8112)):
+        fixture = os.path.join(ROOT, "tests", "golden", name)
+        out = subprocess.run([exe, fixture, "/tmp/lh_io_check_tmp.pcd"], capture_output=True, text=True)
+        assert out.returncode == 0 and "IO_CHECK_OK" in out.stdout, out.stdout + out.stderr
+        line = [l for l in out.stdout.splitlines() if l.startswith("POINTS")][0].split()
+        assert int(line[1]) == n
+        ref = oracle.read_pcd_xyzi(fixture).astype(np.float64).sum(0)
+        assert np.allclose([float(v) for v in line[3:7]], ref, rtol=1e-8)

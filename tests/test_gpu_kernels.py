@@ -246,6 +246,33 @@ def test_cloud_slice_and_concat(ctx, capi):
     assert len(mm) == 1010 and np.array_equal(mm["x"][:1000], a["x"])
 
 
+def test_body_filter_crop_box(ctx, capi):
+    # BodyFilter (body_filter.cc:27-52): CropBox(min, max, yaw) with setNegative(true) removes the robot's own returns
+    rng = np.random.default_rng(13)
+    pts = (rng.uniform(-3, 3, size=(20000, 3))).astype(np.float32)
+    pts[7] = [np.nan, 0, 0]
+    inten = np.arange(len(pts), dtype=np.float32)
+    mn, mx, yaw = np.array([-0.8, -0.5, -0.4], np.float32), np.array([0.9, 0.5, 0.6], np.float32), 0.3
+    c, s = np.float32(np.cos(np.float32(yaw))), np.float32(np.sin(np.float32(yaw)))
+    lx, ly, lz = c * pts[:, 0] + s * pts[:, 1], c * pts[:, 1] - s * pts[:, 0], pts[:, 2]
+    with np.errstate(invalid="ignore"):
+        outside = (lx < mn[0]) | (ly < mn[1]) | (lz < mn[2]) | (lx > mx[0]) | (ly > mx[1]) | (lz > mx[2])
+    finite = np.isfinite(pts).all(1)
+    # points whose rotated coordinate is within rounding of a face may differ between numpy's and the device's cosf/sinf
+    margin = np.minimum.reduce([np.abs(lx - mn[0]), np.abs(lx - mx[0]), np.abs(ly - mn[1]), np.abs(ly - mx[1])]) < 1e-5
+    cloud = capi.Cloud(ctx, capi.make_pointxyzi(pts, inten))
+    for negative in (True, False):
+        keep = finite & (outside if negative else ~outside)
+        got = cloud.crop_box(mn, mx, yaw, negative).download()
+        ids = got["intensity"].astype(np.int64)
+        assert (np.diff(ids) > 0).all()                                    # order preserved
+        expect = np.where(keep)[0]
+        diff = np.setxor1d(ids, expect)
+        assert all(margin[d] for d in diff) and len(diff) <= 2, diff       # identical away from the faces
+        assert np.array_equal(np.stack([got["x"], got["y"], got["z"]], 1), pts[ids])
+    assert 0 < (finite & ~outside).sum() < 2000                            # the box really removed something
+
+
 def test_p2plane_information_kat_and_oracle(ctx, capi, oracle):
     pts, nrm = synth.plane_grid(10, 10, 0.1)
     c = capi.Cloud(ctx, capi.make_pointf(pts, nrm))

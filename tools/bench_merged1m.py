@@ -52,8 +52,9 @@ def main():
     g = capi.Gicp(ctx, P)
 
     def preprocess(parts):
-        merged = capi.Cloud.concat(parts)
-        v = merged.voxel_grid(args.leaf, 2, -100.0, 100.0)
+        merged = capi.Cloud.concat(parts)                                      # PointCloudMerger.cc:158-159
+        merged = merged.crop_box([-0.6, -0.45, -0.3], [0.6, 0.45, 0.5], 0.0, True)  # BodyFilter: drop returns from the robot itself
+        v = merged.voxel_grid(args.leaf, 2, -100.0, 100.0)                     # CustomVoxelGrid + z pass-through
         v.normals_knn(20)
         return merged, v
 
@@ -91,7 +92,7 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps({"workload": "configs[4] (SURVEY 8d config 5): 3 lidars -> merge -> voxel %.2f -> k=20 normals -> GICP 20 iters vs previous frame" % args.leaf,
+        print(json.dumps({"workload": "configs[4] (SURVEY 8d config 5): 3 lidars -> merge -> body crop -> voxel %.2f -> k=20 normals -> GICP 20 iters vs previous frame" % args.leaf,
                           "n_gpus": world, "backend": args.backend if world > 1 else None, "raw_points": n_raw, "voxelised_points": n_vox,
                           "frames_timed": k, "ms_filter_per_frame": round(1e3 * t_filter / k, 3), "ms_gicp_per_frame": round(1e3 * t_align / k, 3),
                           "frames_per_s": round(k / (t_filter + t_align), 3), "max_translation_err_vs_truth_m": max(errs),
