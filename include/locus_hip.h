@@ -213,6 +213,37 @@ lh_status lh_normals_radius(lh_ctx* ctx, const lh_cloud_view* in, float radius, 
 lh_status lh_normals_radius_cloud(lh_cloud* c, float radius);
 lh_status lh_cloud_remove_nan_normals(const lh_cloud* in, lh_cloud** out);
 
+/* ---- NDT: registration_method "ndt" = pclomp::NormalDistributionsTransform<PointF, PointF>
+   (multithreaded_gicp/include/multithreaded_ndt/ndt_omp.h, ndt_omp_impl.hpp; SetupICP NDT branch PointCloudOdometry.cc:182-196).
+   Neighbour search = KDTREE (the class default, never changed by LOCUS): the voxels whose CENTROID lies within `resolution` of
+   the transformed point.  "Parity unpinned": the reference holds no NDT test or stored output. ---- */
+typedef struct {
+  float resolution;               /* setResolution, voxel edge (1.0) */
+  int max_iterations;             /* setMaximumIterations (35; LOCUS: icp_iterations) */
+  double step_size;               /* setStepSize: More-Thuente maximum step (0.1) */
+  double outlier_ratio;           /* setOulierRatio (0.55) */
+  double transformation_epsilon;  /* setTransformationEpsilon (0.1; LOCUS: icp_tf_epsilon) */
+  double min_covar_eigvalue_mult; /* VoxelGridCovariance::setCovEigValueInflationRatio (0.01) */
+  int min_points_per_voxel;       /* VoxelGridCovariance::setMinPointPerVoxel (6) */
+  int reserved0;
+} lh_ndt_params;
+typedef struct lh_ndt lh_ndt;
+void lh_default_ndt_params(lh_ndt_params* p);
+lh_status lh_ndt_create(lh_ctx* ctx, const lh_ndt_params* p, lh_ndt** out);
+void lh_ndt_destroy(lh_ndt* g);
+lh_status lh_ndt_set_params(lh_ndt* g, const lh_ndt_params* p);          /* a new resolution re-initialises the voxel structure */
+lh_status lh_ndt_set_source(lh_ndt* g, const lh_cloud_view* v);
+lh_status lh_ndt_set_target(lh_ndt* g, const lh_cloud_view* v);          /* setInputTarget -> init(): voxel statistics of the target */
+lh_status lh_ndt_set_source_cloud(lh_ndt* g, lh_cloud* c);               /* borrowed device clouds */
+lh_status lh_ndt_set_target_cloud(lh_ndt* g, lh_cloud* c);
+/* align + computeTransformation (ndt_omp_impl.hpp:101-212).  Result fields: T = final_transformation_, converged, iterations,
+   fitness = getTransformationProbability() (score / n), cost_passes = device evaluations, n_correspondences_last = target cells */
+lh_status lh_ndt_align(lh_ndt* g, const float guess[16], lh_gicp_result* out, void* aligned_out, uint32_t stride, uint32_t off_xyz);
+/* test hooks: the target's cells (mean, inverse covariance, float centroid; ascending voxel index) and one evaluation of
+   computeDerivatives (hessian_only = 0) / computeHessian (hessian_only = 1) at the pose p6 = (x, y, z, roll, pitch, yaw) */
+lh_status lh_ndt_debug_cells(lh_ndt* g, int* n_cells, double* mean3, double* icov9, float* centroid4, int cap);
+lh_status lh_ndt_debug_derivatives(lh_ndt* g, const double p6[6], int want_h, int hessian_only, double* score, double grad6[6], double hess36[36]);
+
 /* SURVEY 8f-2 (next row): BodyFilter (body_filter.cc:27-52) = pcl::CropBox with min/max corners, a box yaw (setRotation(0, 0,
    rotation)) and setNegative(true): the points INSIDE the robot's body box are removed.  negative = 0 keeps the inside
    instead.  Order preserved, non-finite points dropped, normals / intensity travel along; LH_EINVAL if nothing survives.

@@ -54,6 +54,19 @@ class GicpParams(C.Structure):
     ]
 
 
+class NdtParams(C.Structure):
+    _fields_ = [
+        ("resolution", C.c_float),
+        ("max_iterations", C.c_int),
+        ("step_size", C.c_double),
+        ("outlier_ratio", C.c_double),
+        ("transformation_epsilon", C.c_double),
+        ("min_covar_eigvalue_mult", C.c_double),
+        ("min_points_per_voxel", C.c_int),
+        ("reserved0", C.c_int),
+    ]
+
+
 class GicpResult(C.Structure):
     _fields_ = [
         ("T", C.c_float * 16),
@@ -94,7 +107,9 @@ EXPORTS = [
     "lh_gicp_set_source", "lh_gicp_set_target", "lh_gicp_set_source_cloud", "lh_gicp_set_target_cloud",
     "lh_gicp_promote_source_to_target", "lh_gicp_align", "lh_gicp_fitness", "lh_set_allreduce", "lh_nn1", "lh_nn1_cloud", "lh_knn_cloud",
     "lh_gicp_align_batch", "lh_cov_knn", "lh_gicp_debug_sweep", "lh_gicp_debug_stats", "lh_debug_traversal_stats", "lh_gicp_debug_cost", "lh_p2plane_information",
-    "lh_icp_covariance", "lh_voxel_grid", "lh_cloud_voxel_grid", "lh_cloud_nearest_neighbors", "lh_cloud_crop_box", "lh_map_create", "lh_map_destroy", "lh_map_insert", "lh_map_refresh", "lh_map_cloud", "lh_map_size", "lh_normals_knn", "lh_normals_knn_cloud",
+    "lh_icp_covariance", "lh_voxel_grid", "lh_cloud_voxel_grid", "lh_cloud_nearest_neighbors", "lh_cloud_crop_box", "lh_default_ndt_params", "lh_ndt_create", "lh_ndt_destroy", "lh_ndt_set_params",
+    "lh_ndt_set_source", "lh_ndt_set_target", "lh_ndt_set_source_cloud", "lh_ndt_set_target_cloud", "lh_ndt_align", "lh_ndt_debug_cells",
+    "lh_ndt_debug_derivatives", "lh_map_create", "lh_map_destroy", "lh_map_insert", "lh_map_refresh", "lh_map_cloud", "lh_map_size", "lh_normals_knn", "lh_normals_knn_cloud",
     "lh_normals_radius", "lh_normals_radius_cloud", "lh_cloud_remove_nan_normals", "lh_profile_enable",
     "lh_profile_reset", "lh_profile_get",
 ]
@@ -159,6 +174,19 @@ def lib():
         L.lh_normals_knn_cloud.argtypes = [vp, i32]
         L.lh_cloud_slice.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(vp)]
         L.lh_cloud_concat.argtypes = [C.POINTER(vp), i32, C.POINTER(vp)]
+        L.lh_default_ndt_params.argtypes = [C.POINTER(NdtParams)]
+        L.lh_default_ndt_params.restype = None
+        L.lh_ndt_create.argtypes = [vp, C.POINTER(NdtParams), C.POINTER(vp)]
+        L.lh_ndt_destroy.argtypes = [vp]
+        L.lh_ndt_destroy.restype = None
+        L.lh_ndt_set_params.argtypes = [vp, C.POINTER(NdtParams)]
+        L.lh_ndt_set_source.argtypes = [vp, C.POINTER(CloudView)]
+        L.lh_ndt_set_target.argtypes = [vp, C.POINTER(CloudView)]
+        L.lh_ndt_set_source_cloud.argtypes = [vp, vp]
+        L.lh_ndt_set_target_cloud.argtypes = [vp, vp]
+        L.lh_ndt_align.argtypes = [vp, vp, C.POINTER(GicpResult), vp, u32, u32]
+        L.lh_ndt_debug_cells.argtypes = [vp, C.POINTER(i32), vp, vp, vp, i32]
+        L.lh_ndt_debug_derivatives.argtypes = [vp, vp, i32, i32, C.POINTER(dbl), vp, vp]
         L.lh_cloud_crop_box.argtypes = [vp, vp, vp, C.c_float, i32, C.POINTER(vp)]
         L.lh_map_create.argtypes = [vp, dbl, C.POINTER(vp)]
         L.lh_map_destroy.argtypes = [vp]
@@ -458,6 +486,82 @@ class Cloud:
         out = C.c_void_p()
         _check(lib().lh_cloud_remove_nan_normals(self.h, C.byref(out)), "lh_cloud_remove_nan_normals")
         return Cloud(self.ctx, None, _handle=out)
+
+
+def default_ndt_params(**kw):
+    p = NdtParams()
+    lib().lh_default_ndt_params(C.byref(p))
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+class Ndt:
+    """lh_ndt: the registration object of registration_method "ndt" (pclomp::NormalDistributionsTransform)."""
+
+    def __init__(self, ctx, params=None):
+        self.ctx = ctx
+        self.params = params or default_ndt_params()
+        self.h = C.c_void_p()
+        _check(lib().lh_ndt_create(ctx.h, C.byref(self.params), C.byref(self.h)), "lh_ndt_create")
+        self._keep = []
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().lh_ndt_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            if self.ctx.h:
+                self.close()
+        except Exception:
+            pass
+
+    def set_params(self, params):
+        self.params = params
+        _check(lib().lh_ndt_set_params(self.h, C.byref(params)), "lh_ndt_set_params")
+
+    def set_source(self, cloud):
+        if isinstance(cloud, Cloud):
+            self._keep.append(cloud)
+            _check(lib().lh_ndt_set_source_cloud(self.h, cloud.h), "lh_ndt_set_source_cloud")
+        else:
+            v, keep = view_of(cloud)
+            _check(lib().lh_ndt_set_source(self.h, C.byref(v)), "lh_ndt_set_source")
+
+    def set_target(self, cloud):
+        if isinstance(cloud, Cloud):
+            self._keep.append(cloud)
+            _check(lib().lh_ndt_set_target_cloud(self.h, cloud.h), "lh_ndt_set_target_cloud")
+        else:
+            v, keep = view_of(cloud)
+            _check(lib().lh_ndt_set_target(self.h, C.byref(v)), "lh_ndt_set_target")
+
+    def align(self, guess=None):
+        r = GicpResult()
+        g = np.ascontiguousarray(guess, np.float32).reshape(16) if guess is not None else None
+        _check(lib().lh_ndt_align(self.h, _ptr(g), C.byref(r), None, 0, 0), "lh_ndt_align")
+        d = _result_dict(r)
+        d["trans_probability"] = d["fitness"]
+        d["evaluations"] = d["cost_passes"]
+        d["n_cells"] = d["n_corr_last"]
+        return d
+
+    def cells(self):
+        n = C.c_int()
+        _check(lib().lh_ndt_debug_cells(self.h, C.byref(n), None, None, None, 0), "lh_ndt_debug_cells")
+        mean, icov, cen = np.empty((n.value, 3)), np.empty((n.value, 3, 3)), np.empty((n.value, 4), np.float32)
+        _check(lib().lh_ndt_debug_cells(self.h, C.byref(n), _ptr(mean), _ptr(icov), _ptr(cen), n.value), "lh_ndt_debug_cells")
+        return mean, icov, cen
+
+    def derivatives(self, p6, want_h=True, hessian_only=False):
+        p = np.ascontiguousarray(p6, np.float64)
+        s = C.c_double()
+        g, H = np.empty(6), np.empty((6, 6))
+        _check(lib().lh_ndt_debug_derivatives(self.h, _ptr(p), 1 if want_h else 0, 1 if hessian_only else 0, C.byref(s), _ptr(g), _ptr(H)),
+               "lh_ndt_debug_derivatives")
+        return s.value, g, H
 
 
 class Map:

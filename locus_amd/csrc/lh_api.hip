@@ -24,6 +24,7 @@
 
 #include "../../include/locus_hip.h"
 #include "lh_bfgs.hpp"
+#include "lh_ndt_host.hpp"
 #include "lh_kernels.hpp"
 
 using namespace lh;
@@ -1795,30 +1796,35 @@ static float dec_ordered_host(uint32_t e) {
   return f;
 }
 // device core: d_in = n x (x, y, z, intensity); on success *d_out (hipMalloc'ed, caller frees) holds *total centroids
-static lh_status voxel_grid_device(lh_ctx* c, const float4* d_in, int n, float leaf, int limit_axis, double lo, double hi,
-                                   float4** d_out, uint32_t* total_out) {
-  *d_out = nullptr;
-  *total_out = 0;
+// voxel segmentation shared by the voxel-grid filter and the NDT target grid: sorted (voxel key, point) pairs in the context's
+// scratch (c->keys1 / c->vals1), segment heads and their inclusive scan; total = number of occupied voxels
+struct VoxelSegments {
+  uint32_t *heads = nullptr, *rank = nullptr;
+  void* scan_tmp = nullptr;
+  uint32_t total = 0;
+  void release() { (void)hipFree(heads); (void)hipFree(rank); (void)hipFree(scan_tmp); heads = rank = nullptr; scan_tmp = nullptr; }
+};
+static lh_status voxel_segments(lh_ctx* c, const float4* d_in, int n, float leaf, int limit_axis, double lo, double hi, VoxelSegments* vs) {
+  vs->total = 0;
   lh_status st = ctx_ensure_scratch(c, n);
   if (st) return st;
-  uint32_t *d_heads = nullptr, *d_rank = nullptr;
-  void* d_scan_tmp = nullptr;
   size_t scan_bytes = scan_temp_bytes(n);
-  HIPCHK(hipMalloc(&d_heads, sizeof(uint32_t) * (size_t)n));
-  HIPCHK(hipMalloc(&d_rank, sizeof(uint32_t) * (size_t)n));
-  HIPCHK(hipMalloc(&d_scan_tmp, scan_bytes ? scan_bytes : 16));
-  auto cleanup = [&]() { (void)hipFree(d_heads); (void)hipFree(d_rank); (void)hipFree(d_scan_tmp); };
+  hipError_t e = hipMalloc(&vs->heads, sizeof(uint32_t) * (size_t)n);
+  if (e == hipSuccess) e = hipMalloc(&vs->rank, sizeof(uint32_t) * (size_t)n);
+  if (e == hipSuccess) e = hipMalloc(&vs->scan_tmp, scan_bytes ? scan_bytes : 16);
+  if (e != hipSuccess) { vs->release(); return LH_ENOMEM; }
   float flo = (float)std::max(lo, -3.0e38), fhi = (float)std::min(hi, 3.0e38);
   { ProfScope p(c, "voxel_bbox", 16.0 * n); launch_voxel_bbox(d_in, n, limit_axis, flo, fhi, c->bbox, c->stream); }
   uint32_t enc[6];
-  HIPCHK(hipMemcpyAsync(enc, c->bbox, sizeof(enc), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
+  e = hipMemcpyAsync(enc, c->bbox, sizeof(enc), hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  if (e != hipSuccess) { vs->release(); return LH_EDEVICE; }
   float mn[3], mx[3];
   for (int a = 0; a < 3; a++) { mn[a] = dec_ordered_host(enc[a]); mx[a] = dec_ordered_host(enc[3 + a]); }
-  if (!(mn[0] <= mx[0])) { cleanup(); return LH_OK; }  // no point passed the filter
+  if (!(mn[0] <= mx[0])) return LH_OK;  // no point passed the filter (total = 0)
   float inv = 1.0f / leaf;
   int64_t dx = (int64_t)((mx[0] - mn[0]) * inv) + 1, dy = (int64_t)((mx[1] - mn[1]) * inv) + 1, dz = (int64_t)((mx[2] - mn[2]) * inv) + 1;
-  if (dx * dy * dz > (int64_t)INT32_MAX) { cleanup(); return LH_EINVAL; }  // PCL: "Leaf size is too small ... Integer indices would overflow"
+  if (dx * dy * dz > (int64_t)INT32_MAX) { vs->release(); return LH_EINVAL; }  // PCL: "Leaf size is too small ... Integer indices would overflow"
   VoxelGridDesc g;
   g.inv_leaf = inv; g.limit_axis = limit_axis; g.lo = flo; g.hi = fhi;
   int divb[3];
@@ -1830,21 +1836,30 @@ static lh_status voxel_grid_device(lh_ctx* c, const float4* d_in, int n, float l
   { ProfScope p(c, "voxel_keys", 24.0 * n); launch_voxel_keys(d_in, n, g, c->keys0, c->vals0, c->stream); }
   { ProfScope p(c, "voxel_radix_sort", 64.0 * n); sort_pairs_u32(c->sort_temp, c->sort_temp_bytes, c->keys0, c->keys1, c->vals0, c->vals1, n, 32, c->stream); }
   { ProfScope p(c, "voxel_segments", 16.0 * n);
-    launch_voxel_heads(c->keys1, n, d_heads, c->stream);
-    inclusive_scan_u32(d_scan_tmp, scan_bytes, d_heads, d_rank, n, c->stream); }
-  uint32_t total = 0;
-  HIPCHK(hipMemcpyAsync(&total, d_rank + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
-  if (total > 0) {
-    HIPCHK(hipMalloc(d_out, sizeof(float4) * (size_t)total));
-    ProfScope p(c, "voxel_centroids", 32.0 * n);
-    launch_voxel_centroids(d_in, c->keys1, c->vals1, d_heads, d_rank, n, *d_out, total, c->stream);
-  }
-  HIPCHK(hipGetLastError());
-  HIPCHK(hipStreamSynchronize(c->stream));
-  *total_out = total;
-  cleanup();
+    launch_voxel_heads(c->keys1, n, vs->heads, c->stream);
+    inclusive_scan_u32(vs->scan_tmp, scan_bytes, vs->heads, vs->rank, n, c->stream); }
+  e = hipMemcpyAsync(&vs->total, vs->rank + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  if (e != hipSuccess) { vs->release(); return LH_EDEVICE; }
   return LH_OK;
+}
+static lh_status voxel_grid_device(lh_ctx* c, const float4* d_in, int n, float leaf, int limit_axis, double lo, double hi,
+                                   float4** d_out, uint32_t* total_out) {
+  *d_out = nullptr;
+  *total_out = 0;
+  VoxelSegments vs;
+  lh_status st = voxel_segments(c, d_in, n, leaf, limit_axis, lo, hi, &vs);
+  if (st) return st;
+  if (vs.total > 0) {
+    if (hipMalloc(d_out, sizeof(float4) * (size_t)vs.total) != hipSuccess) { vs.release(); return LH_ENOMEM; }
+    ProfScope p(c, "voxel_centroids", 32.0 * n);
+    launch_voxel_centroids(d_in, c->keys1, c->vals1, vs.heads, vs.rank, n, *d_out, vs.total, c->stream);
+  }
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  *total_out = vs.total;
+  vs.release();
+  return e == hipSuccess ? LH_OK : LH_EDEVICE;
 }
 
 lh_status lh_voxel_grid(lh_ctx* c, const lh_cloud_view* in, float leaf, int limit_axis, double lo, double hi, float* out_xyzi,
@@ -1914,6 +1929,262 @@ lh_status lh_cloud_voxel_grid(const lh_cloud* in, float leaf, int limit_axis, do
   HIPCHK(hipStreamSynchronize(c->stream));
   (void)hipFree(d_out);
   *out = o;
+  return LH_OK;
+}
+
+// ---- NDT (registration_method: ndt) -------------------------------------------------------------------------------
+// pclomp::NormalDistributionsTransform on the device: the target's voxel statistics and every (score, gradient, hessian)
+// evaluation are kernels (k_ndt_voxel_stats, k_ndt_derivs); the per-cell 3x3 algebra and the Newton / More-Thuente control flow
+// (a handful of evaluations per iteration) run on the host (lh_ndt_host.hpp).
+struct lh_ndt {
+  lh_ctx* ctx = nullptr;
+  lh_ndt_params P;
+  lh_cloud *src = nullptr, *tgt = nullptr;
+  bool own_src = false, own_tgt = false;
+  // target cells (ascending voxel index = the order of VoxelGridCovariance's centroid cloud)
+  bool grid_valid = false;
+  int n_cells = 0;
+  lh_cloud* cells = nullptr;          // centroids as a cloud + its radix-tree index (the kd-tree of the reference)
+  double *d_mean = nullptr, *d_icov = nullptr;
+  std::vector<double> h_mean, h_icov;
+  std::vector<float> h_centroid;
+  // evaluation buffers
+  double* rows = nullptr;             // per-wave partial rows (device)
+  int rows_cap = 0;
+  double* chunks = nullptr;           // [FINAL_CHUNKS][NDT_ROW], pinned, written by k_rows_final
+  float last_T[16];
+  bool have_result = false;
+};
+
+static void ndt_drop_grid(lh_ndt* g) {
+  cloud_free(g->cells);
+  g->cells = nullptr;
+  (void)hipFree(g->d_mean); (void)hipFree(g->d_icov);
+  g->d_mean = g->d_icov = nullptr;
+  g->n_cells = 0;
+  g->grid_valid = false;
+}
+
+// VoxelGridCovariance::filter(true) (ndt_omp.h:257-262): voxel statistics of the target
+static lh_status ndt_build_grid(lh_ndt* g) {
+  lh_ctx* c = g->ctx;
+  lh_cloud* t = g->tgt;
+  if (!t || t->n <= 0) return LH_EINVAL;
+  ndt_drop_grid(g);
+  VoxelSegments vs;
+  lh_status st = voxel_segments(c, t->xyz, t->n, g->P.resolution, -1, -3.0e38, 3.0e38, &vs);
+  if (st) return st;
+  std::vector<NdtVoxelRaw> raw(vs.total);
+  if (vs.total > 0) {
+    NdtVoxelRaw* d_raw = nullptr;
+    if (hipMalloc(&d_raw, sizeof(NdtVoxelRaw) * (size_t)vs.total) != hipSuccess) { vs.release(); return LH_ENOMEM; }
+    { ProfScope p(c, "ndt_voxel_stats", 16.0 * t->n); launch_ndt_voxel_stats(t->xyz, c->keys1, c->vals1, vs.heads, vs.rank, t->n, d_raw, c->stream); }
+    hipError_t e = hipMemcpyAsync(raw.data(), d_raw, sizeof(NdtVoxelRaw) * (size_t)vs.total, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_raw);
+    if (e != hipSuccess) { vs.release(); return LH_EDEVICE; }
+  }
+  vs.release();
+  g->h_mean.clear(); g->h_icov.clear(); g->h_centroid.clear();
+  for (uint32_t v = 0; v < vs.total; v++) {   // a few thousand cells: eigenvalue inflation + inverse on the host
+    double mean[3], icov[9];
+    if (!ndt_finish_cell(raw[v].sum, raw[v].cov, raw[v].count, g->P.min_points_per_voxel, g->P.min_covar_eigvalue_mult, mean, icov)) continue;
+    g->h_mean.insert(g->h_mean.end(), mean, mean + 3);
+    g->h_icov.insert(g->h_icov.end(), icov, icov + 9);
+    float cnt = (float)raw[v].count;
+    g->h_centroid.push_back(raw[v].cen[0] / cnt); g->h_centroid.push_back(raw[v].cen[1] / cnt); g->h_centroid.push_back(raw[v].cen[2] / cnt);
+    g->h_centroid.push_back(1.0f);
+  }
+  g->n_cells = (int)(g->h_mean.size() / 3);
+  if (g->n_cells > 0) {
+    lh_cloud_view cv;
+    cv.base = g->h_centroid.data(); cv.count = (uint32_t)g->n_cells; cv.stride = 16; cv.off_xyz = 0;
+    cv.off_normal = cv.off_intensity = cv.off_curvature = UINT32_MAX;
+    st = upload_view(c, &cv, &g->cells);
+    if (!st) st = cloud_build_index(g->cells);
+    if (st) return st;
+    hipError_t e = hipMalloc(&g->d_mean, sizeof(double) * 3 * (size_t)g->n_cells);
+    if (e == hipSuccess) e = hipMalloc(&g->d_icov, sizeof(double) * 9 * (size_t)g->n_cells);
+    if (e == hipSuccess) e = hipMemcpyAsync(g->d_mean, g->h_mean.data(), sizeof(double) * 3 * (size_t)g->n_cells, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(g->d_icov, g->h_icov.data(), sizeof(double) * 9 * (size_t)g->n_cells, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) return e == hipErrorOutOfMemory ? LH_ENOMEM : LH_EDEVICE;
+  }
+  g->grid_valid = true;
+  return LH_OK;
+}
+
+// one evaluation at pose p: (score, gradient, hessian) = sums over the source points of k_ndt_derivs
+static lh_status ndt_evaluate(lh_ndt* g, const double* p6, const float* T16, int want_h, int hessian_only, double* score, double* grad6, double* hess36) {
+  lh_ctx* c = g->ctx;
+  const int n = g->src->n;
+  *score = 0;
+  for (int k = 0; k < 6; k++) grad6[k] = 0;
+  for (int k = 0; k < 36; k++) hess36[k] = 0;
+  if (g->n_cells == 0) return LH_OK;   // no usable voxel: every neighbourhood is empty
+  int n_rows = ((n + 255) / 256) * 4;
+  if (n_rows > g->rows_cap) {
+    (void)hipFree(g->rows);
+    g->rows = nullptr;
+    HIPCHK(hipMalloc(&g->rows, sizeof(double) * NDT_ROW * (size_t)n_rows));
+    g->rows_cap = n_rows;
+  }
+  if (!g->chunks) HIPCHK(hipHostMalloc(&g->chunks, sizeof(double) * FINAL_CHUNKS * NDT_ROW, hipHostMallocDefault));
+  NdtFrame f;
+  ndt_fill_frame(f, p6, T16, g->P.resolution, g->P.outlier_ratio, want_h);
+  { ProfScope p(c, hessian_only ? "ndt_hessian" : "ndt_derivatives", 16.0 * n);
+    launch_ndt_derivs(g->src->xyz, n, g->cells->view(), g->d_mean, g->d_icov, f, hessian_only, g->rows, g->chunks, c->stream); }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(c->stream));
+  double S[NDT_NSUM];
+  for (int k = 0; k < NDT_NSUM; k++) S[k] = 0.0;
+  for (int ch = 0; ch < FINAL_CHUNKS; ch++)  // fixed order => bitwise reproducible
+    for (int k = 0; k < NDT_NSUM; k++) S[k] += g->chunks[ch * NDT_ROW + k];
+  if (!hessian_only) { *score = S[0]; for (int k = 0; k < 6; k++) grad6[k] = S[1 + k]; }
+  if (want_h) for (int k = 0; k < 36; k++) hess36[k] = S[7 + k];
+  return LH_OK;
+}
+
+void lh_default_ndt_params(lh_ndt_params* p) {
+  if (!p) return;
+  memset(p, 0, sizeof(*p));
+  p->resolution = 1.0f;               // ndt_omp_impl.hpp:50
+  p->step_size = 0.1;                 // :51
+  p->outlier_ratio = 0.55;            // :52
+  p->transformation_epsilon = 0.1;    // :93
+  p->max_iterations = 35;             // :94
+  p->min_points_per_voxel = 6;        // voxel_grid_covariance_omp.h:186
+  p->min_covar_eigvalue_mult = 0.01;  // :187
+}
+lh_status lh_ndt_create(lh_ctx* ctx, const lh_ndt_params* p, lh_ndt** out) {
+  if (!ctx || !out) return LH_EINVAL;
+  lh_ndt* g = new lh_ndt();
+  g->ctx = ctx;
+  if (p) g->P = *p; else lh_default_ndt_params(&g->P);
+  memcpy(g->last_T, I16, sizeof(I16));
+  *out = g;
+  return LH_OK;
+}
+void lh_ndt_destroy(lh_ndt* g) {
+  if (!g) return;
+  (void)hipSetDevice(g->ctx->device);
+  (void)hipStreamSynchronize(g->ctx->stream);
+  ndt_drop_grid(g);
+  if (g->own_src) cloud_free(g->src);
+  if (g->own_tgt) cloud_free(g->tgt);
+  (void)hipFree(g->rows);
+  if (g->chunks) (void)hipHostFree(g->chunks);
+  delete g;
+}
+lh_status lh_ndt_set_params(lh_ndt* g, const lh_ndt_params* p) {
+  if (!g || !p || !(p->resolution > 0.0f)) return LH_EINVAL;
+  bool regrid = p->resolution != g->P.resolution || p->min_points_per_voxel != g->P.min_points_per_voxel ||
+                p->min_covar_eigvalue_mult != g->P.min_covar_eigvalue_mult;
+  g->P = *p;
+  if (regrid) g->grid_valid = false;   // setResolution re-initialises the voxel structure (ndt_omp.h:124-131)
+  return LH_OK;
+}
+lh_status lh_ndt_set_source_cloud(lh_ndt* g, lh_cloud* c) {
+  if (!g || !c || c->ctx != g->ctx) return LH_EINVAL;
+  if (g->own_src) cloud_free(g->src);
+  g->src = c; g->own_src = false;
+  return LH_OK;
+}
+lh_status lh_ndt_set_target_cloud(lh_ndt* g, lh_cloud* c) {
+  if (!g || !c || c->ctx != g->ctx) return LH_EINVAL;
+  if (g->own_tgt) cloud_free(g->tgt);
+  g->tgt = c; g->own_tgt = false;
+  g->grid_valid = false;               // setInputTarget -> init() (ndt_omp.h:116-119)
+  return LH_OK;
+}
+lh_status lh_ndt_set_source(lh_ndt* g, const lh_cloud_view* v) {
+  if (!g || !v) return LH_EINVAL;
+  HIPCHK(hipSetDevice(g->ctx->device));
+  lh_cloud* c = nullptr;
+  lh_status st = upload_view(g->ctx, v, &c);
+  if (st) return st;
+  if (g->own_src) cloud_free(g->src);
+  g->src = c; g->own_src = true;
+  return LH_OK;
+}
+lh_status lh_ndt_set_target(lh_ndt* g, const lh_cloud_view* v) {
+  if (!g || !v) return LH_EINVAL;
+  HIPCHK(hipSetDevice(g->ctx->device));
+  lh_cloud* c = nullptr;
+  lh_status st = upload_view(g->ctx, v, &c);
+  if (st) return st;
+  if (g->own_tgt) cloud_free(g->tgt);
+  g->tgt = c; g->own_tgt = true;
+  g->grid_valid = false;
+  return LH_OK;
+}
+// test hook: the target cells (count returned through *n_cells; arrays nullable, at most cap cells written)
+lh_status lh_ndt_debug_cells(lh_ndt* g, int* n_cells, double* mean3, double* icov9, float* centroid4, int cap) {
+  if (!g || !n_cells || !g->tgt) return LH_EINVAL;
+  HIPCHK(hipSetDevice(g->ctx->device));
+  if (!g->grid_valid) { lh_status st = ndt_build_grid(g); if (st) return st; }
+  *n_cells = g->n_cells;
+  int k = std::min(cap, g->n_cells);
+  if (mean3) memcpy(mean3, g->h_mean.data(), sizeof(double) * 3 * (size_t)k);
+  if (icov9) memcpy(icov9, g->h_icov.data(), sizeof(double) * 9 * (size_t)k);
+  if (centroid4) memcpy(centroid4, g->h_centroid.data(), sizeof(float) * 4 * (size_t)k);
+  return LH_OK;
+}
+// test hook: computeDerivatives (hessian_only = 0) / computeHessian (hessian_only = 1) at pose p6
+lh_status lh_ndt_debug_derivatives(lh_ndt* g, const double p6[6], int want_h, int hessian_only, double* score, double grad6[6], double hess36[36]) {
+  if (!g || !p6 || !score || !grad6 || !hess36 || !g->src || !g->tgt) return LH_EINVAL;
+  HIPCHK(hipSetDevice(g->ctx->device));
+  if (!g->grid_valid) { lh_status st = ndt_build_grid(g); if (st) return st; }
+  float T16[16];
+  ndt_pose_to_matrix(p6, T16);
+  return ndt_evaluate(g, p6, T16, want_h, hessian_only, score, grad6, hess36);
+}
+// pcl::Registration::align + computeTransformation (ndt_omp_impl.hpp:101-212).  out->fitness = trans_probability_ (score / n),
+// out->cost_passes = device evaluations; aligned_out (nullable) receives final_T * input
+lh_status lh_ndt_align(lh_ndt* g, const float guess[16], lh_gicp_result* out, void* aligned_out, uint32_t stride, uint32_t off_xyz) {
+  if (!g || !out || !g->src || !g->tgt || g->src->n <= 0) return LH_EINVAL;
+  lh_ctx* c = g->ctx;
+  HIPCHK(hipSetDevice(c->device));
+  if (!g->grid_valid) { lh_status st = ndt_build_grid(g); if (st) return st; }
+  bool ident = true;
+  if (guess)
+    for (int k = 0; k < 16; k++)
+      if (guess[k] != I16[k]) ident = false;
+  lh_status dev_status = LH_OK;
+  NdtEval eval = [&](const double* p6, const float* T16, int want_h, int hessian_only, double* score, double* grad6, double* hess36) {
+    dev_status = ndt_evaluate(g, p6, T16, want_h, hessian_only, score, grad6, hess36);
+    return dev_status == LH_OK;
+  };
+  NdtOutcome o;
+  memset(out, 0, sizeof(*out));
+  memcpy(out->T, I16, sizeof(I16));
+  out->fitness = NAN;
+  if (!ndt_compute_transformation(eval, guess, ident, g->P.step_size, g->P.transformation_epsilon, g->P.max_iterations, &o)) {
+    out->status = dev_status ? dev_status : LH_EDEVICE;
+    return out->status;
+  }
+  memcpy(out->T, o.T, sizeof(o.T));
+  out->converged = o.converged;
+  out->iterations = o.iterations;
+  out->cost_passes = o.evaluations;
+  out->n_correspondences_last = g->n_cells;
+  out->fitness = o.score / (double)g->src->n;   // trans_probability_ (ndt_omp_impl.hpp:211)
+  out->status = LH_OK;
+  memcpy(g->last_T, o.T, sizeof(o.T));
+  g->have_result = true;
+  if (aligned_out) {
+    float T12[12];
+    fill_T12(o.T, T12);
+    float4* d_out = nullptr;
+    HIPCHK(hipMalloc(&d_out, sizeof(float4) * (size_t)g->src->n));
+    launch_transform(g->src->xyz, nullptr, g->src->n, T12, d_out, nullptr, c->stream);
+    std::vector<float> host((size_t)g->src->n * 4);
+    hipError_t e = hipMemcpyAsync(host.data(), d_out, sizeof(float) * host.size(), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_out);
+    if (e != hipSuccess) return LH_EDEVICE;
+    for (int i = 0; i < g->src->n; i++) memcpy((char*)aligned_out + (size_t)i * stride + off_xyz, &host[4 * (size_t)i], 12);
+  }
   return LH_OK;
 }
 

@@ -13,6 +13,7 @@
 #include <cstdlib>
 
 #include "lh_kernels.hpp"
+#include "lh_ndt.hpp"
 
 namespace lh {
 
@@ -465,10 +466,9 @@ __device__ __forceinline__ void moments_of_point(const SweepJob& job, const Swee
 // Per-wave reduction of 74 per-lane values, no workgroup barriers inside the loop: after ONE barrier (all lanes are done
 // with their traversal stacks) each wave owns a private 4-KB slice [8 values][64 lanes] of the LDS region; a wave's DS
 // operations execute in order, so write -> fence -> read needs no s_barrier.  64 lanes -> 8 strided partial sums -> 3
-// shuffles.  `value(k)` yields the lane's k-th value.  The row gets two more entries: the number of tree walks of the
-// wave's points (feedback for the scheduler's choice of sweep kernel) and a zero.
-template <class F>
-__device__ __forceinline__ void wave_reduce_row(uint64_t* lds_base, double* out, int walks, F value) {
+// shuffles.  `value(k)` yields the lane's k-th of NV values; the row (ROW doubles) is completed with `extra` and zeros.
+template <int NV, int ROW, class F>
+__device__ __forceinline__ void wave_reduce_row(uint64_t* lds_base, double* out, double extra, F value) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   // row stride 72 doubles (not 64): the 16 lanes the LDS serves per cycle read two 64-B pieces of two DIFFERENT rows, and
   // 576-B rows put those on complementary bank halves; with 512-B rows they collided (SQ_LDS_BANK_CONFLICT = 26 % of the
@@ -478,11 +478,11 @@ __device__ __forceinline__ void wave_reduce_row(uint64_t* lds_base, double* out,
   const int v_of = lane >> 3, part = lane & 7;
   __syncthreads();
 #pragma unroll
-  for (int g = 0; g < (MOM_NSUM + 7) / 8; g++) {
+  for (int g = 0; g < (NV + 7) / 8; g++) {
 #pragma unroll
     for (int v = 0; v < 8; v++) {
       int k = g * 8 + v;
-      if (k < MOM_NSUM) wst[v * RS + lane] = value(k);
+      if (k < NV) wst[v * RS + lane] = value(k);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
@@ -491,11 +491,11 @@ __device__ __forceinline__ void wave_reduce_row(uint64_t* lds_base, double* out,
     for (int jj = 0; jj < 8; jj++) s += wst[v_of * RS + jj * 8 + part];
 #pragma unroll
     for (int off = 4; off > 0; off >>= 1) s += __shfl_down(s, off, 8);
-    if (part == 0 && g * 8 + v_of < MOM_NSUM) out[g * 8 + v_of] = s;
+    if (part == 0 && g * 8 + v_of < NV) out[g * 8 + v_of] = s;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
   }
-  if (lane == 0) { out[MOM_NSUM] = (double)walks; out[MOM_NSUM + 1] = 0.0; }
+  if (lane < ROW - NV) out[NV + lane] = lane == 0 ? extra : 0.0;  // the rest of the row: one extra value (e.g. tree walks), zeros
 }
 
 // one point per thread (78 VGPRs, 6 waves per SIMD).  A variant with 4 points per thread and the 74 moments accumulated in
@@ -519,7 +519,7 @@ __global__ void __launch_bounds__(256) k_sweep_fused(const PairDesc* __restrict_
   const double live = sp.matched ? 1.0 : 0.0;
   const int walks = __popcll(__ballot(sp.searched));
   double* out = partials + (size_t)job.slot * partials_stride + ((size_t)blk * 4 + (threadIdx.x >> 6)) * MOM_ROW;
-  wave_reduce_row(lds_stack, out, walks, [&](int k) { return (k == 73) ? live : mom_value(k, M6, Ma, aMa, pt, pp); });
+  wave_reduce_row<MOM_NSUM, MOM_ROW>(lds_stack, out, (double)walks, [&](int k) { return (k == 73) ? live : mom_value(k, M6, Ma, aMa, pt, pp); });
 }
 
 void launch_sweep_fused(const PairDesc* descs, SweepArgs& a, int max_n, double* partials_dev, int partials_stride, hipStream_t s) {
@@ -1105,6 +1105,102 @@ void launch_finite_normal_flags(const float4* nrm, int n, uint32_t* flags, hipSt
 void launch_compact(const uint32_t* incl, int n, const float4* xyz, const float4* nrm, const float* inten, float4* oxyz, float4* onrm,
                     float* ointen, hipStream_t s) {
   hipLaunchKernelGGL(k_compact, dim3((n + 255) / 256), dim3(256), 0, s, incl, n, xyz, nrm, inten, oxyz, onrm, ointen);
+}
+
+// ===== NDT (registration_method: ndt) ==========================================================================
+// target side: per-voxel raw statistics in input order (VoxelGridCovariance::applyFilter, voxel_grid_covariance_omp_impl.hpp:
+// 166-205): double sums of p and p p^T, float centroid sum, count; the few thousand cells are finished on the host
+__global__ void __launch_bounds__(256) k_ndt_voxel_stats(const float4* __restrict__ xyz, const uint32_t* __restrict__ keys,
+                                                         const uint32_t* __restrict__ vals, const uint32_t* __restrict__ heads,
+                                                         const uint32_t* __restrict__ rank, int n, NdtVoxelRaw* __restrict__ out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || !heads[i]) return;
+  uint32_t k = keys[i];
+  NdtVoxelRaw r;
+  r.count = 0;
+  r.cen[0] = r.cen[1] = r.cen[2] = 0.0f;
+#pragma unroll
+  for (int a = 0; a < 3; a++) r.sum[a] = 0.0;
+#pragma unroll
+  for (int a = 0; a < 6; a++) r.cov[a] = 0.0;
+  for (int j = i; j < n && keys[j] == k; j++) {  // stable radix sort => ascending point index inside a voxel
+    float4 p = xyz[vals[j]];
+    double x = p.x, y = p.y, z = p.z;
+    r.sum[0] += x; r.sum[1] += y; r.sum[2] += z;
+    r.cov[0] += x * x; r.cov[1] += x * y; r.cov[2] += x * z; r.cov[3] += y * y; r.cov[4] += y * z; r.cov[5] += z * z;
+    r.cen[0] += p.x; r.cen[1] += p.y; r.cen[2] += p.z;
+    r.count++;
+  }
+  out[rank[i] - 1u] = r;
+}
+void launch_ndt_voxel_stats(const float4* xyz, const uint32_t* keys, const uint32_t* vals, const uint32_t* heads, const uint32_t* rank_incl,
+                            int n, NdtVoxelRaw* out, hipStream_t s) {
+  hipLaunchKernelGGL(k_ndt_voxel_stats, dim3((n + 255) / 256), dim3(256), 0, s, xyz, keys, vals, heads, rank_incl, n, out);
+}
+
+// source side: computeDerivatives (MODE 0, float point derivatives) / computeHessian (MODE 1, double).  One source point per
+// thread; the radius search over the voxel CENTROIDS (KDTREE mode, voxel_grid_covariance_omp.h:433-466) walks the cells'
+// radix tree and every cell inside the radius contributes on the spot; 43 doubles per wave are reduced through LDS.
+template <int MODE>
+struct NdtCollector {
+  float r2;
+  const NdtFrame* f;
+  const double* mean;
+  const double* icov;
+  float x3[3], xt[3];
+  double acc[NDT_NSUM];
+  static constexpr bool kXyz = false;
+  static constexpr bool kGreedy = false;
+  __device__ __forceinline__ float bound() const { return r2; }
+  __device__ __forceinline__ void offer(float d, int id) {
+    if (!(d < r2) || id == 0x7fffffff) return;  // FLANN RadiusResultSet: strict
+    const double* mu = mean + 3 * (size_t)id;
+    double dd[3] = {(double)xt[0] - mu[0], (double)xt[1] - mu[1], (double)xt[2] - mu[2]};
+    if (MODE == 0) ndt_term_float(*f, x3, dd, icov + 9 * (size_t)id, acc);
+    else ndt_term_hessian_double(*f, x3, dd, icov + 9 * (size_t)id, acc + 7);
+  }
+  __device__ __forceinline__ void skip(float) {}
+  __device__ __forceinline__ void count_node(int) {}
+  __device__ __forceinline__ void count_leaf() {}
+};
+template <int MODE>
+__global__ void __launch_bounds__(256) k_ndt_derivs(const float4* __restrict__ src, int n, TreeView cells, const double* __restrict__ mean,
+                                                    const double* __restrict__ icov, NdtFrame f, double* __restrict__ rows) {
+  extern __shared__ __attribute__((aligned(16))) uint64_t lds_stack[];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  NdtCollector<MODE> col;
+  col.r2 = f.r2; col.f = &f; col.mean = mean; col.icov = icov;
+#pragma unroll
+  for (int k = 0; k < NDT_NSUM; k++) col.acc[k] = 0.0;
+  if (i < n) {
+    float4 p = src[i];
+    col.x3[0] = p.x; col.x3[1] = p.y; col.x3[2] = p.z;
+    xform_pt(f.T, p.x, p.y, p.z, col.xt[0], col.xt[1], col.xt[2]);  // transformPointCloud(*input_, trans_cloud, final_transformation_)
+    tree_search(cells, col.xt[0], col.xt[1], col.xt[2], col, lds_stack + threadIdx.x, 256);
+  }
+  double* out = rows + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * NDT_ROW;
+  wave_reduce_row<NDT_NSUM, NDT_ROW>(lds_stack, out, 0.0, [&](int k) { return col.acc[k]; });
+}
+// fixed-order final sum of the per-wave rows: workgroup c adds chunk c into out[c][NDT_ROW]; the host adds the chunks
+__global__ void __launch_bounds__(4 * NDT_ROW) k_rows_final(const double* __restrict__ rows, int n_rows, double* __restrict__ out) {
+  const int c = blockIdx.x, v = threadIdx.x % NDT_ROW, sub = threadIdx.x / NDT_ROW;
+  int per = (n_rows + FINAL_CHUNKS - 1) / FINAL_CHUNKS;
+  int b0 = c * per, b1 = min(n_rows, b0 + per);
+  double s = 0.0;
+  for (int b = b0 + sub; b < b1; b += 4) s += rows[(size_t)b * NDT_ROW + v];
+  __shared__ double sm[4][NDT_ROW];
+  sm[sub][v] = s;
+  __syncthreads();
+  if (sub == 0) out[c * NDT_ROW + v] = ((sm[0][v] + sm[1][v]) + sm[2][v]) + sm[3][v];
+}
+void launch_ndt_derivs(const float4* src, int n, TreeView cells, const double* mean, const double* icov, const NdtFrame& f, int hessian_only,
+                       double* rows_dev, double* out_chunks /*[FINAL_CHUNKS][NDT_ROW], device-visible*/, hipStream_t s) {
+  size_t lds = stack_lds_bytes(0, 256);
+  if (lds < 4 * 8 * 72 * sizeof(double)) lds = 4 * 8 * 72 * sizeof(double);
+  int blocks = (n + 255) / 256;
+  if (hessian_only) hipLaunchKernelGGL(k_ndt_derivs<1>, dim3(blocks), dim3(256), lds, s, src, n, cells, mean, icov, f, rows_dev);
+  else hipLaunchKernelGGL(k_ndt_derivs<0>, dim3(blocks), dim3(256), lds, s, src, n, cells, mean, icov, f, rows_dev);
+  hipLaunchKernelGGL(k_rows_final, dim3(FINAL_CHUNKS), dim3(4 * NDT_ROW), 0, s, rows_dev, blocks * 4, out_chunks);
 }
 
 // ===== BodyFilter (body_filter.cc:27-52): pcl::CropBox with a yaw-rotated box, negative = keep what is OUTSIDE ================

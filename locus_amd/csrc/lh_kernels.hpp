@@ -150,6 +150,16 @@ void launch_compact(const uint32_t* incl, int n, const float4* xyz, const float4
 
 void launch_crop_flags(const float4* xyz, int n, const float* mn, const float* mx, float c, float s, int negative, uint32_t* flags, hipStream_t st);
 
+// ---- NDT ---------------------------------------------------------------------------------------
+struct NdtFrame;
+constexpr int NDT_ROW = 44;   // a partial row: score, gradient[6], hessian[36], one pad
+struct NdtVoxelRaw { double sum[3]; double cov[6]; float cen[3]; int count; };   // raw per-voxel sums (xx xy xz yy yz zz)
+void launch_ndt_voxel_stats(const float4* xyz, const uint32_t* keys, const uint32_t* vals, const uint32_t* heads, const uint32_t* rank_incl,
+                            int n, NdtVoxelRaw* out, hipStream_t s);
+// one evaluation: per-wave rows [ceil(n/256)*4][NDT_ROW] -> FINAL_CHUNKS chunk sums (the host adds them in chunk order)
+void launch_ndt_derivs(const float4* src, int n, TreeView cells, const double* mean, const double* icov, const NdtFrame& f, int hessian_only,
+                       double* rows_dev, double* out_chunks, hipStream_t s);
+
 // ---- local map ------------------------------------------------------------------------------
 void launch_map_keys(const float4* xyz, int n, double inv_res, uint64_t* keys, uint32_t* vals /*nullable*/, hipStream_t s);
 void launch_map_accept(const uint64_t* skeys, const uint32_t* svals, int n, const uint64_t* map_keys, int m, uint32_t* accept, hipStream_t s);

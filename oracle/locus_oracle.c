@@ -1489,6 +1489,17 @@ static int rad_cmp(const void* a, const void* b) {
   if (x->d != y->d) return x->d < y->d ? -1 : 1;
   return (x->i > y->i) - (x->i < y->i);
 }
+/* all points with d2 < r2 around q (3 floats), ascending (d2, index); returns the count (at most cap are written) */
+int lo_radius_search(const lo_tree* t, const float* q, float r2, int32_t* idx, float* d2, int cap) {
+  rad_list L = {NULL, 0, 0};
+  if (t->n > 0) radius_rec(t, 0, q, r2, &L);
+  qsort(L.h, L.cnt, sizeof(rad_hit), rad_cmp);
+  int k = L.cnt < cap ? L.cnt : cap;
+  for (int j = 0; j < k; j++) { idx[j] = L.h[j].i; if (d2) d2[j] = L.h[j].d; }
+  int cnt = L.cnt;
+  free(L.h);
+  return cnt;
+}
 void lo_normals_radius(const float* xyz4, int n, const lo_tree* t, float radius, float* out, int threads) {
   if (threads < 1) threads = 1;
   float r2 = radius * radius;

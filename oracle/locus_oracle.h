@@ -133,6 +133,42 @@ void lo_normals_knn(const float* xyz4, int n, const lo_tree* t, int k, float* ou
    (the nodelet then drops those points, normal_computation.cc:52-56) */
 void lo_normals_radius(const float* xyz4, int n, const lo_tree* t, float radius, float* out_nrm4, int threads);
 
+/* ---- NDT (registration_method: ndt), restated in locus_oracle_ndt.c -- "parity unpinned" (no reference test) ---- */
+typedef struct {
+  float resolution;              /* voxel edge, ndt_omp_impl.hpp:50 (1.0) */
+  double step_size;              /* More-Thuente maximum step, :51 (0.1) */
+  double outlier_ratio;          /* :52 (0.55) */
+  double transformation_epsilon; /* :93 (0.1); LOCUS passes icp_tf_epsilon */
+  int max_iterations;            /* :94 (35); LOCUS passes icp_iterations */
+  int min_points_per_voxel;      /* voxel_grid_covariance_omp.h:186 (6) */
+  double min_covar_eigvalue_mult;/* :187 (0.01) */
+  int num_threads;
+} lo_ndt_params;
+typedef struct {
+  float T[16];                   /* final_transformation_, column-major */
+  int converged, iterations, evaluations, n_cells;
+  double trans_probability;      /* score / n (ndt_omp_impl.hpp:211) */
+} lo_ndt_result;
+typedef struct lo_ndt_grid lo_ndt_grid;
+void lo_ndt_default_params(lo_ndt_params* p);
+lo_ndt_grid* lo_ndt_grid_build(const float* tgt_xyz4, int m, const lo_ndt_params* P);
+void lo_ndt_grid_free(lo_ndt_grid* g);
+/* copies up to cap cells (ascending voxel index = kd-tree order); returns the cell count */
+int lo_ndt_grid_cells(const lo_ndt_grid* g, double* mean3, double* icov9, float* centroid4, int cap);
+void lo_ndt_pose_to_matrix(const double* p6, float* T16);
+void lo_ndt_matrix_to_pose(const float* T16, double* p6);
+/* computeDerivatives (float point derivatives): returns the score; hess36 row-major, zero when want_h == 0 */
+double lo_ndt_derivatives(const lo_ndt_grid* g, const lo_ndt_params* P, const float* src_xyz4, const float* trans_xyz4, int n, const double* p6,
+                          double* grad6, double* hess36, int want_h);
+/* computeHessian (double path) */
+void lo_ndt_hessian(const lo_ndt_grid* g, const lo_ndt_params* P, const float* src_xyz4, const float* trans_xyz4, int n, const double* p6,
+                    double* hess36);
+void lo_svd_solve6(const double* A36, const double* b6, double* x6);
+int lo_ndt_align(const float* src_xyz4, int n, const float* tgt_xyz4, int m, const lo_ndt_params* P, const float* guess16, lo_ndt_result* out);
+
+/* radius search on the exact index: points with d2 < r2, ascending (d2, index); returns the count (<= cap written) */
+int lo_radius_search(const lo_tree* t, const float* q3, float r2, int32_t* idx, float* d2, int cap);
+
 /* PCD v0.7 binary/ascii reader for the reference's own fixtures (x y z intensity). returns n or <0 */
 int lo_read_pcd_xyzi(const char* path, float* out_xyzi, int cap);
 

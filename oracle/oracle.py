@@ -67,6 +67,16 @@ def build(force=False):
     return _LIB
 
 
+class LoNdtParams(C.Structure):
+    _fields_ = [("resolution", C.c_float), ("step_size", C.c_double), ("outlier_ratio", C.c_double), ("transformation_epsilon", C.c_double),
+                ("max_iterations", C.c_int), ("min_points_per_voxel", C.c_int), ("min_covar_eigvalue_mult", C.c_double), ("num_threads", C.c_int)]
+
+
+class LoNdtResult(C.Structure):
+    _fields_ = [("T", C.c_float * 16), ("converged", C.c_int), ("iterations", C.c_int), ("evaluations", C.c_int), ("n_cells", C.c_int),
+                ("trans_probability", C.c_double)]
+
+
 _lib = None
 
 
@@ -103,6 +113,18 @@ def lib():
         L.lo_voxel_grid.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_int]
         L.lo_normals_knn.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
         L.lo_normals_radius.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_void_p, C.c_int]
+        L.lo_ndt_default_params.argtypes = [C.POINTER(LoNdtParams)]
+        L.lo_ndt_grid_build.argtypes = [C.c_void_p, C.c_int, C.POINTER(LoNdtParams)]
+        L.lo_ndt_grid_build.restype = C.c_void_p
+        L.lo_ndt_grid_free.argtypes = [C.c_void_p]
+        L.lo_ndt_grid_cells.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.lo_ndt_pose_to_matrix.argtypes = [C.c_void_p, C.c_void_p]
+        L.lo_ndt_matrix_to_pose.argtypes = [C.c_void_p, C.c_void_p]
+        L.lo_ndt_derivatives.argtypes = [C.c_void_p, C.POINTER(LoNdtParams), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.lo_ndt_derivatives.restype = C.c_double
+        L.lo_ndt_hessian.argtypes = [C.c_void_p, C.POINTER(LoNdtParams), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.lo_svd_solve6.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.lo_ndt_align.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(LoNdtParams), C.c_void_p, C.POINTER(LoNdtResult)]
         L.lo_read_pcd_xyzi.argtypes = [C.c_char_p, C.c_void_p, C.c_int]
         L.lo_default_params.argtypes = [C.POINTER(LoParams)]
     return _lib
@@ -400,3 +422,79 @@ class MapOracle:
         self.extra = [self.extra[k] for k in keep]
         self.occ = {map_voxel(p, self.res) for p in self.pts}
         return keep
+
+
+# ---- NDT -----------------------------------------------------------------------------------------------------
+def ndt_default_params(**kw):
+    p = LoNdtParams()
+    lib().lo_ndt_default_params(C.byref(p))
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+class NdtGrid:
+    def __init__(self, tgt4, params):
+        self.params = params
+        tgt4 = _f4(tgt4)
+        self.h = lib().lo_ndt_grid_build(_p(tgt4), tgt4.shape[0], C.byref(params))
+
+    def __del__(self):
+        try:
+            lib().lo_ndt_grid_free(self.h)
+        except Exception:
+            pass
+
+    def cells(self):
+        n = lib().lo_ndt_grid_cells(self.h, None, None, None, 0)
+        mean, icov, cen = np.empty((n, 3)), np.empty((n, 3, 3)), np.empty((n, 4), np.float32)
+        lib().lo_ndt_grid_cells(self.h, _p(mean), _p(icov), _p(cen), n)
+        return mean, icov, cen
+
+    def derivatives(self, src4, p6, want_h=True):
+        src4 = _f4(src4)
+        p6 = np.ascontiguousarray(p6, np.float64)
+        T = ndt_pose_to_matrix(p6)
+        trans = transform(src4, T)
+        g, H = np.empty(6), np.empty((6, 6))
+        s = lib().lo_ndt_derivatives(self.h, C.byref(self.params), _p(src4), _p(trans), src4.shape[0], _p(p6), _p(g), _p(H), 1 if want_h else 0)
+        return s, g, H
+
+    def hessian(self, src4, p6):
+        src4 = _f4(src4)
+        p6 = np.ascontiguousarray(p6, np.float64)
+        trans = transform(src4, ndt_pose_to_matrix(p6))
+        H = np.empty((6, 6))
+        lib().lo_ndt_hessian(self.h, C.byref(self.params), _p(src4), _p(trans), src4.shape[0], _p(p6), _p(H))
+        return H
+
+
+def ndt_pose_to_matrix(p6):
+    p6 = np.ascontiguousarray(p6, np.float64)
+    T = np.empty(16, np.float32)
+    lib().lo_ndt_pose_to_matrix(_p(p6), _p(T))
+    return T
+
+
+def ndt_matrix_to_pose(T16):
+    T16 = np.ascontiguousarray(T16, np.float32).reshape(16)
+    p = np.empty(6)
+    lib().lo_ndt_matrix_to_pose(_p(T16), _p(p))
+    return p
+
+
+def svd_solve6(A, b):
+    A = np.ascontiguousarray(A, np.float64)
+    b = np.ascontiguousarray(b, np.float64)
+    x = np.empty(6)
+    lib().lo_svd_solve6(_p(A), _p(b), _p(x))
+    return x
+
+
+def ndt_align(src4, tgt4, params, guess=None):
+    src4, tgt4 = _f4(src4), _f4(tgt4)
+    g = np.ascontiguousarray(guess, np.float32).reshape(16) if guess is not None else None
+    r = LoNdtResult()
+    lib().lo_ndt_align(_p(src4), src4.shape[0], _p(tgt4), tgt4.shape[0], C.byref(params), _p(g) if g is not None else None, C.byref(r))
+    return {"T": np.array(r.T[:], np.float32), "converged": r.converged, "iterations": r.iterations, "evaluations": r.evaluations,
+            "n_cells": r.n_cells, "trans_probability": r.trans_probability}

@@ -246,3 +246,44 @@ def test_map_oracle_first_point_per_voxel(oracle):
     kept = m.refresh([0.0, 0.0, 0.0], 0.5)
     assert kept == [0, 2] and len(m.pts) == 2    # |x| <= 0.5 keeps 0.1 and -0.1; 0.6 goes
     assert m.insert(pts) == [2]                  # its voxel is free again
+
+
+def test_ndt_oracle_self_consistency(oracle):
+    """NDT restatement (oracle/locus_oracle_ndt.c; the reference holds no NDT test: "parity unpinned").  Checks that do not need
+    the reference: the analytic gradient against central differences of the score (the score is only piecewise smooth -- cells
+    enter and leave the radius-search neighbourhood -- hence a loose bound on the dominant components), float and double
+    hessian paths agree, the SVD solve, pose <-> matrix round trip, and registration of known motions."""
+    delta = synth.pose_matrix(0.04, -0.03, 0.01, 0.002, -0.001, 0.006)
+    src, tgt, delta = synth.scan_pair(n_rings=16, n_az=600, scale=2.0, noise=0.02, seed=10, delta=delta)
+    s4, t4 = oracle.xyz4(src), oracle.xyz4(tgt)
+    P = oracle.ndt_default_params(transformation_epsilon=1e-3, max_iterations=30)
+    g = oracle.NdtGrid(t4, P)
+    mean, icov, cen = g.cells()
+    assert len(mean) > 100 and np.allclose(mean, cen[:, :3], atol=1e-4)            # double mean vs float centroid of the same points
+    assert (np.linalg.eigvalsh(0.5 * (icov + icov.transpose(0, 2, 1))) > 0).all()  # inflated covariances are positive definite
+    p0 = np.array([0.05, -0.02, 0.01, 0.004, -0.003, 0.01])
+    s, gr, H = g.derivatives(s4, p0)
+    fd = np.zeros(6)
+    for k in range(6):
+        a, b = p0.copy(), p0.copy()
+        a[k] += 1e-3
+        b[k] -= 1e-3
+        fd[k] = (g.derivatives(s4, a, False)[0] - g.derivatives(s4, b, False)[0]) / 2e-3
+    big = np.abs(gr) > 0.2 * np.abs(gr).max()
+    assert np.allclose(fd[big], gr[big], rtol=0.1), (fd, gr)
+    Hd = g.hessian(s4, p0)
+    assert np.abs(H - Hd).max() < 1e-5 * np.abs(Hd).max() and np.abs(Hd - Hd.T).max() < 1e-12 * np.abs(Hd).max()
+    rng = np.random.default_rng(0)
+    A, b = rng.normal(size=(6, 6)), rng.normal(size=6)
+    assert np.allclose(oracle.svd_solve6(A, b), np.linalg.solve(A, b), atol=1e-12)
+    A[:, 5] = A[:, 4]                                                              # rank-deficient: minimum-norm least squares
+    assert np.allclose(oracle.svd_solve6(A, b), np.linalg.pinv(A) @ b, atol=1e-9)
+    for pose in (p0, np.array([0.3, -0.2, 0.1, -0.05, 0.02, 2.5])):                # eulerAngles(0,1,2) may pick the flipped branch:
+        T = oracle.ndt_pose_to_matrix(pose)                                        # compare matrices, not angles
+        assert np.allclose(oracle.ndt_pose_to_matrix(oracle.ndt_matrix_to_pose(T)), T, atol=2e-6)
+    srcd, tgtd, _ = synth.scan_pair(n_rings=32, n_az=900, scale=2.0, noise=0.02, seed=10, delta=delta)   # 1-m voxels need dense walls
+    r = oracle.ndt_align(oracle.xyz4(srcd), oracle.xyz4(tgtd), P)
+    T = oracle.T_to_mat(r["T"])
+    assert r["converged"] == 1 and np.abs(T[:3, 3] - delta[:3, 3]).max() < 0.02 and np.abs(T[:3, :3] - delta[:3, :3]).max() < 2e-3
+    r = oracle.ndt_align(t4, t4, P, oracle.mat_to_T(synth.pose_matrix(0.05, -0.03, 0.0, 0, 0, 0.005).astype(np.float32)))
+    assert np.abs(oracle.T_to_mat(r["T"]) - np.eye(4)).max() < 1e-3                # a cloud against itself, from a small offset
