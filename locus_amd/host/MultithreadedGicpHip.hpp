@@ -9,11 +9,11 @@
 #include <string>
 #include <vector>
 
-#include "point_types.hpp"
+#include "RegistrationHip.hpp"
 
 namespace locus_hip {
 
-class MultithreadedGicpHip {
+class MultithreadedGicpHip : public RegistrationHip {
 public:
   typedef std::shared_ptr<MultithreadedGicpHip> Ptr;
 
@@ -22,13 +22,13 @@ public:
     if (lh_gicp_create(ctx_, &p_, &g_) != LH_OK) throw std::runtime_error("lh_gicp_create failed (no HIP device?)");
     for (int i = 0; i < 16; i++) final_[i] = (i % 5 == 0) ? 1.0f : 0.0f;
   }
-  ~MultithreadedGicpHip() { lh_gicp_destroy(g_); }
+  ~MultithreadedGicpHip() override { lh_gicp_destroy(g_); }
   MultithreadedGicpHip(const MultithreadedGicpHip&) = delete;
   MultithreadedGicpHip& operator=(const MultithreadedGicpHip&) = delete;
 
   // gicp.h setters (names kept)
-  void setNumThreads(int n) { p_.num_threads = n; push(); }                                  // gicp.h:134-141 (ignored on GPU)
-  void enableTimingOutput(bool on) { p_.enable_timing = on ? 1 : 0; push(); }                // gicp.h:143
+  void setNumThreads(int n) override { p_.num_threads = n; push(); }                                  // gicp.h:134-141 (ignored on GPU)
+  void enableTimingOutput(bool on) override { p_.enable_timing = on ? 1 : 0; push(); }                // gicp.h:143
   void setRotationEpsilon(double e) { p_.rotation_epsilon = e; push(); }                     // gicp.h:236
   double getRotationEpsilon() const { return p_.rotation_epsilon; }
   void setCorrespondenceRandomness(int k) { p_.k_correspondences = k; push(); }              // gicp.h:250
@@ -38,22 +38,22 @@ public:
   void RecomputeTargetCovariance(bool r) { p_.recompute_target_cov = r ? 1 : 0; push(); }    // gicp.h:277
   void RecomputeSourceCovariance(bool r) { p_.recompute_source_cov = r ? 1 : 0; push(); }    // gicp.h:285
   // pcl::Registration setters used by SetupICP (PointCloudOdometry.cc:147-155)
-  void setTransformationEpsilon(double e) { p_.transformation_epsilon = e; push(); }
+  void setTransformationEpsilon(double e) override { p_.transformation_epsilon = e; push(); }
   double getTransformationEpsilon() const { return p_.transformation_epsilon; }
-  void setMaxCorrespondenceDistance(double d) { p_.corr_dist = d; push(); }
+  void setMaxCorrespondenceDistance(double d) override { p_.corr_dist = d; push(); }
   double getMaxCorrespondenceDistance() const { return p_.corr_dist; }
-  void setMaximumIterations(int n) { p_.max_iterations = n; push(); }
+  void setMaximumIterations(int n) override { p_.max_iterations = n; push(); }
   int getMaximumIterations() const { return p_.max_iterations; }
-  void setRANSACIterations(int) {}            // accepted, unused by this computeTransformation
-  void setEuclideanFitnessEpsilon(double) {}  // set by SetupICP but never consulted
+  void setRANSACIterations(int) override {}            // accepted, unused by this computeTransformation
+  void setEuclideanFitnessEpsilon(double) override {}  // set by SetupICP but never consulted
   void setCostMode(int mode) { p_.cost_mode = mode; push(); }
 
-  void setInputSource(const PointCloudF::Ptr& cloud) {  // gicp.h:162-179
+  void setInputSource(const PointCloudF::Ptr& cloud) override {  // gicp.h:162-179
     src_ = cloud;
     lh_cloud_view v = ViewOf(*cloud);
     check(lh_gicp_set_source(g_, &v), "setInputSource");
   }
-  void setInputTarget(const PointCloudF::Ptr& cloud) {  // gicp.h:196-200
+  void setInputTarget(const PointCloudF::Ptr& cloud) override {  // gicp.h:196-200
     tgt_ = cloud;
     lh_cloud_view v = ViewOf(*cloud);
     check(lh_gicp_set_target(g_, &v), "setInputTarget");
@@ -62,7 +62,7 @@ public:
   void promoteSourceToTarget() { tgt_ = src_; check(lh_gicp_promote_source_to_target(g_), "promoteSourceToTarget"); }
 
   // pcl::Registration::align(output) / align(output, guess): column-major 4x4 like Eigen::Matrix4f
-  void align(PointCloudF& output, const float* guess = nullptr) {
+  void align(PointCloudF& output, const float* guess = nullptr) override {
     output.points = src_->points;  // PCL copies the input (all fields) and overwrites xyz with the aligned positions
     output.stamp = src_->stamp;
     lh_gicp_result r;
@@ -73,18 +73,17 @@ public:
     iterations_ = r.iterations;
     last_status_ = r.status;
   }
-  const float* getFinalTransformation() const { return final_; }  // column-major
-  float T(int r, int c) const { return final_[c * 4 + r]; }
-  bool hasConverged() const { return converged_; }
+  const float* getFinalTransformation() const override { return final_; }  // column-major
+  bool hasConverged() const override { return converged_; }
   int getNumIterations() const { return iterations_; }
   int getLastStatus() const { return last_status_; }
-  double getFitnessScore() {
+  double getFitnessScore() override {
     double f = 0;
     check(lh_gicp_fitness(g_, &f), "getFitnessScore");
     return f;
   }
   // getSearchMethodTarget()->nearestKSearch(pt, 1, ...) for a whole cloud (PointCloudLocalization.cc:327-336)
-  void nearestTargetIndices(const PointCloudF& q, std::vector<size_t>* out) {
+  void nearestTargetIndices(const PointCloudF& q, std::vector<size_t>* out) override {
     std::vector<int32_t> idx(q.size());
     lh_cloud_view v = ViewOf(q);
     check(lh_nn1(g_, &v, idx.data(), nullptr), "nearestTargetIndices");

@@ -21,18 +21,30 @@ bool PointCloudLocalization::Initialize(const Config& cfg) {
 }
 
 bool PointCloudLocalization::SetupICP() {  // :223-289
+  if (params_.registration_method == "ndt") {  // RegistrationMethod::NDT branch
+    std::shared_ptr<NdtHip> ndt(new NdtHip(ctx_));
+    ndt->setTransformationEpsilon(params_.tf_epsilon);
+    ndt->setMaxCorrespondenceDistance(params_.corr_dist);
+    ndt->setMaximumIterations(params_.iterations);
+    ndt->setRANSACIterations(0);
+    ndt->setNumThreads(params_.num_threads);
+    ndt->enableTimingOutput(params_.enable_timing_output);
+    icp_ = ndt;
+    return true;
+  }
   if (params_.registration_method != "gicp" && params_.registration_method != "gicp_hip")
     throw std::runtime_error("No such Registration mode or not implemented yet " + params_.registration_method);
-  icp_.reset(new MultithreadedGicpHip(ctx_));
+  std::shared_ptr<MultithreadedGicpHip> gicp(new MultithreadedGicpHip(ctx_));
+  icp_ = gicp;
   icp_->setTransformationEpsilon(params_.tf_epsilon);
   icp_->setMaxCorrespondenceDistance(params_.corr_dist);
   icp_->setMaximumIterations(params_.iterations);
-  icp_->setMaximumOptimizerIterations(50);  // :238
+  gicp->setMaximumOptimizerIterations(50);  // :238
   icp_->setRANSACIterations(0);
   icp_->setNumThreads(params_.num_threads);
   icp_->enableTimingOutput(params_.enable_timing_output);
-  icp_->RecomputeTargetCovariance(params_.recompute_covariance_local_map);
-  icp_->RecomputeSourceCovariance(params_.recompute_covariance_scan);
+  gicp->RecomputeTargetCovariance(params_.recompute_covariance_local_map);
+  gicp->RecomputeSourceCovariance(params_.recompute_covariance_scan);
   return true;
 }
 

@@ -6,6 +6,7 @@
 #include <vector>
 
 #include "MultithreadedGicpHip.hpp"
+#include "NdtHip.hpp"
 #include "geometry_utils.hpp"
 
 namespace locus_hip {
@@ -56,7 +57,7 @@ public:
   struct Diagnostics { int level; std::string message; };
   Diagnostics GetDiagnostics() const;
 
-  MultithreadedGicpHip::Ptr icp_;
+  RegistrationHip::Ptr icp_;
 
 private:
   bool SetupICP();

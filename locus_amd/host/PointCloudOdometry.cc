@@ -31,17 +31,29 @@ bool PointCloudOdometry::Initialize(const Config& cfg) {  // Initialize -> LoadP
 }
 
 bool PointCloudOdometry::SetupICP() {  // :136-204
+  if (params_.registration_method == "ndt") {  // RegistrationMethod::NDT branch
+    std::shared_ptr<NdtHip> ndt(new NdtHip(ctx_));
+    ndt->setTransformationEpsilon(params_.icp_tf_epsilon);
+    ndt->setMaxCorrespondenceDistance(params_.icp_corr_dist);
+    ndt->setMaximumIterations((int)params_.icp_iterations);
+    ndt->setRANSACIterations(0);
+    ndt->setNumThreads(params_.num_threads);
+    ndt->enableTimingOutput(params_.enable_timing_output);
+    icp_ = ndt;
+    return true;
+  }
   if (params_.registration_method != "gicp" && params_.registration_method != "gicp_hip")
     throw std::runtime_error("No such Registration mode or not implemented yet " + params_.registration_method);
-  icp_.reset(new MultithreadedGicpHip(ctx_));
+  std::shared_ptr<MultithreadedGicpHip> gicp(new MultithreadedGicpHip(ctx_));
+  icp_ = gicp;
   icp_->setTransformationEpsilon(params_.icp_tf_epsilon);
   icp_->setMaxCorrespondenceDistance(params_.icp_corr_dist);
   icp_->setMaximumIterations((int)params_.icp_iterations);
   icp_->setRANSACIterations(0);
   icp_->setNumThreads(params_.num_threads);
   icp_->enableTimingOutput(params_.enable_timing_output);
-  icp_->RecomputeTargetCovariance(params_.recompute_covariances);
-  icp_->RecomputeSourceCovariance(params_.recompute_covariances);
+  gicp->RecomputeTargetCovariance(params_.recompute_covariances);
+  gicp->RecomputeSourceCovariance(params_.recompute_covariances);
   icp_->setEuclideanFitnessEpsilon(0.005);
   return true;
 }

@@ -5,6 +5,7 @@
 #include <string>
 
 #include "MultithreadedGicpHip.hpp"
+#include "NdtHip.hpp"
 #include "geometry_utils.hpp"
 
 namespace locus_hip {
@@ -12,7 +13,7 @@ namespace locus_hip {
 class PointCloudOdometry {
 public:
   struct Config {                      // rosparam key (PointCloudOdometry.cc:72-96)
-    std::string registration_method = "gicp";  // icp/registration_method   ("gicp" -> the HIP path; "ndt" unsupported)
+    std::string registration_method = "gicp";  // icp/registration_method   ("gicp" | "ndt", registration_settings.h:13-20)
     double icp_tf_epsilon = 0.001;     // icp/tf_epsilon
     double icp_corr_dist = 1.0;        // icp/corr_dist
     unsigned int icp_iterations = 20;  // icp/iterations
@@ -55,7 +56,7 @@ public:
   struct Diagnostics { int level; std::string message; };
   Diagnostics GetDiagnostics() const;
 
-  MultithreadedGicpHip::Ptr icp_;  // the reference keeps this private; tests reach it through a friend accessor
+  RegistrationHip::Ptr icp_;  // the reference keeps this private; tests reach it through a friend accessor
 
 private:
   bool SetupICP();

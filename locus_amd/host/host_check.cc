@@ -157,6 +157,45 @@ int main() {
     EXPECT(pcl_.MotionUpdate(gu::Transform3()));
   }
 
+  {  // the same odometry scenario with registration_method "ndt" (SetupICP NDT branch, PointCloudOdometry.cc:182-196): a dense
+     // wall pattern (NDT needs >= 6 points per 1-m voxel), second scan translated by 5 cm
+    PointCloudOdometry pco(ctx);
+    PointCloudOdometry::Config cfg;
+    cfg.registration_method = "ndt";
+    cfg.icp_tf_epsilon = 1e-3;
+    cfg.icp_iterations = 30;
+    PointCloudF::Ptr room(new PointCloudF);
+    for (int i = 0; i < 120; i++)
+      for (int j = 0; j < 40; j++) {
+        float u = 0.1f * i - 6.0f, v = 0.1f * j - 1.0f, w = 0.003f * (float)((i * 7 + j * 13) % 10);  // a little relief: non-degenerate voxels
+        PointF a, b, c2, d;
+        a.x = 6.0f + w; a.y = u; a.z = v;
+        b.x = -6.0f - w; b.y = u; b.z = v;
+        c2.x = u; c2.y = 6.0f + w; c2.z = v;
+        d.x = u; d.y = -6.0f - w; d.z = v;
+        room->points.push_back(a); room->points.push_back(b); room->points.push_back(c2); room->points.push_back(d);
+      }
+    for (int i = 0; i < 120; i++)
+      for (int j = 0; j < 120; j++) { PointF f; f.x = 0.1f * i - 6.0f; f.y = 0.1f * j - 6.0f; f.z = -1.0f - 0.002f * (float)((i + j) % 7); room->points.push_back(f); }
+    PointCloudF moved = *room;
+    for (auto& p : moved.points) { p.x += 0.05f; p.y -= 0.03f; }
+    EXPECT(pco.Initialize(cfg));
+    EXPECT(pco.SetLidar(*room));
+    EXPECT(!pco.UpdateEstimate());
+    EXPECT(pco.SetLidar(moved));
+    EXPECT(pco.UpdateEstimate());
+    EXPECT(pco.icp_->hasConverged());
+    double inv[12];
+    Inverse4(pco.icp_->getFinalTransformation(), inv);
+    EXPECT_NEAR(inv[3], 0.05, epsiliond);
+    EXPECT_NEAR(inv[7], -0.03, epsiliond);
+    EXPECT_NEAR(inv[11], 0.0, epsiliond);
+    EXPECT(pco.icp_->getFitnessScore() < 0.01);
+    bool threw = false;
+    try { PointCloudOdometry bad(ctx); PointCloudOdometry::Config c3; c3.registration_method = "icp"; bad.Initialize(c3); } catch (const std::exception&) { threw = true; }
+    EXPECT(threw);  // getRegistrationMethodFromString: unknown method (registration_settings.h:13-20)
+  }
+
   {  // mapper_ call order of Locus.cc:462-489 / 531-538 on the device-resident map (no reference test exists: the mapper is un-vendored)
     PointCloudMapperHip mapper(ctx);
     EXPECT(mapper.Initialize(0.05));
