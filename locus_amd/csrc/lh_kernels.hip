@@ -467,13 +467,21 @@ __device__ __forceinline__ void moments_of_point(const SweepJob& job, const Swee
 // with their traversal stacks) each wave owns a private 4-KB slice [8 values][64 lanes] of the LDS region; a wave's DS
 // operations execute in order, so write -> fence -> read needs no s_barrier.  64 lanes -> 8 strided partial sums -> 3
 // shuffles.  `value(k)` yields the lane's k-th of NV values; the row (ROW doubles) is completed with `extra` and zeros.
+// sum of a double with its neighbour lane (lane ^ 1) through DPP quad_perm [1,0,3,2]: two v_mov_dpp + one v_add_f64, no LDS
+__device__ __forceinline__ double pair_sum(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_mov_dpp(lo, 0xB1, 0xF, 0xF, true);
+  hi = __builtin_amdgcn_mov_dpp(hi, 0xB1, 0xF, 0xF, true);
+  return v + __hiloint2double(hi, lo);
+}
 template <int NV, int ROW, class F>
 __device__ __forceinline__ void wave_reduce_row(uint64_t* lds_base, double* out, double extra, F value) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  // row stride 72 doubles (not 64): the 16 lanes the LDS serves per cycle read two 64-B pieces of two DIFFERENT rows, and
-  // 576-B rows put those on complementary bank halves; with 512-B rows they collided (SQ_LDS_BANK_CONFLICT = 26 % of the
-  // LDS-active cycles, and the LDS pipe was busy for 78 % of a late sweep)
-  constexpr int RS = 72;
+  // Lane pairs are added in registers first (DPP), so only the even lanes go through LDS: 32 entries per value.  Row stride
+  // 40 doubles (not 32): the 16 lanes the LDS serves per cycle read two 64-B pieces of two DIFFERENT rows, and 320-B rows put
+  // those on complementary bank halves (with power-of-two rows they collided: SQ_LDS_BANK_CONFLICT was 26 % of the LDS-active
+  // cycles).  A second DPP step (quads, 16 entries per value) measured slightly slower: the VALU is the tighter resource then.
+  constexpr int RS = 40;
   double* wst = reinterpret_cast<double*>(lds_base) + wave * (8 * RS);
   const int v_of = lane >> 3, part = lane & 7;
   __syncthreads();
@@ -482,13 +490,16 @@ __device__ __forceinline__ void wave_reduce_row(uint64_t* lds_base, double* out,
 #pragma unroll
     for (int v = 0; v < 8; v++) {
       int k = g * 8 + v;
-      if (k < NV) wst[v * RS + lane] = value(k);
+      if (k < NV) {
+        double s2 = pair_sum(value(k));
+        if (!(lane & 1)) wst[v * RS + (lane >> 1)] = s2;
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
     double s = 0.0;
 #pragma unroll
-    for (int jj = 0; jj < 8; jj++) s += wst[v_of * RS + jj * 8 + part];
+    for (int jj = 0; jj < 4; jj++) s += wst[v_of * RS + jj * 8 + part];
 #pragma unroll
     for (int off = 4; off > 0; off >>= 1) s += __shfl_down(s, off, 8);
     if (part == 0 && g * 8 + v_of < NV) out[g * 8 + v_of] = s;
