@@ -247,6 +247,28 @@ def main():
             result["cost_mode0"] = {"value": round(args.pairs / dt0, 2), "unit": "scan-pairs/s",
                                     "max_abs_pose_diff_vs_mode1": float(max(np.abs(np.asarray(a["T"]) - np.asarray(b["T"])).max()
                                                                             for a, b in zip(out0, out)))}
+        if world == 1:
+            # SURVEY 8d "natural convergence" run: the same pairs with the production stopping rule (tf_eps 1e-3, rot_eps 2e-3,
+            # gicp.h:119, parameters.yaml) instead of 20 forced iterations: iterations to converge, rate, distance to the forced result
+            Pn = capi.default_params(max_iterations=20, max_inner_iterations=20, corr_dist=1.0, transformation_epsilon=1e-3,
+                                     rotation_epsilon=2e-3, cost_mode=args.cost_mode)
+
+            def stepn():
+                for t in T:
+                    t.drop_index()
+                return capi.align_batch(ctx, Pn, S, T, max_in_flight=args.in_flight)
+
+            stepn()
+            ctx.synchronize()
+            t1 = time.perf_counter()
+            outn = stepn()
+            ctx.synchronize()
+            dtn = time.perf_counter() - t1
+            itn = [int(o["iterations"]) for o in outn]
+            result["natural_convergence"] = {
+                "value": round(args.pairs / dtn, 2), "unit": "scan-pairs/s", "iterations_min_mean_max": [min(itn), float(np.mean(itn)), max(itn)],
+                "all_converged": bool(all(o["converged"] == 1 for o in outn)),
+                "max_abs_pose_diff_vs_20_forced_iterations": float(max(np.abs(np.asarray(a["T"]) - np.asarray(b["T"])).max() for a, b in zip(outn, out)))}
         if world == 1 and not args.no_cpu_baseline:
             cb, poses = cpu_baseline(S, T, host, P)
             # parity of the timed GPU work against the CPU path on the sampled pairs (reported, asserted in tests/)
