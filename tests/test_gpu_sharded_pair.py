@@ -70,6 +70,6 @@ def test_source_sharded_pair_equals_whole():
         Tw, itw, ncw, fw = whole
         assert nc0 == ncw and it0 == itw                # the correspondence count is an integer sum: exact
         assert np.abs(T0 - Tw).max() < 1e-5, (mode, np.abs(T0 - Tw).max())
-        assert abs(f0 - fw) <= 1e-9 * abs(fw)
+        assert abs(f0 - fw) <= 1e-6 * abs(fw)            # the fitness of two transforms that differ by < 1e-5
         Tm = T0.reshape(4, 4).T
         assert np.abs(Tm[:3, 3] - delta[:3, 3]).max() < 0.05
