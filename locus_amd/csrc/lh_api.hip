@@ -13,7 +13,9 @@
 #include <atomic>
 #include <condition_variable>
 #include <functional>
+#include <map>
 #include <mutex>
+#include <unordered_map>
 #include <thread>
 #include <cmath>
 #include <cstdio>
@@ -41,6 +43,74 @@ using namespace lh;
 static const float I16[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
 
 // ---------------------------------------------------------------------------------------------------------
+// ---- device-memory pool ---------------------------------------------------------------------------------------------------
+// Every entry point that returns a new cloud, and every filter stage, needs a few device buffers for the duration of one call.
+// hipMalloc costs tens of microseconds and hipFree synchronises the whole device, which made the pre-processing chain of a
+// 1 M-point frame (merge -> crop -> voxel grid -> normals: ~1 ms of kernels) take 2.9 ms.  Blocks are therefore recycled:
+// lhFree parks a block in a per-device free list (no hipFree, no sync), lhMalloc takes the smallest parked block that fits with
+// <= 25 % slack.  Safe because every user allocates, launches and frees on the context's primary stream (a recycled block is
+// only reused by work queued behind the work that used it last); the second scheduler stream only ever touches per-slot
+// workspaces and context scratch, which are allocated once and not pooled.  The cache is trimmed when it exceeds 8 GB.
+namespace {
+struct DevPool {
+  std::mutex mu;
+  std::unordered_map<void*, size_t> live;   // pooled blocks handed out
+  std::multimap<size_t, void*> parked;
+  size_t parked_bytes = 0;
+};
+DevPool g_pools[64];
+size_t pool_round(size_t b) {
+  if (b < 256) return 256;
+  if (b <= (1u << 20)) { size_t r = 256; while (r < b) r <<= 1; return r; }
+  return (b + (1u << 20) - 1) & ~(size_t)((1u << 20) - 1);
+}
+void pool_trim(DevPool& P) {  // caller holds the lock
+  (void)hipDeviceSynchronize();
+  for (auto& kv : P.parked) (void)hipFree(kv.second);
+  P.parked.clear();
+  P.parked_bytes = 0;
+}
+}  // namespace
+static hipError_t lhMallocRaw(void** p, size_t bytes) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  DevPool& P = g_pools[dev & 63];
+  const size_t want = pool_round(bytes);
+  std::lock_guard<std::mutex> lk(P.mu);
+  auto it = P.parked.lower_bound(want);
+  if (it != P.parked.end() && it->first <= want + want / 4) {
+    *p = it->second;
+    P.live[*p] = it->first;
+    P.parked_bytes -= it->first;
+    P.parked.erase(it);
+    return hipSuccess;
+  }
+  hipError_t e = hipMalloc(p, want);
+  if (e != hipSuccess && !P.parked.empty()) {  // out of memory with blocks parked: give them back and retry
+    (void)hipGetLastError();
+    pool_trim(P);
+    e = hipMalloc(p, want);
+  }
+  if (e == hipSuccess) P.live[*p] = want;
+  return e;
+}
+template <class T>
+static hipError_t lhMalloc(T** p, size_t bytes) { return lhMallocRaw(reinterpret_cast<void**>(p), bytes); }
+static hipError_t lhFree(void* p) {
+  if (!p) return hipSuccess;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  DevPool& P = g_pools[dev & 63];
+  std::lock_guard<std::mutex> lk(P.mu);
+  auto it = P.live.find(p);
+  if (it == P.live.end()) return hipFree(p);  // not from the pool (context scratch, workspaces)
+  P.parked.emplace(it->second, p);
+  P.parked_bytes += it->second;
+  P.live.erase(it);
+  if (P.parked_bytes > ((size_t)8 << 30)) pool_trim(P);
+  return hipSuccess;
+}
+
 struct ProfEntry { std::string name; uint64_t launches = 0; double ms = 0, bytes = 0; };
 struct ProfPending { int entry; hipEvent_t a, b; };
 
@@ -220,15 +290,15 @@ static int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 static void cloud_free(lh_cloud* c) {
   if (!c) return;
-  (void)hipFree(c->xyz); (void)hipFree(c->nrm); (void)hipFree(c->intensity);
-  (void)hipFree(c->sorted); (void)hipFree(c->node_buf); (void)hipFree(c->cov6); (void)hipFree(c->pos);
+  (void)lhFree(c->xyz); (void)lhFree(c->nrm); (void)lhFree(c->intensity);
+  (void)lhFree(c->sorted); (void)lhFree(c->node_buf); (void)lhFree(c->cov6); (void)lhFree(c->pos);
   delete c;
 }
 
 static lh_status ctx_ensure_scratch(lh_ctx* c, int n) {
   if (n <= c->scratch_n) return LH_OK;
   (void)hipStreamSynchronize(c->stream);
-  (void)hipFree(c->keys0); (void)hipFree(c->keys1); (void)hipFree(c->vals0); (void)hipFree(c->vals1); (void)hipFree(c->sort_temp);
+  (void)lhFree(c->keys0); (void)lhFree(c->keys1); (void)lhFree(c->vals0); (void)lhFree(c->vals1); (void)lhFree(c->sort_temp);
   int cap = round_up(n + n / 4, 1024);
   HIPCHK(hipMalloc(&c->keys0, sizeof(uint32_t) * cap));
   HIPCHK(hipMalloc(&c->keys1, sizeof(uint32_t) * cap));
@@ -275,11 +345,11 @@ static lh_status build_indices(lh_ctx* x, lh_cloud* const* clouds, int n_clouds,
       if (c->n > c->index_cap) {
         (void)hipStreamSynchronize(x->stream);
         if (x->stream2) (void)hipStreamSynchronize(x->stream2);
-        (void)hipFree(c->sorted); (void)hipFree(c->pos); (void)hipFree(c->node_buf);
+        (void)lhFree(c->sorted); (void)lhFree(c->pos); (void)lhFree(c->node_buf);
         c->sorted = nullptr; c->pos = nullptr; c->node_buf = nullptr; c->index_cap = 0;
-        HIPCHK(hipMalloc(&c->sorted, sizeof(float4) * ((size_t)c->n + LEAF_CAP)));
-        HIPCHK(hipMalloc(&c->pos, sizeof(int32_t) * (size_t)c->n));
-        HIPCHK(hipMalloc(&c->node_buf, sizeof(NodeX) * ((size_t)c->n + 1)));  // worst case: every point its own leaf
+        HIPCHK(lhMalloc(&c->sorted, sizeof(float4) * ((size_t)c->n + LEAF_CAP)));
+        HIPCHK(lhMalloc(&c->pos, sizeof(int32_t) * (size_t)c->n));
+        HIPCHK(lhMalloc(&c->node_buf, sizeof(NodeX) * ((size_t)c->n + 1)));  // worst case: every point its own leaf
         c->index_cap = c->n;
       }
       IndexDesc& d = x->idx_descs_host[k];
@@ -292,8 +362,8 @@ static lh_status build_indices(lh_ctx* x, lh_cloud* const* clouds, int n_clouds,
     if ((int)total > x->idx_cap) {
       (void)hipStreamSynchronize(x->stream);
       if (x->stream2) (void)hipStreamSynchronize(x->stream2);
-      (void)hipFree(x->k64a); (void)hipFree(x->k64b); (void)hipFree(x->v32a); (void)hipFree(x->v32b); (void)hipFree(x->sort64_temp);
-      (void)hipFree(x->tree_tmp); (void)hipFree(x->scan_tmp);
+      (void)lhFree(x->k64a); (void)lhFree(x->k64b); (void)lhFree(x->v32a); (void)lhFree(x->v32b); (void)lhFree(x->sort64_temp);
+      (void)lhFree(x->tree_tmp); (void)lhFree(x->scan_tmp);
       int cap = round_up((int)std::min<long>(total + total / 4, 0x7fffff00L), 1024);
       HIPCHK(hipMalloc(&x->k64a, sizeof(uint64_t) * (size_t)cap));
       HIPCHK(hipMalloc(&x->k64b, sizeof(uint64_t) * (size_t)cap));
@@ -349,7 +419,7 @@ static lh_status cloud_ensure_cov(lh_cloud* c, int k, double eps) {
   if (c->cov6 && c->cov_k == k && c->cov_eps == eps) return LH_OK;
   if (k > c->n || k > 64 || k < 1) return LH_EINVAL;  // gicp.hpp:72-79
   if (!c->has_index) { lh_status st = cloud_build_index(c); if (st) return st; }
-  if (!c->cov6) HIPCHK(hipMalloc(&c->cov6, sizeof(double) * 6 * (size_t)c->n_pad));
+  if (!c->cov6) HIPCHK(lhMalloc(&c->cov6, sizeof(double) * 6 * (size_t)c->n_pad));
   { ProfScope p(c->ctx, "knn_cov", (16.0 + 20 * 16.0 + 48.0) * c->n); launch_knn_cov(c->xyz, c->n, c->n_pad, c->view(), k, eps, c->cov6, c->ctx->stream); }
   HIPCHK(hipGetLastError());
   c->cov_k = k;
@@ -371,7 +441,7 @@ struct Workspace {
   lh_status ensure(lh_ctx* c, int n) {
     if (n <= cap) return LH_OK;
     (void)hipStreamSynchronize(c->stream);
-    (void)hipFree(corr); (void)hipFree(maha6); (void)hipFree(prev_nn); (void)hipFree(out_xyz); (void)hipFree(cert);
+    (void)lhFree(corr); (void)lhFree(maha6); (void)lhFree(prev_nn); (void)lhFree(out_xyz); (void)lhFree(cert);
     int ncap = round_up(n, 256);
     HIPCHK(hipMalloc(&corr, sizeof(float4) * (size_t)ncap));
     HIPCHK(hipMalloc(&maha6, sizeof(double) * 6 * (size_t)ncap));
@@ -384,7 +454,7 @@ struct Workspace {
     return LH_OK;
   }
   void release() {
-    (void)hipFree(corr); (void)hipFree(maha6); (void)hipFree(prev_nn); (void)hipFree(out_xyz); (void)hipFree(cert);
+    (void)lhFree(corr); (void)lhFree(maha6); (void)lhFree(prev_nn); (void)lhFree(out_xyz); (void)lhFree(cert);
     corr = nullptr; maha6 = nullptr; prev_nn = nullptr; out_xyz = nullptr; cert = nullptr; cap = 0;
   }
 };
@@ -397,8 +467,8 @@ static lh_status ctx_ensure_slots(lh_ctx* c, int n_slots, int max_n) {
   n_slots = std::max(n_slots, c->n_slots);
   per_slot = std::max(per_slot, c->partials_per_slot);
   mom_stride = std::max(mom_stride, c->mom_stride);
-  (void)hipFree(c->descs_dev);
-  (void)hipFree(c->mom_partials_dev);
+  (void)lhFree(c->descs_dev);
+  (void)lhFree(c->mom_partials_dev);
   if (c->descs_host) (void)hipHostFree(c->descs_host);
   if (c->partials_host) (void)hipHostFree(c->partials_host);
   HIPCHK(hipMalloc(&c->descs_dev, sizeof(PairDesc) * n_slots));
@@ -908,9 +978,9 @@ static lh_status upload_view(lh_ctx* c, const lh_cloud_view* v, lh_cloud** out) 
     }
     if (has_i) inten[i] = *(const float*)(p + v->off_intensity);
   }
-  hipError_t e = hipMalloc(&cl->xyz, sizeof(float4) * (size_t)cl->n_pad);
-  if (e == hipSuccess && has_n) e = hipMalloc(&cl->nrm, sizeof(float4) * (size_t)cl->n_pad);
-  if (e == hipSuccess && has_i) e = hipMalloc(&cl->intensity, sizeof(float) * (size_t)cl->n_pad);
+  hipError_t e = lhMalloc(&cl->xyz, sizeof(float4) * (size_t)cl->n_pad);
+  if (e == hipSuccess && has_n) e = lhMalloc(&cl->nrm, sizeof(float4) * (size_t)cl->n_pad);
+  if (e == hipSuccess && has_i) e = lhMalloc(&cl->intensity, sizeof(float) * (size_t)cl->n_pad);
   if (e == hipSuccess) e = hipMemcpyAsync(cl->xyz, xyz.data(), sizeof(float) * 4 * n, hipMemcpyHostToDevice, c->stream);
   if (e == hipSuccess && has_n) e = hipMemcpyAsync(cl->nrm, nrm.data(), sizeof(float) * 4 * n, hipMemcpyHostToDevice, c->stream);
   if (e == hipSuccess && has_i) e = hipMemcpyAsync(cl->intensity, inten.data(), sizeof(float) * n, hipMemcpyHostToDevice, c->stream);
@@ -986,15 +1056,15 @@ void lh_destroy(lh_ctx* c) {
   c->pool = nullptr;
   c->prof_flush();
   for (auto e : c->ev_pool) (void)hipEventDestroy(e);
-  (void)hipFree(c->keys0); (void)hipFree(c->keys1); (void)hipFree(c->vals0); (void)hipFree(c->vals1);
-  (void)hipFree(c->k64a); (void)hipFree(c->k64b); (void)hipFree(c->v32a); (void)hipFree(c->v32b); (void)hipFree(c->sort64_temp);
-  (void)hipFree(c->tree_tmp); (void)hipFree(c->scan_tmp);
-  (void)hipFree(c->idx_bbox); (void)hipFree(c->idx_descs_dev);
+  (void)lhFree(c->keys0); (void)lhFree(c->keys1); (void)lhFree(c->vals0); (void)lhFree(c->vals1);
+  (void)lhFree(c->k64a); (void)lhFree(c->k64b); (void)lhFree(c->v32a); (void)lhFree(c->v32b); (void)lhFree(c->sort64_temp);
+  (void)lhFree(c->tree_tmp); (void)lhFree(c->scan_tmp);
+  (void)lhFree(c->idx_bbox); (void)lhFree(c->idx_descs_dev);
   if (c->idx_descs_host) (void)hipHostFree(c->idx_descs_host);
   if (c->idx_copy_done) (void)hipEventDestroy(c->idx_copy_done);
   if (c->idx_build_done) (void)hipEventDestroy(c->idx_build_done);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
-  (void)hipFree(c->sort_temp); (void)hipFree(c->bbox); (void)hipFree(c->descs_dev); (void)hipFree(c->mom_partials_dev);
+  (void)lhFree(c->sort_temp); (void)lhFree(c->bbox); (void)lhFree(c->descs_dev); (void)lhFree(c->mom_partials_dev);
   if (c->descs_host) (void)hipHostFree(c->descs_host);
   if (c->partials_host) (void)hipHostFree(c->partials_host);
   if (c->small_host) (void)hipHostFree(c->small_host);
@@ -1066,10 +1136,10 @@ lh_status lh_cloud_transform(const lh_cloud* in, const float T[16], int with_nor
   lh_cloud* o = (*out == in) ? const_cast<lh_cloud*>(in) : new lh_cloud();
   if (o != in) {
     o->ctx = c; o->n = in->n; o->n_pad = in->n_pad;
-    HIPCHK(hipMalloc(&o->xyz, sizeof(float4) * (size_t)o->n_pad));
-    if (in->nrm) HIPCHK(hipMalloc(&o->nrm, sizeof(float4) * (size_t)o->n_pad));
+    HIPCHK(lhMalloc(&o->xyz, sizeof(float4) * (size_t)o->n_pad));
+    if (in->nrm) HIPCHK(lhMalloc(&o->nrm, sizeof(float4) * (size_t)o->n_pad));
     if (in->intensity) {
-      HIPCHK(hipMalloc(&o->intensity, sizeof(float) * (size_t)o->n_pad));
+      HIPCHK(lhMalloc(&o->intensity, sizeof(float) * (size_t)o->n_pad));
       HIPCHK(hipMemcpyAsync(o->intensity, in->intensity, sizeof(float) * (size_t)in->n, hipMemcpyDeviceToDevice, c->stream));
     }
     if (in->nrm && !with_normals) HIPCHK(hipMemcpyAsync(o->nrm, in->nrm, sizeof(float4) * (size_t)in->n, hipMemcpyDeviceToDevice, c->stream));
@@ -1093,9 +1163,9 @@ lh_status lh_cloud_slice(const lh_cloud* in, uint32_t first, uint32_t count, lh_
   HIPCHK(hipSetDevice(c->device));
   lh_cloud* o = new lh_cloud();
   o->ctx = c; o->n = (int)count; o->n_pad = round_up(o->n, 256);
-  hipError_t e = hipMalloc(&o->xyz, sizeof(float4) * (size_t)o->n_pad);
-  if (e == hipSuccess && in->nrm) e = hipMalloc(&o->nrm, sizeof(float4) * (size_t)o->n_pad);
-  if (e == hipSuccess && in->intensity) e = hipMalloc(&o->intensity, sizeof(float) * (size_t)o->n_pad);
+  hipError_t e = lhMalloc(&o->xyz, sizeof(float4) * (size_t)o->n_pad);
+  if (e == hipSuccess && in->nrm) e = lhMalloc(&o->nrm, sizeof(float4) * (size_t)o->n_pad);
+  if (e == hipSuccess && in->intensity) e = lhMalloc(&o->intensity, sizeof(float) * (size_t)o->n_pad);
   if (e != hipSuccess) { cloud_free(o); return LH_ENOMEM; }
   e = hipMemcpyAsync(o->xyz, in->xyz + first, sizeof(float4) * (size_t)count, hipMemcpyDeviceToDevice, c->stream);
   if (e == hipSuccess && in->nrm) e = hipMemcpyAsync(o->nrm, in->nrm + first, sizeof(float4) * (size_t)count, hipMemcpyDeviceToDevice, c->stream);
@@ -1122,9 +1192,9 @@ lh_status lh_cloud_concat(lh_cloud* const* parts, int n_parts, lh_cloud** out) {
   HIPCHK(hipSetDevice(c->device));
   lh_cloud* o = new lh_cloud();
   o->ctx = c; o->n = (int)total; o->n_pad = round_up(o->n, 256);
-  hipError_t e = hipMalloc(&o->xyz, sizeof(float4) * (size_t)o->n_pad);
-  if (e == hipSuccess && nrm) e = hipMalloc(&o->nrm, sizeof(float4) * (size_t)o->n_pad);
-  if (e == hipSuccess && inten) e = hipMalloc(&o->intensity, sizeof(float) * (size_t)o->n_pad);
+  hipError_t e = lhMalloc(&o->xyz, sizeof(float4) * (size_t)o->n_pad);
+  if (e == hipSuccess && nrm) e = lhMalloc(&o->nrm, sizeof(float4) * (size_t)o->n_pad);
+  if (e == hipSuccess && inten) e = lhMalloc(&o->intensity, sizeof(float) * (size_t)o->n_pad);
   if (e != hipSuccess) { cloud_free(o); return LH_ENOMEM; }
   size_t at = 0;
   for (int i = 0; i < n_parts && e == hipSuccess; i++) {
@@ -1256,8 +1326,8 @@ static lh_status nn1_device(lh_ctx* c, lh_cloud* target, const float4* q, int nq
   int32_t* d_idx = nullptr;
   float* d_d2 = nullptr;
   double* d_part = nullptr;
-  HIPCHK(hipMalloc(&d_idx, sizeof(int32_t) * (size_t)nq));
-  HIPCHK(hipMalloc(&d_d2, sizeof(float) * (size_t)nq));
+  HIPCHK(lhMalloc(&d_idx, sizeof(int32_t) * (size_t)nq));
+  HIPCHK(lhMalloc(&d_d2, sizeof(float) * (size_t)nq));
   float T12[12];
   if (T16) fill_T12(T16, T12);
   { ProfScope p(c, "nn1", 24.0 * nq); launch_nn1(q, nq, T16 ? T12 : nullptr, target->view(), d_idx, d_d2, c->stream); }
@@ -1266,7 +1336,7 @@ static lh_status nn1_device(lh_ctx* c, lh_cloud* target, const float4* q, int nq
     int nb = sum_blocks(nq);
     rc = ctx_ensure_small(c, (size_t)nb);
     if (!rc) {
-      HIPCHK(hipMalloc(&d_part, sizeof(double) * (size_t)nb));
+      HIPCHK(lhMalloc(&d_part, sizeof(double) * (size_t)nb));
       launch_sum_f32(d_d2, nq, d_part, c->stream);
       HIPCHK(hipMemcpyAsync(c->small_host, d_part, sizeof(double) * nb, hipMemcpyDeviceToHost, c->stream));
       HIPCHK(hipStreamSynchronize(c->stream));
@@ -1278,7 +1348,7 @@ static lh_status nn1_device(lh_ctx* c, lh_cloud* target, const float4* q, int nq
   if (idx) HIPCHK(hipMemcpyAsync(idx, d_idx, sizeof(int32_t) * (size_t)nq, hipMemcpyDeviceToHost, c->stream));
   if (d2) HIPCHK(hipMemcpyAsync(d2, d_d2, sizeof(float) * (size_t)nq, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
-  (void)hipFree(d_idx); (void)hipFree(d_d2); (void)hipFree(d_part);
+  (void)lhFree(d_idx); (void)lhFree(d_d2); (void)lhFree(d_part);
   return rc;
 }
 
@@ -1324,14 +1394,14 @@ lh_status lh_knn_cloud(lh_cloud* target, const lh_cloud* q, int k, int32_t* idx,
   int32_t* d_idx = nullptr;
   float* d_d2 = nullptr;
   size_t cnt = (size_t)q->n * k;
-  HIPCHK(hipMalloc(&d_idx, sizeof(int32_t) * cnt));
-  HIPCHK(hipMalloc(&d_d2, sizeof(float) * cnt));
+  HIPCHK(lhMalloc(&d_idx, sizeof(int32_t) * cnt));
+  HIPCHK(lhMalloc(&d_d2, sizeof(float) * cnt));
   { ProfScope p(c, "knn", (16.0 + 8.0 * k) * q->n); launch_knn(q->xyz, q->n, target->view(), k, d_idx, d_d2, c->stream); }
   HIPCHK(hipGetLastError());
   if (idx) HIPCHK(hipMemcpyAsync(idx, d_idx, sizeof(int32_t) * cnt, hipMemcpyDeviceToHost, c->stream));
   if (d2) HIPCHK(hipMemcpyAsync(d2, d_d2, sizeof(float) * cnt, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
-  (void)hipFree(d_idx); (void)hipFree(d_d2);
+  (void)lhFree(d_idx); (void)lhFree(d_d2);
   return LH_OK;
 }
 
@@ -1440,13 +1510,13 @@ lh_status lh_debug_traversal_stats(lh_cloud* target, const lh_cloud* q, const fl
   HIPCHK(hipSetDevice(c->device));
   if (!target->has_index) { lh_status st = cloud_build_index(target); if (st) return st; }
   unsigned long long* d = nullptr;
-  HIPCHK(hipMalloc(&d, 8 * 24));
+  HIPCHK(lhMalloc(&d, 8 * 24));
   HIPCHK(hipMemsetAsync(d, 0, 8 * 24, c->stream));
   float T12[12];
   if (T) fill_T12(T, T12);
   int32_t* d_cand = nullptr;
   if (cand) {
-    HIPCHK(hipMalloc(&d_cand, sizeof(int32_t) * (size_t)q->n));
+    HIPCHK(lhMalloc(&d_cand, sizeof(int32_t) * (size_t)q->n));
     HIPCHK(hipMemcpyAsync(d_cand, cand, sizeof(int32_t) * (size_t)q->n, hipMemcpyHostToDevice, c->stream));
   }
   launch_nn1_stats(q->xyz, q->n, T ? T12 : nullptr, target->view(), target->xyz, d_cand, d, c->stream);
@@ -1460,8 +1530,8 @@ lh_status lh_debug_traversal_stats(lh_cloud* target, const lh_cloud* q, const fl
     for (int l = 0; l < MAX_DEPTH; l++) fprintf(stderr, " %.2f", (double)lv[8 + l] / q->n);
     fprintf(stderr, "\n");
   }
-  (void)hipFree(d);
-  (void)hipFree(d_cand);
+  (void)lhFree(d);
+  (void)lhFree(d_cand);
   return LH_OK;
 }
 
@@ -1542,9 +1612,9 @@ lh_status lh_p2plane_information(lh_ctx* c, const lh_cloud* query, const lh_clou
   double* d_part = nullptr;
   float4* d_qn = nullptr;
   int64_t* d_corr = nullptr;
-  HIPCHK(hipMalloc(&d_part, sizeof(double) * (size_t)nb * 21));
-  HIPCHK(hipMalloc(&d_qn, sizeof(float4) * (size_t)n));
-  HIPCHK(hipMalloc(&d_corr, sizeof(int64_t) * (size_t)n));
+  HIPCHK(lhMalloc(&d_part, sizeof(double) * (size_t)nb * 21));
+  HIPCHK(lhMalloc(&d_qn, sizeof(float4) * (size_t)n));
+  HIPCHK(lhMalloc(&d_corr, sizeof(int64_t) * (size_t)n));
   HIPCHK(hipMemcpyAsync(d_corr, corr, sizeof(int64_t) * (size_t)n, hipMemcpyHostToDevice, c->stream));
   // normalizePCloud (utils.cc:106-128): centroid, factor = N / sum |p - c|, q' = factor*(p - c).
   // The reference accumulates both sums sequentially in float; here the sums are double with a fixed tree
@@ -1573,7 +1643,7 @@ lh_status lh_p2plane_information(lh_ctx* c, const lh_cloud* query, const lh_clou
   int t = 0;
   for (int r = 0; r < 6; r++)
     for (int cc = r; cc < 6; cc++) { Ap[r * 6 + cc] = U[t]; Ap[cc * 6 + r] = U[t]; t++; }
-  (void)hipFree(d_part); (void)hipFree(d_qn); (void)hipFree(d_corr);
+  (void)lhFree(d_part); (void)lhFree(d_qn); (void)lhFree(d_corr);
   return LH_OK;
 }
 
@@ -1705,7 +1775,7 @@ lh_status lh_normals_knn_cloud(lh_cloud* c, int k) {
   lh_ctx* x = c->ctx;
   HIPCHK(hipSetDevice(x->device));
   if (!c->has_index) { lh_status st = cloud_build_index(c); if (st) return st; }
-  if (!c->nrm) HIPCHK(hipMalloc(&c->nrm, sizeof(float4) * (size_t)c->n_pad));
+  if (!c->nrm) HIPCHK(lhMalloc(&c->nrm, sizeof(float4) * (size_t)c->n_pad));
   { ProfScope p(x, "knn_normals", (16.0 + 16.0 * k + 16.0) * c->n); launch_knn_normals(c->xyz, c->n, c->view(), k, c->nrm, x->stream); }
   HIPCHK(hipGetLastError());
   return LH_OK;
@@ -1716,7 +1786,7 @@ lh_status lh_normals_radius_cloud(lh_cloud* c, float radius) {
   lh_ctx* x = c->ctx;
   HIPCHK(hipSetDevice(x->device));
   if (!c->has_index) { lh_status st = cloud_build_index(c); if (st) return st; }
-  if (!c->nrm) HIPCHK(hipMalloc(&c->nrm, sizeof(float4) * (size_t)c->n_pad));
+  if (!c->nrm) HIPCHK(lhMalloc(&c->nrm, sizeof(float4) * (size_t)c->n_pad));
   { ProfScope p(x, "radius_normals", 32.0 * c->n); launch_radius_normals(c->xyz, c->n, c->view(), radius, c->nrm, x->stream); }
   HIPCHK(hipGetLastError());
   return LH_OK;
@@ -1745,9 +1815,9 @@ lh_status lh_cloud_remove_nan_normals(const lh_cloud* in, lh_cloud** out) {
   uint32_t *d_flags = nullptr, *d_incl = nullptr;
   void* d_tmp = nullptr;
   size_t tmp_bytes = scan_temp_bytes(n);
-  HIPCHK(hipMalloc(&d_flags, sizeof(uint32_t) * (size_t)n));
-  HIPCHK(hipMalloc(&d_incl, sizeof(uint32_t) * (size_t)n));
-  HIPCHK(hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 16));
+  HIPCHK(lhMalloc(&d_flags, sizeof(uint32_t) * (size_t)n));
+  HIPCHK(lhMalloc(&d_incl, sizeof(uint32_t) * (size_t)n));
+  HIPCHK(lhMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 16));
   launch_finite_normal_flags(in->nrm, n, d_flags, c->stream);
   inclusive_scan_u32(d_tmp, tmp_bytes, d_flags, d_incl, n, c->stream);
   uint32_t total = 0;
@@ -1759,15 +1829,15 @@ lh_status lh_cloud_remove_nan_normals(const lh_cloud* in, lh_cloud** out) {
   if (!st) {
     o = new lh_cloud();
     o->ctx = c; o->n = (int)total; o->n_pad = round_up(o->n, 256);
-    if (hipMalloc(&o->xyz, sizeof(float4) * (size_t)o->n_pad) != hipSuccess || hipMalloc(&o->nrm, sizeof(float4) * (size_t)o->n_pad) != hipSuccess ||
-        (in->intensity && hipMalloc(&o->intensity, sizeof(float) * (size_t)o->n_pad) != hipSuccess))
+    if (lhMalloc(&o->xyz, sizeof(float4) * (size_t)o->n_pad) != hipSuccess || lhMalloc(&o->nrm, sizeof(float4) * (size_t)o->n_pad) != hipSuccess ||
+        (in->intensity && lhMalloc(&o->intensity, sizeof(float) * (size_t)o->n_pad) != hipSuccess))
       st = LH_ENOMEM;
   }
   if (!st) {
     launch_compact(d_incl, n, in->xyz, in->nrm, in->intensity, o->xyz, o->nrm, o->intensity, c->stream);
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) st = LH_EDEVICE;
   }
-  (void)hipFree(d_flags); (void)hipFree(d_incl); (void)hipFree(d_tmp);
+  (void)lhFree(d_flags); (void)lhFree(d_incl); (void)lhFree(d_tmp);
   if (st) { cloud_free(o); return st; }
   *out = o;
   return LH_OK;
@@ -1802,16 +1872,16 @@ struct VoxelSegments {
   uint32_t *heads = nullptr, *rank = nullptr;
   void* scan_tmp = nullptr;
   uint32_t total = 0;
-  void release() { (void)hipFree(heads); (void)hipFree(rank); (void)hipFree(scan_tmp); heads = rank = nullptr; scan_tmp = nullptr; }
+  void release() { (void)lhFree(heads); (void)lhFree(rank); (void)lhFree(scan_tmp); heads = rank = nullptr; scan_tmp = nullptr; }
 };
 static lh_status voxel_segments(lh_ctx* c, const float4* d_in, int n, float leaf, int limit_axis, double lo, double hi, VoxelSegments* vs) {
   vs->total = 0;
   lh_status st = ctx_ensure_scratch(c, n);
   if (st) return st;
   size_t scan_bytes = scan_temp_bytes(n);
-  hipError_t e = hipMalloc(&vs->heads, sizeof(uint32_t) * (size_t)n);
-  if (e == hipSuccess) e = hipMalloc(&vs->rank, sizeof(uint32_t) * (size_t)n);
-  if (e == hipSuccess) e = hipMalloc(&vs->scan_tmp, scan_bytes ? scan_bytes : 16);
+  hipError_t e = lhMalloc(&vs->heads, sizeof(uint32_t) * (size_t)n);
+  if (e == hipSuccess) e = lhMalloc(&vs->rank, sizeof(uint32_t) * (size_t)n);
+  if (e == hipSuccess) e = lhMalloc(&vs->scan_tmp, scan_bytes ? scan_bytes : 16);
   if (e != hipSuccess) { vs->release(); return LH_ENOMEM; }
   float flo = (float)std::max(lo, -3.0e38), fhi = (float)std::min(hi, 3.0e38);
   { ProfScope p(c, "voxel_bbox", 16.0 * n); launch_voxel_bbox(d_in, n, limit_axis, flo, fhi, c->bbox, c->stream); }
@@ -1851,7 +1921,7 @@ static lh_status voxel_grid_device(lh_ctx* c, const float4* d_in, int n, float l
   lh_status st = voxel_segments(c, d_in, n, leaf, limit_axis, lo, hi, &vs);
   if (st) return st;
   if (vs.total > 0) {
-    if (hipMalloc(d_out, sizeof(float4) * (size_t)vs.total) != hipSuccess) { vs.release(); return LH_ENOMEM; }
+    if (lhMalloc(d_out, sizeof(float4) * (size_t)vs.total) != hipSuccess) { vs.release(); return LH_ENOMEM; }
     ProfScope p(c, "voxel_centroids", 32.0 * n);
     launch_voxel_centroids(d_in, c->keys1, c->vals1, vs.heads, vs.rank, n, *d_out, vs.total, c->stream);
   }
@@ -1878,7 +1948,7 @@ lh_status lh_voxel_grid(lh_ctx* c, const lh_cloud_view* in, float leaf, int limi
     host[4 * (size_t)i + 3] = (in->off_intensity != UINT32_MAX) ? *(const float*)(p + in->off_intensity) : 0.0f;
   }
   float4 *d_in = nullptr, *d_out = nullptr;
-  HIPCHK(hipMalloc(&d_in, sizeof(float4) * (size_t)n));
+  HIPCHK(lhMalloc(&d_in, sizeof(float4) * (size_t)n));
   HIPCHK(hipMemcpyAsync(d_in, host.data(), sizeof(float) * host.size(), hipMemcpyHostToDevice, c->stream));
   uint32_t total = 0;
   lh_status st = voxel_grid_device(c, d_in, n, leaf, limit_axis, lo, hi, &d_out, &total);
@@ -1887,8 +1957,8 @@ lh_status lh_voxel_grid(lh_ctx* c, const lh_cloud_view* in, float leaf, int limi
     uint32_t ncopy = std::min(total, out_capacity);
     if (ncopy && hipMemcpy(out_xyzi, d_out, sizeof(float4) * (size_t)ncopy, hipMemcpyDeviceToHost) != hipSuccess) st = LH_EDEVICE;
   }
-  (void)hipFree(d_in);
-  (void)hipFree(d_out);
+  (void)lhFree(d_in);
+  (void)lhFree(d_out);
   return st;
 }
 
@@ -1911,23 +1981,23 @@ lh_status lh_cloud_voxel_grid(const lh_cloud* in, float leaf, int limit_axis, do
   lh_ctx* c = in->ctx;
   HIPCHK(hipSetDevice(c->device));
   float4 *d_in = nullptr, *d_out = nullptr;
-  HIPCHK(hipMalloc(&d_in, sizeof(float4) * (size_t)in->n));
+  HIPCHK(lhMalloc(&d_in, sizeof(float4) * (size_t)in->n));
   hipLaunchKernelGGL(k_pack_xyzi, dim3((in->n + 255) / 256), dim3(256), 0, c->stream, in->xyz, in->intensity, in->n, d_in);
   uint32_t total = 0;
   lh_status st = voxel_grid_device(c, d_in, in->n, leaf, limit_axis, lo, hi, &d_out, &total);
-  (void)hipFree(d_in);
-  if (st) { (void)hipFree(d_out); return st; }
-  if (total == 0) { (void)hipFree(d_out); return LH_EINVAL; }  // every point was filtered out: no cloud to return
+  (void)lhFree(d_in);
+  if (st) { (void)lhFree(d_out); return st; }
+  if (total == 0) { (void)lhFree(d_out); return LH_EINVAL; }  // every point was filtered out: no cloud to return
   lh_cloud* o = new lh_cloud();
   o->ctx = c;
   o->n = (int)total;
   o->n_pad = round_up(o->n, 256);
-  HIPCHK(hipMalloc(&o->xyz, sizeof(float4) * (size_t)o->n_pad));
-  HIPCHK(hipMalloc(&o->intensity, sizeof(float) * (size_t)o->n_pad));
+  HIPCHK(lhMalloc(&o->xyz, sizeof(float4) * (size_t)o->n_pad));
+  HIPCHK(lhMalloc(&o->intensity, sizeof(float) * (size_t)o->n_pad));
   hipLaunchKernelGGL(k_unpack_xyzi, dim3((o->n + 255) / 256), dim3(256), 0, c->stream, d_out, o->n, o->xyz, o->intensity);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(c->stream));
-  (void)hipFree(d_out);
+  (void)lhFree(d_out);
   *out = o;
   return LH_OK;
 }
@@ -1946,8 +2016,6 @@ struct lh_ndt {
   int n_cells = 0;
   lh_cloud* cells = nullptr;          // centroids as a cloud + its radix-tree index (the kd-tree of the reference)
   double *d_mean = nullptr, *d_icov = nullptr;
-  std::vector<double> h_mean, h_icov;
-  std::vector<float> h_centroid;
   // evaluation buffers
   double* rows = nullptr;             // per-wave partial rows (device)
   int rows_cap = 0;
@@ -1959,13 +2027,15 @@ struct lh_ndt {
 static void ndt_drop_grid(lh_ndt* g) {
   cloud_free(g->cells);
   g->cells = nullptr;
-  (void)hipFree(g->d_mean); (void)hipFree(g->d_icov);
+  (void)lhFree(g->d_mean); (void)lhFree(g->d_icov);
   g->d_mean = g->d_icov = nullptr;
   g->n_cells = 0;
   g->grid_valid = false;
 }
 
-// VoxelGridCovariance::filter(true) (ndt_omp.h:257-262): voxel statistics of the target
+// VoxelGridCovariance::filter(true) (ndt_omp.h:257-262): voxel statistics of the target, entirely on the device: raw sums per
+// voxel -> per-voxel algebra (covariance, eigenvalue inflation, inverse) -> compaction of the voxels with enough points (ascending
+// voxel index) -> the centroids become a cloud with the usual radix-tree index.  The host only learns the cell count.
 static lh_status ndt_build_grid(lh_ndt* g) {
   lh_ctx* c = g->ctx;
   lh_cloud* t = g->tgt;
@@ -1974,42 +2044,46 @@ static lh_status ndt_build_grid(lh_ndt* g) {
   VoxelSegments vs;
   lh_status st = voxel_segments(c, t->xyz, t->n, g->P.resolution, -1, -3.0e38, 3.0e38, &vs);
   if (st) return st;
-  std::vector<NdtVoxelRaw> raw(vs.total);
-  if (vs.total > 0) {
-    NdtVoxelRaw* d_raw = nullptr;
-    if (hipMalloc(&d_raw, sizeof(NdtVoxelRaw) * (size_t)vs.total) != hipSuccess) { vs.release(); return LH_ENOMEM; }
-    { ProfScope p(c, "ndt_voxel_stats", 16.0 * t->n); launch_ndt_voxel_stats(t->xyz, c->keys1, c->vals1, vs.heads, vs.rank, t->n, d_raw, c->stream); }
-    hipError_t e = hipMemcpyAsync(raw.data(), d_raw, sizeof(NdtVoxelRaw) * (size_t)vs.total, hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    (void)hipFree(d_raw);
-    if (e != hipSuccess) { vs.release(); return LH_EDEVICE; }
+  const int nv = (int)vs.total;
+  if (nv == 0) { vs.release(); g->grid_valid = true; return LH_OK; }
+  NdtVoxelRaw* d_raw = nullptr;
+  double *v_mean = nullptr, *v_icov = nullptr;
+  float4* v_cen = nullptr;
+  uint32_t *d_flags = nullptr, *d_incl = nullptr;
+  void* d_scan = nullptr;
+  size_t scan_bytes = scan_temp_bytes(nv);
+  auto cleanup = [&]() { (void)lhFree(d_raw); (void)lhFree(v_mean); (void)lhFree(v_icov); (void)lhFree(v_cen); (void)lhFree(d_flags); (void)lhFree(d_incl); (void)lhFree(d_scan); vs.release(); };
+  hipError_t e = lhMalloc(&d_raw, sizeof(NdtVoxelRaw) * (size_t)nv);
+  if (e == hipSuccess) e = lhMalloc(&v_mean, sizeof(double) * 3 * (size_t)nv);
+  if (e == hipSuccess) e = lhMalloc(&v_icov, sizeof(double) * 9 * (size_t)nv);
+  if (e == hipSuccess) e = lhMalloc(&v_cen, sizeof(float4) * (size_t)nv);
+  if (e == hipSuccess) e = lhMalloc(&d_flags, sizeof(uint32_t) * (size_t)nv);
+  if (e == hipSuccess) e = lhMalloc(&d_incl, sizeof(uint32_t) * (size_t)nv);
+  if (e == hipSuccess) e = lhMalloc(&d_scan, scan_bytes ? scan_bytes : 16);
+  if (e != hipSuccess) { cleanup(); return LH_ENOMEM; }
+  { ProfScope p(c, "ndt_voxel_stats", 16.0 * t->n);
+    launch_ndt_voxel_stats(t->xyz, c->keys1, c->vals1, vs.heads, vs.rank, t->n, d_raw, c->stream);
+    launch_ndt_finish_cells(d_raw, nv, g->P.min_points_per_voxel, g->P.min_covar_eigvalue_mult, v_mean, v_icov, v_cen, d_flags, c->stream);
+    inclusive_scan_u32(d_scan, scan_bytes, d_flags, d_incl, nv, c->stream); }
+  uint32_t n_cells = 0;
+  e = hipMemcpyAsync(&n_cells, d_incl + (nv - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  if (e != hipSuccess) { cleanup(); return LH_EDEVICE; }
+  g->n_cells = (int)n_cells;
+  if (n_cells > 0) {
+    lh_cloud* cl = new lh_cloud();
+    cl->ctx = c; cl->n = (int)n_cells; cl->n_pad = round_up(cl->n, 256);
+    e = lhMalloc(&cl->xyz, sizeof(float4) * (size_t)cl->n_pad);
+    if (e == hipSuccess) e = lhMalloc(&g->d_mean, sizeof(double) * 3 * (size_t)n_cells);
+    if (e == hipSuccess) e = lhMalloc(&g->d_icov, sizeof(double) * 9 * (size_t)n_cells);
+    if (e != hipSuccess) { cloud_free(cl); cleanup(); return LH_ENOMEM; }
+    g->cells = cl;
+    launch_ndt_compact_cells(d_incl, nv, v_mean, v_icov, v_cen, g->d_mean, g->d_icov, cl->xyz, c->stream);
+    st = cloud_build_index(cl);
+    if (!st && (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess)) st = LH_EDEVICE;
   }
-  vs.release();
-  g->h_mean.clear(); g->h_icov.clear(); g->h_centroid.clear();
-  for (uint32_t v = 0; v < vs.total; v++) {   // a few thousand cells: eigenvalue inflation + inverse on the host
-    double mean[3], icov[9];
-    if (!ndt_finish_cell(raw[v].sum, raw[v].cov, raw[v].count, g->P.min_points_per_voxel, g->P.min_covar_eigvalue_mult, mean, icov)) continue;
-    g->h_mean.insert(g->h_mean.end(), mean, mean + 3);
-    g->h_icov.insert(g->h_icov.end(), icov, icov + 9);
-    float cnt = (float)raw[v].count;
-    g->h_centroid.push_back(raw[v].cen[0] / cnt); g->h_centroid.push_back(raw[v].cen[1] / cnt); g->h_centroid.push_back(raw[v].cen[2] / cnt);
-    g->h_centroid.push_back(1.0f);
-  }
-  g->n_cells = (int)(g->h_mean.size() / 3);
-  if (g->n_cells > 0) {
-    lh_cloud_view cv;
-    cv.base = g->h_centroid.data(); cv.count = (uint32_t)g->n_cells; cv.stride = 16; cv.off_xyz = 0;
-    cv.off_normal = cv.off_intensity = cv.off_curvature = UINT32_MAX;
-    st = upload_view(c, &cv, &g->cells);
-    if (!st) st = cloud_build_index(g->cells);
-    if (st) return st;
-    hipError_t e = hipMalloc(&g->d_mean, sizeof(double) * 3 * (size_t)g->n_cells);
-    if (e == hipSuccess) e = hipMalloc(&g->d_icov, sizeof(double) * 9 * (size_t)g->n_cells);
-    if (e == hipSuccess) e = hipMemcpyAsync(g->d_mean, g->h_mean.data(), sizeof(double) * 3 * (size_t)g->n_cells, hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(g->d_icov, g->h_icov.data(), sizeof(double) * 9 * (size_t)g->n_cells, hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    if (e != hipSuccess) return e == hipErrorOutOfMemory ? LH_ENOMEM : LH_EDEVICE;
-  }
+  cleanup();
+  if (st) return st;
   g->grid_valid = true;
   return LH_OK;
 }
@@ -2024,9 +2098,9 @@ static lh_status ndt_evaluate(lh_ndt* g, const double* p6, const float* T16, int
   if (g->n_cells == 0) return LH_OK;   // no usable voxel: every neighbourhood is empty
   int n_rows = ((n + 255) / 256) * 4;
   if (n_rows > g->rows_cap) {
-    (void)hipFree(g->rows);
+    (void)lhFree(g->rows);
     g->rows = nullptr;
-    HIPCHK(hipMalloc(&g->rows, sizeof(double) * NDT_ROW * (size_t)n_rows));
+    HIPCHK(lhMalloc(&g->rows, sizeof(double) * NDT_ROW * (size_t)n_rows));
     g->rows_cap = n_rows;
   }
   if (!g->chunks) HIPCHK(hipHostMalloc(&g->chunks, sizeof(double) * FINAL_CHUNKS * NDT_ROW, hipHostMallocDefault));
@@ -2072,7 +2146,7 @@ void lh_ndt_destroy(lh_ndt* g) {
   ndt_drop_grid(g);
   if (g->own_src) cloud_free(g->src);
   if (g->own_tgt) cloud_free(g->tgt);
-  (void)hipFree(g->rows);
+  (void)lhFree(g->rows);
   if (g->chunks) (void)hipHostFree(g->chunks);
   delete g;
 }
@@ -2125,9 +2199,13 @@ lh_status lh_ndt_debug_cells(lh_ndt* g, int* n_cells, double* mean3, double* ico
   if (!g->grid_valid) { lh_status st = ndt_build_grid(g); if (st) return st; }
   *n_cells = g->n_cells;
   int k = std::min(cap, g->n_cells);
-  if (mean3) memcpy(mean3, g->h_mean.data(), sizeof(double) * 3 * (size_t)k);
-  if (icov9) memcpy(icov9, g->h_icov.data(), sizeof(double) * 9 * (size_t)k);
-  if (centroid4) memcpy(centroid4, g->h_centroid.data(), sizeof(float) * 4 * (size_t)k);
+  if (k > 0) {
+    lh_ctx* c = g->ctx;
+    if (mean3) HIPCHK(hipMemcpyAsync(mean3, g->d_mean, sizeof(double) * 3 * (size_t)k, hipMemcpyDeviceToHost, c->stream));
+    if (icov9) HIPCHK(hipMemcpyAsync(icov9, g->d_icov, sizeof(double) * 9 * (size_t)k, hipMemcpyDeviceToHost, c->stream));
+    if (centroid4) HIPCHK(hipMemcpyAsync(centroid4, g->cells->xyz, sizeof(float) * 4 * (size_t)k, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+  }
   return LH_OK;
 }
 // test hook: computeDerivatives (hessian_only = 0) / computeHessian (hessian_only = 1) at pose p6
@@ -2176,12 +2254,12 @@ lh_status lh_ndt_align(lh_ndt* g, const float guess[16], lh_gicp_result* out, vo
     float T12[12];
     fill_T12(o.T, T12);
     float4* d_out = nullptr;
-    HIPCHK(hipMalloc(&d_out, sizeof(float4) * (size_t)g->src->n));
+    HIPCHK(lhMalloc(&d_out, sizeof(float4) * (size_t)g->src->n));
     launch_transform(g->src->xyz, nullptr, g->src->n, T12, d_out, nullptr, c->stream);
     std::vector<float> host((size_t)g->src->n * 4);
     hipError_t e = hipMemcpyAsync(host.data(), d_out, sizeof(float) * host.size(), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    (void)hipFree(d_out);
+    (void)lhFree(d_out);
     if (e != hipSuccess) return LH_EDEVICE;
     for (int i = 0; i < g->src->n; i++) memcpy((char*)aligned_out + (size_t)i * stride + off_xyz, &host[4 * (size_t)i], 12);
   }
@@ -2195,9 +2273,9 @@ static lh_status compact_cloud(const lh_cloud* in, uint32_t* d_flags, lh_cloud**
   uint32_t* d_incl = nullptr;
   void* d_tmp = nullptr;
   size_t tmp_bytes = scan_temp_bytes(n);
-  hipError_t e = hipMalloc(&d_incl, sizeof(uint32_t) * (size_t)n);
-  if (e == hipSuccess) e = hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 16);
-  if (e != hipSuccess) { (void)hipFree(d_incl); (void)hipFree(d_tmp); return LH_ENOMEM; }
+  hipError_t e = lhMalloc(&d_incl, sizeof(uint32_t) * (size_t)n);
+  if (e == hipSuccess) e = lhMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 16);
+  if (e != hipSuccess) { (void)lhFree(d_incl); (void)lhFree(d_tmp); return LH_ENOMEM; }
   inclusive_scan_u32(d_tmp, tmp_bytes, d_flags, d_incl, n, c->stream);
   uint32_t total = 0;
   e = hipMemcpyAsync(&total, d_incl + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
@@ -2208,16 +2286,16 @@ static lh_status compact_cloud(const lh_cloud* in, uint32_t* d_flags, lh_cloud**
   if (!st) {
     o = new lh_cloud();
     o->ctx = c; o->n = (int)total; o->n_pad = round_up(o->n, 256);
-    if (hipMalloc(&o->xyz, sizeof(float4) * (size_t)o->n_pad) != hipSuccess ||
-        (in->nrm && hipMalloc(&o->nrm, sizeof(float4) * (size_t)o->n_pad) != hipSuccess) ||
-        (in->intensity && hipMalloc(&o->intensity, sizeof(float) * (size_t)o->n_pad) != hipSuccess))
+    if (lhMalloc(&o->xyz, sizeof(float4) * (size_t)o->n_pad) != hipSuccess ||
+        (in->nrm && lhMalloc(&o->nrm, sizeof(float4) * (size_t)o->n_pad) != hipSuccess) ||
+        (in->intensity && lhMalloc(&o->intensity, sizeof(float) * (size_t)o->n_pad) != hipSuccess))
       st = LH_ENOMEM;
   }
   if (!st) {
     launch_map_compact(d_incl, n, in->xyz, in->nrm, in->intensity, 1.0, 0, o->xyz, o->nrm, o->intensity, nullptr, c->stream);
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) st = LH_EDEVICE;
   }
-  (void)hipFree(d_incl); (void)hipFree(d_tmp);
+  (void)lhFree(d_incl); (void)lhFree(d_tmp);
   if (st) { cloud_free(o); return st; }
   *out = o;
   return LH_OK;
@@ -2227,10 +2305,10 @@ lh_status lh_cloud_crop_box(const lh_cloud* in, const float min_pt[3], const flo
   lh_ctx* c = in->ctx;
   HIPCHK(hipSetDevice(c->device));
   uint32_t* d_flags = nullptr;
-  HIPCHK(hipMalloc(&d_flags, sizeof(uint32_t) * (size_t)in->n));
+  HIPCHK(lhMalloc(&d_flags, sizeof(uint32_t) * (size_t)in->n));
   { ProfScope p(c, "crop_box", 20.0 * in->n); launch_crop_flags(in->xyz, in->n, min_pt, max_pt, cosf(yaw), sinf(yaw), negative, d_flags, c->stream); }
   lh_status st = compact_cloud(in, d_flags, out);
-  (void)hipFree(d_flags);
+  (void)lhFree(d_flags);
   return st;
 }
 
@@ -2257,10 +2335,10 @@ static lh_status map_reserve(lh_map* m, int need, bool with_nrm, bool with_inten
   float* inten = nullptr;
   uint64_t* keys = nullptr;
   bool want_n = with_nrm || c->nrm, want_i = with_inten || c->intensity;
-  hipError_t e = hipMalloc(&xyz, sizeof(float4) * (size_t)cap);
-  if (e == hipSuccess && want_n) e = hipMalloc(&nrm, sizeof(float4) * (size_t)cap);
-  if (e == hipSuccess && want_i) e = hipMalloc(&inten, sizeof(float) * (size_t)cap);
-  if (e == hipSuccess) e = hipMalloc(&keys, sizeof(uint64_t) * (size_t)cap);
+  hipError_t e = lhMalloc(&xyz, sizeof(float4) * (size_t)cap);
+  if (e == hipSuccess && want_n) e = lhMalloc(&nrm, sizeof(float4) * (size_t)cap);
+  if (e == hipSuccess && want_i) e = lhMalloc(&inten, sizeof(float) * (size_t)cap);
+  if (e == hipSuccess) e = lhMalloc(&keys, sizeof(uint64_t) * (size_t)cap);
   if (e == hipSuccess && want_n) e = hipMemsetAsync(nrm, 0, sizeof(float4) * (size_t)cap, x->stream);
   if (e == hipSuccess && want_i) e = hipMemsetAsync(inten, 0, sizeof(float) * (size_t)cap, x->stream);
   if (e == hipSuccess && c->n > 0) {
@@ -2270,8 +2348,8 @@ static lh_status map_reserve(lh_map* m, int need, bool with_nrm, bool with_inten
     if (e == hipSuccess) e = hipMemcpyAsync(keys, m->keys, sizeof(uint64_t) * (size_t)c->n, hipMemcpyDeviceToDevice, x->stream);
   }
   if (e == hipSuccess) e = hipStreamSynchronize(x->stream);
-  if (e != hipSuccess) { (void)hipFree(xyz); (void)hipFree(nrm); (void)hipFree(inten); (void)hipFree(keys); return e == hipErrorOutOfMemory ? LH_ENOMEM : LH_EDEVICE; }
-  (void)hipFree(c->xyz); (void)hipFree(c->nrm); (void)hipFree(c->intensity); (void)hipFree(m->keys); (void)hipFree(c->cov6);
+  if (e != hipSuccess) { (void)lhFree(xyz); (void)lhFree(nrm); (void)lhFree(inten); (void)lhFree(keys); return e == hipErrorOutOfMemory ? LH_ENOMEM : LH_EDEVICE; }
+  (void)lhFree(c->xyz); (void)lhFree(c->nrm); (void)lhFree(c->intensity); (void)lhFree(m->keys); (void)lhFree(c->cov6);
   c->xyz = xyz; c->nrm = nrm; c->intensity = inten; m->keys = keys; c->cov6 = nullptr; c->cov_k = 0;
   c->n_pad = cap;
   m->cap = cap;
@@ -2292,7 +2370,7 @@ void lh_map_destroy(lh_map* m) {
   if (!m) return;
   (void)hipSetDevice(m->ctx->device);
   (void)hipStreamSynchronize(m->ctx->stream);
-  (void)hipFree(m->keys);
+  (void)lhFree(m->keys);
   cloud_free(m->cloud);
   delete m;
 }
@@ -2306,14 +2384,14 @@ static lh_status map_sort_keys(lh_map* m, int n) {
   uint64_t* tmp = nullptr;
   void* st = nullptr;
   size_t sb = sort_keys64_temp_bytes(n);
-  hipError_t e = hipMalloc(&tmp, sizeof(uint64_t) * (size_t)n);
-  if (e == hipSuccess) e = hipMalloc(&st, sb ? sb : 16);
+  hipError_t e = lhMalloc(&tmp, sizeof(uint64_t) * (size_t)n);
+  if (e == hipSuccess) e = lhMalloc(&st, sb ? sb : 16);
   if (e == hipSuccess) {
     sort_keys_u64(st, sb, m->keys, tmp, n, x->stream);
     e = hipMemcpyAsync(m->keys, tmp, sizeof(uint64_t) * (size_t)n, hipMemcpyDeviceToDevice, x->stream);
   }
   if (e == hipSuccess) e = hipStreamSynchronize(x->stream);
-  (void)hipFree(tmp); (void)hipFree(st);
+  (void)lhFree(tmp); (void)lhFree(st);
   return e == hipSuccess ? LH_OK : LH_EDEVICE;
 }
 
@@ -2327,15 +2405,15 @@ lh_status lh_map_insert(lh_map* m, const lh_cloud* pts, uint32_t* n_inserted) {
   uint32_t *v0 = nullptr, *v1 = nullptr, *acc = nullptr, *incl = nullptr;
   void *st = nullptr, *sc = nullptr;
   size_t sb = sort64_temp_bytes(n), cb = scan_temp_bytes(n);
-  auto cleanup = [&]() { (void)hipFree(k0); (void)hipFree(k1); (void)hipFree(v0); (void)hipFree(v1); (void)hipFree(acc); (void)hipFree(incl); (void)hipFree(st); (void)hipFree(sc); };
-  hipError_t e = hipMalloc(&k0, 8 * (size_t)n);
-  if (e == hipSuccess) e = hipMalloc(&k1, 8 * (size_t)n);
-  if (e == hipSuccess) e = hipMalloc(&v0, 4 * (size_t)n);
-  if (e == hipSuccess) e = hipMalloc(&v1, 4 * (size_t)n);
-  if (e == hipSuccess) e = hipMalloc(&acc, 4 * (size_t)n);
-  if (e == hipSuccess) e = hipMalloc(&incl, 4 * (size_t)n);
-  if (e == hipSuccess) e = hipMalloc(&st, sb ? sb : 16);
-  if (e == hipSuccess) e = hipMalloc(&sc, cb ? cb : 16);
+  auto cleanup = [&]() { (void)lhFree(k0); (void)lhFree(k1); (void)lhFree(v0); (void)lhFree(v1); (void)lhFree(acc); (void)lhFree(incl); (void)lhFree(st); (void)lhFree(sc); };
+  hipError_t e = lhMalloc(&k0, 8 * (size_t)n);
+  if (e == hipSuccess) e = lhMalloc(&k1, 8 * (size_t)n);
+  if (e == hipSuccess) e = lhMalloc(&v0, 4 * (size_t)n);
+  if (e == hipSuccess) e = lhMalloc(&v1, 4 * (size_t)n);
+  if (e == hipSuccess) e = lhMalloc(&acc, 4 * (size_t)n);
+  if (e == hipSuccess) e = lhMalloc(&incl, 4 * (size_t)n);
+  if (e == hipSuccess) e = lhMalloc(&st, sb ? sb : 16);
+  if (e == hipSuccess) e = lhMalloc(&sc, cb ? cb : 16);
   if (e != hipSuccess) { cleanup(); return LH_ENOMEM; }
   uint32_t total = 0;
   {
@@ -2379,14 +2457,14 @@ lh_status lh_map_refresh(lh_map* m, const float center[3], float half_extent) {
   float4 *xyz = nullptr, *nrm = nullptr;
   float* inten = nullptr;
   uint64_t* keys = nullptr;
-  auto cleanup = [&]() { (void)hipFree(flags); (void)hipFree(incl); (void)hipFree(sc); (void)hipFree(xyz); (void)hipFree(nrm); (void)hipFree(inten); (void)hipFree(keys); };
-  hipError_t e = hipMalloc(&flags, 4 * (size_t)n);
-  if (e == hipSuccess) e = hipMalloc(&incl, 4 * (size_t)n);
-  if (e == hipSuccess) e = hipMalloc(&sc, cb ? cb : 16);
-  if (e == hipSuccess) e = hipMalloc(&xyz, sizeof(float4) * (size_t)m->cap);
-  if (e == hipSuccess && c->nrm) e = hipMalloc(&nrm, sizeof(float4) * (size_t)m->cap);
-  if (e == hipSuccess && c->intensity) e = hipMalloc(&inten, sizeof(float) * (size_t)m->cap);
-  if (e == hipSuccess) e = hipMalloc(&keys, sizeof(uint64_t) * (size_t)m->cap);
+  auto cleanup = [&]() { (void)lhFree(flags); (void)lhFree(incl); (void)lhFree(sc); (void)lhFree(xyz); (void)lhFree(nrm); (void)lhFree(inten); (void)lhFree(keys); };
+  hipError_t e = lhMalloc(&flags, 4 * (size_t)n);
+  if (e == hipSuccess) e = lhMalloc(&incl, 4 * (size_t)n);
+  if (e == hipSuccess) e = lhMalloc(&sc, cb ? cb : 16);
+  if (e == hipSuccess) e = lhMalloc(&xyz, sizeof(float4) * (size_t)m->cap);
+  if (e == hipSuccess && c->nrm) e = lhMalloc(&nrm, sizeof(float4) * (size_t)m->cap);
+  if (e == hipSuccess && c->intensity) e = lhMalloc(&inten, sizeof(float) * (size_t)m->cap);
+  if (e == hipSuccess) e = lhMalloc(&keys, sizeof(uint64_t) * (size_t)m->cap);
   if (e != hipSuccess) { cleanup(); return LH_ENOMEM; }
   uint32_t total = 0;
   {
@@ -2427,19 +2505,19 @@ lh_status lh_cloud_nearest_neighbors(lh_cloud* map, const lh_cloud* query, lh_cl
   int n = query->n;
   int32_t* d_idx = nullptr;
   float* d_d2 = nullptr;
-  HIPCHK(hipMalloc(&d_idx, sizeof(int32_t) * (size_t)n));
-  HIPCHK(hipMalloc(&d_d2, sizeof(float) * (size_t)n));
+  HIPCHK(lhMalloc(&d_idx, sizeof(int32_t) * (size_t)n));
+  HIPCHK(lhMalloc(&d_d2, sizeof(float) * (size_t)n));
   { ProfScope p(c, "nn1", 24.0 * n); launch_nn1(query->xyz, n, nullptr, map->view(), d_idx, d_d2, c->stream); }
   lh_cloud* o = new lh_cloud();
   o->ctx = c; o->n = n; o->n_pad = round_up(n, 256);
-  HIPCHK(hipMalloc(&o->xyz, sizeof(float4) * (size_t)o->n_pad));
-  if (map->nrm) HIPCHK(hipMalloc(&o->nrm, sizeof(float4) * (size_t)o->n_pad));
-  if (map->intensity) HIPCHK(hipMalloc(&o->intensity, sizeof(float) * (size_t)o->n_pad));
+  HIPCHK(lhMalloc(&o->xyz, sizeof(float4) * (size_t)o->n_pad));
+  if (map->nrm) HIPCHK(lhMalloc(&o->nrm, sizeof(float4) * (size_t)o->n_pad));
+  if (map->intensity) HIPCHK(lhMalloc(&o->intensity, sizeof(float) * (size_t)o->n_pad));
   hipLaunchKernelGGL(k_gather_cloud, dim3((n + 255) / 256), dim3(256), 0, c->stream, map->xyz, map->nrm, map->intensity, d_idx, n, o->xyz, o->nrm,
                      o->intensity);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(c->stream));
-  (void)hipFree(d_idx); (void)hipFree(d_d2);
+  (void)lhFree(d_idx); (void)lhFree(d_d2);
   *out = o;
   return LH_OK;
 }

@@ -1120,7 +1120,7 @@ void launch_compact(const uint32_t* incl, int n, const float4* xyz, const float4
 
 // ===== NDT (registration_method: ndt) ==========================================================================
 // target side: per-voxel raw statistics in input order (VoxelGridCovariance::applyFilter, voxel_grid_covariance_omp_impl.hpp:
-// 166-205): double sums of p and p p^T, float centroid sum, count; the few thousand cells are finished on the host
+// 166-205): double sums of p and p p^T, float centroid sum, count (then k_ndt_finish_cells, one thread per voxel)
 __global__ void __launch_bounds__(256) k_ndt_voxel_stats(const float4* __restrict__ xyz, const uint32_t* __restrict__ keys,
                                                          const uint32_t* __restrict__ vals, const uint32_t* __restrict__ heads,
                                                          const uint32_t* __restrict__ rank, int n, NdtVoxelRaw* __restrict__ out) {
@@ -1149,6 +1149,47 @@ void launch_ndt_voxel_stats(const float4* xyz, const uint32_t* keys, const uint3
   hipLaunchKernelGGL(k_ndt_voxel_stats, dim3((n + 255) / 256), dim3(256), 0, s, xyz, keys, vals, heads, rank_incl, n, out);
 }
 
+// per voxel: raw sums -> cell (mean, inverse covariance, float centroid) + "becomes a cell" flag (>= min_points points)
+__global__ void __launch_bounds__(256) k_ndt_finish_cells(const NdtVoxelRaw* __restrict__ raw, int n_vox, int min_points, double eig_mult,
+                                                          double* __restrict__ mean, double* __restrict__ icov, float4* __restrict__ cen,
+                                                          uint32_t* __restrict__ flags) {
+  int v = blockIdx.x * 256 + threadIdx.x;
+  if (v >= n_vox) return;
+  NdtVoxelRaw r = raw[v];
+  double m3[3], ic[9];
+  bool cell = ndt_finish_cell(r.sum, r.cov, r.count, min_points, eig_mult, m3, ic);
+  flags[v] = cell ? 1u : 0u;
+  if (!cell) return;
+#pragma unroll
+  for (int k = 0; k < 3; k++) mean[3 * (size_t)v + k] = m3[k];
+#pragma unroll
+  for (int k = 0; k < 9; k++) icov[9 * (size_t)v + k] = ic[k];
+  float c = (float)r.count;
+  cen[v] = make_float4(r.cen[0] / c, r.cen[1] / c, r.cen[2] / c, 1.0f);
+}
+// keep the flagged voxels, in ascending voxel order (the order of VoxelGridCovariance's centroid cloud / kd-tree)
+__global__ void __launch_bounds__(256) k_ndt_compact_cells(const uint32_t* __restrict__ incl, int n_vox, const double* __restrict__ mean,
+                                                           const double* __restrict__ icov, const float4* __restrict__ cen,
+                                                           double* __restrict__ omean, double* __restrict__ oicov, float4* __restrict__ ocen) {
+  int v = blockIdx.x * 256 + threadIdx.x;
+  if (v >= n_vox) return;
+  uint32_t here = incl[v], before = v ? incl[v - 1] : 0u;
+  if (here == before) return;
+#pragma unroll
+  for (int k = 0; k < 3; k++) omean[3 * (size_t)before + k] = mean[3 * (size_t)v + k];
+#pragma unroll
+  for (int k = 0; k < 9; k++) oicov[9 * (size_t)before + k] = icov[9 * (size_t)v + k];
+  ocen[before] = cen[v];
+}
+void launch_ndt_finish_cells(const NdtVoxelRaw* raw, int n_vox, int min_points, double eig_mult, double* mean, double* icov, float4* cen,
+                             uint32_t* flags, hipStream_t s) {
+  hipLaunchKernelGGL(k_ndt_finish_cells, dim3((n_vox + 255) / 256), dim3(256), 0, s, raw, n_vox, min_points, eig_mult, mean, icov, cen, flags);
+}
+void launch_ndt_compact_cells(const uint32_t* incl, int n_vox, const double* mean, const double* icov, const float4* cen, double* omean,
+                              double* oicov, float4* ocen, hipStream_t s) {
+  hipLaunchKernelGGL(k_ndt_compact_cells, dim3((n_vox + 255) / 256), dim3(256), 0, s, incl, n_vox, mean, icov, cen, omean, oicov, ocen);
+}
+
 // source side: computeDerivatives (MODE 0, float point derivatives) / computeHessian (MODE 1, double).  One source point per
 // thread; the radius search over the voxel CENTROIDS (KDTREE mode, voxel_grid_covariance_omp.h:433-466) walks the cells'
 // radix tree and every cell inside the radius contributes on the spot; 43 doubles per wave are reduced through LDS.
@@ -1167,7 +1208,8 @@ struct NdtCollector {
     if (!(d < r2) || id == 0x7fffffff) return;  // FLANN RadiusResultSet: strict
     const double* mu = mean + 3 * (size_t)id;
     double dd[3] = {(double)xt[0] - mu[0], (double)xt[1] - mu[1], (double)xt[2] - mu[2]};
-    if (MODE == 0) ndt_term_float(*f, x3, dd, icov + 9 * (size_t)id, acc);
+    if (MODE == 0) ndt_term_float<true>(*f, x3, dd, icov + 9 * (size_t)id, acc);
+    else if (MODE == 2) ndt_term_float<false>(*f, x3, dd, icov + 9 * (size_t)id, acc);   // line-search evaluations: score + gradient only
     else ndt_term_hessian_double(*f, x3, dd, icov + 9 * (size_t)id, acc + 7);
   }
   __device__ __forceinline__ void skip(float) {}
@@ -1190,7 +1232,8 @@ __global__ void __launch_bounds__(256) k_ndt_derivs(const float4* __restrict__ s
     tree_search(cells, col.xt[0], col.xt[1], col.xt[2], col, lds_stack + threadIdx.x, 256);
   }
   double* out = rows + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * NDT_ROW;
-  wave_reduce_row<NDT_NSUM, NDT_ROW>(lds_stack, out, 0.0, [&](int k) { return col.acc[k]; });
+  if constexpr (MODE == 2) wave_reduce_row<7, NDT_ROW>(lds_stack, out, 0.0, [&](int k) { return col.acc[k]; });  // the hessian columns are zero
+  else wave_reduce_row<NDT_NSUM, NDT_ROW>(lds_stack, out, 0.0, [&](int k) { return col.acc[k]; });
 }
 // fixed-order final sum of the per-wave rows: workgroup c adds chunk c into out[c][NDT_ROW]; the host adds the chunks
 __global__ void __launch_bounds__(4 * NDT_ROW) k_rows_final(const double* __restrict__ rows, int n_rows, double* __restrict__ out) {
@@ -1210,7 +1253,8 @@ void launch_ndt_derivs(const float4* src, int n, TreeView cells, const double* m
   if (lds < 4 * 8 * 72 * sizeof(double)) lds = 4 * 8 * 72 * sizeof(double);
   int blocks = (n + 255) / 256;
   if (hessian_only) hipLaunchKernelGGL(k_ndt_derivs<1>, dim3(blocks), dim3(256), lds, s, src, n, cells, mean, icov, f, rows_dev);
-  else hipLaunchKernelGGL(k_ndt_derivs<0>, dim3(blocks), dim3(256), lds, s, src, n, cells, mean, icov, f, rows_dev);
+  else if (f.want_h) hipLaunchKernelGGL(k_ndt_derivs<0>, dim3(blocks), dim3(256), lds, s, src, n, cells, mean, icov, f, rows_dev);
+  else hipLaunchKernelGGL(k_ndt_derivs<2>, dim3(blocks), dim3(256), lds, s, src, n, cells, mean, icov, f, rows_dev);
   hipLaunchKernelGGL(k_rows_final, dim3(FINAL_CHUNKS), dim3(4 * NDT_ROW), 0, s, rows_dev, blocks * 4, out_chunks);
 }
 

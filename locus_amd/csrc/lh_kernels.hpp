@@ -156,6 +156,10 @@ constexpr int NDT_ROW = 44;   // a partial row: score, gradient[6], hessian[36],
 struct NdtVoxelRaw { double sum[3]; double cov[6]; float cen[3]; int count; };   // raw per-voxel sums (xx xy xz yy yz zz)
 void launch_ndt_voxel_stats(const float4* xyz, const uint32_t* keys, const uint32_t* vals, const uint32_t* heads, const uint32_t* rank_incl,
                             int n, NdtVoxelRaw* out, hipStream_t s);
+void launch_ndt_finish_cells(const NdtVoxelRaw* raw, int n_vox, int min_points, double eig_mult, double* mean, double* icov, float4* cen,
+                             uint32_t* flags, hipStream_t s);
+void launch_ndt_compact_cells(const uint32_t* incl, int n_vox, const double* mean, const double* icov, const float4* cen, double* omean,
+                              double* oicov, float4* ocen, hipStream_t s);
 // one evaluation: per-wave rows [ceil(n/256)*4][NDT_ROW] -> FINAL_CHUNKS chunk sums (the host adds them in chunk order)
 void launch_ndt_derivs(const float4* src, int n, TreeView cells, const double* mean, const double* icov, const NdtFrame& f, int hessian_only,
                        double* rows_dev, double* out_chunks, hipStream_t s);

@@ -7,6 +7,8 @@
 //   :576-652  updateDerivatives (float)                         > ndt_term_float
 //   :532-574, :713-748 computePointDerivatives (double), updateHessian -> ndt_term_hessian_double
 #pragma once
+#include <math.h>
+
 #include "lh_device.hpp"
 
 namespace lh {
@@ -28,6 +30,7 @@ LH_HD float ndt_dot4(const float* a, const float* b) { return ((a[0] * b[0] + a[
 
 // one (point, cell) term of computeDerivatives.  x = original point, xt = transformed point - cell mean (double), icov = cell's
 // inverse covariance (row-major double[9]).  Adds to acc[0] (score), acc[1..6] (gradient), acc[7..42] (hessian, row-major).
+template <bool WANT_H>
 LH_HD void ndt_term_float(const NdtFrame& f, const float* x3, const double* xt, const double* icov, double* acc) {
   float x4[4] = {x3[0], x3[1], x3[2], 0.0f};
   float pg[4][6];
@@ -66,7 +69,7 @@ LH_HD void ndt_term_float(const NdtFrame& f, const float* x3, const double* xt, 
   acc[0] += (double)score_inc;
 #pragma unroll
   for (int j = 0; j < 6; j++) acc[1 + j] += (double)(e * xcg[j]);
-  if (!f.want_h) return;
+  if (!WANT_H) return;
   float xh[15];
 #pragma unroll
   for (int r = 0; r < 15; r++) xh[r] = ndt_dot4(f.h_ang[r], x4);
@@ -140,5 +143,73 @@ LH_HD void ndt_term_hessian_double(const NdtFrame& f, const float* x3, const dou
     }
   }
 }
+
+// ---- target cells: VoxelGridCovariance::applyFilter's per-leaf algebra (voxel_grid_covariance_omp_impl.hpp:215-282), one voxel per
+// thread on the device.  3x3 symmetric eigen-decomposition by cyclic Jacobi sweeps, ascending (stands in for SelfAdjointEigenSolver).
+LH_HD void ndt_eig_sym3(const double* A, double* ev, double* V /*row-major, eigenvectors in columns*/) {
+  double a[9];
+  for (int i = 0; i < 9; i++) a[i] = A[i];
+  for (int i = 0; i < 9; i++) V[i] = (i % 4 == 0) ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 64; sweep++) {
+    double off = a[1] * a[1] + a[2] * a[2] + a[5] * a[5];
+    if (off < 1e-300) break;
+    for (int p = 0; p < 3; p++)
+      for (int q = p + 1; q < 3; q++) {
+        double apq = a[p * 3 + q];
+        if (fabs(apq) < 1e-300) continue;
+        double theta = (a[q * 3 + q] - a[p * 3 + p]) / (2.0 * apq);
+        double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+        for (int k = 0; k < 3; k++) { double akp = a[k * 3 + p], akq = a[k * 3 + q]; a[k * 3 + p] = c * akp - s * akq; a[k * 3 + q] = s * akp + c * akq; }
+        for (int k = 0; k < 3; k++) { double apk = a[p * 3 + k], aqk = a[q * 3 + k]; a[p * 3 + k] = c * apk - s * aqk; a[q * 3 + k] = s * apk + c * aqk; }
+        for (int k = 0; k < 3; k++) { double vkp = V[k * 3 + p], vkq = V[k * 3 + q]; V[k * 3 + p] = c * vkp - s * vkq; V[k * 3 + q] = s * vkp + c * vkq; }
+      }
+  }
+  int order[3] = {0, 1, 2};
+  double d[3] = {a[0], a[4], a[8]};
+  for (int i = 0; i < 2; i++)
+    for (int j = 0; j < 2 - i; j++)
+      if (d[order[j]] > d[order[j + 1]]) { int t = order[j]; order[j] = order[j + 1]; order[j + 1] = t; }
+  double Vs[9];
+  for (int k = 0; k < 3; k++) { ev[k] = d[order[k]]; for (int r = 0; r < 3; r++) Vs[r * 3 + k] = V[r * 3 + order[k]]; }
+  for (int i = 0; i < 9; i++) V[i] = Vs[i];
+}
+
+// one voxel: raw sums -> (mean, inverse covariance); returns false if the voxel holds too few points (it does not become a cell)
+LH_HD bool ndt_finish_cell(const double* sum3, const double* cov6_raw, int np, int min_points, double eig_mult, double* mean3, double* icov9) {
+  if (np < min_points) return false;
+  double mean[3], cov[9];
+  for (int a = 0; a < 3; a++) mean3[a] = mean[a] = sum3[a] / np;
+  const double raw[9] = {cov6_raw[0], cov6_raw[1], cov6_raw[2], cov6_raw[1], cov6_raw[3], cov6_raw[4], cov6_raw[2], cov6_raw[4], cov6_raw[5]};
+  for (int a = 0; a < 3; a++)
+    for (int b = 0; b < 3; b++) {
+      double v = (raw[a * 3 + b] - 2.0 * (sum3[a] * mean[b])) / np + mean[a] * mean[b];  // :236
+      cov[a * 3 + b] = v * ((np - 1.0) / np);                                             // :237
+    }
+  double sym[9], ev[3], V[9];
+  for (int a = 0; a < 3; a++)
+    for (int b = 0; b < 3; b++) sym[a * 3 + b] = cov[(a > b ? a : b) * 3 + (a > b ? b : a)];  // the solver reads the lower triangle
+  ndt_eig_sym3(sym, ev, V);
+  for (int k = 0; k < 9; k++) icov9[k] = 0.0;
+  if (ev[0] < 0 || ev[1] < 0 || ev[2] <= 0) return true;  // rejected by the eigenvalue check (:250-254): stays searchable, icov = 0
+  double minev = eig_mult * ev[2];
+  if (ev[0] < minev) {                                      // :258-268
+    ev[0] = minev;
+    if (ev[1] < minev) ev[1] = minev;
+    for (int a = 0; a < 3; a++)
+      for (int b = 0; b < 3; b++) {
+        double v = 0;
+        for (int k = 0; k < 3; k++) v += V[a * 3 + k] * ev[k] * V[b * 3 + k];
+        cov[a * 3 + b] = v;
+      }
+  }
+  double c00 = cov[4] * cov[8] - cov[5] * cov[7], c01 = cov[5] * cov[6] - cov[3] * cov[8], c02 = cov[3] * cov[7] - cov[4] * cov[6];
+  double id = 1.0 / (cov[0] * c00 + cov[1] * c01 + cov[2] * c02);
+  icov9[0] = c00 * id; icov9[1] = (cov[2] * cov[7] - cov[1] * cov[8]) * id; icov9[2] = (cov[1] * cov[5] - cov[2] * cov[4]) * id;
+  icov9[3] = c01 * id; icov9[4] = (cov[0] * cov[8] - cov[2] * cov[6]) * id; icov9[5] = (cov[2] * cov[3] - cov[0] * cov[5]) * id;
+  icov9[6] = c02 * id; icov9[7] = (cov[1] * cov[6] - cov[0] * cov[7]) * id; icov9[8] = (cov[0] * cov[4] - cov[1] * cov[3]) * id;
+  return true;
+}
+
 
 }  // namespace lh

@@ -82,72 +82,6 @@ inline void ndt_fill_frame(NdtFrame& f, const double* p, const float* T16, float
   f.want_h = want_h;
 }
 
-// ---- 3x3 symmetric eigen-decomposition (cyclic Jacobi), ascending; stands in for SelfAdjointEigenSolver<Matrix3d> ---------
-inline void ndt_eig_sym3(const double* A, double* ev, double* V /*row-major, eigenvectors in columns*/) {
-  double a[9];
-  memcpy(a, A, sizeof(a));
-  for (int i = 0; i < 9; i++) V[i] = (i % 4 == 0) ? 1.0 : 0.0;
-  for (int sweep = 0; sweep < 64; sweep++) {
-    double off = a[1] * a[1] + a[2] * a[2] + a[5] * a[5];
-    if (off < 1e-300) break;
-    for (int p = 0; p < 3; p++)
-      for (int q = p + 1; q < 3; q++) {
-        double apq = a[p * 3 + q];
-        if (fabs(apq) < 1e-300) continue;
-        double theta = (a[q * 3 + q] - a[p * 3 + p]) / (2.0 * apq);
-        double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-        double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
-        for (int k = 0; k < 3; k++) { double akp = a[k * 3 + p], akq = a[k * 3 + q]; a[k * 3 + p] = c * akp - s * akq; a[k * 3 + q] = s * akp + c * akq; }
-        for (int k = 0; k < 3; k++) { double apk = a[p * 3 + k], aqk = a[q * 3 + k]; a[p * 3 + k] = c * apk - s * aqk; a[q * 3 + k] = s * apk + c * aqk; }
-        for (int k = 0; k < 3; k++) { double vkp = V[k * 3 + p], vkq = V[k * 3 + q]; V[k * 3 + p] = c * vkp - s * vkq; V[k * 3 + q] = s * vkp + c * vkq; }
-      }
-  }
-  int order[3] = {0, 1, 2};
-  double d[3] = {a[0], a[4], a[8]};
-  for (int i = 0; i < 2; i++)
-    for (int j = 0; j < 2 - i; j++)
-      if (d[order[j]] > d[order[j + 1]]) { int t = order[j]; order[j] = order[j + 1]; order[j + 1] = t; }
-  double Vs[9];
-  for (int k = 0; k < 3; k++) { ev[k] = d[order[k]]; for (int r = 0; r < 3; r++) Vs[r * 3 + k] = V[r * 3 + order[k]]; }
-  memcpy(V, Vs, sizeof(Vs));
-}
-
-// one voxel: raw sums -> (mean, inverse covariance); returns false if the voxel holds too few points (it does not become a cell)
-inline bool ndt_finish_cell(const double* sum3, const double* cov6_raw, int np, int min_points, double eig_mult, double* mean3, double* icov9) {
-  if (np < min_points) return false;
-  double mean[3], cov[9];
-  for (int a = 0; a < 3; a++) mean3[a] = mean[a] = sum3[a] / np;
-  const double raw[9] = {cov6_raw[0], cov6_raw[1], cov6_raw[2], cov6_raw[1], cov6_raw[3], cov6_raw[4], cov6_raw[2], cov6_raw[4], cov6_raw[5]};
-  for (int a = 0; a < 3; a++)
-    for (int b = 0; b < 3; b++) {
-      double v = (raw[a * 3 + b] - 2.0 * (sum3[a] * mean[b])) / np + mean[a] * mean[b];  // :236
-      cov[a * 3 + b] = v * ((np - 1.0) / np);                                             // :237
-    }
-  double sym[9], ev[3], V[9];
-  for (int a = 0; a < 3; a++)
-    for (int b = 0; b < 3; b++) sym[a * 3 + b] = cov[(a > b ? a : b) * 3 + (a > b ? b : a)];  // the solver reads the lower triangle
-  ndt_eig_sym3(sym, ev, V);
-  for (int k = 0; k < 9; k++) icov9[k] = 0.0;
-  if (ev[0] < 0 || ev[1] < 0 || ev[2] <= 0) return true;  // rejected by the eigenvalue check (:250-254): stays searchable, icov = 0
-  double minev = eig_mult * ev[2];
-  if (ev[0] < minev) {                                      // :258-268
-    ev[0] = minev;
-    if (ev[1] < minev) ev[1] = minev;
-    for (int a = 0; a < 3; a++)
-      for (int b = 0; b < 3; b++) {
-        double v = 0;
-        for (int k = 0; k < 3; k++) v += V[a * 3 + k] * ev[k] * V[b * 3 + k];
-        cov[a * 3 + b] = v;
-      }
-  }
-  double c00 = cov[4] * cov[8] - cov[5] * cov[7], c01 = cov[5] * cov[6] - cov[3] * cov[8], c02 = cov[3] * cov[7] - cov[4] * cov[6];
-  double id = 1.0 / (cov[0] * c00 + cov[1] * c01 + cov[2] * c02);
-  icov9[0] = c00 * id; icov9[1] = (cov[2] * cov[7] - cov[1] * cov[8]) * id; icov9[2] = (cov[1] * cov[5] - cov[2] * cov[4]) * id;
-  icov9[3] = c01 * id; icov9[4] = (cov[0] * cov[8] - cov[2] * cov[6]) * id; icov9[5] = (cov[2] * cov[3] - cov[0] * cov[5]) * id;
-  icov9[6] = c02 * id; icov9[7] = (cov[1] * cov[6] - cov[0] * cov[7]) * id; icov9[8] = (cov[0] * cov[4] - cov[1] * cov[3]) * id;
-  return true;
-}
-
 // ---- x = pinv(A) b for 6x6 through a one-sided Jacobi SVD: JacobiSVD<Matrix6d>(hessian, FullU|FullV).solve(-gradient) ------
 inline void ndt_svd_solve6(const double* A36, const double* b6, double* x6) {
   double U[36], V[36];
