@@ -512,7 +512,7 @@ __device__ __forceinline__ void wave_reduce_row(uint64_t* lds_base, double* out,
 // one point per thread (78 VGPRs, 6 waves per SIMD).  A variant with 4 points per thread and the 74 moments accumulated in
 // registers (239 VGPRs, 2 waves per SIMD) pays the reduction once per 4 points but was slower even on certificate-only
 // sweeps (142 vs 128 us): with so few waves the dependent src -> neighbour gathers are no longer hidden.
-__global__ void __launch_bounds__(256) k_sweep_fused(const PairDesc* __restrict__ descs, SweepArgs a, double* __restrict__ partials,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) k_sweep_fused(const PairDesc* __restrict__ descs, SweepArgs a, double* __restrict__ partials,
                                                      int partials_stride) {
   extern __shared__ __attribute__((aligned(16))) uint64_t lds_stack[];  // [entries][256], later reused as double[8][256]
   int jb, blk;
@@ -530,7 +530,56 @@ __global__ void __launch_bounds__(256) k_sweep_fused(const PairDesc* __restrict_
   const double live = sp.matched ? 1.0 : 0.0;
   const int walks = __popcll(__ballot(sp.searched));
   double* out = partials + (size_t)job.slot * partials_stride + ((size_t)blk * 4 + (threadIdx.x >> 6)) * MOM_ROW;
-  wave_reduce_row<MOM_NSUM, MOM_ROW>(lds_stack, out, (double)walks, [&](int k) { return (k == 73) ? live : mom_value(k, M6, Ma, aMa, pt, pp); });
+  {
+    // The 74 moments of a wave are one 16x16 Gram matrix over its 64 points: D = sum_i a_i b_i^T with
+    //   a_i = (M00 M01 M02 M11 M12 M22 | Ma0 Ma1 Ma2 | aMa | live)   b_i = (xx xy xz x yy yz y zz z 1)
+    // (H = rows 0-5 x cols 0-9, B = rows 6-8 x cols {3,6,8,9}, c0 = D[9][9], count = D[10][9]).  v_mfma_f64_16x16x4_f64 adds four
+    // points per instruction on the matrix pipe, which runs beside the VALU: the products, the cross-lane adds and most of the
+    // LDS traffic of the shuffle reduction disappear from the vector pipe.  Operands go through LDS once (lane = point ->
+    // lane = (element, point)), half a wave at a time so that the staging fits the traversal-stack region.
+    typedef double v4d __attribute__((ext_vector_type(4)));
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    constexpr int RS = 21;  // doubles per staged point: a (11) then b (10); odd => conflict-free column writes
+    double* wl = reinterpret_cast<double*>(lds_stack) + wave * (32 * RS);
+    const double av[11] = {M6[0], M6[1], M6[2], M6[3], M6[4], M6[5], Ma[0], Ma[1], Ma[2], aMa, live};
+    v4d acc = {0.0, 0.0, 0.0, 0.0};
+    __syncthreads();  // every lane of the workgroup is done with its traversal stack
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+      if ((lane >> 5) == half) {
+        double* row = wl + (lane & 31) * RS;
+#pragma unroll
+        for (int e = 0; e < 11; e++) row[e] = av[e];
+#pragma unroll
+        for (int e = 0; e < 10; e++) row[11 + e] = pp[e];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      const int E = lane & 15;
+#pragma unroll
+      for (int m = 0; m < 8; m++) {  // points 4m .. 4m+3 of this half: A[i = lane & 15][k = lane >> 4], B[k = lane >> 4][j = lane & 15]
+        const double* row = wl + (4 * m + (lane >> 4)) * RS;
+        double A = (E < 11) ? row[E] : 0.0;
+        double B = (E < 10) ? row[11 + E] : 0.0;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A, B, acc, 0, 0, 0);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+    }
+    // D[row = (lane >> 4) + 4 r][col = lane & 15] is acc[r] (the f64 C/D map)
+    const int j = lane & 15;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int i = (lane >> 4) + 4 * r;
+      int k = -1;
+      if (i < 6 && j < 10) k = 13 + i * 10 + j;
+      else if (i < 9 && i >= 6 && (j == 3 || j == 6 || j == 8 || j == 9)) k = 1 + (i - 6) * 4 + (j == 3 ? 0 : (j == 6 ? 1 : (j == 8 ? 2 : 3)));
+      else if (i == 9 && j == 9) k = 0;
+      else if (i == 10 && j == 9) k = 73;
+      if (k >= 0) out[k] = acc[r];
+    }
+    if (lane < MOM_ROW - MOM_NSUM) out[MOM_NSUM + lane] = lane == 0 ? (double)walks : 0.0;
+  }
 }
 
 void launch_sweep_fused(const PairDesc* descs, SweepArgs& a, int max_n, double* partials_dev, int partials_stride, hipStream_t s) {
