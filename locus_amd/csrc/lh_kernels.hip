@@ -67,8 +67,13 @@ __global__ void __launch_bounds__(256) k_key_b(const IndexDesc* __restrict__ des
                                                uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
   const IndexDesc d = descs[blockIdx.y];
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= d.n) return;
   const uint32_t* bb = bbox + blockIdx.y * 8;
+  if (i == 0) {  // the grid the node boxes are quantised on (also for empty clouds: block 0 always runs)
+    const float lo[3] = {dec_ordered(bb[0]), dec_ordered(bb[1]), dec_ordered(bb[2])};
+    const float hi[3] = {dec_ordered(bb[3]), dec_ordered(bb[4]), dec_ordered(bb[5])};
+    quant_frame(lo, hi, d.hdr);
+  }
+  if (i >= d.n) return;
   float4 p = d.xyz[i];
   // 30 bits (7.8 cm cells on an 80 m scene) are enough: 16 bits/axis (spatial_key48) leaves the visit counts unchanged
   uint32_t k = spatial_key30(p.x, p.y, p.z, dec_ordered(bb[0]), dec_ordered(bb[1]), dec_ordered(bb[2]), dec_ordered(bb[3]),
@@ -204,13 +209,12 @@ __global__ void __launch_bounds__(256) k_nodex_b(const IndexDesc* __restrict__ d
   if (cloud != (int)(t.lkey[hi] >> 32)) return;  // joins two clouds: not part of any cloud's tree
   const IndexDesc d = descs[cloud];
   const int a_c = (int)t.lid[d.offset] - 1, b_c = (int)t.lid[d.offset + d.n - 1] - 1;
+  const TreeHeader fr = *d.hdr;   // the quantisation frame, written by k_key_b (an earlier launch)
   NodeX nd;
 #pragma unroll
   for (int k = 0; k < 4; k++) {
-    nd.lox[k] = nd.loy[k] = nd.loz[k] = INFINITY;
-    nd.hix[k] = nd.hiy[k] = nd.hiz[k] = -INFINITY;
-    nd.child[k] = 0x7fffffff;
-    nd.pad[k] = 0;
+    nd.lo_xy[k] = 0xffffffffu; nd.hi_xy[k] = 0u; nd.z_lohi[k] = 0xffffffffu;
+    nd.child[k] = NO_CHILD;
   }
   int cnt = 0;
   auto emit = [&](int ref) {
@@ -224,8 +228,7 @@ __global__ void __launch_bounds__(256) k_nodex_b(const IndexDesc* __restrict__ d
       bx = range_box(t, t.irange[2 * ref], t.irange[2 * ref + 1] + 1);
       cref = ref - a_c;
     }
-    nd.lox[cnt] = bx.lx; nd.loy[cnt] = bx.ly; nd.loz[cnt] = bx.lz;
-    nd.hix[cnt] = bx.hx; nd.hiy[cnt] = bx.hy; nd.hiz[cnt] = bx.hz;
+    quant_box(fr, bx.lx, bx.ly, bx.lz, bx.hx, bx.hy, bx.hz, nd.lo_xy[cnt], nd.hi_xy[cnt], nd.z_lohi[cnt]);
     nd.child[cnt] = cref;
     cnt++;
   };

@@ -33,6 +33,7 @@ static HostTree build(const std::vector<float4>& pts, uint64_t cloud_id = 3) {
     lo[1] = fminf(lo[1], p.y); hi[1] = fmaxf(hi[1], p.y);
     lo[2] = fminf(lo[2], p.z); hi[2] = fmaxf(hi[2], p.z);
   }
+  quant_frame(lo, hi, &t.hdr);  // k_key_b
   std::vector<std::pair<uint64_t, uint32_t>> kv(n);
   for (int i = 0; i < n; i++)
     kv[i] = {(cloud_id << 32) | spatial_key30(pts[i].x, pts[i].y, pts[i].z, lo[0], lo[1], lo[2], hi[0], hi[1], hi[2]), (uint32_t)i};
@@ -92,11 +93,21 @@ static HostTree build(const std::vector<float4>& pts, uint64_t cloud_id = 3) {
   t.nodes.resize(L);
   for (int i = 0; i < L - 1; i++) {
     NodeX nd;
-    for (int k = 0; k < 4; k++) { nd.lox[k] = nd.loy[k] = nd.loz[k] = INFINITY; nd.hix[k] = nd.hiy[k] = nd.hiz[k] = -INFINITY; nd.child[k] = 0x7fffffff; nd.pad[k] = 0; }
+    for (int k = 0; k < 4; k++) { nd.lo_xy[k] = 0xffffffffu; nd.hi_xy[k] = 0u; nd.z_lohi[k] = 0xffffffffu; nd.child[k] = NO_CHILD; }
     int cnt = 0;
     auto emit = [&](int ref) {
       B6 b = ref < 0 ? leaf_box(~ref) : ibox[ref];
-      nd.lox[cnt] = b.v[0]; nd.loy[cnt] = b.v[1]; nd.loz[cnt] = b.v[2]; nd.hix[cnt] = b.v[3]; nd.hiy[cnt] = b.v[4]; nd.hiz[cnt] = b.v[5];
+      quant_box(t.hdr, b.v[0], b.v[1], b.v[2], b.v[3], b.v[4], b.v[5], nd.lo_xy[cnt], nd.hi_xy[cnt], nd.z_lohi[cnt]);
+      // the decoded box must enclose the float box with at least half a step to spare (double arithmetic = ground truth)
+      const uint32_t qlo[3] = {nd.lo_xy[cnt] & 0xffffu, nd.lo_xy[cnt] >> 16, nd.z_lohi[cnt] & 0xffffu};
+      const uint32_t qhi[3] = {nd.hi_xy[cnt] & 0xffffu, nd.hi_xy[cnt] >> 16, 65535u - (nd.z_lohi[cnt] >> 16)};
+      for (int a = 0; a < 3; a++) {
+        double dlo = (double)t.hdr.org[a] + (double)qlo[a] * (double)t.hdr.scl;
+        double dhi = (double)t.hdr.org[a] + (double)qhi[a] * (double)t.hdr.scl;
+        double half = 0.5 * (double)t.hdr.scl;
+        bool lo_ok = qlo[a] == 0 ? dlo <= (double)b.v[a] : dlo + half <= (double)b.v[a];
+        if (!lo_ok || dhi - half < (double)b.v[3 + a]) { printf("quantised box does not enclose: axis %d\n", a); exit(2); }
+      }
       nd.child[cnt] = ref < 0 ? leaf_ref(lstart[~ref], (int)(lstart[~ref + 1] - lstart[~ref])) : ref;
       cnt++;
     };
