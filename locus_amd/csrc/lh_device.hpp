@@ -26,6 +26,22 @@
 // 16-B load from GLOBAL memory: the tree and point pointers reach the walk through descriptor structs, so the compiler
 // only knows them as generic pointers and would emit flat_load (which also takes a slot in the LDS queue and makes every
 // wait on the loads a wait on the traversal-stack LDS traffic too)
+template <class T>
+__host__ __device__ __forceinline__ T gld(const T* p) {   // typed load / store through a GLOBAL pointer (see gload16)
+#if defined(__HIP_DEVICE_COMPILE__)
+  return *reinterpret_cast<const T __attribute__((address_space(1)))*>(reinterpret_cast<uintptr_t>(p));
+#else
+  return *p;
+#endif
+}
+template <class T>
+__host__ __device__ __forceinline__ void gst(T* p, const T& v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  *reinterpret_cast<T __attribute__((address_space(1)))*>(reinterpret_cast<uintptr_t>(p)) = v;
+#else
+  *p = v;
+#endif
+}
 template <class V>
 __host__ __device__ __forceinline__ V gload16(const void* p) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -291,9 +307,13 @@ template <class Collector>
 LH_HD void tree_search(const TreeView& t, float qx, float qy, float qz, Collector& col, uint64_t* stack, int stride) {
   const uint32_t NONE = 0xffffffffu;
   const float INF = inf_f();
-  const int32_t root = t.hdr->root;
-  const GridQuery gq = grid_query(*t.hdr, qx, qy, qz);
-  const float scl2 = t.hdr->scl2;
+  TreeHeader h;   // only the fields the walk needs (uniform address: scalar loads once the pointer is known to be global)
+  h.root = gld(&t.hdr->root);
+  h.org[0] = gld(&t.hdr->org[0]); h.org[1] = gld(&t.hdr->org[1]); h.org[2] = gld(&t.hdr->org[2]);
+  h.inv = gld(&t.hdr->inv); h.scl2 = gld(&t.hdr->scl2);
+  const int32_t root = h.root;
+  const GridQuery gq = grid_query(h, qx, qy, qz);
+  const float scl2 = h.scl2;
   // box distances of a node's four children (+inf for an absent child)
   auto child_dists = [&](const NodeX& nd, int4& ch, float& d0, float& d1, float& d2, float& d3) {
     const uint4 a = gload16<uint4>(nd.lo_xy);
@@ -326,9 +346,16 @@ LH_HD void tree_search(const TreeView& t, float qx, float qy, float qz, Collecto
   }
   int sp = 0;
   uint64_t spill[SPILL_MAX];
+#if defined(__HIP_DEVICE_COMPILE__)
+  // the kernels' stack base is LDS: say so, or the pop below (LDS entry or spilled entry) becomes ONE flat load through a
+  // selected generic pointer, with the flat path's latency on every pop
+  __attribute__((address_space(3))) uint64_t* const lstack = (__attribute__((address_space(3))) uint64_t*)stack;
+#else
+  uint64_t* const lstack = stack;
+#endif
   auto push = [&](uint32_t key, int32_t ref) {
     uint64_t e = ((uint64_t)key << 32) | (uint32_t)ref;
-    if (sp < LDS_STACK) stack[sp * stride] = e;
+    if (sp < LDS_STACK) lstack[sp * stride] = e;
     else spill[sp - LDS_STACK] = e;
     sp++;
   };
@@ -337,7 +364,9 @@ LH_HD void tree_search(const TreeView& t, float qx, float qy, float qz, Collecto
     for (;;) {
       if (sp == 0) return DONE;
       --sp;
-      uint64_t e = (sp < LDS_STACK) ? stack[sp * stride] : spill[sp - LDS_STACK];
+      uint64_t e;
+      if (sp < LDS_STACK) e = lstack[sp * stride];
+      else e = spill[sp - LDS_STACK];
       float dk = u2f((uint32_t)(e >> 32) & ~3u);  // key = distance bits with the child slot in the two low mantissa bits (rounded DOWN)
       if (dk <= col.bound()) return (int32_t)(uint32_t)e;
       col.skip(dk);

@@ -340,23 +340,23 @@ struct SweepPoint {
   bool searched; // the certificate did not cover this query: the tree was walked
 };
 __device__ __forceinline__ void sweep_point(const PairDesc& d, const SweepJob& job, int i, uint64_t* stack, SweepPoint& o) {
-  o.p = d.src[i];
+  o.p = gld(d.src + i);
   float qx, qy, qz;
   xform_pt(job.T, o.p.x, o.p.y, o.p.z, qx, qy, qz);  // gicp.hpp:469
   TreeView tv{d.tgt_sorted, d.tgt_nodes, d.tgt_hdr, d.m};
   Nn1CertCollector col{INFINITY, 0x7fffffff, INFINITY};
-  int w = d.prev_nn[i];
+  int w = gld(d.prev_nn + i);
   bool need_search = true;
   if (w >= 0) {
     // warm start: last sweep's neighbour is a valid candidate => tight initial bound, still exact
-    float4 t = d.tgt_xyz[w];
+    float4 t = gld(d.tgt_xyz + w);
     col.bd = d2f(qx, qy, qz, t.x, t.y, t.z);
     col.bi = w;
     // certificate from the last full search at query position cq: every other target point was at squared distance
     // >= cq.w from cq, so it is at distance >= sqrt(cq.w) - |q - cq| from q.  If the candidate is strictly closer
     // (1e-5 relative margin >> float rounding of the d2 evaluations), the traversal cannot change the result.
     // (float arithmetic: sqrtf is correctly rounded to ~1e-7 relative, two orders below the 1e-5 margins)
-    float4 cq = d.cert[i];
+    float4 cq = gld(d.cert + i);
     float e = sqrtf(d2f(qx, qy, qz, cq.x, cq.y, cq.z));
     float dw = sqrtf(col.bd), lo = sqrtf(cq.w);
     if (dw * (1.0f + 1e-5f) + e * (1.0f + 1e-5f) + 1e-12f < lo * (1.0f - 1e-5f)) need_search = false;
@@ -364,12 +364,12 @@ __device__ __forceinline__ void sweep_point(const PairDesc& d, const SweepJob& j
   o.searched = need_search;
   if (need_search) {
     tree_search(tv, qx, qy, qz, col, stack, 256);
-    d.cert[i] = make_float4(qx, qy, qz, col.lb);
+    gst(d.cert + i, make_float4(qx, qy, qz, col.lb));
     if (d.stats) atomicAdd(&d.stats[0], 1ull);  // instrumentation only (lh_gicp_debug_sweep): contended atomics
   }
   if (d.stats) atomicAdd(&d.stats[1], 1ull);
   int j = (col.bi == 0x7fffffff) ? -1 : col.bi;
-  if (j != w) d.prev_nn[i] = j;
+  if (j != w) gst(d.prev_nn + i, j);
   o.j = j;
   o.matched = j >= 0 && (double)col.bd < d.corr_dist2;  // gicp.hpp:483
   if (o.matched) {
@@ -377,19 +377,19 @@ __device__ __forceinline__ void sweep_point(const PairDesc& d, const SweepJob& j
     if (d.src_cov6) {
       double s6[6];
 #pragma unroll
-      for (int k = 0; k < 6; k++) s6[k] = d.src_cov6[(size_t)k * d.src_cov_pad + i];
+      for (int k = 0; k < 6; k++) s6[k] = gld(d.src_cov6 + (size_t)k * d.src_cov_pad + i);
       sym6_to_mat9(s6, C1);
     } else {
-      float4 nn = d.src_nrm[i];
+      float4 nn = gld(d.src_nrm + i);
       cov_from_normal(nn.x, nn.y, nn.z, d.gicp_eps, C1);
     }
     if (d.tgt_cov6) {
       double s6[6];
 #pragma unroll
-      for (int k = 0; k < 6; k++) s6[k] = d.tgt_cov6[(size_t)k * d.m_pad + j];
+      for (int k = 0; k < 6; k++) s6[k] = gld(d.tgt_cov6 + (size_t)k * d.m_pad + j);
       sym6_to_mat9(s6, C2);
     } else {
-      float4 nn = d.tgt_nrm[j];
+      float4 nn = gld(d.tgt_nrm + j);
       cov_from_normal(nn.x, nn.y, nn.z, d.gicp_eps, C2);
     }
     // transform_R = double(transformation_) * double(guess), top-left 3x3 (gicp.hpp:450-460); the k = 3 term is T(i,3)*0
@@ -408,7 +408,7 @@ __device__ __forceinline__ void sweep_point(const PairDesc& d, const SweepJob& j
                            (double)job.T[r * 4 + 2] * d.guess3[2 * 3 + cc]) + (double)job.T[r * 4 + 3] * 0.0;
     }
     mahalanobis(R, C1, C2, o.M);  // gicp.hpp:488-493
-    o.tgt = d.tgt_xyz[j];
+    o.tgt = gld(d.tgt_xyz + j);
   }
 }
 
