@@ -135,11 +135,31 @@ static int run_case(int n, int nq, int k, unsigned seed, int dup) {
   }
   for (int i = 0; i < nq; i++) {
     if (i % 4 == 0) qs[i] = pts[rng() % n];  // exact hits
+    else if (i % 16 == 1) qs[i] = make_float4(-3.f - 0.5f * fabsf(g(rng)), 4.f + 5.f * g(rng), g(rng), 1.f);  // just outside the cloud's box (the grid's e2 term)
+    else if (i % 16 == 5) qs[i] = make_float4(3.0e4f * g(rng), 2.0e4f * g(rng), 1.0e3f * g(rng), 1.f);      // hundreds of extents away
+    else if (i % 16 == 9) qs[i] = make_float4(1.0e12f, -1.0e12f, 1.0e12f, 1.f);                             // absurdly far: e2 stays finite
     else qs[i] = make_float4(10.f + 8.f * g(rng), 4.f + 5.f * g(rng), g(rng), 1.f);
   }
   HostTree t = build(pts);
   TreeView tv = t.view();
   int bad = 0;
+  // the quantised box bound must never exceed the float distance to any point of the leaf it bounds (what pruning relies on)
+  if (t.n_leaves > 1) {
+    for (int i = 0; i < std::min(nq, 64); i++) {
+      GridQuery gq = grid_query(t.hdr, qs[i].x, qs[i].y, qs[i].z);
+      for (int nd = 0; nd < t.n_leaves - 1; nd++)
+        for (int c = 0; c < 4; c++) {
+          int32_t ref = t.nodes[nd].child[c];
+          if (ref == NO_CHILD || ref >= 0) continue;
+          float bnd = boxd2_q(gq, t.nodes[nd].lo_xy[c], t.nodes[nd].hi_xy[c], t.nodes[nd].z_lohi[c], t.hdr.scl2);
+          uint32_t u = (uint32_t)~ref;
+          for (uint32_t e = 0; e <= (u & 15u); e++) {
+            float4 p = t.sorted[(u >> 4) + e];
+            if (!(bnd <= d2f(qs[i].x, qs[i].y, qs[i].z, p.x, p.y, p.z))) { printf("box bound above a point distance\n"); bad++; }
+          }
+        }
+    }
+  }
   std::vector<uint64_t> stk(LDS_STACK);
   std::vector<float> kd(k), bd(n);
   std::vector<int> ki(k), ord(n);

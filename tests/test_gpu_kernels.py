@@ -168,6 +168,26 @@ def test_warm_sweeps_with_certificates_stay_bit_exact(ctx, capi, oracle):
     assert fracs[0] == 1.0 and fracs[8] < 0.01  # a repeated transform needs (almost) no traversal
 
 
+def test_sweep_queries_outside_the_target_box_stay_bit_exact(ctx, capi, oracle):
+    # node boxes are 16-bit fixed point on the target's own grid; a query outside that grid is clamped onto it and carries
+    # its overshoot as a separate term.  Shift the source a little, a lot and absurdly far out of the target's bounding box:
+    # the nearest neighbours must still be the exhaustive-search ones, bit for bit.
+    src, tgt, _ = synth.scan_pair(n_rings=16, n_az=400, scale=1.0, noise=0.01, seed=23)
+    ttree = oracle.Tree(oracle.xyz4(tgt))
+    nt = oracle.normals_knn(oracle.xyz4(tgt), 20, threads=4, tree=ttree)
+    ns = oracle.normals_knn(oracle.xyz4(src), 20, threads=4)
+    g = capi.Gicp(ctx, capi.default_params(corr_dist=1.0e7))
+    g.set_source(capi.make_pointf(src, ns))
+    g.set_target(capi.make_pointf(tgt, nt))
+    for shift in [(0.7, -0.4, 0.2), (35.0, 5.0, -3.0), (-900.0, 1400.0, 60.0), (2.0e5, -1.0e5, 3.0e4), (0.0, 0.0, 0.0)]:
+        T16 = oracle.apply_state(np.array([shift[0], shift[1], shift[2], 0.01, -0.02, 0.3]))
+        idx, _ = g.debug_sweep(T16, src.shape[0])
+        q = oracle.transform(oracle.xyz4(src), T16)
+        io, do = ttree.nn1(q, threads=4)
+        io = np.where(do.astype(np.float64) < 1.0e14, io, -1)
+        assert (idx == io).all(), (shift, int((idx != io).sum()))
+
+
 def test_voxel_grid_bit_exact(ctx, capi, oracle):
     pts = synth.scan(rings=32, azimuths=900, scale=2.0, seed=8)
     rng = np.random.default_rng(9)
