@@ -113,7 +113,15 @@ def main():
     ap.add_argument("--cost-mode", type=int, default=1, help="lh_gicp_params.cost_mode (1 = moments, 0 = per-evaluation passes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--single-latency", action="store_true", help="also time one-pair-at-a-time lh_gicp_align")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the measured configuration) or gloo (functional check)")
+    ap.add_argument("--same-gpu", action="store_true",
+                    help="functional check of the N > 1 code path on a 1-GPU box: every rank uses cuda:0 (needs --dist-backend gloo); "
+                         "the printed rate is meaningless")
     args = ap.parse_args()
+
+    # safety net: a rank that stops making progress dumps every thread's Python stack and exits instead of hanging the box
+    import faulthandler
+    faulthandler.dump_traceback_later(float(os.environ.get("LH_BENCH_WATCHDOG_S", "1500")), exit=True)
 
     import torch
     import torch.distributed as dist
@@ -123,10 +131,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if args.same_gpu:
+        assert args.dist_backend == "gloo", "--same-gpu needs --dist-backend gloo (RCCL cannot put two ranks on one device)"
+        local_rank = 0
     torch.cuda.set_device(local_rank)
+    ddev = "cuda" if args.dist_backend == "nccl" else None   # where the tiny exchange tensors live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend="gloo")
     assert world == args.gpus or world == 1, (world, args.gpus)
 
     ctx = capi.Context(local_rank)
@@ -136,12 +151,12 @@ def main():
     S, T, host = make_pairs(ctx, args.pairs, rank, args.rings, args.azimuths, args.scale)
     n_pts = len(S[0])
 
-    def step(in_flight=None):
+    def step(in_flight=None, exchange=True):
         for t in T:
             t.drop_index()  # align() rebuilds the target index every scan, like pcl::Registration::initCompute
         out = capi.align_batch(ctx, P, S, T, max_in_flight=in_flight or args.in_flight)
-        if world > 1:  # result gather over RCCL/xGMI: 16 floats per pair; no data-path collective
-            ldist.gather_poses(np.stack([o["T"] for o in out]), world, device="cuda")
+        if world > 1 and exchange:  # result gather over RCCL/xGMI: 16 floats per pair; no data-path collective
+            ldist.gather_poses(np.stack([o["T"] for o in out]), world, device=ddev)
         return out
 
     def barrier():
@@ -159,7 +174,7 @@ def main():
         out = step()
     barrier()
     elapsed = time.perf_counter() - t0
-    elapsed = ldist.max_over_ranks(elapsed, world, device="cuda")
+    elapsed = ldist.max_over_ranks(elapsed, world, device=ddev)
     total_pairs = args.pairs * args.steps * world
     value = total_pairs / elapsed
     ok = all(o["status"] == 0 for o in out)
@@ -181,7 +196,7 @@ def main():
         ctx.profile(True)
         ctx.profile_reset()
         for _ in range(max(1, min(args.steps, 2))):
-            step(prof_in_flight)
+            step(prof_in_flight, exchange=False)  # rank 0 only: no collective may be called here
         stats = ctx.profile_get()
         ctx.profile(False)
         dom = max(stats.items(), key=lambda kv: kv[1]["ms"])
