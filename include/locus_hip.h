@@ -100,6 +100,9 @@ typedef struct {
 /* ---- context -------------------------------------------------------------------------------- */
 int lh_abi_version(void);
 const char* lh_status_string(lh_status s);
+/* One context per GPU per process is the supported configuration (the host classes share it, locus_amd/host): calls on a
+ * context are issued in order on its stream, and temporary device buffers are recycled in that order.  Two contexts on
+ * the SAME device must not have asynchronous work in flight at the same time (call lh_synchronize between them). */
 lh_status lh_create(lh_ctx** out, int device_id);
 void lh_destroy(lh_ctx* ctx);
 lh_status lh_synchronize(lh_ctx* ctx);
