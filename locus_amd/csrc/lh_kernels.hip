@@ -347,9 +347,13 @@ __device__ __forceinline__ void sweep_point(const PairDesc& d, const SweepJob& j
   Nn1CertCollector col{INFINITY, 0x7fffffff, INFINITY};
   int w = gld(d.prev_nn + i);
   bool need_search = true;
+  float4 t = make_float4(0.f, 0.f, 0.f, 0.f), tn = make_float4(0.f, 0.f, 0.f, 0.f);
   if (w >= 0) {
     // warm start: last sweep's neighbour is a valid candidate => tight initial bound, still exact
-    float4 t = gld(d.tgt_xyz + w);
+    t = gld(d.tgt_xyz + w);
+    // its normal is fetched in the same round: when the certificate holds (every late sweep) the neighbour is w and the
+    // normal would otherwise be a third dependent memory level; after a walk both are re-read, so neither stays live across it
+    if (d.tgt_nrm) tn = gld(d.tgt_nrm + w);
     col.bd = d2f(qx, qy, qz, t.x, t.y, t.z);
     col.bi = w;
     // certificate from the last full search at query position cq: every other target point was at squared distance
@@ -370,6 +374,10 @@ __device__ __forceinline__ void sweep_point(const PairDesc& d, const SweepJob& j
   if (d.stats) atomicAdd(&d.stats[1], 1ull);
   int j = (col.bi == 0x7fffffff) ? -1 : col.bi;
   if (j != w) gst(d.prev_nn + i, j);
+  if (need_search && j >= 0) {
+    t = gld(d.tgt_xyz + j);
+    if (d.tgt_nrm) tn = gld(d.tgt_nrm + j);
+  }
   o.j = j;
   o.matched = j >= 0 && (double)col.bd < d.corr_dist2;  // gicp.hpp:483
   if (o.matched) {
@@ -389,8 +397,7 @@ __device__ __forceinline__ void sweep_point(const PairDesc& d, const SweepJob& j
       for (int k = 0; k < 6; k++) s6[k] = gld(d.tgt_cov6 + (size_t)k * d.m_pad + j);
       sym6_to_mat9(s6, C2);
     } else {
-      float4 nn = gld(d.tgt_nrm + j);
-      cov_from_normal(nn.x, nn.y, nn.z, d.gicp_eps, C2);
+      cov_from_normal(tn.x, tn.y, tn.z, d.gicp_eps, C2);
     }
     // transform_R = double(transformation_) * double(guess), top-left 3x3 (gicp.hpp:450-460); the k = 3 term is T(i,3)*0
     double R[9];
@@ -408,7 +415,7 @@ __device__ __forceinline__ void sweep_point(const PairDesc& d, const SweepJob& j
                            (double)job.T[r * 4 + 2] * d.guess3[2 * 3 + cc]) + (double)job.T[r * 4 + 3] * 0.0;
     }
     mahalanobis(R, C1, C2, o.M);  // gicp.hpp:488-493
-    o.tgt = gld(d.tgt_xyz + j);
+    o.tgt = t;
   }
 }
 
