@@ -10,8 +10,25 @@ from locus_amd import capi, synth
 ctx = capi.Context(0)
 P = capi.default_params(max_iterations=20, max_inner_iterations=20, corr_dist=1.0, transformation_epsilon=1e-12, rotation_epsilon=1e-12)
 S, T = [], []
+
+
+def morton_order(pts, bits=10):
+    """permutation that sorts points along a 3-D Z-order curve (LH_PROBE_SORT=1: what would a spatially sorted SOURCE buy?)"""
+    lo, hi = pts.min(0), pts.max(0)
+    g = np.clip(((pts - lo) / max(float((hi - lo).max()), 1e-9) * ((1 << bits) - 1)).astype(np.uint64), 0, (1 << bits) - 1)
+    key = np.zeros(len(pts), np.uint64)
+    for b in range(bits):
+        for a in range(3):
+            key |= ((g[:, a] >> np.uint64(b)) & np.uint64(1)) << np.uint64(3 * b + a)
+    return np.argsort(key, kind="stable")
+
+
 for p in range(32):
     src, tgt, _ = synth.scan_pair(n_rings=64, n_az=1563, scale=2.0, noise=0.02, seed=10 + 2 * p)
+    if os.environ.get("LH_PROBE_SORT") == "1":
+        src = src[morton_order(src)]
+    elif os.environ.get("LH_PROBE_SORT") == "2":
+        src = src[np.random.default_rng(p).permutation(len(src))]
     cs, ct = capi.Cloud(ctx, src), capi.Cloud(ctx, tgt)
     cs.normals_knn(20); ct.normals_knn(20); ct.drop_index()
     S.append(cs); T.append(ct)
