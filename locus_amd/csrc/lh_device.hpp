@@ -10,13 +10,14 @@
 //     space; equal-count runs of the curve (the previous layout) overlap their neighbours at every level and cost 2-3x
 //     the node visits per query (measured: 17.8 -> 10.2 dependent steps warm, 31.8 -> 10.4 cold)
 //   * a binary radix tree over the leaves' keys (Karras 2012: one thread per internal node, no scans) gives the
-//     hierarchy; every internal node adopts its GRANDCHILDREN, so the walk sees 4-ary nodes (NodeX, 128 B = one cache
-//     line: the float AABBs of <= 4 children as SoA + their references) and half the dependent steps of the binary tree
+//     hierarchy; every internal node adopts its GRANDCHILDREN, so the walk sees 4-ary nodes (NodeX, 64 B: the 16-bit
+//     fixed-point AABBs of <= 4 children + their references) and half the dependent steps of the binary tree
 //   * sorted point = float4(x, y, z, bitcast(original index)) so one 16-B load yields position + id
-// Exactness: distances are float ((dx*dx+dy*dy)+dz*dz), no FMA contraction (the TU is compiled with
-// -ffp-contract=off).  The box distance uses the same operation order, and float rounding is monotone, so
-// box_d2 <= d2(any point inside) holds exactly; pruning on box_d2 > best is therefore exact, and ties are
-// resolved to the lowest original index -- the same rule as the CPU oracle, so indices match bit-for-bit.
+// Exactness: point distances are float ((dx*dx+dy*dy)+dz*dz), no FMA contraction (the TU is compiled with
+// -ffp-contract=off).  The box distance is a LOWER bound of that float value for every point inside (boxes are rounded
+// outwards by a whole grid step, which dominates every rounding error of the bound -- see quant_lo / boxd2_q), so pruning
+// on box_d2 > best is exact, and ties are resolved to the lowest original index -- the same rule as the CPU oracle, so
+// indices match bit-for-bit.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
