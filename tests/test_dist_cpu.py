@@ -109,3 +109,26 @@ def test_source_shard_sum_hook_over_gloo():
     for rank, out in res:
         for n, got in zip((74, 14, 2), out):
             assert np.array_equal(got, np.array([3.0 * (i + 0.5) for i in range(n)]))  # (1 + 2) * (i + 0.5), exact
+
+
+def test_bench_rank0_only_block_calls_no_collective():
+    """bench.py's roofline / extra legs run on rank 0 only while the other ranks already wait at the final barrier: a
+    collective inside that block (it once reached the pose all_gather through step()) deadlocks every N > 1 run."""
+    import ast
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")).read()
+    tree = ast.parse(src)
+    main = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "main")
+    blocks = [n for n in ast.walk(main) if isinstance(n, ast.If) and isinstance(n.test, ast.Compare)
+              and isinstance(n.test.left, ast.Name) and n.test.left.id == "rank" and isinstance(n.test.ops[0], ast.Eq)]
+    assert blocks, "rank == 0 block not found"
+    big = max(blocks, key=lambda n: n.end_lineno - n.lineno)
+    assert big.end_lineno - big.lineno > 30  # the roofline leg, not the final print
+    for call in [n for n in ast.walk(big) if isinstance(n, ast.Call)]:
+        f = call.func
+        if isinstance(f, ast.Attribute) and isinstance(f.value, ast.Name):
+            assert f.value.id not in ("dist", "ldist"), "collective %s.%s inside the rank-0-only block (line %d)" % (f.value.id, f.attr, call.lineno)
+        if isinstance(f, ast.Name) and f.id in ("step", "barrier"):
+            assert f.id != "barrier", "barrier() inside the rank-0-only block"
+            kw = {k.arg: k.value for k in call.keywords}
+            assert "exchange" in kw and isinstance(kw["exchange"], ast.Constant) and kw["exchange"].value is False, \
+                "step() inside the rank-0-only block must pass exchange=False (line %d)" % call.lineno
