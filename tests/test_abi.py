@@ -100,6 +100,18 @@ def test_traversal_device_functions_on_host():
     assert "TRAVERSAL_CHECK_OK" in out.stdout
 
 
+def test_ndt_host_algebra_matches_oracle(oracle):
+    """lh_ndt_host.hpp (pose <-> matrix, the 6x6 SVD solve of the Newton step) against the oracle's restatement of the same
+    pclomp pieces; the `oracle` fixture makes sure oracle/liblocus_oracle.so is built"""
+    exe = "/tmp/lh_ndt_host_check"
+    src = os.path.join(ROOT, "tests", "host_emu", "ndt_host_check.cpp")
+    odir = os.path.join(ROOT, "oracle")
+    subprocess.check_call(["hipcc", "-O2", "-std=c++17", "-ffp-contract=off", "--offload-arch=gfx950", src, "-L", odir, "-llocus_oracle",
+                           "-Wl,-rpath," + odir, "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and "NDT_HOST_CHECK_OK" in out.stdout, out.stdout + out.stderr
+
+
 def test_adaptive_voxelization_controller_on_host():
     """Locus::ApplyAdaptiveInputVoxelization (Locus.cc:780-810) restated in locus_amd/host/AdaptiveVoxelization.hpp: plain C++"""
     exe = "/tmp/lh_controller_check"
