@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstring>
 #include <random>
+#include <vector>
 
 #include "../../locus_amd/csrc/lh_ndt_host.hpp"
 extern "C" {
@@ -59,6 +60,54 @@ int main() {
       }
       if (!(res <= 1e-6 * (1.0 + nb))) { bad++; if (bad < 5) std::printf("svd solve residual %.3e at %d\n", res, it); }
     }
+  }
+  // the Newton / More-Thuente control flow: the product's ndt_compute_transformation driven by the ORACLE's derivative passes
+  // (standing in for the device kernels) must retrace lo_ndt_align step for step -- same transform, iteration and evaluation counts
+  for (int scene = 0; scene < 3; scene++) {
+    const int n = 6000;
+    std::vector<float> tgt(4 * n), src(4 * n);
+    std::uniform_real_distribution<float> u(-1.f, 1.f);
+    for (int i = 0; i < n; i++) {  // three walls and a floor of a 12 x 8 x 3 m room, 1 cm noise
+      float a = u(rng), b = u(rng), x, y, z;
+      switch (i % 4) {
+        case 0: x = 6.f * a; y = 4.f * b; z = 0.f; break;
+        case 1: x = 6.f; y = 4.f * a; z = 1.5f + 1.5f * b; break;
+        case 2: x = 6.f * a; y = 4.f; z = 1.5f + 1.5f * b; break;
+        default: x = -6.f; y = 4.f * a; z = 1.5f + 1.5f * b; break;
+      }
+      tgt[4 * i] = x + 0.01f * (float)g(rng); tgt[4 * i + 1] = y + 0.01f * (float)g(rng); tgt[4 * i + 2] = z + 0.01f * (float)g(rng); tgt[4 * i + 3] = 1.f;
+    }
+    const double truth[6] = {0.15 + 0.1 * scene, -0.1, 0.03, 0.004, -0.006, 0.02 + 0.01 * scene};
+    float Tt[16];
+    lo_ndt_pose_to_matrix(truth, Tt);
+    lo_transform(tgt.data(), nullptr, n, Tt, src.data(), nullptr);  // source = moved target (then NDT must undo the motion)
+    lo_ndt_params P;
+    lo_ndt_default_params(&P);
+    P.resolution = 1.0f;
+    P.transformation_epsilon = 1e-3;
+    P.max_iterations = 20;
+    float G[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    if (scene == 2) { const double gp[6] = {-0.1, 0.05, 0.0, 0.0, 0.0, -0.01}; lo_ndt_pose_to_matrix(gp, G); }
+    lo_ndt_result ro;
+    lo_ndt_align(src.data(), n, tgt.data(), n, &P, G, &ro);
+    lo_ndt_grid* grid = lo_ndt_grid_build(tgt.data(), n, &P);
+    std::vector<float> trans(4 * n);
+    lh::NdtEval eval = [&](const double* p, const float* T16, int want_h, int hessian_only, double* score, double* grad, double* hess) {
+      lo_transform(src.data(), nullptr, n, T16, trans.data(), nullptr);
+      if (hessian_only) lo_ndt_hessian(grid, &P, src.data(), trans.data(), n, p, hess);
+      else *score = lo_ndt_derivatives(grid, &P, src.data(), trans.data(), n, p, grad, hess, want_h);
+      return true;
+    };
+    lh::NdtOutcome po;
+    bool ident = scene != 2;
+    if (!lh::ndt_compute_transformation(eval, G, ident, P.step_size, P.transformation_epsilon, P.max_iterations, &po)) { bad++; std::printf("compute_transformation failed\n"); }
+    if (std::memcmp(po.T, ro.T, sizeof(po.T)) != 0 || po.iterations != ro.iterations || po.evaluations != ro.evaluations || po.converged != ro.converged) {
+      bad++;
+      std::printf("scene %d: control flow differs: iterations %d/%d evaluations %d/%d converged %d/%d\n", scene, po.iterations, ro.iterations,
+                  po.evaluations, ro.evaluations, po.converged, ro.converged);
+    }
+    if (ro.iterations < 1) { bad++; std::printf("scene %d: the oracle did not iterate\n", scene); }
+    lo_ndt_grid_free(grid);
   }
   std::printf(bad ? "NDT_HOST_CHECK_FAILED (%d)\n" : "NDT_HOST_CHECK_OK\n", bad);
   return bad ? 1 : 0;
