@@ -17,6 +17,7 @@
 #include <mutex>
 #include <unordered_map>
 #include <thread>
+#include <cfloat>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -174,6 +175,21 @@ struct HostPool {
   }
 };
 
+// per-pair device workspace (owned by a registration object, or -- batch mode -- by a scheduler slot of the context)
+struct lh_ctx;
+struct Workspace {
+  int cap = 0;
+  float4* corr = nullptr;
+  double* maha6 = nullptr;
+  int32_t* prev_nn = nullptr;
+  float4* cert = nullptr;     // NN certificates (see Nn1CertCollector)
+  unsigned long long* stats = nullptr;  // 2 counters
+  float4* out_xyz = nullptr;  // guess * input when guess != I
+  int n_pad = 0;
+  lh_status ensure(lh_ctx* c, int n);
+  void release();
+};
+
 struct lh_ctx {
   int device = 0;
   HostPool* pool = nullptr;
@@ -202,6 +218,9 @@ struct lh_ctx {
   size_t partials_per_slot = 0;    // doubles
   double* mom_partials_dev = nullptr;  // [n_slots][mom_stride] per-block moment partials (device)
   int mom_stride = 0;
+  // batch mode: one workspace per scheduler slot.  They live here (not in a thread-local) so that they are tied to this
+  // context's device, reused by every thread that drives the context, and released by lh_destroy.
+  std::vector<Workspace> slot_ws;
   // misc pinned scratch for small downloads
   double* small_host = nullptr;
   size_t small_host_doubles = 0;
@@ -294,6 +313,25 @@ static void cloud_free(lh_cloud* c) {
   (void)lhFree(c->sorted); (void)lhFree(c->node_buf); (void)lhFree(c->cov6); (void)lhFree(c->pos);
   delete c;
 }
+
+// Scope guard of one entry point: temporary device buffers and a cloud under construction are handed back on EVERY exit
+// path (the HIPCHK early returns included).  lhFree only parks a block, and the pool hands it out again in stream order, so
+// freeing while the call's own kernels are still queued is safe.
+struct DevGuard {
+  std::vector<void*> bufs;
+  lh_cloud* cloud = nullptr;
+  template <class T>
+  hipError_t alloc(T** p, size_t bytes) {
+    hipError_t e = lhMalloc(p, bytes);
+    if (e == hipSuccess) bufs.push_back(*p);
+    return e;
+  }
+  lh_cloud* keep_cloud() { lh_cloud* c = cloud; cloud = nullptr; return c; }
+  ~DevGuard() {
+    for (void* b : bufs) (void)lhFree(b);
+    if (cloud) cloud_free(cloud);
+  }
+};
 
 static lh_status ctx_ensure_scratch(lh_ctx* c, int n) {
   if (n <= c->scratch_n) return LH_OK;
@@ -428,42 +466,34 @@ static lh_status cloud_ensure_cov(lh_cloud* c, int k, double eps) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// per-pair device workspace
-struct Workspace {
-  int cap = 0;
-  float4* corr = nullptr;
-  double* maha6 = nullptr;
-  int32_t* prev_nn = nullptr;
-  float4* cert = nullptr;     // NN certificates (see Nn1CertCollector)
-  unsigned long long* stats = nullptr;  // 2 counters
-  float4* out_xyz = nullptr;  // guess * input when guess != I
-  int n_pad = 0;
-  lh_status ensure(lh_ctx* c, int n) {
-    if (n <= cap) return LH_OK;
-    (void)hipStreamSynchronize(c->stream);
-    (void)lhFree(corr); (void)lhFree(maha6); (void)lhFree(prev_nn); (void)lhFree(out_xyz); (void)lhFree(cert);
-    int ncap = round_up(n, 256);
-    HIPCHK(hipMalloc(&corr, sizeof(float4) * (size_t)ncap));
-    HIPCHK(hipMalloc(&maha6, sizeof(double) * 6 * (size_t)ncap));
-    HIPCHK(hipMalloc(&prev_nn, sizeof(int32_t) * (size_t)ncap));
-    HIPCHK(hipMalloc(&out_xyz, sizeof(float4) * (size_t)ncap));
-    HIPCHK(hipMalloc(&cert, sizeof(float4) * (size_t)ncap));
-    if (!stats) { HIPCHK(hipMalloc(&stats, 16)); HIPCHK(hipMemset(stats, 0, 16)); }
-    cap = ncap;
-    n_pad = ncap;
-    return LH_OK;
-  }
-  void release() {
-    (void)lhFree(corr); (void)lhFree(maha6); (void)lhFree(prev_nn); (void)lhFree(out_xyz); (void)lhFree(cert);
-    corr = nullptr; maha6 = nullptr; prev_nn = nullptr; out_xyz = nullptr; cert = nullptr; cap = 0;
-  }
-};
+lh_status Workspace::ensure(lh_ctx* c, int n) {
+  if (n <= cap) return LH_OK;
+  (void)hipStreamSynchronize(c->stream);  // a slot may belong to either scheduler group: nothing may still use the old buffers
+  if (c->stream2) (void)hipStreamSynchronize(c->stream2);
+  (void)lhFree(corr); (void)lhFree(maha6); (void)lhFree(prev_nn); (void)lhFree(out_xyz); (void)lhFree(cert);
+  corr = nullptr; maha6 = nullptr; prev_nn = nullptr; out_xyz = nullptr; cert = nullptr; cap = 0;
+  int ncap = round_up(n, 256);
+  HIPCHK(hipMalloc(&corr, sizeof(float4) * (size_t)ncap));
+  HIPCHK(hipMalloc(&maha6, sizeof(double) * 6 * (size_t)ncap));
+  HIPCHK(hipMalloc(&prev_nn, sizeof(int32_t) * (size_t)ncap));
+  HIPCHK(hipMalloc(&out_xyz, sizeof(float4) * (size_t)ncap));
+  HIPCHK(hipMalloc(&cert, sizeof(float4) * (size_t)ncap));
+  if (!stats) { HIPCHK(hipMalloc(&stats, 16)); HIPCHK(hipMemset(stats, 0, 16)); }
+  cap = ncap;
+  n_pad = ncap;
+  return LH_OK;
+}
+void Workspace::release() {
+  (void)lhFree(corr); (void)lhFree(maha6); (void)lhFree(prev_nn); (void)lhFree(out_xyz); (void)lhFree(cert); (void)lhFree(stats);
+  corr = nullptr; maha6 = nullptr; prev_nn = nullptr; out_xyz = nullptr; cert = nullptr; stats = nullptr; cap = 0;
+}
 
 static lh_status ctx_ensure_slots(lh_ctx* c, int n_slots, int max_n) {
   size_t per_slot = std::max<size_t>((size_t)cost_blocks(max_n) * COST_NSUM, (size_t)FINAL_CHUNKS * MOM_ROW);
   int mom_stride = ((max_n + 255) / 256) * 4 * MOM_ROW;  // one partial row per wave of every 256-point workgroup of the fused sweep
   if (n_slots <= c->n_slots && per_slot <= c->partials_per_slot && mom_stride <= c->mom_stride) return LH_OK;
   (void)hipStreamSynchronize(c->stream);
+  if (c->stream2) (void)hipStreamSynchronize(c->stream2);
   n_slots = std::max(n_slots, c->n_slots);
   per_slot = std::max(per_slot, c->partials_per_slot);
   mom_stride = std::max(mom_stride, c->mom_stride);
@@ -895,11 +925,18 @@ static lh_status run_tasks(lh_ctx* c, std::vector<Task*>& tasks, int in_flight, 
       if (!groups[gi].active.empty() || groups[gi].inflight) return true;
     return false;
   };
+  // error exit: the other scheduler group may still have kernels queued that read or write pooled device buffers (index
+  // build, sweeps); nothing may be handed back to the pool, or to the caller, before both streams have drained
+  auto fail = [&](lh_status st) {
+    (void)hipStreamSynchronize(c->stream);
+    if (c->stream2) (void)hipStreamSynchronize(c->stream2);
+    return st;
+  };
   while (next < tasks.size() || busy()) {
     for (int gi = 0; gi < G; gi++) {
       Group& g = groups[gi];
       lh_status st = group_collect(c, g);  // waits for THIS group's kernels; the other group's are still queued/running
-      if (st) return st;
+      if (st) return fail(st);
       // admit new pairs: the NN indexes of all newly admitted targets are built together (batched launches + one sort)
       if (next < tasks.size() && !g.free_slots.empty()) {
         std::vector<lh_cloud*> to_build;
@@ -911,7 +948,7 @@ static lh_status run_tasks(lh_ctx* c, std::vector<Task*>& tasks, int in_flight, 
         }
         if (!to_build.empty()) {
           st = build_indices(c, to_build.data(), (int)to_build.size(), g.stream);
-          if (st) return st;
+          if (st) return fail(st);
         }
         while (next < tasks.size() && !g.free_slots.empty()) {
           Task* t = tasks[next++];
@@ -934,7 +971,7 @@ static lh_status run_tasks(lh_ctx* c, std::vector<Task*>& tasks, int in_flight, 
         }
       }
       st = group_launch(c, g);
-      if (st) return st;
+      if (st) return fail(st);
     }
   }
   return err;
@@ -1052,8 +1089,11 @@ void lh_destroy(lh_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
+  if (c->stream2) (void)hipStreamSynchronize(c->stream2);
   delete c->pool;
   c->pool = nullptr;
+  for (auto& w : c->slot_ws) w.release();
+  c->slot_ws.clear();
   c->prof_flush();
   for (auto e : c->ev_pool) (void)hipEventDestroy(e);
   (void)lhFree(c->keys0); (void)lhFree(c->keys1); (void)lhFree(c->vals0); (void)lhFree(c->vals1);
@@ -1133,8 +1173,10 @@ lh_status lh_cloud_transform(const lh_cloud* in, const float T[16], int with_nor
   if (!in || !T || !out) return LH_EINVAL;
   lh_ctx* c = in->ctx;
   HIPCHK(hipSetDevice(c->device));
+  DevGuard guard;
   lh_cloud* o = (*out == in) ? const_cast<lh_cloud*>(in) : new lh_cloud();
   if (o != in) {
+    guard.cloud = o;  // released again on any failure below
     o->ctx = c; o->n = in->n; o->n_pad = in->n_pad;
     HIPCHK(lhMalloc(&o->xyz, sizeof(float4) * (size_t)o->n_pad));
     if (in->nrm) HIPCHK(lhMalloc(&o->nrm, sizeof(float4) * (size_t)o->n_pad));
@@ -1151,6 +1193,7 @@ lh_status lh_cloud_transform(const lh_cloud* in, const float T[16], int with_nor
   HIPCHK(hipGetLastError());
   o->has_index = false;
   o->cov_k = 0;
+  (void)guard.keep_cloud();
   *out = o;
   return LH_OK;
 }
@@ -1326,29 +1369,30 @@ static lh_status nn1_device(lh_ctx* c, lh_cloud* target, const float4* q, int nq
   int32_t* d_idx = nullptr;
   float* d_d2 = nullptr;
   double* d_part = nullptr;
-  HIPCHK(lhMalloc(&d_idx, sizeof(int32_t) * (size_t)nq));
-  HIPCHK(lhMalloc(&d_d2, sizeof(float) * (size_t)nq));
+  DevGuard guard;
+  HIPCHK(guard.alloc(&d_idx, sizeof(int32_t) * (size_t)nq));
+  HIPCHK(guard.alloc(&d_d2, sizeof(float) * (size_t)nq));
   float T12[12];
   if (T16) fill_T12(T16, T12);
   { ProfScope p(c, "nn1", 24.0 * nq); launch_nn1(q, nq, T16 ? T12 : nullptr, target->view(), d_idx, d_d2, c->stream); }
   lh_status rc = LH_OK;
   if (fitness_sum) {
     int nb = sum_blocks(nq);
-    rc = ctx_ensure_small(c, (size_t)nb);
+    rc = ctx_ensure_small(c, (size_t)nb * 2);
     if (!rc) {
-      HIPCHK(lhMalloc(&d_part, sizeof(double) * (size_t)nb));
-      launch_sum_f32(d_d2, nq, d_part, c->stream);
-      HIPCHK(hipMemcpyAsync(c->small_host, d_part, sizeof(double) * nb, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(guard.alloc(&d_part, sizeof(double) * 2 * (size_t)nb));
+      launch_sum_f32(d_d2, d_idx, nq, d_part, c->stream);
+      HIPCHK(hipMemcpyAsync(c->small_host, d_part, sizeof(double) * 2 * nb, hipMemcpyDeviceToHost, c->stream));
       HIPCHK(hipStreamSynchronize(c->stream));
-      double s = 0;
-      for (int b = 0; b < nb; b++) s += c->small_host[b];
-      *fitness_sum = s;
+      double s = 0, k = 0;
+      for (int b = 0; b < nb; b++) { s += c->small_host[2 * b]; k += c->small_host[2 * b + 1]; }
+      fitness_sum[0] = s;   // sum of d2 over the queries that found a neighbour ...
+      fitness_sum[1] = k;   // ... and how many did (a non-finite query point finds none)
     }
   }
   if (idx) HIPCHK(hipMemcpyAsync(idx, d_idx, sizeof(int32_t) * (size_t)nq, hipMemcpyDeviceToHost, c->stream));
   if (d2) HIPCHK(hipMemcpyAsync(d2, d_d2, sizeof(float) * (size_t)nq, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
-  (void)lhFree(d_idx); (void)lhFree(d_d2); (void)lhFree(d_part);
   return rc;
 }
 
@@ -1362,12 +1406,12 @@ lh_status lh_set_allreduce(lh_ctx* ctx, lh_allreduce_fn fn, void* user) {
 lh_status lh_gicp_fitness(lh_gicp* g, double* fitness) {
   if (!g || !fitness || !g->src || !g->tgt || !g->have_result) return LH_EINVAL;
   HIPCHK(hipSetDevice(g->ctx->device));
-  double s = 0;
-  lh_status st = nn1_device(g->ctx, g->tgt, g->src->xyz, g->src->n, g->last_T, nullptr, nullptr, &s);
+  double sn[2] = {0.0, 0.0};
+  lh_status st = nn1_device(g->ctx, g->tgt, g->src->xyz, g->src->n, g->last_T, nullptr, nullptr, sn);
   if (st) return st;
-  double sn[2] = {s, (double)g->src->n};
   if (g->ctx->reduce_fn && g->ctx->reduce_fn(sn, 2, g->ctx->reduce_user) != 0) return LH_EDEVICE;
-  *fitness = sn[0] / sn[1];  // every query finds a neighbour (max_range = DBL_MAX)
+  // mean over the queries that found a neighbour (every finite query does: max_range = DBL_MAX); none -> DBL_MAX like PCL
+  *fitness = sn[1] > 0 ? sn[0] / sn[1] : DBL_MAX;
   return LH_OK;
 }
 
@@ -1419,8 +1463,7 @@ lh_status lh_gicp_align_batch(lh_ctx* ctx, const lh_gicp_params* p, int n_pairs,
   }
   lh_status st = ctx_ensure_slots(ctx, in_flight, max_n);
   if (st) return st;
-  static thread_local std::vector<Workspace> ws_pool;  // grow-only, reused across calls
-  if ((int)ws_pool.size() < in_flight) ws_pool.resize(in_flight);
+  if ((int)ctx->slot_ws.size() < in_flight) ctx->slot_ws.resize(in_flight);  // grow-only, reused across calls, freed by lh_destroy
   std::vector<Task> tasks(n_pairs);
   std::vector<Task*> ptrs(n_pairs);
   for (int i = 0; i < n_pairs; i++) {
@@ -1429,7 +1472,7 @@ lh_status lh_gicp_align_batch(lh_ctx* ctx, const lh_gicp_params* p, int n_pairs,
     memcpy(t.guess, guesses ? guesses + 16 * (size_t)i : I16, sizeof(I16));
     ptrs[i] = &t;
   }
-  st = run_tasks(ctx, ptrs, in_flight, /*rebuild_index=*/true, &ws_pool);
+  st = run_tasks(ctx, ptrs, in_flight, /*rebuild_index=*/true, &ctx->slot_ws);
   for (int i = 0; i < n_pairs; i++) out[i] = tasks[i].result;
   return st;
 }
@@ -1612,9 +1655,10 @@ lh_status lh_p2plane_information(lh_ctx* c, const lh_cloud* query, const lh_clou
   double* d_part = nullptr;
   float4* d_qn = nullptr;
   int64_t* d_corr = nullptr;
-  HIPCHK(lhMalloc(&d_part, sizeof(double) * (size_t)nb * 21));
-  HIPCHK(lhMalloc(&d_qn, sizeof(float4) * (size_t)n));
-  HIPCHK(lhMalloc(&d_corr, sizeof(int64_t) * (size_t)n));
+  DevGuard guard;
+  HIPCHK(guard.alloc(&d_part, sizeof(double) * (size_t)nb * 21));
+  HIPCHK(guard.alloc(&d_qn, sizeof(float4) * (size_t)n));
+  HIPCHK(guard.alloc(&d_corr, sizeof(int64_t) * (size_t)n));
   HIPCHK(hipMemcpyAsync(d_corr, corr, sizeof(int64_t) * (size_t)n, hipMemcpyHostToDevice, c->stream));
   // normalizePCloud (utils.cc:106-128): centroid, factor = N / sum |p - c|, q' = factor*(p - c).
   // The reference accumulates both sums sequentially in float; here the sums are double with a fixed tree
@@ -1643,7 +1687,6 @@ lh_status lh_p2plane_information(lh_ctx* c, const lh_cloud* query, const lh_clou
   int t = 0;
   for (int r = 0; r < 6; r++)
     for (int cc = r; cc < 6; cc++) { Ap[r * 6 + cc] = U[t]; Ap[cc * 6 + r] = U[t]; t++; }
-  (void)lhFree(d_part); (void)lhFree(d_qn); (void)lhFree(d_corr);
   return LH_OK;
 }
 
@@ -2493,6 +2536,13 @@ __global__ void __launch_bounds__(256) k_gather_cloud(const float4* __restrict__
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   int j = idx[i];
+  if (j < 0) {  // no neighbour (a non-finite query point: every comparison of the search fails): a NaN point, never an out-of-bounds read
+    const float qn = __int_as_float(0x7fc00000);
+    oxyz[i] = make_float4(qn, qn, qn, 1.0f);
+    if (nrm && onrm) onrm[i] = make_float4(qn, qn, qn, qn);
+    if (inten && ointen) ointen[i] = qn;
+    return;
+  }
   oxyz[i] = xyz[j];
   if (nrm && onrm) onrm[i] = nrm[j];
   if (inten && ointen) ointen[i] = inten[j];
@@ -2505,10 +2555,12 @@ lh_status lh_cloud_nearest_neighbors(lh_cloud* map, const lh_cloud* query, lh_cl
   int n = query->n;
   int32_t* d_idx = nullptr;
   float* d_d2 = nullptr;
-  HIPCHK(lhMalloc(&d_idx, sizeof(int32_t) * (size_t)n));
-  HIPCHK(lhMalloc(&d_d2, sizeof(float) * (size_t)n));
+  DevGuard guard;
+  HIPCHK(guard.alloc(&d_idx, sizeof(int32_t) * (size_t)n));
+  HIPCHK(guard.alloc(&d_d2, sizeof(float) * (size_t)n));
   { ProfScope p(c, "nn1", 24.0 * n); launch_nn1(query->xyz, n, nullptr, map->view(), d_idx, d_d2, c->stream); }
   lh_cloud* o = new lh_cloud();
+  guard.cloud = o;
   o->ctx = c; o->n = n; o->n_pad = round_up(n, 256);
   HIPCHK(lhMalloc(&o->xyz, sizeof(float4) * (size_t)o->n_pad));
   if (map->nrm) HIPCHK(lhMalloc(&o->nrm, sizeof(float4) * (size_t)o->n_pad));
@@ -2517,8 +2569,7 @@ lh_status lh_cloud_nearest_neighbors(lh_cloud* map, const lh_cloud* query, lh_cl
                      o->intensity);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(c->stream));
-  (void)lhFree(d_idx); (void)lhFree(d_d2);
-  *out = o;
+  *out = guard.keep_cloud();
   return LH_OK;
 }
 

@@ -900,24 +900,25 @@ void launch_nn1_stats(const float4* q, int nq, const float* T12p, TreeView tree,
   hipLaunchKernelGGL(k_nn1_stats, dim3((nq + 255) / 256), dim3(256), stack_lds_bytes(0, 256), s, q, nq, T, T12p ? 1 : 0, tree, tgt_xyz, cand, stats);
 }
 
-// double sum of floats: 1024 values per block, fixed tree
-__global__ void __launch_bounds__(256) k_sum_f32(const float* __restrict__ v, int n, double* __restrict__ partials) {
+// double sum of the float d2 of the queries that found a neighbour (idx >= 0) + their number: 1024 values per block, fixed
+// tree.  partials[2 b] = sum, partials[2 b + 1] = count (getFitnessScore only averages over the matched queries)
+__global__ void __launch_bounds__(256) k_sum_f32(const float* __restrict__ v, const int32_t* __restrict__ idx, int n, double* __restrict__ partials) {
   int base = blockIdx.x * 1024;
-  double acc = 0.0;
+  double acc = 0.0, cnt = 0.0;
 #pragma unroll
   for (int r = 0; r < 4; r++) {
     int i = base + r * 256 + threadIdx.x;
-    if (i < n) acc += (double)v[i];
+    if (i < n && idx[i] >= 0) { acc += (double)v[i]; cnt += 1.0; }
   }
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
-  __shared__ double sm[4];
-  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+  for (int off = 32; off > 0; off >>= 1) { acc += __shfl_down(acc, off, 64); cnt += __shfl_down(cnt, off, 64); }
+  __shared__ double sm[4][2];
+  if ((threadIdx.x & 63) == 0) { sm[threadIdx.x >> 6][0] = acc; sm[threadIdx.x >> 6][1] = cnt; }
   __syncthreads();
-  if (threadIdx.x == 0) partials[blockIdx.x] = ((sm[0] + sm[1]) + sm[2]) + sm[3];
+  if (threadIdx.x < 2) partials[2 * blockIdx.x + threadIdx.x] = ((sm[0][threadIdx.x] + sm[1][threadIdx.x]) + sm[2][threadIdx.x]) + sm[3][threadIdx.x];
 }
-void launch_sum_f32(const float* v, int n, double* partials, hipStream_t s) {
-  hipLaunchKernelGGL(k_sum_f32, dim3(sum_blocks(n)), dim3(256), 0, s, v, n, partials);
+void launch_sum_f32(const float* v, const int32_t* idx, int n, double* partials, hipStream_t s) {
+  hipLaunchKernelGGL(k_sum_f32, dim3(sum_blocks(n)), dim3(256), 0, s, v, idx, n, partials);
 }
 
 // ===== K3: k-NN, covariances, normals ======================================================================

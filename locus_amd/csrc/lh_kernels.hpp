@@ -133,8 +133,8 @@ void launch_nn1(const float4* q, int nq, const float* T12, TreeView tree, int32_
 // the per-wave max (nodes+leaves), number of waves, max (nodes+leaves) of any query
 void launch_nn1_stats(const float4* q, int nq, const float* T12, TreeView tree, const float4* tgt_xyz,
                       const int32_t* cand /*nullable: warm-start candidates*/, unsigned long long* stats, hipStream_t s);
-// deterministic double sum of float d2 (fitness): partials[ceil(n/1024)]
-void launch_sum_f32(const float* v, int n, double* partials, hipStream_t s);
+// deterministic double sum of the float d2 of the queries with idx >= 0, and their number (fitness): partials[ceil(n/1024)][2]
+void launch_sum_f32(const float* v, const int32_t* idx, int n, double* partials, hipStream_t s);
 inline int sum_blocks(int n) { return (n + 1023) / 1024; }
 
 // ---- K3 ----------------------------------------------------------------------------------------------

@@ -5,11 +5,6 @@
 
 namespace locus_hip {
 
-static void Mat4dToColMajorF(const double* rowmajor16, float* out) {
-  for (int r = 0; r < 4; r++)
-    for (int c = 0; c < 4; c++) out[c * 4 + r] = (float)rowmajor16[r * 4 + c];
-}
-
 PointCloudOdometry::PointCloudOdometry(lh_ctx* ctx) : ctx_(ctx) {
   query_.reset(new PointCloudF);
   reference_.reset(new PointCloudF);
@@ -91,14 +86,14 @@ bool PointCloudOdometry::UpdateICP() {  // :249-322
     have_prior = true;
   }
   *query_trans_ = *query_;
-  if (have_prior) {  // pcl::transformPointCloud(*query_, *query_trans_, prior): xyz only, float arithmetic
-    float P[16];
-    Mat4dToColMajorF(prior, P);
+  if (have_prior) {
+    // pcl::transformPointCloud(*query_, *query_trans_, prior) with an Eigen::Matrix4d (:255, :260): xyz only; PCL promotes the
+    // float point to the matrix' scalar, evaluates the row in DOUBLE left to right and rounds once to float
     for (auto& p : query_trans_->points) {
-      float x = p.x, y = p.y, z = p.z;
-      p.x = ((P[0] * x + P[4] * y) + P[8] * z) + P[12];
-      p.y = ((P[1] * x + P[5] * y) + P[9] * z) + P[13];
-      p.z = ((P[2] * x + P[6] * y) + P[10] * z) + P[14];
+      const double x = p.x, y = p.y, z = p.z;
+      p.x = static_cast<float>(prior[0] * x + prior[1] * y + prior[2] * z + prior[3]);
+      p.y = static_cast<float>(prior[4] * x + prior[5] * y + prior[6] * z + prior[7]);
+      p.z = static_cast<float>(prior[8] * x + prior[9] * y + prior[10] * z + prior[11]);
     }
   }
   icp_->setInputSource(query_trans_);

@@ -44,6 +44,8 @@ public:
   gu::Transform3 integrated_estimate_;
 
   bool GetLastPointCloud(PointCloudF::Ptr& out) const;
+  // the source cloud the registration was given: the query moved by the sensor prior (query_trans_, PointCloudOdometry.cc:255-262)
+  PointCloudF::Ptr GetQueryTransformed() const { return query_trans_; }
 
   PointCloudF icpAlignedPointsOdometry_;  // aligned point cloud returned by ICP
 

@@ -95,6 +95,40 @@ int main() {
     EXPECT_NEAR(pco.GetIncrementalEstimate().translation.z, 0.0, 1e-12);
   }
 
+  {  // a NON-identity odometry prior (PointCloudOdometry.cc:256-275): the query is moved by the prior in double arithmetic
+     // (pcl::transformPointCloud with a Matrix4d), GICP only finds the remainder, and T * prior is the whole motion
+    PointCloudOdometry pco(ctx);
+    PointCloudOdometry::Config cfg;
+    cfg.num_threads = 2;
+    auto pc_box = GenerateHollowCubic(ctx);
+    PointCloudF translated = *pc_box;
+    for (auto& p : translated.points) { p.x += 0.05f; p.y += 0.05f; }
+    EXPECT(pco.Initialize(cfg));
+    pco.EnableOdometryIntegration();
+    const double prior[16] = {1, 0, 0, -0.04, 0, 1, 0, -0.05, 0, 0, 1, 0, 0, 0, 0, 1};  // most of the motion, row-major
+    pco.SetOdometryDelta(prior);
+    EXPECT(pco.SetLidar(*pc_box));
+    EXPECT(!pco.UpdateEstimate());
+    EXPECT(pco.SetLidar(translated));
+    EXPECT(pco.UpdateEstimate());
+    const float* Tg = pco.icp_->getFinalTransformation();  // what GICP itself had to find: about (-0.01, 0, 0)
+    EXPECT_NEAR(Tg[12], -0.01, epsiliond);
+    EXPECT_NEAR(Tg[13], 0.0, epsiliond);
+    EXPECT_NEAR(pco.GetIncrementalEstimate().translation.x, -0.05, epsiliond);
+    EXPECT_NEAR(pco.GetIncrementalEstimate().translation.y, -0.05, epsiliond);
+    EXPECT_NEAR(pco.GetIncrementalEstimate().translation.z, 0.0, epsiliond);
+    // the prior is applied in double and rounded once: the source the registration saw is float(prior * double(p))
+    PointCloudF::Ptr src = pco.GetQueryTransformed();
+    EXPECT(src && src->size() == translated.size());
+    if (src && src->size() == translated.size())
+      for (size_t i = 0; i < src->size(); i += 37) {
+        EXPECT(src->points[i].x == static_cast<float>(1.0 * (double)translated.points[i].x + 0.0 * (double)translated.points[i].y +
+                                                      0.0 * (double)translated.points[i].z + -0.04));
+        EXPECT(src->points[i].y == static_cast<float>(0.0 * (double)translated.points[i].x + 1.0 * (double)translated.points[i].y +
+                                                      0.0 * (double)translated.points[i].z + -0.05));
+      }
+  }
+
   {  // TransformPointsToFixedFrame / ToSensorFrame (z = +-3) and the covariance KATs
     PointCloudLocalization pcl_(ctx);
     PointCloudLocalization::Config cfg;
