@@ -171,6 +171,31 @@ lh_status lh_knn_cloud(lh_cloud* target, const lh_cloud* q, int k, int32_t* idx,
 lh_status lh_gicp_align_batch(lh_ctx* ctx, const lh_gicp_params* p, int n_pairs, lh_cloud* const* src,
                               lh_cloud* const* tgt, const float* guesses /* n_pairs*16 or NULL */,
                               lh_gicp_result* out, int max_in_flight /* 0 = default */);
+/* the same, plus align()'s output cloud of every pair (gicp.hpp:586, pcl::transformPointCloud(*input_, output,
+   final_transformation_)): aligned[i] = final T * src[i], xyz transformed and every other field copied, written on the device
+   as the pair retires.  aligned[i] == NULL on entry: a new device cloud is created (the caller destroys it); otherwise an
+   existing cloud of src[i]'s size on this context, overwritten.  aligned == NULL: lh_gicp_align_batch. */
+lh_status lh_gicp_align_batch_out(lh_ctx* ctx, const lh_gicp_params* p, int n_pairs, lh_cloud* const* src, lh_cloud* const* tgt,
+                                  const float* guesses, lh_gicp_result* out, lh_cloud** aligned /* n_pairs, nullable */, int max_in_flight);
+
+/* ---- several GPUs from one process (BASELINE configs 4/5) ---------------------------------------------------
+   Independent scan pairs shard over GPUs with NO exchange step, so a single C++ process (the LOCUS node is one,
+   locus/src/Locus.cc:47-71) needs no collective: create one context per visible device (lh_device_count, lh_create) and hand
+   the whole batch over.
+     lh_gicp_align_batch_multi        device-resident clouds: pair i runs on the context that owns src[i] and tgt[i] (both on the
+                                      same one, which must be in ctxs); one host thread per device; results in pair order
+     lh_gicp_align_batch_multi_views  host-resident clouds (PCL point arrays): contiguous blocks of pairs per context (pair i ->
+                                      ctxs[i * n_ctx / n_pairs]), uploaded there, aligned, freed; when tgt[i] describes the same
+                                      buffer as src[i-1] (an odometry stream) and both fall on one device it is uploaded once
+   Contexts that share a device are served one after the other (see lh_create).  Ranks of a multi-process job (one process per
+   GPU, torch.distributed / MPI) use the single-context calls and gather lh_gicp_result with their runtime's all-gather;
+   liblocus_hip_rccl.so (include/locus_hip_rccl.h) does it with RCCL. */
+int lh_device_count(void);
+lh_status lh_gicp_align_batch_multi(int n_ctx, lh_ctx* const* ctxs, const lh_gicp_params* p, int n_pairs, lh_cloud* const* src,
+                                    lh_cloud* const* tgt, const float* guesses, lh_gicp_result* out, lh_cloud** aligned /* nullable */,
+                                    int max_in_flight);
+lh_status lh_gicp_align_batch_multi_views(int n_ctx, lh_ctx* const* ctxs, const lh_gicp_params* p, int n_pairs, const lh_cloud_view* src,
+                                          const lh_cloud_view* tgt, const float* guesses, lh_gicp_result* out, int max_in_flight);
 
 /* ---- building blocks exported for parity tests and for the localization wrapper ---------------- */
 /* K3: computeCovariances k-NN branch (gicp.hpp:85-154) -> row-major 3x3 doubles [n][9] on the host */
@@ -204,6 +229,11 @@ lh_status lh_voxel_grid(lh_ctx* ctx, const lh_cloud_view* in, float leaf, int li
 /* device-resident K1: the voxelised cloud (x, y, z, intensity centroids) is created on the GPU; with lh_normals_knn_cloud and
    lh_gicp_set_*_cloud a raw scan goes voxel grid -> normals -> GICP without crossing PCIe */
 lh_status lh_cloud_voxel_grid(const lh_cloud* in, float leaf, int limit_axis, double lo, double hi, lh_cloud** out);
+/* the second voxel-grid site of the path: pcl::VoxelGrid<PointF> in PointCloudFilter::Filter (PointCloudFilter.cc:119-124,
+   PointF = pcl::PointXYZINormal, no limit field).  Same voxels in the same order as K1, but EVERY field is averaged the way
+   pcl::CentroidPoint's accumulators do it: x, y, z, intensity and curvature are float sums / n, the normal is the float sum
+   of the voxel's normals, normalised (a zero sum stays zero).  `in` must carry normals (LH_EINVAL otherwise). */
+lh_status lh_cloud_voxel_grid_pointf(const lh_cloud* in, float leaf, lh_cloud** out);
 /* K3 (filter flavour): NormalComputation::filter (normal_computation.cc:26-59), k-NN, viewpoint (0,0,0).
    out = float[count][4] (nx, ny, nz, curvature) */
 lh_status lh_normals_knn(lh_ctx* ctx, const lh_cloud_view* in, int k, float* out_normals4);

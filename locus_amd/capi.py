@@ -106,8 +106,8 @@ EXPORTS = [
     "lh_cloud_download", "lh_cloud_transform", "lh_cloud_slice", "lh_cloud_concat", "lh_gicp_create", "lh_gicp_destroy", "lh_gicp_set_params",
     "lh_gicp_set_source", "lh_gicp_set_target", "lh_gicp_set_source_cloud", "lh_gicp_set_target_cloud",
     "lh_gicp_promote_source_to_target", "lh_gicp_align", "lh_gicp_fitness", "lh_set_allreduce", "lh_nn1", "lh_nn1_cloud", "lh_knn_cloud",
-    "lh_gicp_align_batch", "lh_cov_knn", "lh_gicp_debug_sweep", "lh_gicp_debug_stats", "lh_debug_traversal_stats", "lh_gicp_debug_cost", "lh_p2plane_information",
-    "lh_icp_covariance", "lh_voxel_grid", "lh_cloud_voxel_grid", "lh_cloud_nearest_neighbors", "lh_cloud_crop_box", "lh_default_ndt_params", "lh_ndt_create", "lh_ndt_destroy", "lh_ndt_set_params",
+    "lh_gicp_align_batch", "lh_gicp_align_batch_out", "lh_device_count", "lh_gicp_align_batch_multi", "lh_gicp_align_batch_multi_views", "lh_cov_knn", "lh_gicp_debug_sweep", "lh_gicp_debug_stats", "lh_debug_traversal_stats", "lh_gicp_debug_cost", "lh_p2plane_information",
+    "lh_icp_covariance", "lh_voxel_grid", "lh_cloud_voxel_grid", "lh_cloud_voxel_grid_pointf", "lh_cloud_nearest_neighbors", "lh_cloud_crop_box", "lh_default_ndt_params", "lh_ndt_create", "lh_ndt_destroy", "lh_ndt_set_params",
     "lh_ndt_set_source", "lh_ndt_set_target", "lh_ndt_set_source_cloud", "lh_ndt_set_target_cloud", "lh_ndt_align", "lh_ndt_debug_cells",
     "lh_ndt_debug_derivatives", "lh_map_create", "lh_map_destroy", "lh_map_insert", "lh_map_refresh", "lh_map_cloud", "lh_map_size", "lh_normals_knn", "lh_normals_knn_cloud",
     "lh_normals_radius", "lh_normals_radius_cloud", "lh_cloud_remove_nan_normals", "lh_profile_enable",
@@ -160,6 +160,13 @@ def lib():
         L.lh_knn_cloud.argtypes = [vp, vp, i32, vp, vp]
         L.lh_gicp_align_batch.argtypes = [vp, C.POINTER(GicpParams), i32, C.POINTER(vp), C.POINTER(vp), vp,
                                           C.POINTER(GicpResult), i32]
+        L.lh_gicp_align_batch_out.argtypes = [vp, C.POINTER(GicpParams), i32, C.POINTER(vp), C.POINTER(vp), vp,
+                                              C.POINTER(GicpResult), C.POINTER(vp), i32]
+        L.lh_device_count.restype = i32
+        L.lh_gicp_align_batch_multi.argtypes = [i32, C.POINTER(vp), C.POINTER(GicpParams), i32, C.POINTER(vp), C.POINTER(vp), vp,
+                                                C.POINTER(GicpResult), C.POINTER(vp), i32]
+        L.lh_gicp_align_batch_multi_views.argtypes = [i32, C.POINTER(vp), C.POINTER(GicpParams), i32, C.POINTER(CloudView), C.POINTER(CloudView), vp,
+                                                      C.POINTER(GicpResult), i32]
         L.lh_cov_knn.argtypes = [vp, i32, dbl, vp]
         L.lh_gicp_debug_sweep.argtypes = [vp, vp, vp, vp, vp]
         L.lh_gicp_debug_stats.argtypes = [vp, vp, i32]
@@ -169,6 +176,7 @@ def lib():
         L.lh_icp_covariance.argtypes = [vp, dbl, vp, C.POINTER(dbl)]
         L.lh_voxel_grid.argtypes = [vp, C.POINTER(CloudView), C.c_float, i32, dbl, dbl, vp, u32, C.POINTER(u32)]
         L.lh_cloud_voxel_grid.argtypes = [vp, C.c_float, i32, dbl, dbl, C.POINTER(vp)]
+        L.lh_cloud_voxel_grid_pointf.argtypes = [vp, C.c_float, C.POINTER(vp)]
         L.lh_cloud_nearest_neighbors.argtypes = [vp, vp, C.POINTER(vp)]
         L.lh_normals_knn.argtypes = [vp, C.POINTER(CloudView), i32, vp]
         L.lh_normals_knn_cloud.argtypes = [vp, i32]
@@ -430,6 +438,12 @@ class Cloud:
         out = C.c_void_p()
         _check(lib().lh_cloud_voxel_grid(self.h, leaf, limit_axis, float(max(lo, -3e38)), float(min(hi, 3e38)), C.byref(out)),
                "lh_cloud_voxel_grid")
+        return Cloud(self.ctx, None, _handle=out)
+
+    def voxel_grid_pointf(self, leaf):
+        """pcl::VoxelGrid<PointXYZINormal> (PointCloudFilter.cc:119-124): every field averaged, normals re-normalised"""
+        out = C.c_void_p()
+        _check(lib().lh_cloud_voxel_grid_pointf(self.h, leaf, C.byref(out)), "lh_cloud_voxel_grid_pointf")
         return Cloud(self.ctx, None, _handle=out)
 
     def crop_box(self, min_pt, max_pt, yaw=0.0, negative=True):
@@ -723,4 +737,64 @@ def align_batch(ctx, params, src_clouds, tgt_clouds, guesses=None, max_in_flight
     st = lib().lh_gicp_align_batch(ctx.h, C.byref(params), n, S, T, _ptr(g), out, max_in_flight)
     if st not in (LH_OK, LH_ETOO_FEW_CORR, LH_ESOLVER):
         raise LocusHipError(st, "lh_gicp_align_batch")
+    return [_result_dict(out[i]) for i in range(n)]
+
+
+def align_batch_out(ctx, params, src_clouds, tgt_clouds, guesses=None, max_in_flight=0, aligned=None, raw=False):
+    """lh_gicp_align_batch_out: results plus align()'s output clouds.  aligned = list of Cloud / None per pair (None: created);
+    returns (results, aligned clouds).  raw=True returns the ctypes result array instead of dicts (bench.py gathers it)."""
+    n = len(src_clouds)
+    assert n == len(tgt_clouds)
+    S = (C.c_void_p * n)(*[c.h for c in src_clouds])
+    T = (C.c_void_p * n)(*[c.h for c in tgt_clouds])
+    A = (C.c_void_p * n)(*[(a.h if a is not None else None) for a in (aligned or [None] * n)])
+    out = (GicpResult * n)()
+    g = np.ascontiguousarray(guesses, np.float32).reshape(n * 16) if guesses is not None else None
+    st = lib().lh_gicp_align_batch_out(ctx.h, C.byref(params), n, S, T, _ptr(g), out, A, max_in_flight)
+    if st not in (LH_OK, LH_ETOO_FEW_CORR, LH_ESOLVER):
+        raise LocusHipError(st, "lh_gicp_align_batch_out")
+    clouds = []
+    for i in range(n):
+        if aligned is not None and aligned[i] is not None:
+            clouds.append(aligned[i])
+        else:
+            clouds.append(Cloud(ctx, None, _handle=C.c_void_p(A[i])))
+    return (out if raw else [_result_dict(out[i]) for i in range(n)]), clouds
+
+
+def device_count():
+    return lib().lh_device_count()
+
+
+def align_batch_multi(ctxs, params, src_clouds, tgt_clouds, guesses=None, max_in_flight=0):
+    """lh_gicp_align_batch_multi: every pair runs on the context (GPU) that owns its clouds, one host thread per device"""
+    n = len(src_clouds)
+    assert n == len(tgt_clouds)
+    X = (C.c_void_p * len(ctxs))(*[c.h for c in ctxs])
+    S = (C.c_void_p * n)(*[c.h for c in src_clouds])
+    T = (C.c_void_p * n)(*[c.h for c in tgt_clouds])
+    out = (GicpResult * n)()
+    g = np.ascontiguousarray(guesses, np.float32).reshape(n * 16) if guesses is not None else None
+    st = lib().lh_gicp_align_batch_multi(len(ctxs), X, C.byref(params), n, S, T, _ptr(g), out, None, max_in_flight)
+    if st not in (LH_OK, LH_ETOO_FEW_CORR, LH_ESOLVER):
+        raise LocusHipError(st, "lh_gicp_align_batch_multi")
+    return [_result_dict(out[i]) for i in range(n)]
+
+
+def align_batch_multi_views(ctxs, params, src_points, tgt_points, guesses=None, max_in_flight=0):
+    """lh_gicp_align_batch_multi_views: host arrays (PointXYZINormal records) in, results out; contiguous pair blocks per context"""
+    n = len(src_points)
+    assert n == len(tgt_points)
+    X = (C.c_void_p * len(ctxs))(*[c.h for c in ctxs])
+    keep, SV, TV = [], (CloudView * n)(), (CloudView * n)()
+    for i in range(n):
+        sv, k1 = view_of(src_points[i])
+        tv, k2 = view_of(tgt_points[i])
+        SV[i], TV[i] = sv, tv
+        keep += [k1, k2]
+    out = (GicpResult * n)()
+    g = np.ascontiguousarray(guesses, np.float32).reshape(n * 16) if guesses is not None else None
+    st = lib().lh_gicp_align_batch_multi_views(len(ctxs), X, C.byref(params), n, SV, TV, _ptr(g), out, max_in_flight)
+    if st not in (LH_OK, LH_ETOO_FEW_CORR, LH_ESOLVER):
+        raise LocusHipError(st, "lh_gicp_align_batch_multi_views")
     return [_result_dict(out[i]) for i in range(n)]

@@ -528,6 +528,7 @@ struct Task : public CostFn {
   int slot = 0;
   hipStream_t stream = nullptr;  // the stream of the scheduler group that owns the task
   lh_gicp_trace* trace = nullptr;
+  lh_cloud* aligned = nullptr;   // batch API: receives final_transformation_ * input (gicp.hpp:586) when the pair retires
   // coroutine
   ucontext_t ctx, sched;
   std::vector<char> stack;
@@ -897,6 +898,14 @@ static lh_status group_collect(lh_ctx* c, Group& g) {
   g.costs.clear(); g.moms.clear(); g.sweeps.clear();
   for (size_t i = 0; i < g.active.size();) {  // retire finished pairs
     if (g.active[i]->req == REQ_DONE) {
+      Task* t = g.active[i];
+      if (t->aligned) {  // pcl::transformPointCloud(*input_, output, final_transformation_) (gicp.hpp:586), on the group's stream
+        float T12[12];
+        Task::T16_to_T12(t->result.T, T12);
+        ProfScope p(c, "transform", 32.0 * t->src->n, g.stream);
+        launch_transform_copy(t->src->xyz, t->aligned->nrm ? t->src->nrm : nullptr, t->aligned->intensity ? t->src->intensity : nullptr, t->src->n, T12,
+                              t->aligned->xyz, t->aligned->nrm, t->aligned->intensity, g.stream);
+      }
       g.free_slots.push_back(g.active[i]->slot);
       g.active.erase(g.active.begin() + i);
     } else
@@ -1449,8 +1458,20 @@ lh_status lh_knn_cloud(lh_cloud* target, const lh_cloud* q, int k, int32_t* idx,
   return LH_OK;
 }
 
-lh_status lh_gicp_align_batch(lh_ctx* ctx, const lh_gicp_params* p, int n_pairs, lh_cloud* const* src, lh_cloud* const* tgt,
-                              const float* guesses, lh_gicp_result* out, int max_in_flight) {
+// a cloud shaped like `in` (same fields, same size) whose contents are about to be overwritten
+static lh_status cloud_like(const lh_cloud* in, lh_cloud** out) {
+  lh_cloud* o = new lh_cloud();
+  o->ctx = in->ctx; o->n = in->n; o->n_pad = in->n_pad;
+  hipError_t e = lhMalloc(&o->xyz, sizeof(float4) * (size_t)o->n_pad);
+  if (e == hipSuccess && in->nrm) e = lhMalloc(&o->nrm, sizeof(float4) * (size_t)o->n_pad);
+  if (e == hipSuccess && in->intensity) e = lhMalloc(&o->intensity, sizeof(float) * (size_t)o->n_pad);
+  if (e != hipSuccess) { cloud_free(o); return LH_ENOMEM; }
+  *out = o;
+  return LH_OK;
+}
+
+lh_status lh_gicp_align_batch_out(lh_ctx* ctx, const lh_gicp_params* p, int n_pairs, lh_cloud* const* src, lh_cloud* const* tgt,
+                                  const float* guesses, lh_gicp_result* out, lh_cloud** aligned, int max_in_flight) {
   if (!ctx || !p || n_pairs < 0 || !src || !tgt || !out) return LH_EINVAL;
   if (n_pairs == 0) return LH_OK;
   HIPCHK(hipSetDevice(ctx->device));
@@ -1459,21 +1480,139 @@ lh_status lh_gicp_align_batch(lh_ctx* ctx, const lh_gicp_params* p, int n_pairs,
   int max_n = 1;
   for (int i = 0; i < n_pairs; i++) {
     if (!src[i] || !tgt[i] || src[i]->ctx != ctx || tgt[i]->ctx != ctx) return LH_EINVAL;
+    if (aligned && aligned[i] && (aligned[i]->ctx != ctx || aligned[i]->n != src[i]->n || aligned[i] == src[i] || aligned[i] == tgt[i])) return LH_EINVAL;
     max_n = std::max(max_n, src[i]->n);
   }
   lh_status st = ctx_ensure_slots(ctx, in_flight, max_n);
   if (st) return st;
   if ((int)ctx->slot_ws.size() < in_flight) ctx->slot_ws.resize(in_flight);  // grow-only, reused across calls, freed by lh_destroy
+  std::vector<int> created;  // entries of `aligned` made by this call: released again if an allocation fails
+  if (aligned)
+    for (int i = 0; i < n_pairs; i++)
+      if (!aligned[i]) {
+        st = cloud_like(src[i], &aligned[i]);
+        if (st) {
+          for (int k : created) { cloud_free(aligned[k]); aligned[k] = nullptr; }
+          aligned[i] = nullptr;
+          return st;
+        }
+        created.push_back(i);
+      }
   std::vector<Task> tasks(n_pairs);
   std::vector<Task*> ptrs(n_pairs);
   for (int i = 0; i < n_pairs; i++) {
     Task& t = tasks[i];
     t.P = *p; t.src = src[i]; t.tgt = tgt[i]; t.trace = nullptr;
+    t.aligned = aligned ? aligned[i] : nullptr;
     memcpy(t.guess, guesses ? guesses + 16 * (size_t)i : I16, sizeof(I16));
     ptrs[i] = &t;
   }
   st = run_tasks(ctx, ptrs, in_flight, /*rebuild_index=*/true, &ctx->slot_ws);
   for (int i = 0; i < n_pairs; i++) out[i] = tasks[i].result;
+  if (aligned) {  // the output clouds were written on the scheduler streams: complete before the caller touches them
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
+  }
+  return st;
+}
+
+lh_status lh_gicp_align_batch(lh_ctx* ctx, const lh_gicp_params* p, int n_pairs, lh_cloud* const* src, lh_cloud* const* tgt,
+                              const float* guesses, lh_gicp_result* out, int max_in_flight) {
+  return lh_gicp_align_batch_out(ctx, p, n_pairs, src, tgt, guesses, out, nullptr, max_in_flight);
+}
+
+int lh_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  return n;
+}
+
+// Independent scan pairs over several GPUs from ONE process (SURVEY 8b "shards over visible GPUs", 8e): the pairs need no
+// exchange step, so there is no collective -- one host thread per device drives that device's context(s) with the pairs whose
+// clouds live there.  Contexts that share a device are served by the same thread, one after the other (the buffer pool's
+// one-context-at-a-time contract, locus_hip.h).
+lh_status lh_gicp_align_batch_multi(int n_ctx, lh_ctx* const* ctxs, const lh_gicp_params* p, int n_pairs, lh_cloud* const* src,
+                                    lh_cloud* const* tgt, const float* guesses, lh_gicp_result* out, lh_cloud** aligned, int max_in_flight) {
+  if (n_ctx < 1 || !ctxs || !p || n_pairs < 0 || !src || !tgt || !out) return LH_EINVAL;
+  for (int d = 0; d < n_ctx; d++) {
+    if (!ctxs[d]) return LH_EINVAL;
+    for (int e = 0; e < d; e++)
+      if (ctxs[e] == ctxs[d]) return LH_EINVAL;
+  }
+  if (n_pairs == 0) return LH_OK;
+  std::vector<std::vector<int>> mine(n_ctx);
+  for (int i = 0; i < n_pairs; i++) {
+    if (!src[i] || !tgt[i] || src[i]->ctx != tgt[i]->ctx) return LH_EINVAL;
+    int d = 0;
+    while (d < n_ctx && ctxs[d] != src[i]->ctx) d++;
+    if (d == n_ctx) return LH_EINVAL;  // a pair whose clouds live on none of the given contexts
+    mine[d].push_back(i);
+  }
+  std::vector<lh_status> rc(n_ctx, LH_OK);
+  auto run_ctx = [&](int d) {
+    const std::vector<int>& idx = mine[d];
+    if (idx.empty()) return;
+    const int k = (int)idx.size();
+    std::vector<lh_cloud*> s(k), t(k), a(k, nullptr);
+    std::vector<float> g;
+    std::vector<lh_gicp_result> r(k);
+    if (guesses) g.resize((size_t)16 * k);
+    for (int j = 0; j < k; j++) {
+      s[j] = src[idx[j]]; t[j] = tgt[idx[j]];
+      if (aligned) a[j] = aligned[idx[j]];
+      if (guesses) memcpy(&g[(size_t)16 * j], guesses + (size_t)16 * idx[j], sizeof(float) * 16);
+    }
+    rc[d] = lh_gicp_align_batch_out(ctxs[d], p, k, s.data(), t.data(), guesses ? g.data() : nullptr, r.data(), aligned ? a.data() : nullptr, max_in_flight);
+    for (int j = 0; j < k; j++) {
+      out[idx[j]] = r[j];
+      if (aligned) aligned[idx[j]] = a[j];
+    }
+  };
+  std::vector<int> devices;  // one thread per distinct device
+  for (int d = 0; d < n_ctx; d++)
+    if (std::find(devices.begin(), devices.end(), ctxs[d]->device) == devices.end()) devices.push_back(ctxs[d]->device);
+  auto run_device = [&](int dev) {
+    for (int d = 0; d < n_ctx; d++)
+      if (ctxs[d]->device == dev) run_ctx(d);
+  };
+  std::vector<std::thread> threads;
+  for (size_t k = 1; k < devices.size(); k++) threads.emplace_back(run_device, devices[k]);
+  run_device(devices[0]);  // the calling thread takes the first device
+  for (auto& th : threads) th.join();
+  for (int d = 0; d < n_ctx; d++)
+    if (rc[d]) return rc[d];
+  return LH_OK;
+}
+
+// the same from host-resident clouds (what a C++ ROS node holds: PCL point arrays): pair i goes to context i * n_ctx / n_pairs
+// (contiguous blocks, so that consecutive scans of an odometry stream -- target of pair i = source of pair i - 1 -- are
+// uploaded once per device), is aligned there, and only the results come back
+lh_status lh_gicp_align_batch_multi_views(int n_ctx, lh_ctx* const* ctxs, const lh_gicp_params* p, int n_pairs, const lh_cloud_view* src,
+                                          const lh_cloud_view* tgt, const float* guesses, lh_gicp_result* out, int max_in_flight) {
+  if (n_ctx < 1 || !ctxs || !p || n_pairs < 0 || !src || !tgt || !out) return LH_EINVAL;
+  for (int d = 0; d < n_ctx; d++)
+    if (!ctxs[d]) return LH_EINVAL;
+  if (n_pairs == 0) return LH_OK;
+  std::vector<lh_cloud*> S(n_pairs, nullptr), T(n_pairs, nullptr), owned;
+  lh_status st = LH_OK;
+  auto same = [](const lh_cloud_view& a, const lh_cloud_view& b) {
+    return a.base == b.base && a.count == b.count && a.stride == b.stride && a.off_xyz == b.off_xyz && a.off_normal == b.off_normal;
+  };
+  for (int i = 0; i < n_pairs && !st; i++) {
+    const int d = (int)(((long)i * n_ctx) / n_pairs);
+    const bool chained = i > 0 && (int)(((long)(i - 1) * n_ctx) / n_pairs) == d && same(tgt[i], src[i - 1]);
+    st = upload_view(ctxs[d], &src[i], &S[i]);
+    if (!st) owned.push_back(S[i]);
+    if (!st) {
+      if (chained) T[i] = S[i - 1];  // the previous scan is already on this device
+      else { st = upload_view(ctxs[d], &tgt[i], &T[i]); if (!st) owned.push_back(T[i]); }
+    }
+  }
+  if (!st) st = lh_gicp_align_batch_multi(n_ctx, ctxs, p, n_pairs, S.data(), T.data(), guesses, out, nullptr, max_in_flight);
+  for (lh_cloud* c : owned) {
+    (void)hipSetDevice(c->ctx->device);
+    cloud_free(c);
+  }
   return st;
 }
 
@@ -1957,16 +2096,20 @@ static lh_status voxel_segments(lh_ctx* c, const float4* d_in, int n, float leaf
   return LH_OK;
 }
 static lh_status voxel_grid_device(lh_ctx* c, const float4* d_in, int n, float leaf, int limit_axis, double lo, double hi,
-                                   float4** d_out, uint32_t* total_out) {
+                                   float4** d_out, uint32_t* total_out, const float4* d_nrm = nullptr, float4** d_out_nrm = nullptr) {
   *d_out = nullptr;
   *total_out = 0;
+  if (d_out_nrm) *d_out_nrm = nullptr;
   VoxelSegments vs;
   lh_status st = voxel_segments(c, d_in, n, leaf, limit_axis, lo, hi, &vs);
   if (st) return st;
   if (vs.total > 0) {
     if (lhMalloc(d_out, sizeof(float4) * (size_t)vs.total) != hipSuccess) { vs.release(); return LH_ENOMEM; }
-    ProfScope p(c, "voxel_centroids", 32.0 * n);
-    launch_voxel_centroids(d_in, c->keys1, c->vals1, vs.heads, vs.rank, n, *d_out, vs.total, c->stream);
+    if (d_nrm && d_out_nrm && lhMalloc(d_out_nrm, sizeof(float4) * (size_t)round_up((int)vs.total, 256)) != hipSuccess) {  // n_pad entries, like every cloud's normals
+      (void)lhFree(*d_out); *d_out = nullptr; vs.release(); return LH_ENOMEM;
+    }
+    ProfScope p(c, "voxel_centroids", (d_nrm ? 64.0 : 32.0) * n);
+    launch_voxel_centroids(d_in, d_nrm, c->keys1, c->vals1, vs.heads, vs.rank, n, *d_out, d_out_nrm ? *d_out_nrm : nullptr, vs.total, c->stream);
   }
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
@@ -2019,30 +2162,42 @@ __global__ void __launch_bounds__(256) k_unpack_xyzi(const float4* __restrict__ 
   xyz[i] = make_float4(p.x, p.y, p.z, 1.0f);
   inten[i] = p.w;
 }
-lh_status lh_cloud_voxel_grid(const lh_cloud* in, float leaf, int limit_axis, double lo, double hi, lh_cloud** out) {
+static lh_status cloud_voxel_grid(const lh_cloud* in, float leaf, int limit_axis, double lo, double hi, bool all_fields, lh_cloud** out) {
   if (!in || !out || !(leaf > 0.0f) || limit_axis > 2 || in->n <= 0) return LH_EINVAL;
+  if (all_fields && !in->nrm) return LH_EINVAL;  // the PointXYZINormal flavour needs the normal / curvature fields
   lh_ctx* c = in->ctx;
   HIPCHK(hipSetDevice(c->device));
-  float4 *d_in = nullptr, *d_out = nullptr;
+  float4 *d_in = nullptr, *d_out = nullptr, *d_out_nrm = nullptr;
   HIPCHK(lhMalloc(&d_in, sizeof(float4) * (size_t)in->n));
   hipLaunchKernelGGL(k_pack_xyzi, dim3((in->n + 255) / 256), dim3(256), 0, c->stream, in->xyz, in->intensity, in->n, d_in);
   uint32_t total = 0;
-  lh_status st = voxel_grid_device(c, d_in, in->n, leaf, limit_axis, lo, hi, &d_out, &total);
+  lh_status st = voxel_grid_device(c, d_in, in->n, leaf, limit_axis, lo, hi, &d_out, &total, all_fields ? in->nrm : nullptr,
+                                   all_fields ? &d_out_nrm : nullptr);
   (void)lhFree(d_in);
-  if (st) { (void)lhFree(d_out); return st; }
-  if (total == 0) { (void)lhFree(d_out); return LH_EINVAL; }  // every point was filtered out: no cloud to return
+  DevGuard guard;
+  guard.bufs.push_back(d_out);
+  if (st) { (void)lhFree(d_out_nrm); return st; }
+  if (total == 0) { (void)lhFree(d_out_nrm); return LH_EINVAL; }  // every point was filtered out: no cloud to return
   lh_cloud* o = new lh_cloud();
+  guard.cloud = o;
   o->ctx = c;
   o->n = (int)total;
   o->n_pad = round_up(o->n, 256);
+  o->nrm = d_out_nrm;
   HIPCHK(lhMalloc(&o->xyz, sizeof(float4) * (size_t)o->n_pad));
   HIPCHK(lhMalloc(&o->intensity, sizeof(float) * (size_t)o->n_pad));
   hipLaunchKernelGGL(k_unpack_xyzi, dim3((o->n + 255) / 256), dim3(256), 0, c->stream, d_out, o->n, o->xyz, o->intensity);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(c->stream));
-  (void)lhFree(d_out);
-  *out = o;
+  *out = guard.keep_cloud();
   return LH_OK;
+}
+lh_status lh_cloud_voxel_grid(const lh_cloud* in, float leaf, int limit_axis, double lo, double hi, lh_cloud** out) {
+  return cloud_voxel_grid(in, leaf, limit_axis, lo, hi, false, out);
+}
+// pcl::VoxelGrid<PointF> of PointCloudFilter::Filter (PointCloudFilter.cc:119-124): same voxels, same order, every field averaged
+lh_status lh_cloud_voxel_grid_pointf(const lh_cloud* in, float leaf, lh_cloud** out) {
+  return cloud_voxel_grid(in, leaf, -1, -3.0e38, 3.0e38, true, out);
 }
 
 // ---- NDT (registration_method: ndt) -------------------------------------------------------------------------------

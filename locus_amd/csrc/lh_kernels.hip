@@ -830,6 +830,26 @@ void launch_transform(const float4* in_xyz, const float4* in_nrm, int n, const f
   hipLaunchKernelGGL(k_transform, dim3((n + 255) / 256), dim3(256), 0, s, in_xyz, in_nrm, n, T, out_xyz, out_nrm);
 }
 
+// align()'s output cloud (gicp.hpp:586, pcl::transformPointCloud(*input_, output, final_transformation_)): xyz transformed, every
+// other field of the point copied -- one launch per pair
+__global__ void __launch_bounds__(256) k_transform_copy(const float4* __restrict__ in_xyz, const float4* __restrict__ in_nrm, const float* __restrict__ in_int,
+                                                        int n, T12 T, float4* __restrict__ out_xyz, float4* __restrict__ out_nrm, float* __restrict__ out_int) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float4 p = in_xyz[i];
+  float x, y, z;
+  xform_pt(T.v, p.x, p.y, p.z, x, y, z);
+  out_xyz[i] = make_float4(x, y, z, 1.0f);
+  if (in_nrm && out_nrm) out_nrm[i] = in_nrm[i];
+  if (in_int && out_int) out_int[i] = in_int[i];
+}
+void launch_transform_copy(const float4* in_xyz, const float4* in_nrm, const float* in_int, int n, const float* T12p, float4* out_xyz,
+                           float4* out_nrm, float* out_int, hipStream_t s) {
+  T12 T;
+  for (int k = 0; k < 12; k++) T.v[k] = T12p[k];
+  hipLaunchKernelGGL(k_transform_copy, dim3((n + 255) / 256), dim3(256), 0, s, in_xyz, in_nrm, in_int, n, T, out_xyz, out_nrm, out_int);
+}
+
 __global__ void __launch_bounds__(256) k_fill_i32(int32_t* p, int n, int32_t v) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = v;
@@ -1529,26 +1549,42 @@ void launch_voxel_heads(const uint32_t* keys, int n, uint32_t* heads, hipStream_
   hipLaunchKernelGGL(k_voxel_heads, dim3((n + 255) / 256), dim3(256), 0, s, keys, n, heads);
 }
 
-__global__ void __launch_bounds__(256) k_voxel_centroids(const float4* __restrict__ xyzi, const uint32_t* __restrict__ keys,
+// nrm / out_nrm non-null: the pcl::VoxelGrid<PointXYZINormal> flavour (PointCloudFilter.cc:119-124) -- every field is
+// averaged by pcl::CentroidPoint's accumulators: xyz, intensity and curvature are float sums / n, the normal is the float
+// sum of the 4-vectors (normal_x, normal_y, normal_z, 0) NORMALISED (a zero sum stays zero)
+__global__ void __launch_bounds__(256) k_voxel_centroids(const float4* __restrict__ xyzi, const float4* __restrict__ nrm, const uint32_t* __restrict__ keys,
                                                          const uint32_t* __restrict__ vals, const uint32_t* __restrict__ heads,
-                                                         const uint32_t* __restrict__ rank, int n, float4* __restrict__ out, uint32_t cap) {
+                                                         const uint32_t* __restrict__ rank, int n, float4* __restrict__ out, float4* __restrict__ out_nrm,
+                                                         uint32_t cap) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n || !heads[i]) return;
   uint32_t k = keys[i];
   float ax = 0.f, ay = 0.f, az = 0.f, ai = 0.f;
+  float nx = 0.f, ny = 0.f, nz = 0.f, cu = 0.f;
   int cnt = 0;
   for (int j = i; j < n && keys[j] == k; j++) {  // stable radix sort => ascending point index inside a voxel
-    float4 p = xyzi[vals[j]];
+    uint32_t v = vals[j];
+    float4 p = xyzi[v];
     ax += p.x; ay += p.y; az += p.z; ai += p.w;
+    if (nrm) {
+      float4 q = nrm[v];
+      nx += q.x; ny += q.y; nz += q.z; cu += q.w;
+    }
     cnt++;
   }
   float c = (float)cnt;
   uint32_t r = rank[i] - 1u;
-  if (r < cap) out[r] = make_float4(ax / c, ay / c, az / c, ai / c);
+  if (r >= cap) return;
+  out[r] = make_float4(ax / c, ay / c, az / c, ai / c);
+  if (nrm && out_nrm) {
+    float z = (nx * nx + ny * ny) + nz * nz;
+    if (z > 0.0f) { float l = sqrtf(z); nx = nx / l; ny = ny / l; nz = nz / l; }
+    out_nrm[r] = make_float4(nx, ny, nz, cu / c);
+  }
 }
-void launch_voxel_centroids(const float4* xyzi, const uint32_t* keys, const uint32_t* vals, const uint32_t* heads,
-                            const uint32_t* rank_incl, int n, float4* out, uint32_t out_cap, hipStream_t s) {
-  hipLaunchKernelGGL(k_voxel_centroids, dim3((n + 255) / 256), dim3(256), 0, s, xyzi, keys, vals, heads, rank_incl, n, out, out_cap);
+void launch_voxel_centroids(const float4* xyzi, const float4* nrm, const uint32_t* keys, const uint32_t* vals, const uint32_t* heads,
+                            const uint32_t* rank_incl, int n, float4* out, float4* out_nrm, uint32_t out_cap, hipStream_t s) {
+  hipLaunchKernelGGL(k_voxel_centroids, dim3((n + 255) / 256), dim3(256), 0, s, xyzi, nrm, keys, vals, heads, rank_incl, n, out, out_nrm, out_cap);
 }
 
 }  // namespace lh

@@ -126,6 +126,9 @@ inline int mom_blocks(int n) { return (n + MOM_CHUNK - 1) / MOM_CHUNK; }
 // ---- K6 / K7 / misc ---------------------------------------------------------------------------------
 void launch_transform(const float4* in_xyz, const float4* in_nrm, int n, const float* T12, float4* out_xyz, float4* out_nrm,
                       hipStream_t s);
+// xyz transformed, normals / intensity copied unchanged (pcl::transformPointCloud on a PointXYZINormal cloud)
+void launch_transform_copy(const float4* in_xyz, const float4* in_nrm, const float* in_int, int n, const float* T12, float4* out_xyz,
+                           float4* out_nrm, float* out_int, hipStream_t s);
 void launch_fill_i32(int32_t* p, int n, int32_t v, hipStream_t s);
 // ungated 1-NN of T*q against a tree; T12 may be null (identity)
 void launch_nn1(const float4* q, int nq, const float* T12, TreeView tree, int32_t* idx, float* d2, hipStream_t s);
@@ -185,8 +188,9 @@ void launch_voxel_keys(const float4* xyzi, int n, VoxelGridDesc g, uint32_t* key
 // heads[i] = 1 where a new voxel starts in the sorted key array
 void launch_voxel_heads(const uint32_t* keys, int n, uint32_t* heads, hipStream_t s);
 // one thread per voxel head: sequential float centroid of the segment in sorted (= input) order
-void launch_voxel_centroids(const float4* xyzi, const uint32_t* keys, const uint32_t* vals, const uint32_t* heads,
-                            const uint32_t* rank_incl, int n, float4* out, uint32_t out_cap, hipStream_t s);
+// (nrm / out_nrm non-null: the PointXYZINormal flavour -- normals summed and normalised, curvature averaged)
+void launch_voxel_centroids(const float4* xyzi, const float4* nrm, const uint32_t* keys, const uint32_t* vals, const uint32_t* heads,
+                            const uint32_t* rank_incl, int n, float4* out, float4* out_nrm, uint32_t out_cap, hipStream_t s);
 size_t sort_keys64_temp_bytes(int n);
 void sort_keys_u64(void* temp, size_t temp_bytes, const uint64_t* keys_in, uint64_t* keys_out, int n, hipStream_t s);
 size_t scan_temp_bytes(int n);

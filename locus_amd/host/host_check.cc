@@ -2,11 +2,14 @@
 // (test_point_cloud_odometry.cpp:280-305; test_point_cloud_localization.cpp:243-276, 288-507, 509-528).
 #include <cmath>
 #include <cstdio>
+#include <cstring>
 #include <numeric>
 
 #include "PointCloudLocalization.hpp"
 #include "PointCloudMapperHip.hpp"
 #include "PointCloudOdometry.hpp"
+#include "pcd_io.hpp"
+#include "ros_msgs.hpp"
 
 using namespace locus_hip;
 
@@ -156,8 +159,8 @@ int main() {
     // observability eigenvalues of the plane: (0,0,0,56.7753,56.7753,100), Ap diag KAT
     double evec[36], eval[6], A[36];
     pcl_.ComputeIcpObservability(*plane, *plane, corr, I16, evec, eval, A);
-    EXPECT_NEAR(A[0], 56.7753, epsilion * 10); EXPECT_NEAR(A[7], 56.7753, epsilion * 10); EXPECT_NEAR(A[35], 100.0, epsilion);
-    EXPECT_NEAR(eval[0], 0, 1e-3); EXPECT_NEAR(eval[2], 0, 1e-3); EXPECT_NEAR(eval[3], 56.7753, 1e-3); EXPECT_NEAR(eval[5], 100.0, 1e-3);
+    EXPECT_NEAR(A[0], 56.7753, epsilion); EXPECT_NEAR(A[7], 56.7753, epsilion); EXPECT_NEAR(A[35], 100.0, epsilion);
+    EXPECT_NEAR(eval[0], 0, epsilion); EXPECT_NEAR(eval[2], 0, epsilion); EXPECT_NEAR(eval[3], 56.7753, epsilion); EXPECT_NEAR(eval[5], 100.0, epsilion);
 
     // three orthogonal planes + yaw-30deg offset -> ~1e-6 on the diagonal
     PointCloudF all = *plane, p1 = *plane, p2 = *plane;
@@ -259,6 +262,98 @@ int main() {
     mapper.Refresh(pose);                             // window moved away: nothing left
     EXPECT(mapper.Size() == 0);
     EXPECT(!mapper.ApproxNearestNeighbors(shifted, &nb));
+  }
+
+  {  // wire formats THROUGH the device: the filter nodelets receive sensor_msgs/PointCloud2 and hand PCL clouds on
+     // (pcl::fromROSMsg / toROSMsg, normal_computation.cc:30,58; pcl_conversions::toPCL, custom_voxel_grid.cc:81).  A velodyne
+     // driver message (x y z @0, intensity @16, ring @20, time @24; point_step 32) is read IN PLACE by lh_cloud_create through
+     // the view ros_msgs.hpp derives from its field table, runs K1 -> K3 on the GPU, and comes back in the layout pcl::toROSMsg
+     // gives a PointCloud<PointXYZINormal>.
+    const uint32_t n = 5000;
+    PointCloud2 in;
+    in.width = n; in.height = 1; in.point_step = 32; in.row_step = 32 * n;
+    auto fld = [](const char* name, uint32_t off, uint8_t type) { PointField f; f.name = name; f.offset = off; f.datatype = type; return f; };
+    in.fields = {fld("x", 0, PointField::FLOAT32), fld("y", 4, PointField::FLOAT32), fld("z", 8, PointField::FLOAT32),
+                 fld("intensity", 16, PointField::FLOAT32), fld("ring", 20, PointField::UINT16), fld("time", 24, PointField::FLOAT32)};
+    in.data.assign((size_t)in.row_step, 0xAB);   // the padding bytes are garbage on purpose
+    PointCloudF same;                            // the same points as a PCL array, for the reference route
+    for (uint32_t i = 0; i < n; i++) {
+      float u = 0.013f * (float)(i % 97), v = 0.017f * (float)(i / 97), w = 0.002f * (float)((i * 31) % 11);
+      float xyz[3] = {u, v, (i % 3 == 0) ? w : 1.5f + w}, inten = (float)(i % 255);
+      uint16_t ring = (uint16_t)(i % 16);
+      memcpy(&in.data[(size_t)i * 32 + 0], xyz, 12);
+      memcpy(&in.data[(size_t)i * 32 + 16], &inten, 4);
+      memcpy(&in.data[(size_t)i * 32 + 20], &ring, 2);
+      PointF p; p.x = xyz[0]; p.y = xyz[1]; p.z = xyz[2]; p.intensity = inten;
+      same.points.push_back(p);
+    }
+    lh_cloud_view v;
+    EXPECT(ViewFromPointCloud2(in, &v));
+    EXPECT(v.base == in.data.data() && v.stride == 32 && v.off_xyz == 0 && v.off_intensity == 16 && v.off_normal == UINT32_MAX);
+    lh_cloud *c_msg = nullptr, *c_pcl = nullptr, *vox_msg = nullptr, *vox_pcl = nullptr;
+    EXPECT(lh_cloud_create(ctx, &v, &c_msg) == LH_OK);
+    lh_cloud_view vp = ViewOf(same);
+    vp.off_normal = UINT32_MAX; vp.off_curvature = UINT32_MAX;
+    EXPECT(lh_cloud_create(ctx, &vp, &c_pcl) == LH_OK);
+    EXPECT(c_msg && c_pcl && lh_cloud_size(c_msg) == n && lh_cloud_size(c_pcl) == n);
+    if (c_msg && c_pcl) {
+      // upload from the message == upload from the PCL array, bit for bit
+      PointCloud2 back;
+      LayoutPointCloud2(&back, n, false);          // pcl::toROSMsg layout of PointCloud<PointXYZI>
+      lh_cloud_view vb;
+      EXPECT(ViewFromPointCloud2(back, &vb));
+      EXPECT(lh_cloud_download(c_msg, back.data.data(), vb.stride, vb.off_xyz, vb.off_normal, vb.off_intensity, vb.off_curvature) == LH_OK);
+      bool ok = true;
+      for (uint32_t i = 0; i < n && ok; i++)
+        ok = memcmp(&back.data[(size_t)i * vb.stride + vb.off_xyz], &in.data[(size_t)i * 32], 12) == 0 &&
+             memcmp(&back.data[(size_t)i * vb.stride + vb.off_intensity], &in.data[(size_t)i * 32 + 16], 4) == 0;
+      EXPECT(ok);
+      // CustomVoxelGrid::filter on the message == on the PCL array (custom_voxel_grid.cc:76-87), then NormalComputation::filter
+      EXPECT(lh_cloud_voxel_grid(c_msg, 0.1f, -1, -3e38, 3e38, &vox_msg) == LH_OK);
+      EXPECT(lh_cloud_voxel_grid(c_pcl, 0.1f, -1, -3e38, 3e38, &vox_pcl) == LH_OK);
+      EXPECT(vox_msg && vox_pcl && lh_cloud_size(vox_msg) == lh_cloud_size(vox_pcl) && lh_cloud_size(vox_msg) > 100);
+      if (vox_msg && vox_pcl) {
+        EXPECT(lh_normals_knn_cloud(vox_msg, 10) == LH_OK);
+        EXPECT(lh_normals_knn_cloud(vox_pcl, 10) == LH_OK);
+        const uint32_t m = lh_cloud_size(vox_msg);
+        PointCloud2 out;                            // what NormalComputation publishes: toROSMsg(PointCloud<PointXYZINormal>)
+        LayoutPointCloud2(&out, m, true);
+        lh_cloud_view vo;
+        EXPECT(ViewFromPointCloud2(out, &vo));
+        EXPECT(vo.stride == 48 && vo.off_normal == 16 && vo.off_intensity == 32 && vo.off_curvature == 36);
+        EXPECT(lh_cloud_download(vox_msg, out.data.data(), vo.stride, vo.off_xyz, vo.off_normal, vo.off_intensity, vo.off_curvature) == LH_OK);
+        PointCloudF ref;
+        ref.points.resize(m);
+        lh_cloud_view vr = ViewOf(ref);
+        EXPECT(lh_cloud_download(vox_pcl, ref.points.data(), vr.stride, vr.off_xyz, vr.off_normal, vr.off_intensity, vr.off_curvature) == LH_OK);
+        bool same_out = true;
+        int unit = 0;
+        for (uint32_t i = 0; i < m; i++) {
+          const uint8_t* p = &out.data[(size_t)i * 48];
+          const PointF& r = ref.points[i];
+          same_out = same_out && memcmp(p + 0, &r.x, 12) == 0 && memcmp(p + 16, &r.normal_x, 12) == 0 && memcmp(p + 32, &r.intensity, 4) == 0 &&
+                     memcmp(p + 36, &r.curvature, 4) == 0;
+          double l = std::sqrt((double)r.normal_x * r.normal_x + (double)r.normal_y * r.normal_y + (double)r.normal_z * r.normal_z);
+          unit += std::fabs(l - 1.0) < 1e-4;
+        }
+        EXPECT(same_out);                          // message route == PCL route, every field of every point
+        EXPECT(unit > (int)(0.95 * m));
+        // and a map dump (Locus.cc:749-751): the published cloud written as PCD v0.7 binary and read back
+        const char* tmp = "/tmp/locus_hip_host_check.pcd";
+        EXPECT(WritePCDBinary(tmp, ref));
+        PointCloudF rd;
+        EXPECT(ReadPCD(tmp, &rd) && rd.size() == ref.size());
+        bool pcd_ok = rd.size() == ref.size();
+        for (size_t i = 0; pcd_ok && i < ref.size(); i++) pcd_ok = memcmp(&rd.points[i], &ref.points[i], sizeof(PointF)) == 0;
+        EXPECT(pcd_ok);
+        remove(tmp);
+      }
+    }
+    lh_cloud_destroy(vox_msg); lh_cloud_destroy(vox_pcl); lh_cloud_destroy(c_msg); lh_cloud_destroy(c_pcl);
+    // a layout the C ABI cannot read in place (double coordinates) is refused before anything is uploaded
+    PointCloud2 bad = in;
+    bad.fields[0].datatype = PointField::FLOAT64;
+    EXPECT(!ViewFromPointCloud2(bad, &v));
   }
 
   lh_destroy(ctx);

@@ -93,6 +93,14 @@ def scan_pair(n_rings=64, n_az=1563, scale=2.0, noise=0.02, seed=10, delta=None,
     return src, tgt, delta
 
 
+def config1_pair():
+    """BASELINE configs[0] / SURVEY 8d row 1: VLP-16 pattern (16 rings -15..+15 deg x 1800 azimuths = 28.8 k rays) in the
+    unscaled room, range noise 0.02 m, seeds 1 / 2; the source is the same scene seen from
+    delta = (0.20, -0.10, 0.02 m; yaw 2 deg, pitch 0.3 deg).  Voxelised at 0.25 m it is the ~5 k-point plumbing case."""
+    delta = pose_matrix(0.20, -0.10, 0.02, 0.0, np.deg2rad(0.3), np.deg2rad(2.0))
+    return scan_pair(n_rings=16, n_az=1800, scale=1.0, noise=0.02, seed=1, delta=delta, elev_deg=(-15.0, 15.0))
+
+
 def hollow_cube(nx=10, ny=10, nz=10, step=0.1):
     """GenerateHollowCubic of the reference's odometry test (test_point_cloud_odometry.cpp:60-79): the four
     side walls of a 10x10x10 lattice (no top/bottom)."""

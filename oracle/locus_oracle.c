@@ -1277,7 +1277,13 @@ static int vox_cmp(const void* a, const void* b) {
   return x->pt < y->pt ? -1 : (x->pt > y->pt);
 }
 
-int lo_voxel_grid(const float* xyzi, int n, float leaf, int limit_axis, double lo, double hi, float* out, int out_cap) {
+/* nrm4 / out_nrm4 non-NULL: pcl::VoxelGrid<pcl::PointXYZINormal> (PointCloudFilter.cc:119-124).  PCL >= 1.8 fills a
+ * pcl::CentroidPoint<PointT> per voxel (filters/impl/voxel_grid.hpp); its accumulators (common/impl/accumulators.hpp, not
+ * vendored) are float sums in leaf order: AccumulatorXYZ, AccumulatorIntensity and AccumulatorCurvature return sum / n,
+ * AccumulatorNormal returns the NORMALISED sum of the normal 4-vectors (normal_x, normal_y, normal_z, 0); a zero sum stays
+ * zero (Eigen >= 3.3 normalized()). */
+static int voxel_grid_impl(const float* xyzi, const float* nrm4, int n, float leaf, int limit_axis, double lo, double hi, float* out,
+                           float* out_nrm4, int out_cap) {
   float inv = 1.0f / leaf;
   float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
   int any = 0;
@@ -1320,10 +1326,14 @@ int lo_voxel_grid(const float* xyzi, int n, float leaf, int limit_axis, double l
   int nout = 0;
   for (int s = 0; s < cnt;) {
     int e = s;
-    float acc[4] = {0, 0, 0, 0};
+    float acc[4] = {0, 0, 0, 0}, na[4] = {0, 0, 0, 0};
     while (e < cnt && pairs[e].idx == pairs[s].idx) {
       const float* p = xyzi + 4 * (size_t)pairs[e].pt;
       acc[0] += p[0]; acc[1] += p[1]; acc[2] += p[2]; acc[3] += p[3];
+      if (nrm4) {
+        const float* q = nrm4 + 4 * (size_t)pairs[e].pt;
+        na[0] += q[0]; na[1] += q[1]; na[2] += q[2]; na[3] += q[3];   /* [3] = curvature (its own accumulator) */
+      }
       e++;
     }
     float c = (float)(e - s);
@@ -1332,12 +1342,27 @@ int lo_voxel_grid(const float* xyzi, int n, float leaf, int limit_axis, double l
       out[4 * (size_t)nout + 1] = acc[1] / c;
       out[4 * (size_t)nout + 2] = acc[2] / c;
       out[4 * (size_t)nout + 3] = acc[3] / c;
+      if (nrm4 && out_nrm4) {
+        float z = (na[0] * na[0] + na[1] * na[1]) + na[2] * na[2];
+        if (z > 0.0f) { float l = sqrtf(z); na[0] = na[0] / l; na[1] = na[1] / l; na[2] = na[2] / l; }
+        out_nrm4[4 * (size_t)nout + 0] = na[0];
+        out_nrm4[4 * (size_t)nout + 1] = na[1];
+        out_nrm4[4 * (size_t)nout + 2] = na[2];
+        out_nrm4[4 * (size_t)nout + 3] = na[3] / c;
+      }
     }
     nout++;
     s = e;
   }
   free(pairs);
   return nout;
+}
+
+int lo_voxel_grid(const float* xyzi, int n, float leaf, int limit_axis, double lo, double hi, float* out, int out_cap) {
+  return voxel_grid_impl(xyzi, NULL, n, leaf, limit_axis, lo, hi, out, NULL, out_cap);
+}
+int lo_voxel_grid_pointf(const float* xyzi, const float* nrm4, int n, float leaf, float* out, float* out_nrm4, int out_cap) {
+  return voxel_grid_impl(xyzi, nrm4, n, leaf, -1, 0.0, 0.0, out, out_nrm4, out_cap);
 }
 
 /* ------------------------------------------------------------------------------------------

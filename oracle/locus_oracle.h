@@ -126,6 +126,9 @@ void lo_eig_sym(const double* A, int n, double* evals, double* evecs);
    (PCL then copies input to output). */
 int lo_voxel_grid(const float* xyzi, int n, float leaf, int limit_axis, double lo, double hi, float* out_xyzi,
                   int out_cap);
+/* the PointXYZINormal flavour, pcl::VoxelGrid<PointF> (PointCloudFilter.cc:119-124): nrm4 = nx,ny,nz,curvature per point;
+   same voxels and order, every field averaged (pcl::CentroidPoint accumulators), normals re-normalised */
+int lo_voxel_grid_pointf(const float* xyzi, const float* nrm4, int n, float leaf, float* out_xyzi, float* out_nrm4, int out_cap);
 /* K3 (filter flavour): pcl::NormalEstimationOMP k-NN (normal_computation.cc:26-59), viewpoint (0,0,0).
    out_nrm4 = nx,ny,nz,curvature. */
 void lo_normals_knn(const float* xyz4, int n, const lo_tree* t, int k, float* out_nrm4, int threads);

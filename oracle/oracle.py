@@ -111,6 +111,7 @@ def lib():
         L.lo_icp_covariance.argtypes = [C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]
         L.lo_eig_sym.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.lo_voxel_grid.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_int]
+        L.lo_voxel_grid_pointf.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_int]
         L.lo_normals_knn.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
         L.lo_normals_radius.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_void_p, C.c_int]
         L.lo_ndt_default_params.argtypes = [C.POINTER(LoNdtParams)]
@@ -358,6 +359,16 @@ def voxel_grid(xyzi, leaf, limit_axis=-1, lo=-np.inf, hi=np.inf):
     if n < 0:
         return None
     return out[:n].copy()
+
+
+def voxel_grid_pointf(xyzi, nrm4, leaf):
+    """pcl::VoxelGrid<PointXYZINormal> (PointCloudFilter.cc:119-124): returns (xyzi centroids, (nx, ny, nz, curvature))"""
+    xyzi, nrm4 = _f4(xyzi), _f4(nrm4)
+    out, out_n = np.empty_like(xyzi), np.empty_like(nrm4)
+    n = lib().lo_voxel_grid_pointf(_p(xyzi), _p(nrm4), xyzi.shape[0], leaf, _p(out), _p(out_n), xyzi.shape[0])
+    if n < 0:
+        return None
+    return out[:n].copy(), out_n[:n].copy()
 
 
 def normals_knn(pts4, k=20, threads=1, tree=None):

@@ -56,6 +56,17 @@ def test_no_cpu_fallback(capi):
     assert e.value.status == capi.LH_EDEVICE
 
 
+@pytest.mark.skipif(_has_gpu(), reason="only meaningful on a box without a GPU")
+def test_multi_device_entry_points_without_a_gpu(capi):
+    """the multi-GPU entry points load, validate their arguments and report "no device" without touching a GPU"""
+    L = capi.lib()
+    assert capi.device_count() == 0
+    P = capi.default_params()
+    assert L.lh_gicp_align_batch_multi(0, None, C.byref(P), 0, None, None, None, None, None, 0) == capi.LH_EINVAL
+    assert L.lh_gicp_align_batch_multi_views(1, None, C.byref(P), 0, None, None, None, None, 0) == capi.LH_EINVAL
+    assert L.lh_gicp_align_batch_out(None, C.byref(P), 0, None, None, None, None, None, 0) == capi.LH_EINVAL
+
+
 def test_missing_library_fails_loudly():
     code = ("import sys; sys.path.insert(0, %r); from locus_amd import capi; capi.LIB_PATH = '/nonexistent/liblocus_hip.so'; "
             "capi.lib()" % ROOT)

@@ -14,6 +14,53 @@ def _voxel(ctx, capi, pts, leaf):
     return out[:, :3].copy()
 
 
+def test_config1_plumbing_chain(ctx, capi, oracle):
+    """BASELINE configs[0]: 28.8 k-ray VLP-16 pair -> voxel grid 0.25 -> k = 20 normals -> GICP with the odometry
+    parameters.  Every stage of the HIP chain against the same stage of the oracle chain, then the two chains end to end."""
+    import importlib.util
+    import os
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("make_config1_golden", os.path.join(here, "make_config1_golden.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    c = mod.chain(threads=8)
+    ro = c["result"]
+    kw = dict(max_iterations=20, corr_dist=1.0, transformation_epsilon=1e-3)
+    # stage 1: K1 on the device, bit-exact (voxel order and centroids)
+    hs = capi.Cloud(ctx, capi.make_pointxyzi(c["src"])).voxel_grid(0.25)
+    ht = capi.Cloud(ctx, capi.make_pointxyzi(c["tgt"])).voxel_grid(0.25)
+    ds, dt_ = hs.download(), ht.download()
+    assert (np.stack([ds["x"], ds["y"], ds["z"]], 1) == c["vs"][:, :3]).all()
+    assert (np.stack([dt_["x"], dt_["y"], dt_["z"]], 1) == c["vt"][:, :3]).all()
+    # stage 2: K3 normals on the device vs the restatement (libm vs device trigonometry in pcl::eigen33: angle tolerance)
+    hs.normals_knn(20)
+    ht.normals_knn(20)
+    ds = hs.download()
+    cosang = np.abs((np.stack([ds["normal_x"], ds["normal_y"], ds["normal_z"]], 1) * c["ns"][:, :3]).sum(1))
+    assert np.quantile(cosang, 0.01) > 1 - 1e-4
+    # stage 3: GICP on IDENTICAL inputs (the restatement's voxels and normals), both cost modes
+    for mode, tol_t, tol_r in ((0, 1e-4, 1e-4), (1, 2e-3, 2.5e-3)):
+        g = capi.Gicp(ctx, capi.default_params(cost_mode=mode, **kw))
+        g.set_source(capi.make_pointf(c["vs"][:, :3], c["ns"]))
+        g.set_target(capi.make_pointf(c["vt"][:, :3], c["nt"]))
+        r = g.align()
+        A, B = oracle.T_to_mat(r["T"]), oracle.T_to_mat(ro["T"])
+        dt, dR = np.abs(A[:3, 3] - B[:3, 3]).max(), np.abs(A[:3, :3] - B[:3, :3]).max()
+        print("config 1, cost_mode %d on the oracle's inputs: |dt| %.2e |dR| %.2e, iterations %d / %d" % (mode, dt, dR, r["iterations"], ro["iterations"]))
+        assert r["status"] == 0 and r["converged"] == 1 and dt <= tol_t and dR <= tol_r
+        if mode == 0:
+            assert r["iterations"] == ro["iterations"] and r["n_corr_last"] == ro["n_corr_last"]
+    # the whole chain on the device (nothing crosses PCIe between the stages) against the whole chain on the CPU
+    g = capi.Gicp(ctx, capi.default_params(**kw))
+    g.set_source(hs)
+    g.set_target(ht)
+    r = g.align()
+    A, B = oracle.T_to_mat(r["T"]), oracle.T_to_mat(ro["T"])
+    assert r["status"] == 0 and r["converged"] == 1
+    assert np.abs(A[:3, 3] - B[:3, 3]).max() < 2.5e-3 and np.abs(A[:3, :3] - B[:3, :3]).max() < 2.5e-3
+    assert np.abs(A[:3, 3] - c["delta"][:3, 3]).max() < 0.01
+
+
 def test_config3_scan_to_submap_2M(ctx, capi, oracle):
     # map = union of scans along a 20 m path, voxelised at 0.05 m (SURVEY 8d config 3); localization parameters
     scans = []
