@@ -16,6 +16,13 @@ import os
 import sys
 import time
 
+# the CPU leg runs with OMP_PROC_BIND=close; the variable is read when the OpenMP runtime starts, so it has to
+# be in the environment before anything (torch, the oracle) loads one
+os.environ.setdefault("OMP_PROC_BIND", "close")
+os.environ.setdefault("OMP_PLACES", "cores")
+
+import ctypes as C
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -44,60 +51,83 @@ def make_pairs(ctx, n_pairs, rank, rings, az, scale):
     return S, T, host
 
 
-def cpu_baseline(S, T, host, P, budget_s=20.0):
-    """Reference-algorithm restatement (oracle) timed on the host cores: OMP on the two loops the reference
-    parallelises (k-NN/NN), serial cost functor (gicp.hpp:291-402).  Bounded sample of the same workload.  The thread
-    count matters a lot (the serial functor dominates and idle OMP teams get in its way), so one pair is timed at each of
-    1 / 4 (LOCUS default, locus.launch:75-77) / 16 / 64 / all hardware threads and the rest of the budget goes to the
-    fastest setting; `value` is that setting's rate, the others are listed in `by_threads`."""
-    from oracle import oracle as O
-    ncores = os.cpu_count() or 1
+# The reference's own float noise floor at this configuration (tests/perf/reference_noise_floor.py ->
+# profiles/r02_reference_noise_floor.json: the restatement built with vs. without FMA contraction in the functor's float T*p,
+# 16 bench pairs): |dt| 15 of 16 pairs <= 2.4e-4 m, max 2.5e-3 m; |dR| max 1.24e-4.  The benched mode is held to
+# max(1e-4, floor) against the CPU path: asserted below on the pairs the CPU leg samples.
+PARITY_TOL_T = max(1e-4, 2.5e-3)
+PARITY_TOL_R = max(1e-4, 1.3e-4)
+PARITY_TYPICAL_T = max(1e-4, 2.4e-4)
 
-    def params(threads):
+
+def physical_cores():
+    try:
+        import psutil
+        n = psutil.cpu_count(logical=False)
+        if n:
+            return int(n)
+    except Exception:
+        pass
+    return max(1, (os.cpu_count() or 2) // 2)
+
+
+def cpu_baseline(S, T, host, P):
+    """BASELINE.md 2 / SURVEY 8d CPU leg: the reference-algorithm restatement (oracle; NOT PCL) on the step's own pairs, with the
+    reference's parallelisation (OMP on the two NN loops, SERIAL cost functor, gicp.hpp:90,464,291-402) at OMP threads 1, 4
+    (LOCUS Husky default, locus.launch:75-77) and all physical cores, OMP_PROC_BIND=close, warm-up + timed pairs, MEDIAN
+    pairs/s; plus the "fully parallel CPU" variant (cost functor with an OMP reduction) at all physical cores.  Bounded
+    sample (~20 s of CPU work): 10 timed pairs at 4 threads, 3 at 1 thread, 5 at all cores, 5 fully parallel.
+    `value` = the best median of the reference-structured settings."""
+    from oracle import oracle as O
+    phys = physical_cores()
+
+    def params(threads, parallel_cost):
         return O.default_params(max_iterations=P.max_iterations, max_inner_iterations=P.max_inner_iterations, corr_dist=P.corr_dist,
                                 transformation_epsilon=P.transformation_epsilon, rotation_epsilon=P.rotation_epsilon,
-                                gicp_epsilon=P.gicp_epsilon, num_threads=threads)
+                                gicp_epsilon=P.gicp_epsilon, num_threads=threads, parallel_cost=parallel_cost)
+
+    cache = {}
 
     def host_pair(p):
-        a, b = S[p].download(), T[p].download()
-        return (O.xyz4(np.stack([a["x"], a["y"], a["z"]], 1)), O.nrm4(np.stack([a["normal_x"], a["normal_y"], a["normal_z"]], 1)),
-                O.xyz4(np.stack([b["x"], b["y"], b["z"]], 1)), O.nrm4(np.stack([b["normal_x"], b["normal_y"], b["normal_z"]], 1)))
+        if p not in cache:
+            a, b = S[p].download(), T[p].download()
+            cache[p] = (O.xyz4(np.stack([a["x"], a["y"], a["z"]], 1)), O.nrm4(np.stack([a["normal_x"], a["normal_y"], a["normal_z"]], 1)),
+                        O.xyz4(np.stack([b["x"], b["y"], b["z"]], 1)), O.nrm4(np.stack([b["normal_x"], b["normal_y"], b["normal_z"]], 1)))
+        return cache[p]
 
-    poses, stats, t_total = {}, {}, 0.0
-    cands = [t for t in (1, 4, 16, 64) if t < ncores] + [ncores]
-    nxt = 0
-
-    def run_one(th):
-        nonlocal nxt, t_total
-        src4, ns, tgt4, nt = host_pair(nxt)
-        t0 = time.perf_counter()
-        r = O.gicp_align(src4, ns, tgt4, nt, params(th), want_trace=False)
-        dt = time.perf_counter() - t0
-        poses[nxt] = r["T"]
-        st = stats.setdefault(th, [0, 0.0])
-        st[0] += 1
-        st[1] += dt
-        t_total += dt
-        nxt += 1
-
-    def rate(th):
-        return stats[th][0] / stats[th][1]
-
-    for th in cands:                        # round 1: one pair per setting
-        if nxt < len(S):
-            run_one(th)
-    for th in sorted(stats, key=rate, reverse=True)[:3]:   # round 2: a second pair for the three fastest (single pairs are noisy)
-        if nxt < len(S) and t_total < budget_s:
-            run_one(th)
-    best = max((th for th in stats if stats[th][0] >= min(2, max(v[0] for v in stats.values()))), key=rate)
-    while t_total < budget_s and nxt < len(S) and stats[best][0] < 10:
-        run_one(best)
-    k, tt = stats[best]
-    return {"value": k / tt, "unit": "scan-pairs/s", "cores": best, "kind": "port",
-            "by_threads": {str(th): round(v[0] / v[1], 4) for th, v in stats.items()},
-            "sample": "%d of the step's %d-pt pairs at %d OMP threads (fastest of %s on this %d-thread host; %.1f s of CPU work in all), "
-                      "20 outer iterations, OMP on NN loops + serial cost functor like the reference"
-                      % (k, len(S[0]), best, "/".join(str(c) for c in stats), ncores, t_total)}, poses
+    poses, rows, t_total = {}, [], 0.0
+    plan = [(4, 0, 1, 10), (1, 0, 0, 3), (phys, 0, 1, 5), (phys, 1, 1, 5)]   # threads, parallel cost functor, warm-up pairs, timed pairs
+    for threads, par, warm, timed in plan:
+        times, stages = [], []
+        for k in range(warm + timed):
+            p = (k - warm) % len(S) if k >= warm else len(S) - 1 - k
+            src4, ns, tgt4, nt = host_pair(p)
+            t0 = time.perf_counter()
+            r = O.gicp_align(src4, ns, tgt4, nt, params(threads, par), want_trace=False)
+            dt = time.perf_counter() - t0
+            t_total += dt
+            if k >= warm:
+                times.append(dt)
+                stages.append((r["t_index"], r["t_cov"], r["t_nn"], r["t_opt"]))
+                if not par:
+                    poses.setdefault(p, r["T"])
+        med = float(np.median(times))
+        st = np.median(np.array(stages), 0)
+        rows.append({"threads": threads, "cost_functor": "omp-reduction (fully parallel variant)" if par else "serial (reference)",
+                     "pairs_timed": timed, "median_s_per_pair": round(med, 4), "pairs_per_s": round(1.0 / med, 4),
+                     "stage_median_s": {"index": round(float(st[0]), 4), "covariances": round(float(st[1]), 4),
+                                        "nn_sweeps": round(float(st[2]), 4), "optimiser": round(float(st[3]), 4)}})
+    ref_rows = [r for r in rows if r["cost_functor"].startswith("serial")]
+    best = max(ref_rows, key=lambda r: r["pairs_per_s"])
+    par_row = [r for r in rows if not r["cost_functor"].startswith("serial")][0]
+    return {"value": best["pairs_per_s"], "unit": "scan-pairs/s", "cores": best["threads"], "kind": "port",
+            "by_threads": {str(r["threads"]): r["pairs_per_s"] for r in ref_rows},
+            "fully_parallel_variant": {"value": par_row["pairs_per_s"], "cores": par_row["threads"]},
+            "rows": rows, "physical_cores": phys, "omp_proc_bind": os.environ.get("OMP_PROC_BIND"),
+            "sample": "median over %d timed pairs of the step's %d-pt pairs at %d OMP threads (1 / 4 / %d physical cores sampled: 3 / 10 / 5 "
+                      "timed pairs after a warm-up pair; fully parallel variant 5 pairs; %.1f s of CPU work in all), 20 outer iterations, "
+                      "OMP on the NN loops + serial cost functor like the reference, OMP_PROC_BIND=close"
+                      % (best["pairs_timed"], len(S[0]), best["threads"], phys, t_total)}, poses
 
 
 def main():
@@ -112,7 +142,7 @@ def main():
     ap.add_argument("--scale", type=float, default=2.0)
     ap.add_argument("--cost-mode", type=int, default=1, help="lh_gicp_params.cost_mode (1 = moments, 0 = per-evaluation passes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--single-latency", action="store_true", help="also time one-pair-at-a-time lh_gicp_align")
+    ap.add_argument("--no-single-latency", action="store_true", help="skip the one-pair-at-a-time lh_gicp_align latency leg")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the measured configuration) or gloo (functional check)")
     ap.add_argument("--same-gpu", action="store_true",
                     help="functional check of the N > 1 code path on a 1-GPU box: every rank uses cuda:0 (needs --dist-backend gloo); "
@@ -151,13 +181,23 @@ def main():
     S, T, host = make_pairs(ctx, args.pairs, rank, args.rings, args.azimuths, args.scale)
     n_pts = len(S[0])
 
+    # align()'s output clouds (gicp.hpp:586) are part of every alignment: lh_gicp_align_batch_out writes them on the device as the
+    # pairs retire.  They are created once, outside the timed region, like every other buffer (a streaming caller keeps them).
+    _, A = capi.align_batch_out(ctx, P, S, T, max_in_flight=args.in_flight)
+    gathered = [None]
+
     def step(in_flight=None, exchange=True):
         for t in T:
             t.drop_index()  # align() rebuilds the target index every scan, like pcl::Registration::initCompute
-        out = capi.align_batch(ctx, P, S, T, max_in_flight=in_flight or args.in_flight)
-        if world > 1 and exchange:  # result gather over RCCL/xGMI: 16 floats per pair; no data-path collective
-            ldist.gather_poses(np.stack([o["T"] for o in out]), world, device=ddev)
-        return out
+        raw, _ = capi.align_batch_out(ctx, P, S, T, max_in_flight=in_flight or args.in_flight, aligned=A, raw=True)
+        if world > 1 and exchange:
+            # the ONLY exchange of the pair-sharded path: one all_gather of the lh_gicp_result records (96 B per pair)
+            # on device tensors over RCCL/xGMI; no data-path collective
+            gathered[0] = ldist.gather_records(raw, world, device=ddev)
+        return raw
+
+    def results(raw):
+        return [capi._result_dict(raw[i]) for i in range(len(raw))]
 
     def barrier():
         ctx.synchronize()
@@ -175,6 +215,11 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     elapsed = ldist.max_over_ranks(elapsed, world, device=ddev)
+    if world > 1:   # the gathered table holds this rank's records at its own offset, bit for bit
+        mine = bytes(bytearray(out))
+        got = bytes(gathered[0].cpu().numpy().tobytes())[rank * len(mine):(rank + 1) * len(mine)]
+        assert got == mine, "result all_gather corrupted the records"
+    out = results(out)
     total_pairs = args.pairs * args.steps * world
     value = total_pairs / elapsed
     ok = all(o["status"] == 0 for o in out)
@@ -212,9 +257,13 @@ def main():
                     traffic = traffic * prof_in_flight / ent["jobs_per_launch"]
             except Exception:
                 traffic = None
+        avg_us = 1e3 * st["ms"] / max(1, st["launches"])
+        # hbm_frac_real: the kernel's MEASURED DRAM traffic (PMC, profiles/pmc_latest.json) / its launch time / peak -- how busy HBM
+        # really is.  A fused kernel legitimately moves fewer bytes than the algorithmic model, so this sits below `frac`.
+        hbm_frac_real = round(traffic / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5) if traffic else None
         roofline = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                    "avg_launch_us": round(1e3 * st["ms"] / max(1, st["launches"]), 2), "launches": st["launches"],
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "hbm_frac_real": hbm_frac_real,
+                    "avg_launch_us": round(avg_us, 2), "launches": st["launches"],
                     "jobs_per_launch": prof_in_flight,
                     "algorithmic_bytes_per_launch": round(st["bytes"] / max(1, st["launches"]), 1),
                     "kernels_ms": {k: round(v["ms"], 3) for k, v in sorted(stats.items(), key=lambda kv: -kv[1]["ms"])}}
@@ -223,15 +272,17 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 geometry / f64 cost",
             "data": "synthetic",
-            "config": {"workload": "configs[1]: 100k-pt Velodyne-style scan-to-scan GICP, 20 outer iterations, odometry params "
-                                   "(corr_dist 1.0, inner 20), covariances from k=20 normals; %d independent pairs per GPU per step, "
-                                   "%d in flight" % (args.pairs, args.in_flight),
+            "config": {"workload": "configs[1]: 100k-pt Velodyne-style scan-to-scan GICP, 20 outer iterations (stopping thresholds "
+                                   "-> 0; a pair whose iterate repeats bit for bit stops earlier, gicp.hpp:566, exactly as the reference "
+                                   "does: see outer_iterations_min_mean_max), odometry params (corr_dist 1.0, inner 20), covariances from "
+                                   "k=20 normals, index rebuilt and aligned output cloud written for every pair; %d independent pairs per "
+                                   "GPU per step, %d in flight" % (args.pairs, args.in_flight),
                        "points_per_scan": n_pts, "pairs_per_gpu_per_step": args.pairs, "parallelism": "pairs sharded over %d GPU(s)" % world},
             "all_ok": bool(ok), "outer_iterations_min_mean_max": [min(iters), float(np.mean(iters)), max(iters)],
             "cost_mode": args.cost_mode, "mean_cost_evaluations_per_pair": passes, "max_translation_err_vs_truth_m": float(np.max(errs)),
             "roofline": roofline,
         }
-        if args.single_latency:
+        if not args.no_single_latency:
             g = capi.Gicp(ctx, P)
             g.set_source(S[0])
             g.set_target(T[0])
@@ -286,17 +337,33 @@ def main():
                 "max_abs_pose_diff_vs_20_forced_iterations": float(max(np.abs(np.asarray(a["T"]) - np.asarray(b["T"])).max() for a, b in zip(outn, out)))}
         if world == 1 and not args.no_cpu_baseline:
             cb, poses = cpu_baseline(S, T, host, P)
-            # parity of the timed GPU work against the CPU path on the sampled pairs (reported, asserted in tests/)
-            d = 0.0
-            for k, To in poses.items():
-                d = max(d, float(np.abs(np.asarray(out[k]["T"]) - np.asarray(To)).max()))
-            cb["max_abs_pose_diff_vs_gpu"] = d
+            # parity of the TIMED GPU work against the CPU path on every pair the CPU leg sampled: asserted against the stated
+            # tolerance max(1e-4, reference noise floor at this configuration) -- tests/test_gpu_align.py holds the same bar
+            dts, drs = [], []
+            for k, To in sorted(poses.items()):
+                A_, B_ = np.asarray(out[k]["T"], np.float64).reshape(4, 4).T, np.asarray(To, np.float64).reshape(4, 4).T
+                dts.append(float(np.abs(A_[:3, 3] - B_[:3, 3]).max()))
+                drs.append(float(np.abs(A_[:3, :3] - B_[:3, :3]).max()))
+            cb["max_abs_pose_diff_vs_gpu"] = max(max(dts), max(drs))
             result["cpu_baseline"] = cb
+            tol_t, tol_r = (1e-4, 1e-4) if args.cost_mode == 0 else (PARITY_TOL_T, PARITY_TOL_R)
+            result["parity"] = {
+                "against": "cpu_baseline poses (reference arithmetic), the %d pairs the CPU leg sampled" % len(dts),
+                "tolerance_translation_m": tol_t, "tolerance_rotation": tol_r, "typical_translation_m": PARITY_TYPICAL_T,
+                "tolerance_is": "1e-4 (SURVEY 8d)" if args.cost_mode == 0 else
+                                "max(1e-4, the reference's own FMA / non-FMA noise floor at this configuration, profiles/r02_reference_noise_floor.json)",
+                "max_dt_m": max(dts), "median_dt_m": float(np.median(dts)), "max_dR": max(drs),
+                "pairs_within_typical": int(sum(d <= PARITY_TYPICAL_T for d in dts)), "n_pairs": len(dts)}
+            parity_ok = max(dts) <= tol_t and max(drs) <= tol_r and (args.cost_mode == 0 or float(np.median(dts)) <= PARITY_TYPICAL_T)
+            result["parity"]["ok"] = bool(parity_ok)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(result))
+        sys.stdout.flush()
+        if "parity" in result:   # a fast kernel whose results differ from the reference's is not done
+            assert result["parity"]["ok"], "GPU vs CPU pose parity outside the stated tolerance: %r" % (result["parity"],)
 
 
 if __name__ == "__main__":

@@ -71,7 +71,10 @@ typedef struct {
                                     1 = (default) second-order moments: the sums are exactly quadratic in the 12 entries of T,
                                         so ONE 74-moment reduction per outer iteration serves every BFGS evaluation (double
                                         T*p instead of float: differs from mode 0 by the reference's own float rounding noise) */
-  int reserved0;
+  int solver;                    /* where the loop between two sweeps runs in cost_mode 1 (the BFGS solve on the 74 moments, the convergence
+                                    test): 0 = (default) on the device, k_solve -- the host only enqueues iterations and looks at the pairs'
+                                    states every few rounds; 1 = on the host, one sync per outer iteration (the path the source-sharded
+                                    pair takes anyway, lh_set_allreduce).  Same code, same arithmetic (lh_math.hpp): identical results. */
 } lh_gicp_params;
 
 typedef struct {

@@ -50,7 +50,7 @@ class GicpParams(C.Structure):
         ("num_threads", C.c_int),
         ("enable_timing", C.c_int),
         ("cost_mode", C.c_int),
-        ("reserved0", C.c_int),
+        ("solver", C.c_int),
     ]
 
 

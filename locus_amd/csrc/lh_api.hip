@@ -218,6 +218,12 @@ struct lh_ctx {
   size_t partials_per_slot = 0;    // doubles
   double* mom_partials_dev = nullptr;  // [n_slots][mom_stride] per-block moment partials (device)
   int mom_stride = 0;
+  // device-driven loop (cost_mode 1, k_solve): per-slot loop state, the chunk sums k_moments_final leaves for k_solve
+  OuterState* states_dev = nullptr;    // [n_slots]
+  OuterState* states_host = nullptr;   // pinned: upload staging at admission / download target when the host looks
+  OuterState* states_init = nullptr;   // pinned: initial states (separate from the download target: uploads and downloads overlap)
+  double* chunks_dev = nullptr;        // [n_slots][FINAL_CHUNKS * MOM_ROW]
+  hipEvent_t group_ev[2] = {nullptr, nullptr};
   // batch mode: one workspace per scheduler slot.  They live here (not in a thread-local) so that they are tied to this
   // context's device, reused by every thread that drives the context, and released by lh_destroy.
   std::vector<Workspace> slot_ws;
@@ -499,10 +505,20 @@ static lh_status ctx_ensure_slots(lh_ctx* c, int n_slots, int max_n) {
   mom_stride = std::max(mom_stride, c->mom_stride);
   (void)lhFree(c->descs_dev);
   (void)lhFree(c->mom_partials_dev);
+  (void)lhFree(c->states_dev);
+  (void)lhFree(c->chunks_dev);
   if (c->descs_host) (void)hipHostFree(c->descs_host);
   if (c->partials_host) (void)hipHostFree(c->partials_host);
+  if (c->states_host) (void)hipHostFree(c->states_host);
+  if (c->states_init) (void)hipHostFree(c->states_init);
   HIPCHK(hipMalloc(&c->descs_dev, sizeof(PairDesc) * n_slots));
   HIPCHK(hipMalloc(&c->mom_partials_dev, sizeof(double) * (size_t)mom_stride * n_slots));
+  HIPCHK(hipMalloc(&c->states_dev, sizeof(OuterState) * n_slots));
+  HIPCHK(hipMalloc(&c->chunks_dev, sizeof(double) * (size_t)FINAL_CHUNKS * MOM_ROW * n_slots));
+  HIPCHK(hipHostMalloc(&c->states_host, sizeof(OuterState) * n_slots, hipHostMallocDefault));
+  HIPCHK(hipHostMalloc(&c->states_init, sizeof(OuterState) * n_slots, hipHostMallocDefault));
+  for (int k = 0; k < 2; k++)
+    if (!c->group_ev[k]) HIPCHK(hipEventCreateWithFlags(&c->group_ev[k], hipEventDisableTiming));
   c->mom_stride = mom_stride;
   HIPCHK(hipHostMalloc(&c->descs_host, sizeof(PairDesc) * n_slots, hipHostMallocDefault));
   HIPCHK(hipHostMalloc(&c->partials_host, sizeof(double) * per_slot * n_slots, hipHostMallocDefault));
@@ -518,7 +534,7 @@ enum Req { REQ_NONE = 0, REQ_SWEEP, REQ_COST, REQ_DONE };
 struct Task;
 static thread_local Task* g_boot_task = nullptr;
 
-struct Task : public CostFn {
+struct Task {
   // inputs
   lh_gicp_params P;
   lh_cloud *src = nullptr, *tgt = nullptr;
@@ -529,18 +545,22 @@ struct Task : public CostFn {
   hipStream_t stream = nullptr;  // the stream of the scheduler group that owns the task
   lh_gicp_trace* trace = nullptr;
   lh_cloud* aligned = nullptr;   // batch API: receives final_transformation_ * input (gicp.hpp:586) when the pair retires
-  // coroutine
+  // coroutine (host-driven loop)
   ucontext_t ctx, sched;
   std::vector<char> stack;
   Req req = REQ_NONE;
   float req_T12[12];
-  double req_R9[9];
   double res_sums[COST_NSUM];
-  MomentModel mom;  // cost_mode 1: filled by the scheduler after each sweep
+  MomentModel mom;  // cost_mode 1 on the host: filled by the scheduler after each sweep
   bool sweep_bytes_pending = false;
   bool count_stats = false;  // debug sweeps only
   bool first_sweep = true;   // cold: gets a seed pre-pass
   long last_walks = -1;      // tree walks of the previous fused sweep (instrumentation: how many certificates failed)
+  // device-driven loop
+  lh_gicp_trace* trace_dev = nullptr;
+  int enq_iters = 0;         // outer iterations enqueued so far
+  // the loop's state (host-driven: advanced by run(); device-driven: the last download of the pair's device state)
+  OuterState os;
   // outputs
   lh_gicp_result result;
 
@@ -555,88 +575,74 @@ struct Task : public CostFn {
     for (int r = 0; r < 3; r++)
       for (int c = 0; c < 4; c++) T12[r * 4 + c] = T16[c * 4 + r];
   }
-  // CostFn: one fused device pass (gicp.hpp:362-402)
-  void pass(const double x[6], double sums13[13], double* count) override {
-    float T16[16];
-    apply_state(x, T16);  // base_transformation_ = I (gicp.hpp:435, 367-368)
-    if (P.cost_mode == 1) {  // every evaluation of this outer iteration comes from the 74 moments of the last sweep
-      mom.sums(T16, sums13);
-      *count = mom.count();
-      return;
+  // cost_mode 0: one fused device pass per evaluation (gicp.hpp:362-402), reference arithmetic; libm on the host like the oracle
+  struct DevicePass {
+    Task* t;
+    void operator()(const double x[6], double sums13[13], double* count) {
+      float T16[16];
+      apply_state<LibmMath>(x, T16);  // base_transformation_ = I (gicp.hpp:435, 367-368)
+      T16_to_T12(T16, t->req_T12);
+      t->yield(REQ_COST);
+      memcpy(sums13, t->res_sums, sizeof(double) * 13);
+      *count = t->res_sums[13];
     }
-    T16_to_T12(T16, req_T12);
-    yield(REQ_COST);
-    memcpy(sums13, res_sums, sizeof(double) * 13);
-    *count = res_sums[13];
-  }
+  };
 
-  // computeTransformation (gicp.hpp:406-617); covariances / index were prepared by the caller
-  void run() {
+  // final_transformation_ = previous_transformation_ * guess (gicp.hpp:583), float; result fields from the loop state
+  void finish_result() {
     memset(&result, 0, sizeof(result));
     result.fitness = NAN;
-    float transformation[16], previous[16];
-    memcpy(transformation, I16, sizeof(I16));  // pcl::Registration::align resets transformation_ to identity
-    memcpy(previous, I16, sizeof(I16));
-    int nr_iterations = 0;
-    bool converged = false;
-    double delta = 0;
-    if (trace) trace->n_iters = 0;
-    while (!converged) {
-      // transform_R = double(transformation_) * double(guess)   (gicp.hpp:450-460)
-      double TR[16];
-      for (int i = 0; i < 4; i++)
-        for (int j = 0; j < 4; j++) {
-          double s = 0.0;
-          for (int k = 0; k < 4; k++) s += (double)transformation[k * 4 + i] * (double)guess[j * 4 + k];
-          TR[i * 4 + j] = s;
-        }
-      for (int r = 0; r < 3; r++)
-        for (int c = 0; c < 3; c++) req_R9[r * 3 + c] = TR[r * 4 + c];
-      T16_to_T12(transformation, req_T12);
-      yield(REQ_SWEEP);                                   // gicp.hpp:464-498
-      memcpy(previous, transformation, sizeof(previous)); // gicp.hpp:518
-      have = false;                                       // new correspondences invalidate the functor cache
-      int before = passes, n_inner = 0;
-      double f_end = 0;
-      int st = estimate_rigid_bfgs(this, P.max_inner_iterations, transformation, &n_inner, &f_end);
-      result.n_correspondences_last = (int)count();
-      if (st != 0) {                                      // exception caught -> break (gicp.hpp:542-547)
-        result.status = (st == -4) ? LH_ETOO_FEW_CORR : LH_ESOLVER;
-        break;
-      }
-      delta = 0.;                                         // gicp.hpp:526-541
-      for (int k = 0; k < 4; k++)
-        for (int l = 0; l < 4; l++) {
-          double ratio = (k < 3 && l < 3) ? 1. / P.rotation_epsilon : 1. / P.transformation_epsilon;
-          double c_delta = ratio * fabs((double)previous[l * 4 + k] - (double)transformation[l * 4 + k]);
-          if (c_delta > delta) delta = c_delta;
-        }
-      if (trace && nr_iterations < LH_MAX_TRACE) {
-        int it = nr_iterations;
-        memcpy(trace->T[it], transformation, sizeof(transformation));
-        trace->n_corr[it] = (int)count();
-        trace->n_passes[it] = passes - before;
-        trace->n_inner[it] = n_inner;
-        trace->f_end[it] = f_end;
-        trace->delta[it] = delta;
-        trace->n_iters = it + 1;
-      }
-      nr_iterations++;
-      if (nr_iterations >= P.max_iterations || delta < 1) {  // gicp.hpp:566
-        converged = true;
-        memcpy(previous, transformation, sizeof(previous));
-      }
-    }
-    // final_transformation_ = previous_transformation_ * guess (gicp.hpp:583), float
     for (int c = 0; c < 4; c++)
       for (int r = 0; r < 4; r++) {
-        float s = 0.0f;
-        for (int k = 0; k < 4; k++) s += previous[k * 4 + r] * guess[c * 4 + k];
-        result.T[c * 4 + r] = s;
+        float sm = 0.0f;
+        for (int k = 0; k < 4; k++) sm += os.prev[k * 4 + r] * guess[c * 4 + k];
+        result.T[c * 4 + r] = sm;
       }
-    result.converged = converged ? 1 : 0;
-    result.iterations = nr_iterations;
-    result.cost_passes = passes;
+    result.converged = os.converged;
+    result.iterations = os.iter;
+    result.n_correspondences_last = os.n_corr_last;
+    result.cost_passes = os.passes;
+    result.status = os.status == 0 ? LH_OK : (os.status == -4 ? LH_ETOO_FEW_CORR : LH_ESOLVER);  // the exception the reference caught (gicp.hpp:542-547)
+  }
+
+  // computeTransformation (gicp.hpp:406-617), host-driven; covariances / index were prepared by the caller
+  void run() {
+    outer_state_init(&os);  // pcl::Registration::align resets transformation_ to identity
+    if (trace) trace->n_iters = 0;
+    const OuterParams OP{P.max_iterations, P.max_inner_iterations, P.rotation_epsilon, P.transformation_epsilon};
+    while (!os.done) {
+      T16_to_T12(os.T, req_T12);
+      yield(REQ_SWEEP);                                   // gicp.hpp:464-498 (transform_R is formed in the kernel from T and the guess)
+      const int before = os.passes, it = os.iter;
+      double k_t;
+      if (P.cost_mode == 1) {  // every evaluation of this outer iteration comes from the 74 moments of the sweep: no device pass
+        typedef MomentPass<PortableMath> Pass;
+        typedef CostEval<Pass, PortableMath> Fn;
+        Pass pass{&mom};
+        Fn fn;               // new correspondences: a fresh functor cache
+        fn.pass = &pass;
+        outer_step<Fn, PortableMath>(&fn, OP, &os);
+        k_t = mom.count();
+      } else {
+        typedef CostEval<DevicePass, LibmMath> Fn;
+        DevicePass pass{this};
+        Fn fn;
+        fn.pass = &pass;
+        outer_step<Fn, LibmMath>(&fn, OP, &os);
+        k_t = fn.count();
+      }
+      os.corr_sum += k_t;
+      if (trace && os.status == 0 && it < LH_MAX_TRACE) {
+        memcpy(trace->T[it], os.T, sizeof(os.T));
+        trace->n_corr[it] = os.n_corr_last;
+        trace->n_passes[it] = os.passes - before;
+        trace->n_inner[it] = os.n_inner;
+        trace->f_end[it] = os.f_end;
+        trace->delta[it] = os.delta;
+        trace->n_iters = it + 1;
+      }
+    }
+    finish_result();
     yield(REQ_DONE);
   }
 
@@ -653,8 +659,6 @@ struct Task : public CostFn {
     ctx.uc_link = &sched;
     makecontext(&ctx, (void (*)())entry, 0);
     g_boot_task = this;
-    have = false;
-    passes = 0;
     req = REQ_NONE;
     first_sweep = true;
     resume();  // runs until the first request
@@ -715,6 +719,11 @@ static lh_status task_prepare(lh_ctx* c, Task* t, bool rebuild_index) {
   d.guess_identity = 1;
   for (int k = 0; k < 9; k++)
     if (d.guess3[k] != ((k % 4 == 0) ? 1.0 : 0.0)) d.guess_identity = 0;
+  d.max_iterations = P.max_iterations;
+  d.max_inner_iterations = P.max_inner_iterations;
+  d.rotation_epsilon = P.rotation_epsilon;
+  d.transformation_epsilon = P.transformation_epsilon;
+  d.trace = t->trace_dev;
   HIPCHK(hipMemcpyAsync(&c->descs_dev[t->slot], &d, sizeof(PairDesc), hipMemcpyHostToDevice, ts));
   HIPCHK(hipGetLastError());
   return LH_OK;
@@ -795,8 +804,8 @@ static lh_status group_launch(lh_ctx* c, Group& g) {
         g.moms.push_back(t);
       }
       ProfScope p(c, "nn_sweep", bytes, st);
-      launch_sweep_fused(c->descs_dev, a, max_n, c->mom_partials_dev, c->mom_stride, st);
-      launch_moments_final(c->descs_dev, ca, c->mom_partials_dev, c->mom_stride, c->partials_host, st);
+      launch_sweep_fused(c->descs_dev, a, max_n, c->mom_partials_dev, c->mom_stride, nullptr, st);
+      launch_moments_final(c->descs_dev, ca, c->mom_partials_dev, c->mom_stride, c->partials_host, nullptr, st);
     } else {
       {
         ProfScope p(c, "nn_sweep", bytes, st);
@@ -914,9 +923,209 @@ static lh_status group_collect(lh_ctx* c, Group& g) {
   return LH_OK;
 }
 
+// ---- device-driven loop (cost_mode 1) --------------------------------------------------------------------------------
+// The whole outer loop of a pair lives on the GPU: every iteration is k_sweep_fused -> k_moments_final -> k_solve on the pair's
+// device state, and the next sweep reads the transform k_solve left there.  The host only enqueues: ROUNDS iterations per
+// group back to back, then one small download of the group's states to see which pairs have ended (converged, failed, or
+// out of iterations); those retire (result, aligned output cloud), new pairs are admitted into their slots, and the next
+// rounds go out.  Two groups on two streams as in the host-driven scheduler: one group's k_solve (a single wave per pair) and
+// launch gaps are covered by the other group's sweeps.  Pairs that end early are skipped by the kernels until the host looks.
+struct DevGroup {
+  hipStream_t stream = nullptr;
+  hipEvent_t ev = nullptr;
+  std::vector<Task*> active;
+  std::vector<int> free_slots;
+  int slot_lo = 0, slot_hi = 0;  // this group's contiguous slot range
+  bool pending = false;          // rounds are enqueued and a state download is in flight behind them
+};
+
+static lh_status dev_retire(lh_ctx* c, DevGroup& g, Task* t) {
+  t->os = c->states_host[t->slot];
+  t->finish_result();
+  if (c->prof)  // fused K4+K5': algorithmic bytes B_nn + one B_fdf per iteration = 20 N + (232 + 108) K_t
+    c->prof_entries[c->prof_entry("nn_sweep")].bytes += 340.0 * t->os.corr_sum;
+  if (t->aligned) {  // pcl::transformPointCloud(*input_, output, final_transformation_) (gicp.hpp:586), on the group's stream
+    float T12[12];
+    Task::T16_to_T12(t->result.T, T12);
+    ProfScope p(c, "transform", 32.0 * t->src->n, g.stream);
+    launch_transform_copy(t->src->xyz, t->aligned->nrm ? t->src->nrm : nullptr, t->aligned->intensity ? t->src->intensity : nullptr, t->src->n, T12,
+                          t->aligned->xyz, t->aligned->nrm, t->aligned->intensity, g.stream);
+  }
+  if (t->trace && t->trace_dev) {
+    HIPCHK(hipMemcpyAsync(t->trace, t->trace_dev, sizeof(lh_gicp_trace), hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+  }
+  if (t->trace_dev) { (void)lhFree(t->trace_dev); t->trace_dev = nullptr; }
+  return LH_OK;
+}
+
+// enqueue `rounds` outer iterations for every active pair of the group, then the download of the group's states
+static lh_status dev_enqueue(lh_ctx* c, DevGroup& g, int rounds) {
+  hipStream_t st = g.stream;
+  for (int r = 0; r < rounds; r++) {
+    for (size_t o = 0; o < g.active.size(); o += MAX_JOBS) {
+      SweepArgs a;
+      CostArgs ca;
+      SolveArgs sa;
+      a.njobs = (int)std::min<size_t>(MAX_JOBS, g.active.size() - o);
+      a.bpj = 0; a.max_depth = 0; a.pad = 0;
+      ca.njobs = a.njobs; ca.pad = 0;
+      sa.njobs = a.njobs;
+      int max_n = 0;
+      double bytes = 0;
+      SweepArgs seed;
+      seed.njobs = 0; seed.max_depth = 0; seed.pad = 0; seed.bpj = 0;
+      int smax = 0;
+      for (int j = 0; j < a.njobs; j++) {
+        Task* t = g.active[o + j];
+        a.job[j].slot = t->slot;
+        a.job[j].pad = 0;
+        Task::T16_to_T12(I16, a.job[j].T);  // only the seed pass of a cold pair reads it (transformation_ = I); sweeps read the device state
+        ca.job[j].slot = t->slot;
+        ca.job[j].out_offset = t->slot * (FINAL_CHUNKS * MOM_ROW);
+        memcpy(ca.job[j].T, a.job[j].T, sizeof(a.job[j].T));
+        sa.slot[j] = t->slot;
+        max_n = std::max(max_n, t->src->n);
+        if (t->enq_iters < t->P.max_iterations) bytes += 20.0 * t->src->n;  // SURVEY 8d B_nn = 20 N + 232 K_t; the K_t terms are added at retirement
+        if (t->first_sweep) {  // cold pair: seed pre-pass so its first sweep starts warm
+          seed.job[seed.njobs++] = a.job[j];
+          smax = std::max(smax, t->src->n);
+          t->first_sweep = false;
+        }
+        t->enq_iters++;
+      }
+      if (seed.njobs > 0) {
+        ProfScope p(c, "nn_seed", 0.0, st);
+        launch_seed(c->descs_dev, seed, smax, st);
+      }
+      {
+        ProfScope p(c, "nn_sweep", bytes, st);
+        launch_sweep_fused(c->descs_dev, a, max_n, c->mom_partials_dev, c->mom_stride, c->states_dev, st);
+        launch_moments_final(c->descs_dev, ca, c->mom_partials_dev, c->mom_stride, c->chunks_dev, c->states_dev, st);
+      }
+      {
+        ProfScope p(c, "bfgs_solve", 0.0, st);
+        launch_solve(c->descs_dev, sa, c->chunks_dev, FINAL_CHUNKS * MOM_ROW, c->states_dev, st);
+      }
+    }
+  }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(c->states_host + g.slot_lo, c->states_dev + g.slot_lo, sizeof(OuterState) * (size_t)(g.slot_hi - g.slot_lo),
+                        hipMemcpyDeviceToHost, st));
+  HIPCHK(hipEventRecord(g.ev, st));
+  g.pending = true;
+  return LH_OK;
+}
+
+static lh_status run_tasks_device(lh_ctx* c, std::vector<Task*>& tasks, int in_flight, bool rebuild_index, std::vector<Workspace>* slot_ws) {
+  static const int rounds_cfg = []() { const char* e = getenv("LH_DEVICE_ROUNDS"); int v = e ? atoi(e) : 4; return v < 1 ? 1 : v; }();
+  const int G = (in_flight >= 16 && !c->prof) ? 2 : 1;  // profiling keeps one group so HIP-event times do not overlap
+  if (G == 2 && !c->stream2) HIPCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+  DevGroup groups[2];
+  groups[0].stream = c->stream;
+  groups[1].stream = c->stream2;
+  {
+    int per = (in_flight + G - 1) / G, s = 0;
+    for (int gi = 0; gi < G; gi++) {
+      groups[gi].ev = c->group_ev[gi];
+      groups[gi].slot_lo = s;
+      for (int k = 0; k < per && s < in_flight; k++, s++) groups[gi].free_slots.push_back(s);
+      groups[gi].slot_hi = s;
+    }
+  }
+  size_t next = 0;
+  lh_status err = LH_OK;
+  auto fail = [&](lh_status st) {
+    (void)hipStreamSynchronize(c->stream);
+    if (c->stream2) (void)hipStreamSynchronize(c->stream2);
+    for (Task* t : tasks)
+      if (t->trace_dev) { (void)lhFree(t->trace_dev); t->trace_dev = nullptr; }
+    return st;
+  };
+  auto busy = [&]() {
+    for (int gi = 0; gi < G; gi++)
+      if (!groups[gi].active.empty()) return true;
+    return false;
+  };
+  while (next < tasks.size() || busy()) {
+    for (int gi = 0; gi < G; gi++) {
+      DevGroup& g = groups[gi];
+      lh_status st;
+      if (g.pending) {  // wait for THIS group's rounds; the other group's are still queued / running
+        HIPCHK(hipEventSynchronize(g.ev));
+        g.pending = false;
+        for (size_t i = 0; i < g.active.size();) {
+          Task* t = g.active[i];
+          const OuterState& os = c->states_host[t->slot];
+          if (os.done) {
+            st = dev_retire(c, g, t);
+            if (st) return fail(st);
+            g.free_slots.push_back(t->slot);
+            g.active.erase(g.active.begin() + i);
+          } else
+            i++;
+        }
+      }
+      if (next < tasks.size() && !g.free_slots.empty()) {  // admit: the NN indexes of all newly admitted targets are built together
+        std::vector<lh_cloud*> to_build;
+        size_t nn = next;
+        for (size_t k = 0; k < g.free_slots.size() && nn < tasks.size(); k++, nn++) {
+          lh_cloud* tg = tasks[nn]->tgt;
+          if (tg && tg->n > 0 && (rebuild_index || !tg->has_index) && std::find(to_build.begin(), to_build.end(), tg) == to_build.end())
+            to_build.push_back(tg);
+        }
+        if (!to_build.empty()) {
+          st = build_indices(c, to_build.data(), (int)to_build.size(), g.stream);
+          if (st) return fail(st);
+        }
+        while (next < tasks.size() && !g.free_slots.empty()) {
+          Task* t = tasks[next++];
+          t->slot = g.free_slots.back();
+          g.free_slots.pop_back();
+          t->stream = g.stream;
+          if (slot_ws) t->ws = &(*slot_ws)[t->slot];
+          t->trace_dev = nullptr;
+          st = LH_OK;
+          if (t->trace) {
+            if (lhMalloc(&t->trace_dev, sizeof(lh_gicp_trace)) != hipSuccess) st = LH_ENOMEM;
+            else if (hipMemsetAsync(t->trace_dev, 0, sizeof(int), g.stream) != hipSuccess) st = LH_EDEVICE;  // n_iters = 0
+            t->trace->n_iters = 0;
+          }
+          if (!st) st = task_prepare(c, t, false);
+          if (!st) {  // the pair's loop state: transformation_ = I, nothing done yet (pcl::Registration::align)
+            OuterState* init = &c->states_init[t->slot];
+            outer_state_init(init);
+            if (hipMemcpyAsync(&c->states_dev[t->slot], init, sizeof(OuterState), hipMemcpyHostToDevice, g.stream) != hipSuccess) st = LH_EDEVICE;
+          }
+          if (st) {
+            if (t->trace_dev) { (void)lhFree(t->trace_dev); t->trace_dev = nullptr; }
+            memset(&t->result, 0, sizeof(t->result));
+            memcpy(t->result.T, I16, sizeof(I16));
+            t->result.status = st;
+            t->result.fitness = NAN;
+            g.free_slots.push_back(t->slot);
+            err = st;
+            continue;
+          }
+          t->first_sweep = true;
+          t->enq_iters = 0;
+          g.active.push_back(t);
+        }
+      }
+      if (!g.active.empty()) {
+        // how many iterations before the host looks again: no pair needs more than what is left of its max_iterations
+        int need = 0;
+        for (Task* t : g.active) need = std::max(need, t->P.max_iterations - t->enq_iters);
+        st = dev_enqueue(c, g, std::max(1, std::min(rounds_cfg, need)));
+        if (st) return fail(st);
+      }
+    }
+  }
+  return err;
+}
+
 // run a set of tasks to completion, at most `in_flight` concurrently
-static lh_status run_tasks(lh_ctx* c, std::vector<Task*>& tasks, int in_flight, bool rebuild_index,
-                          std::vector<Workspace>* slot_ws = nullptr) {
+static lh_status run_tasks_host(lh_ctx* c, std::vector<Task*>& tasks, int in_flight, bool rebuild_index, std::vector<Workspace>* slot_ws) {
   const int G = (in_flight >= 16 && !c->prof) ? 2 : 1;  // profiling keeps one group so HIP-event times do not overlap
   if (G == 2 && !c->stream2) HIPCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
   Group groups[2];
@@ -984,6 +1193,15 @@ static lh_status run_tasks(lh_ctx* c, std::vector<Task*>& tasks, int in_flight, 
     }
   }
   return err;
+}
+
+// cost_mode 1 runs the loop on the device unless something needs the host inside it: the source-sharded pair's SUM hook
+// (its sums cross ranks through a host callback), a debug-statistics sweep, or an explicit request (lh_gicp_params.solver = 1)
+static lh_status run_tasks(lh_ctx* c, std::vector<Task*>& tasks, int in_flight, bool rebuild_index, std::vector<Workspace>* slot_ws = nullptr) {
+  bool device_loop = !c->reduce_fn;
+  for (Task* t : tasks)
+    if (t->P.cost_mode != 1 || t->P.solver == 1 || t->count_stats || t->P.max_iterations < 1) device_loop = false;
+  return device_loop ? run_tasks_device(c, tasks, in_flight, rebuild_index, slot_ws) : run_tasks_host(c, tasks, in_flight, rebuild_index, slot_ws);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1074,7 +1292,7 @@ void lh_default_gicp_params(lh_gicp_params* p) {
   p->num_threads = 1;
   p->enable_timing = 0;
   p->cost_mode = 1;
-  p->reserved0 = 0;
+  p->solver = 0;
 }
 
 lh_status lh_create(lh_ctx** out, int device_id) {
@@ -1114,6 +1332,11 @@ void lh_destroy(lh_ctx* c) {
   if (c->idx_build_done) (void)hipEventDestroy(c->idx_build_done);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
   (void)lhFree(c->sort_temp); (void)lhFree(c->bbox); (void)lhFree(c->descs_dev); (void)lhFree(c->mom_partials_dev);
+  (void)lhFree(c->states_dev); (void)lhFree(c->chunks_dev);
+  if (c->states_host) (void)hipHostFree(c->states_host);
+  if (c->states_init) (void)hipHostFree(c->states_init);
+  for (int k = 0; k < 2; k++)
+    if (c->group_ev[k]) (void)hipEventDestroy(c->group_ev[k]);
   if (c->descs_host) (void)hipHostFree(c->descs_host);
   if (c->partials_host) (void)hipHostFree(c->partials_host);
   if (c->small_host) (void)hipHostFree(c->small_host);

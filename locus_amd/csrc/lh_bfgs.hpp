@@ -1,22 +1,43 @@
-// lh_bfgs.hpp -- host-side solver of the product path: estimateRigidTransformationBFGS (gicp.hpp:218-287)
-// on top of pcl::BFGS (PCL 1.10 registration/bfgs.h: Eigen port of GSL vector_bfgs2 + Fletcher line search).
+// lh_bfgs.hpp -- the solver of the product path: estimateRigidTransformationBFGS (gicp.hpp:218-287) on top of pcl::BFGS
+// (PCL 1.10 registration/bfgs.h: Eigen port of GSL vector_bfgs2 + Fletcher line search), and the part of
+// computeTransformation's loop body that follows the NN sweep (gicp.hpp:518-568).
 //
-// The cost functor is abstract: every evaluation request (x -> f, g) is served by ONE fused device pass
-// (k_cost computes the 13 sums that operator(), df and fdf of gicp.hpp:291-402 all share), so the wrapper
-// caches the last evaluated x: the reference's "f(alpha) then df(alpha)" pair costs one pass instead of two
-// and returns bit-identical numbers for both.
+// Everything here is __host__ __device__ (LH_FN) and templated on
+//   Fn : the cost functor of one outer iteration -- eval(x, &f, g) / count() / passes
+//   M  : the elementary functions (lh_math.hpp): LibmMath on the host for cost_mode 0 (reference arithmetic, follows the oracle
+//        bit for bit), PortableMath for cost_mode 1, where the SAME code runs in k_solve on the GPU and -- for the
+//        source-sharded pair, whose sums cross ranks through a host callback -- on the host, with identical bits.
+// The functor is served by ONE fused pass per evaluation (the 13 sums that operator(), df and fdf of gicp.hpp:291-402 all
+// share), so the wrapper caches the last evaluated x: the reference's "f(alpha) then df(alpha)" pair costs one pass
+// instead of two and returns bit-identical numbers for both.
 #pragma once
 #include <cfloat>
 #include <cmath>
+#include <cstdint>
 #include <cstring>
+
+#include "lh_math.hpp"
 
 namespace lh {
 
 enum { BFGS_RUNNING = -1, BFGS_SUCCESS = 0, BFGS_NOPROGRESS = 1 };
 
+LH_FN bool same_bits6(const double* a, const double* b) {  // memcmp of six doubles
+  bool eq = true;
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    uint64_t u, v;
+    __builtin_memcpy(&u, a + i, 8);
+    __builtin_memcpy(&v, b + i, 8);
+    eq = eq && (u == v);
+  }
+  return eq;
+}
+
 // ---- state <-> matrix -------------------------------------------------------------------------------
 // applyState (gicp.hpp:619-634), float quaternion path of Eigen's AngleAxisf products; T = 16 floats column-major
-inline void apply_state(const double* x, float* T) {
+template <class M>
+LH_FN void apply_state(const double* x, float* T) {
   struct Q { float w, x, y, z; };
   auto mul = [](Q a, Q b) {
     Q r;
@@ -27,7 +48,11 @@ inline void apply_state(const double* x, float* T) {
     return r;
   };
   float hz = 0.5f * (float)x[5], hy = 0.5f * (float)x[4], hx = 0.5f * (float)x[3];
-  Q qz{cosf(hz), 0.f, 0.f, sinf(hz)}, qy{cosf(hy), 0.f, sinf(hy), 0.f}, qx{cosf(hx), sinf(hx), 0.f, 0.f};
+  float sz, cz, sy, cy, sx, cx;
+  M::sincos_f(hz, &sz, &cz);
+  M::sincos_f(hy, &sy, &cy);
+  M::sincos_f(hx, &sx, &cx);
+  Q qz{cz, 0.f, 0.f, sz}, qy{cy, 0.f, sy, 0.f}, qx{cx, sx, 0.f, 0.f};
   Q q = mul(mul(qz, qy), qx);
   float tx = 2.0f * q.x, ty = 2.0f * q.y, tz = 2.0f * q.z;
   float twx = tx * q.w, twy = ty * q.w, twz = tz * q.w;
@@ -35,16 +60,23 @@ inline void apply_state(const double* x, float* T) {
   float tyy = ty * q.y, tyz = tz * q.y, tzz = tz * q.z;
   float R[9] = {1.0f - (tyy + tzz), txy - twz, txz + twy, txy + twz, 1.0f - (txx + tzz), tyz - twx,
                 txz - twy, tyz + twx, 1.0f - (txx + tyy)};
+#pragma unroll
   for (int c = 0; c < 3; c++)
+#pragma unroll
     for (int r = 0; r < 3; r++) T[c * 4 + r] = R[r * 3 + c];
   T[3] = T[7] = T[11] = 0.0f;
   T[12] = (float)x[0]; T[13] = (float)x[1]; T[14] = (float)x[2]; T[15] = 1.0f;
 }
+inline void apply_state(const double* x, float* T) { apply_state<LibmMath>(x, T); }  // host, libm (reference build)
 
 // computeRDerivative (gicp.hpp:160-214) + matricesInnerProd (gicp.h:361-370); R row-major
-inline void compute_r_derivative(const double* x, const double* R, double* g) {
+template <class M>
+LH_FN void compute_r_derivative(const double* x, const double* R, double* g) {
   double phi = x[3], theta = x[4], psi = x[5];
-  double cphi = cos(phi), sphi = sin(phi), cth = cos(theta), sth = sin(theta), cpsi = cos(psi), spsi = sin(psi);
+  double cphi, sphi, cth, sth, cpsi, spsi;
+  M::sincos_d(phi, &sphi, &cphi);
+  M::sincos_d(theta, &sth, &cth);
+  M::sincos_d(psi, &spsi, &cpsi);
   double dPhi[9] = {0, sphi * spsi + cphi * cpsi * sth, cphi * spsi - cpsi * sphi * sth,
                     0, -cpsi * sphi + cphi * spsi * sth, -cphi * cpsi - sphi * spsi * sth,
                     0, cphi * cth, -cth * sphi};
@@ -55,7 +87,9 @@ inline void compute_r_derivative(const double* x, const double* R, double* g) {
                     cpsi * cth, -cphi * spsi + cpsi * sphi * sth, sphi * spsi + cphi * cpsi * sth,
                     0, 0, 0};
   double r3 = 0, r4 = 0, r5 = 0;
+#pragma unroll
   for (int i = 0; i < 3; i++)
+#pragma unroll
     for (int j = 0; j < 3; j++) {
       r3 += dPhi[j * 3 + i] * R[i * 3 + j];
       r4 += dTheta[j * 3 + i] * R[i * 3 + j];
@@ -65,106 +99,149 @@ inline void compute_r_derivative(const double* x, const double* R, double* g) {
 }
 
 // f /= m, g_t *= 2/m, R *= 2/m, rotation gradient (gicp.hpp:398-401); S = f, g_t[3], R[9]
-inline void cost_finish(const double* S, double m, const double* x, double* f, double* g) {
+template <class M>
+LH_FN void cost_finish(const double* S, double m, const double* x, double* f, double* g) {
   *f = S[0] / m;
   double s = 2.0 / m;
   g[0] = S[1] * s; g[1] = S[2] * s; g[2] = S[3] * s;
   double R[9];
+#pragma unroll
   for (int i = 0; i < 9; i++) R[i] = S[4 + i] * s;
-  compute_r_derivative(x, R, g);
+  compute_r_derivative<M>(x, R, g);
 }
+inline void cost_finish(const double* S, double m, const double* x, double* f, double* g) { cost_finish<LibmMath>(S, m, x, f, g); }
 
 // ---- functor with a one-entry cache ------------------------------------------------------------------
-struct CostFn {
-  virtual ~CostFn() {}
-  // one fused device pass: returns the 13 sums + correspondence count
-  virtual void pass(const double x[6], double sums13[13], double* count) = 0;
+// Pass: void operator()(const double x[6], double sums13[13], double* count) -- one fused pass: the 13 sums + correspondence count
+template <class Pass, class M>
+struct CostEval {
+  Pass* pass = nullptr;
   bool have = false;
   double cx[6], cf = 0, cg[6], cm = 0;
   int passes = 0;
-  void eval(const double x[6], double* f, double* g) {
-    if (!have || memcmp(x, cx, sizeof(cx)) != 0) {
+  LH_FN void eval(const double x[6], double* f, double* g) {
+    if (!have || !same_bits6(x, cx)) {
       double S[13];
-      pass(x, S, &cm);
+      (*pass)(x, S, &cm);
       passes++;
-      memcpy(cx, x, sizeof(cx));
-      if (cm > 0) cost_finish(S, cm, x, &cf, cg);
-      else { cf = 0; memset(cg, 0, sizeof(cg)); }
+#pragma unroll
+      for (int i = 0; i < 6; i++) cx[i] = x[i];
+      if (cm > 0) cost_finish<M>(S, cm, x, &cf, cg);
+      else {
+        cf = 0;
+#pragma unroll
+        for (int i = 0; i < 6; i++) cg[i] = 0.0;
+      }
       have = true;
     }
     if (f) *f = cf;
-    if (g) memcpy(g, cg, sizeof(cg));
+    if (g) {
+#pragma unroll
+      for (int i = 0; i < 6; i++) g[i] = cg[i];
+    }
   }
-  double count() const { return cm; }
+  LH_FN double count() const { return cm; }
 };
 
 // ---- second-order moment model of the cost (cost_mode 1) ------------------------------------------------
-// Device side: k_moments (lh_kernels.hip).  S = c0, B[3][4], H[6][10], count; T0 = transformation_ at sweep time.
+// Device side: the fused sweep (lh_kernels.hip).  S = c0, B[3][4], H[6][10], count; T0 = transformation_ at sweep time.
 struct MomentModel {
   double S[74];
   float T0[16];    // column-major
   double H12[144]; // expanded symmetric 12x12 form of H, row (r,c) = 4r+c, filled by prepare()
-  static int sym3(int r, int s) { static const int m[3][3] = {{0, 1, 2}, {1, 3, 4}, {2, 4, 5}}; return m[r][s]; }
-  static int sym4(int c, int e) { static const int m[4][4] = {{0, 1, 2, 3}, {1, 4, 5, 6}, {2, 5, 7, 8}, {3, 6, 8, 9}}; return m[c][e]; }
-  double count() const { return S[73]; }
-  void prepare() {  // once per sweep; the ~600 evaluations of a pair's BFGS solves then cost one 12x12 mat-vec each
-    const double* H = S + 13;
-    for (int r = 0; r < 3; r++)
-      for (int c = 0; c < 4; c++)
-        for (int s = 0; s < 3; s++)
-          for (int e = 0; e < 4; e++) H12[(4 * r + c) * 12 + 4 * s + e] = H[sym3(r, s) * 10 + sym4(c, e)];
+  LH_FN static int sym3(int r, int s) {  // index of (r, s) in (00 01 02 11 12 22)
+    int a = r < s ? r : s, b = r < s ? s : r;
+    return a == 0 ? b : (a == 1 ? 2 + b : 5);
+  }
+  LH_FN static int sym4(int c, int e) {  // index of (c, e) in (00 01 02 03 11 12 13 22 23 33)
+    int a = c < e ? c : e, b = c < e ? e : c;
+    return a == 0 ? b : (a == 1 ? 3 + b : (a == 2 ? 5 + b : 9));
+  }
+  LH_FN static int h_index(int i, int k) {  // entry of S's H block behind H12[i][k]
+    return 13 + sym3(i >> 2, k >> 2) * 10 + sym4(i & 3, k & 3);
+  }
+  LH_FN double count() const { return S[73]; }
+  LH_FN void prepare() {  // once per sweep; the ~600 evaluations of a pair's BFGS solves then cost one 12x12 mat-vec each
+    for (int i = 0; i < 12; i++)
+      for (int k = 0; k < 12; k++) H12[i * 12 + k] = S[h_index(i, k)];
   }
   // the 13 sums of gicp.hpp:388-396 at T (column-major float matrix from applyState)
-  void sums(const float* T16, double* sums13) const {
+  LH_FN void sums(const float* T16, double* sums13) const {
     double d[12];
+#pragma unroll
     for (int r = 0; r < 3; r++)
+#pragma unroll
       for (int c = 0; c < 4; c++) d[4 * r + c] = (double)T16[c * 4 + r] - (double)T0[c * 4 + r];
     const double* B = S + 1;
     double G[12], f = S[0];
     for (int i = 0; i < 12; i++) {
       const double* row = H12 + 12 * i;
       double g = 0.0;
+#pragma unroll
       for (int k = 0; k < 12; k++) g += row[k] * d[k];  // same summation order (s outer, e inner) as the sym-indexed form
       G[i] = B[i] + g;
     }
+#pragma unroll
     for (int k = 0; k < 12; k++) f += d[k] * (B[k] + G[k]);
     sums13[0] = f;
     sums13[1] = G[3]; sums13[2] = G[7]; sums13[3] = G[11];
+#pragma unroll
     for (int a = 0; a < 3; a++)
+#pragma unroll
       for (int b = 0; b < 3; b++) sums13[4 + 3 * a + b] = G[4 * b + a];  // R(a,b) = sum p_a (M res)_b
   }
 };
 
+// the Pass of cost_mode 1: every evaluation of an outer iteration comes from the 74 moments of its sweep.  base_transformation_
+// is the identity here (gicp.hpp:435, 367-368), so T(x) = applyState(x).
+template <class M>
+struct MomentPass {
+  const MomentModel* mom;
+  LH_FN void operator()(const double x[6], double sums13[13], double* count) const {
+    float T16[16];
+    apply_state<M>(x, T16);
+    mom->sums(T16, sums13);
+    *count = mom->count();
+  }
+};
+
 // ---- pcl::BFGS ----------------------------------------------------------------------------------------
+template <class Fn>
 struct Bfgs {
-  CostFn* fn = nullptr;
+  Fn* fn = nullptr;
   double rho = 0.01, sigma = 0.01, tau1 = 9, tau2 = 0.05, tau3 = 0.5, step_size = 1;  // gicp.hpp:253-257
   int order = 3, bracket_iters = 100, section_iters = 100;
   double f = 0, delta_f = 0, fp0 = 0, pnorm = 0, g0norm = 0;
   double x0[6], g0[6], dx0[6], dg0[6], p[6], gradient[6];
   double x_alpha[6], g_alpha[6], f_alpha = 0, df_alpha = 0, f_key = 0, df_key = 0, x_key = 0, g_key = 0;
 
-  static double dot(const double* a, const double* b) {
+  LH_FN static double dot(const double* a, const double* b) {
     double s = 0;
+#pragma unroll
     for (int i = 0; i < 6; i++) s += a[i] * b[i];
     return s;
   }
-  static double norm(const double* a) { return sqrt(dot(a, a)); }
+  LH_FN static double norm(const double* a) { return sqrt(dot(a, a)); }
+  LH_FN static void copy6(double* d, const double* s) {
+#pragma unroll
+    for (int i = 0; i < 6; i++) d[i] = s[i];
+  }
 
-  void moveto(double alpha) {
+  LH_FN void moveto(double alpha) {
     if (alpha == x_key) return;
+#pragma unroll
     for (int i = 0; i < 6; i++) x_alpha[i] = x0[i] + alpha * p[i];
     x_key = alpha;
   }
-  double slope() const { return dot(g_alpha, p); }
-  double apply_f(double alpha) {
+  LH_FN double slope() const { return dot(g_alpha, p); }
+  LH_FN double apply_f(double alpha) {
     if (alpha == f_key) return f_alpha;
     moveto(alpha);
     fn->eval(x_alpha, &f_alpha, nullptr);
     f_key = alpha;
     return f_alpha;
   }
-  double apply_df(double alpha) {
+  LH_FN double apply_df(double alpha) {
     if (alpha == df_key) return df_alpha;
     moveto(alpha);
     if (alpha != g_key) {
@@ -175,7 +252,7 @@ struct Bfgs {
     df_key = alpha;
     return df_alpha;
   }
-  void apply_fdf(double alpha, double* fo, double* dfo) {
+  LH_FN void apply_fdf(double alpha, double* fo, double* dfo) {
     if (alpha == f_key && alpha == df_key) { *fo = f_alpha; *dfo = df_alpha; return; }
     if (alpha == f_key || alpha == df_key) { *fo = apply_f(alpha); *dfo = apply_df(alpha); return; }
     moveto(alpha);
@@ -186,9 +263,9 @@ struct Bfgs {
     *fo = f_alpha; *dfo = df_alpha;
   }
 
-  static double cubic(double c0, double c1, double c2, double c3, double z) { return c0 + z * (c1 + z * (c2 + z * c3)); }
+  LH_FN static double cubic(double c0, double c1, double c2, double c3, double z) { return c0 + z * (c1 + z * (c2 + z * c3)); }
 
-  static double interpolate(double a, double fa, double fpa, double b, double fb, double fpb, double xmin, double xmax, int order) {
+  LH_FN static double interpolate(double a, double fa, double fpa, double b, double fb, double fpb, double xmin, double xmax, int order) {
     double y, ymin = (xmin - a) / (b - a), ymax = (xmax - a) / (b - a), fmin;
     if (ymin > ymax) { double t = ymin; ymin = ymax; ymax = t; }
     if (order > 2 && !(fpb != fpb) && fpb != INFINITY) {
@@ -230,7 +307,7 @@ struct Bfgs {
     return a + y * (b - a);
   }
 
-  int line_search(double alpha1, double* alpha_new) {
+  LH_FN int line_search(double alpha1, double* alpha_new) {
     double f0, fp0l, falpha, falpha_prev, fpalpha = 0, fpalpha_prev, delta, alpha_next;
     double alpha = alpha1, alpha_prev = 0.0, a, b, fa, fb, fpa, fpb;
     int i = 0;
@@ -277,23 +354,24 @@ struct Bfgs {
     return BFGS_SUCCESS;
   }
 
-  void init(CostFn* f_, const double* x) {  // minimizeInit
+  LH_FN void init(Fn* f_, const double* x) {  // minimizeInit
     fn = f_;
     delta_f = 0;
     fn->eval(x, &f, gradient);
-    memcpy(x0, x, sizeof(x0));
-    memcpy(g0, gradient, sizeof(g0));
+    copy6(x0, x);
+    copy6(g0, gradient);
     g0norm = norm(g0);
+#pragma unroll
     for (int i = 0; i < 6; i++) p[i] = gradient[i] * (-1.0 / g0norm);
     pnorm = norm(p);
     fp0 = -g0norm;
-    memcpy(x_alpha, x0, sizeof(x0)); x_key = 0;
+    copy6(x_alpha, x0); x_key = 0;
     f_alpha = f; f_key = 0;
-    memcpy(g_alpha, g0, sizeof(g0)); g_key = 0;
+    copy6(g_alpha, g0); g_key = 0;
     df_alpha = slope(); df_key = 0;
   }
 
-  int one_step(double* x) {  // minimizeOneStep
+  LH_FN int one_step(double* x) {  // minimizeOneStep
     double alpha = 0.0, alpha1, f0 = f;
     if (pnorm == 0.0 || g0norm == 0.0 || fp0 == 0) return BFGS_NOPROGRESS;
     if (delta_f < 0) {
@@ -307,10 +385,11 @@ struct Bfgs {
       double fa, dfa;
       apply_fdf(alpha, &fa, &dfa);
       f = f_alpha;
-      memcpy(x, x_alpha, sizeof(x_alpha));
-      memcpy(gradient, g_alpha, sizeof(g_alpha));
+      copy6(x, x_alpha);
+      copy6(gradient, g_alpha);
     }
     delta_f = f - f0;
+#pragma unroll
     for (int i = 0; i < 6; i++) { dx0[i] = x[i] - x0[i]; dg0[i] = gradient[i] - g0[i]; }
     double dxg = dot(dx0, gradient), dgg = dot(dg0, gradient), dxdg = dot(dx0, dg0), dgnorm = norm(dg0), A, B;
     if (dxdg != 0) {
@@ -319,21 +398,25 @@ struct Bfgs {
     } else {
       B = 0; A = 0;
     }
+#pragma unroll
     for (int i = 0; i < 6; i++) p[i] = -A * dx0[i];
+#pragma unroll
     for (int i = 0; i < 6; i++) p[i] += gradient[i];
+#pragma unroll
     for (int i = 0; i < 6; i++) p[i] += -B * dg0[i];
-    memcpy(g0, gradient, sizeof(g0));
-    memcpy(x0, x, sizeof(x0));
+    copy6(g0, gradient);
+    copy6(x0, x);
     g0norm = norm(g0);
     pnorm = norm(p);
     double dir = (dot(p, gradient) > 0) ? -1.0 : 1.0;
+#pragma unroll
     for (int i = 0; i < 6; i++) p[i] *= dir / pnorm;
     pnorm = norm(p);
     fp0 = dot(p, g0);
     // changeDirection
-    memcpy(x_alpha, x0, sizeof(x0)); x_key = 0.0;
+    copy6(x_alpha, x0); x_key = 0.0;
     f_key = 0.0;
-    memcpy(g_alpha, g0, sizeof(g0)); g_key = 0.0;
+    copy6(g_alpha, g0); g_key = 0.0;
     df_alpha = slope(); df_key = 0.0;
     return BFGS_SUCCESS;
   }
@@ -341,11 +424,12 @@ struct Bfgs {
 
 // estimateRigidTransformationBFGS (gicp.hpp:218-287).  T16 column-major in/out.
 // returns 0 ok, -4 too few correspondences, -5 solver failure
-inline int estimate_rigid_bfgs(CostFn* fn, int max_inner, float* T16, int* n_inner, double* f_end) {
+template <class Fn, class M>
+LH_FN int estimate_rigid_bfgs(Fn* fn, int max_inner, float* T16, int* n_inner, double* f_end) {
   auto TM = [&](int r, int c) { return (double)T16[c * 4 + r]; };
-  double x[6] = {TM(0, 3), TM(1, 3), TM(2, 3), atan2(TM(2, 1), TM(2, 2)), asin(-TM(2, 0)), atan2(TM(1, 0), TM(0, 0))};
+  double x[6] = {TM(0, 3), TM(1, 3), TM(2, 3), M::atan2_d(TM(2, 1), TM(2, 2)), M::asin_d(-TM(2, 0)), M::atan2_d(TM(1, 0), TM(0, 0))};
   const double gradient_tol = 1e-2;
-  Bfgs b;
+  Bfgs<Fn> b;
   int inner = 0, result;
   b.init(fn, x);
   if (fn->count() < 4) return -4;  // gicp.hpp:225 (the count is known after the first fused pass)
@@ -353,15 +437,73 @@ inline int estimate_rigid_bfgs(CostFn* fn, int max_inner, float* T16, int* n_inn
     inner++;
     result = b.one_step(x);
     if (result) break;
-    result = (Bfgs::norm(b.gradient) < gradient_tol) ? BFGS_SUCCESS : BFGS_RUNNING;  // testGradient
+    result = (Bfgs<Fn>::norm(b.gradient) < gradient_tol) ? BFGS_SUCCESS : BFGS_RUNNING;  // testGradient
   } while (result == BFGS_RUNNING && inner < max_inner);
   *n_inner = inner;
   *f_end = b.f;
   if (result == BFGS_NOPROGRESS || result == BFGS_SUCCESS || inner == max_inner) {
-    apply_state(x, T16);  // gicp.hpp:277-278
+    apply_state<M>(x, T16);  // gicp.hpp:277-278
     return 0;
   }
   return -5;
+}
+
+// ---- one outer iteration after its NN sweep (gicp.hpp:518-568) -------------------------------------------------------
+struct OuterParams {
+  int max_iterations, max_inner_iterations;
+  double rotation_epsilon, transformation_epsilon;
+};
+struct OuterState {
+  float T[16];      // transformation_ (column-major): where the next sweep transforms the source to
+  float prev[16];   // previous_transformation_: what final_transformation_ is composed from (gicp.hpp:583)
+  int iter;         // nr_iterations_
+  int done;         // the loop has ended: converged_, or an exception was caught (gicp.hpp:542-547)
+  int converged, status;       // status: 0, -4 (NotEnoughPointsException) or -5 (SolverDidntConvergeException)
+  int n_corr_last, passes, n_inner, pad;
+  double f_end, delta;
+  double corr_sum;  // correspondences summed over the iterations (instrumentation: the algorithmic bytes of SURVEY 8d scale with it)
+};
+LH_FN void outer_state_init(OuterState* s) {
+#pragma unroll
+  for (int i = 0; i < 16; i++) { s->T[i] = (i % 5 == 0) ? 1.0f : 0.0f; s->prev[i] = s->T[i]; }  // align() resets transformation_ to identity
+  s->iter = 0; s->done = 0; s->converged = 0; s->status = 0; s->n_corr_last = 0; s->passes = 0; s->n_inner = 0; s->pad = 0;
+  s->f_end = 0.0; s->delta = 0.0; s->corr_sum = 0.0;
+}
+// fn = the functor of THIS iteration's correspondences (a fresh cache)
+template <class Fn, class M>
+LH_FN void outer_step(Fn* fn, const OuterParams& P, OuterState* s) {
+#pragma unroll
+  for (int i = 0; i < 16; i++) s->prev[i] = s->T[i];  // previous_transformation_ = transformation_ (gicp.hpp:518)
+  const int before = fn->passes;
+  int n_inner = 0;
+  double f_end = 0.0;
+  int st = estimate_rigid_bfgs<Fn, M>(fn, P.max_inner_iterations, s->T, &n_inner, &f_end);
+  s->n_corr_last = (int)fn->count();
+  s->passes += fn->passes - before;
+  s->n_inner = n_inner;
+  s->f_end = f_end;
+  if (st != 0) {  // exception caught -> break (gicp.hpp:542-547): final_transformation_ comes from previous_transformation_
+    s->status = st;
+    s->done = 1;
+    return;
+  }
+  double delta = 0.0;  // gicp.hpp:526-541
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+#pragma unroll
+    for (int l = 0; l < 4; l++) {
+      double ratio = (k < 3 && l < 3) ? 1. / P.rotation_epsilon : 1. / P.transformation_epsilon;
+      double c_delta = ratio * fabs((double)s->prev[l * 4 + k] - (double)s->T[l * 4 + k]);
+      if (c_delta > delta) delta = c_delta;
+    }
+  s->delta = delta;
+  s->iter++;
+  if (s->iter >= P.max_iterations || delta < 1) {  // gicp.hpp:566
+    s->converged = 1;
+    s->done = 1;
+#pragma unroll
+    for (int i = 0; i < 16; i++) s->prev[i] = s->T[i];
+  }
 }
 
 }  // namespace lh

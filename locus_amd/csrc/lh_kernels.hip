@@ -303,7 +303,7 @@ __global__ void __launch_bounds__(256) k_seed(const PairDesc* __restrict__ descs
   extern __shared__ __attribute__((aligned(16))) uint64_t lds_stack[];  // [entries][256]
   int jb, blk;
   if (!xcd_job_map(a.njobs, a.bpj, jb, blk)) return;
-  const SweepJob& job = a.job[jb];
+  const SweepJob& job = a.job[jb];  // (a cold pair's transformation_ is the identity in both loop flavours: job.T carries it)
   const PairDesc d = descs[job.slot];
   const int group = a.pad;  // seed group size (runtime so it can be tuned)
   int g = blk * 256 + threadIdx.x;
@@ -330,6 +330,25 @@ void launch_seed(const PairDesc* descs, SweepArgs& a, int max_n, hipStream_t s) 
   hipLaunchKernelGGL(k_seed, dim3(xcd_grid(a.njobs, a.bpj)), dim3(256), stack_lds_bytes(a.max_depth, 256), s, descs, a);
 }
 
+// transformation_ of a job as 12 row-major floats in SCALAR registers: from the launch arguments (host-driven loop: the host
+// solved the last iteration) or from the pair's device state (device-driven loop: k_solve did).  The state is read through a
+// uniform address and pinned to SGPRs with readfirstlane -- twelve VGPRs would cost the fused sweep its 6 waves per SIMD.
+// Returns false when the pair's loop has already ended (the launch covers it only because the host has not looked yet).
+__device__ __forceinline__ bool job_transform(const SweepJob& job, const OuterState* __restrict__ states, float* T) {
+  if (!states) {
+#pragma unroll
+    for (int k = 0; k < 12; k++) T[k] = job.T[k];
+    return true;
+  }
+  const OuterState* st = states + job.slot;
+  if (__builtin_amdgcn_readfirstlane(gld(&st->done))) return false;
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int c = 0; c < 4; c++) T[r * 4 + c] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(gld(&st->T[c * 4 + r]))));
+  return true;
+}
+
 // one source point of a sweep: exact NN (warm start + certificate) and, if gated in, M = (R C1 R^T + C2)^-1
 struct SweepPoint {
   float4 p;      // source point
@@ -339,10 +358,10 @@ struct SweepPoint {
   bool matched;
   bool searched; // the certificate did not cover this query: the tree was walked
 };
-__device__ __forceinline__ void sweep_point(const PairDesc& d, const SweepJob& job, int i, uint64_t* stack, SweepPoint& o) {
+__device__ __forceinline__ void sweep_point(const PairDesc& d, const float* __restrict__ T, int i, uint64_t* stack, SweepPoint& o) {
   o.p = gld(d.src + i);
   float qx, qy, qz;
-  xform_pt(job.T, o.p.x, o.p.y, o.p.z, qx, qy, qz);  // gicp.hpp:469
+  xform_pt(T, o.p.x, o.p.y, o.p.z, qx, qy, qz);  // gicp.hpp:469
   TreeView tv{d.tgt_sorted, d.tgt_nodes, d.tgt_hdr, d.m};
   Nn1CertCollector col{INFINITY, 0x7fffffff, INFINITY};
   int w = gld(d.prev_nn + i);
@@ -405,14 +424,14 @@ __device__ __forceinline__ void sweep_point(const PairDesc& d, const SweepJob& j
 #pragma unroll
       for (int r = 0; r < 3; r++)
 #pragma unroll
-        for (int cc = 0; cc < 3; cc++) R[r * 3 + cc] = (double)job.T[r * 4 + cc];
+        for (int cc = 0; cc < 3; cc++) R[r * 3 + cc] = (double)T[r * 4 + cc];
     } else {
 #pragma unroll
       for (int r = 0; r < 3; r++)
 #pragma unroll
         for (int cc = 0; cc < 3; cc++)
-          R[r * 3 + cc] = (((double)job.T[r * 4 + 0] * d.guess3[0 * 3 + cc] + (double)job.T[r * 4 + 1] * d.guess3[1 * 3 + cc]) +
-                           (double)job.T[r * 4 + 2] * d.guess3[2 * 3 + cc]) + (double)job.T[r * 4 + 3] * 0.0;
+          R[r * 3 + cc] = (((double)T[r * 4 + 0] * d.guess3[0 * 3 + cc] + (double)T[r * 4 + 1] * d.guess3[1 * 3 + cc]) +
+                           (double)T[r * 4 + 2] * d.guess3[2 * 3 + cc]) + (double)T[r * 4 + 3] * 0.0;
     }
     mahalanobis(R, C1, C2, o.M);  // gicp.hpp:488-493
     o.tgt = t;
@@ -428,7 +447,7 @@ __global__ void __launch_bounds__(256) k_sweep(const PairDesc* __restrict__ desc
   int i = blk * 256 + threadIdx.x;
   if (i >= d.n) return;
   SweepPoint sp;
-  sweep_point(d, job, i, lds_stack + threadIdx.x, sp);
+  sweep_point(d, job.T, i, lds_stack + threadIdx.x, sp);
   float4 c = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
   if (sp.matched) {
     d.maha6[(size_t)0 * d.n_pad + i] = sp.M[0];
@@ -453,11 +472,11 @@ __device__ __forceinline__ double mom_value(int k, const double* M6, const doubl
   return 1.0;
 }
 // the moment contributions of one matched point, added to acc[0..73] (acc must be zero-initialised by the caller)
-__device__ __forceinline__ void moments_of_point(const SweepJob& job, const SweepPoint& sp, double* M6, double* Ma, double& aMa, double* pt, double* pp) {
+__device__ __forceinline__ void moments_of_point(const float* __restrict__ T, const SweepPoint& sp, double* M6, double* Ma, double& aMa, double* pt, double* pp) {
   pt[0] = (double)sp.p.x; pt[1] = (double)sp.p.y; pt[2] = (double)sp.p.z; pt[3] = 1.0;
   double T0[12];
 #pragma unroll
-  for (int k = 0; k < 12; k++) T0[k] = (double)job.T[k];
+  for (int k = 0; k < 12; k++) T0[k] = (double)T[k];
   double a0 = (((T0[0] * pt[0] + T0[1] * pt[1]) + T0[2] * pt[2]) + T0[3]) - (double)sp.tgt.x;
   double a1 = (((T0[4] * pt[0] + T0[5] * pt[1]) + T0[6] * pt[2]) + T0[7]) - (double)sp.tgt.y;
   double a2 = (((T0[8] * pt[0] + T0[9] * pt[1]) + T0[10] * pt[2]) + T0[11]) - (double)sp.tgt.z;
@@ -523,20 +542,22 @@ __device__ __forceinline__ void wave_reduce_row(uint64_t* lds_base, double* out,
 // registers (239 VGPRs, 2 waves per SIMD) pays the reduction once per 4 points but was slower even on certificate-only
 // sweeps (142 vs 128 us): with so few waves the dependent src -> neighbour gathers are no longer hidden.
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) k_sweep_fused(const PairDesc* __restrict__ descs, SweepArgs a, double* __restrict__ partials,
-                                                     int partials_stride) {
+                                                     int partials_stride, const OuterState* __restrict__ states) {
   extern __shared__ __attribute__((aligned(16))) uint64_t lds_stack[];  // [entries][256], later reused as double[8][256]
   int jb, blk;
   if (!xcd_job_map(a.njobs, a.bpj, jb, blk)) return;
   const SweepJob& job = a.job[jb];
   const PairDesc d = descs[job.slot];
   if (blk * 256 >= d.n) return;  // whole workgroup out of range (uniform)
+  float T[12];
+  if (!job_transform(job, states, T)) return;  // device-driven loop: this pair has already converged
   int i = blk * 256 + threadIdx.x;
   SweepPoint sp;
   sp.matched = false;
   sp.searched = false;
-  if (i < d.n) sweep_point(d, job, i, lds_stack + threadIdx.x, sp);
+  if (i < d.n) sweep_point(d, T, i, lds_stack + threadIdx.x, sp);
   double M6[6] = {0, 0, 0, 0, 0, 0}, Ma[3] = {0, 0, 0}, pt[4] = {0, 0, 0, 0}, pp[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, aMa = 0.0;
-  if (sp.matched) moments_of_point(job, sp, M6, Ma, aMa, pt, pp);
+  if (sp.matched) moments_of_point(T, sp, M6, Ma, aMa, pt, pp);
   const double live = sp.matched ? 1.0 : 0.0;
   const int walks = __popcll(__ballot(sp.searched));
   double* out = partials + (size_t)job.slot * partials_stride + ((size_t)blk * 4 + (threadIdx.x >> 6)) * MOM_ROW;
@@ -592,11 +613,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) k
   }
 }
 
-void launch_sweep_fused(const PairDesc* descs, SweepArgs& a, int max_n, double* partials_dev, int partials_stride, hipStream_t s) {
+void launch_sweep_fused(const PairDesc* descs, SweepArgs& a, int max_n, double* partials_dev, int partials_stride, const OuterState* states,
+                        hipStream_t s) {
   size_t lds = stack_lds_bytes(a.max_depth, 256);
   if (lds < 4 * 8 * 72 * sizeof(double)) lds = 4 * 8 * 72 * sizeof(double);
   a.bpj = (max_n + 255) / 256;
-  hipLaunchKernelGGL(k_sweep_fused, dim3(xcd_grid(a.njobs, a.bpj)), dim3(256), lds, s, descs, a, partials_dev, partials_stride);
+  hipLaunchKernelGGL(k_sweep_fused, dim3(xcd_grid(a.njobs, a.bpj)), dim3(256), lds, s, descs, a, partials_dev, partials_stride, states);
 }
 void launch_sweep(const PairDesc* descs, SweepArgs& a, int max_n, hipStream_t s) {
   a.bpj = (max_n + 255) / 256;
@@ -768,8 +790,10 @@ __global__ void __launch_bounds__(256) k_moments(const PairDesc* __restrict__ de
 // rows of a job = ceil(n / ppb) * rpb  (ppb points per workgroup of the producing kernel, rpb rows per workgroup)
 constexpr int FINAL_SUB = 4;
 __global__ void __launch_bounds__(FINAL_SUB * MOM_ROW) k_moments_final(const PairDesc* __restrict__ descs, CostArgs a, const double* __restrict__ partials,
-                                                                      int partials_stride, int ppb, int rpb, double* __restrict__ out) {
+                                                                      int partials_stride, int ppb, int rpb, double* __restrict__ out,
+                                                                      const OuterState* __restrict__ states) {
   const CostJob& job = a.job[blockIdx.y];
+  if (states && states[job.slot].done) return;  // device-driven loop: the pair's sweep did not run either
   const int c = blockIdx.x;
   int n = descs[job.slot].n;
   int nb = ((n + ppb - 1) / ppb) * rpb;
@@ -801,10 +825,66 @@ __global__ void __launch_bounds__(FINAL_SUB * MOM_ROW) k_moments_final(const Pai
 void launch_moments(const PairDesc* descs, const CostArgs& a, int max_n, double* partials_dev, int partials_stride, double* out,
                     hipStream_t s) {
   hipLaunchKernelGGL(k_moments, dim3(mom_blocks(max_n), a.njobs), dim3(256), 0, s, descs, a, partials_dev, partials_stride);
-  hipLaunchKernelGGL(k_moments_final, dim3(FINAL_CHUNKS, a.njobs), dim3(FINAL_SUB * MOM_ROW), 0, s, descs, a, partials_dev, partials_stride, MOM_CHUNK, 1, out);
+  hipLaunchKernelGGL(k_moments_final, dim3(FINAL_CHUNKS, a.njobs), dim3(FINAL_SUB * MOM_ROW), 0, s, descs, a, partials_dev, partials_stride, MOM_CHUNK, 1, out,
+                     (const OuterState*)nullptr);
 }
-void launch_moments_final(const PairDesc* descs, const CostArgs& a, double* partials_dev, int partials_stride, double* out, hipStream_t s) {
-  hipLaunchKernelGGL(k_moments_final, dim3(FINAL_CHUNKS, a.njobs), dim3(FINAL_SUB * MOM_ROW), 0, s, descs, a, partials_dev, partials_stride, 256, 4, out);
+void launch_moments_final(const PairDesc* descs, const CostArgs& a, double* partials_dev, int partials_stride, double* out, const OuterState* states,
+                          hipStream_t s) {
+  hipLaunchKernelGGL(k_moments_final, dim3(FINAL_CHUNKS, a.njobs), dim3(FINAL_SUB * MOM_ROW), 0, s, descs, a, partials_dev, partials_stride, 256, 4, out, states);
+}
+
+// ===== the solve of one outer iteration on the device (cost_mode 1) =========================================
+// One wave per pair runs the part of computeTransformation's loop body that follows the sweep (gicp.hpp:518-568): the whole BFGS
+// solve on the pair's 74-moment model, the convergence test, and the update of the pair's state (transformation_, iteration
+// count, done flag) that the next sweep launch reads -- the host is not in the loop.  The code is lh_bfgs.hpp's, the same
+// templates the host instantiates for the source-sharded pair, with PortableMath (lh_math.hpp): identical bits on both sides.
+// Every lane executes the (uniform) control flow; the model lives in LDS.
+__global__ void __launch_bounds__(64) k_solve(const PairDesc* __restrict__ descs, SolveArgs a, const double* __restrict__ chunks, int chunk_stride,
+                                              OuterState* __restrict__ states) {
+  const int slot = a.slot[blockIdx.x];
+  OuterState* sp = states + slot;
+  if (sp->done) return;
+  __shared__ MomentModel mom;
+  const int lane = threadIdx.x;
+  const double* part = chunks + (size_t)slot * chunk_stride;  // FINAL_CHUNKS x MOM_ROW chunk sums of this iteration's sweep
+  for (int k = lane; k < MOM_NSUM; k += 64) {
+    double s = 0.0;
+#pragma unroll
+    for (int ch = 0; ch < FINAL_CHUNKS; ch++) s += part[ch * MOM_ROW + k];  // chunk order, like the host: bitwise the same sums
+    mom.S[k] = s;
+  }
+  if (lane < 16) mom.T0[lane] = sp->T[lane];  // the transform the sweep used
+  __syncthreads();
+  for (int e = lane; e < 144; e += 64) mom.H12[e] = mom.S[MomentModel::h_index(e / 12, e % 12)];
+  __syncthreads();
+  const PairDesc* d = descs + slot;
+  OuterParams P{d->max_iterations, d->max_inner_iterations, d->rotation_epsilon, d->transformation_epsilon};
+  OuterState s = *sp;
+  typedef MomentPass<PortableMath> Pass;
+  typedef CostEval<Pass, PortableMath> Fn;
+  Pass pass{&mom};
+  Fn fn;
+  fn.pass = &pass;
+  const int before = s.passes, it = s.iter;
+  outer_step<Fn, PortableMath>(&fn, P, &s);
+  s.corr_sum += mom.count();
+  if (lane == 0) {
+    *sp = s;
+    lh_gicp_trace* tr = d->trace;
+    if (tr && s.status == 0 && it < LH_MAX_TRACE) {  // the per-iteration trace of lh_gicp_align (parity tests)
+#pragma unroll
+      for (int k = 0; k < 16; k++) tr->T[it][k] = s.T[k];
+      tr->n_corr[it] = s.n_corr_last;
+      tr->n_passes[it] = s.passes - before;
+      tr->n_inner[it] = s.n_inner;
+      tr->f_end[it] = s.f_end;
+      tr->delta[it] = s.delta;
+      tr->n_iters = it + 1;
+    }
+  }
+}
+void launch_solve(const PairDesc* descs, const SolveArgs& a, const double* chunks, int chunk_stride, OuterState* states, hipStream_t s) {
+  hipLaunchKernelGGL(k_solve, dim3(a.njobs), dim3(64), 0, s, descs, a, chunks, chunk_stride, states);
 }
 
 // ===== K6 / misc ===========================================================================================

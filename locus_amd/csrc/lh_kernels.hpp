@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "../../include/locus_hip.h"
+#include "lh_bfgs.hpp"
 #include "lh_device.hpp"
 
 namespace lh {
@@ -36,6 +38,10 @@ struct PairDesc {
   double corr_dist2;
   double gicp_eps;
   double guess3[9];  // top-left 3x3 of `guess` (row-major, as double): R = double(transformation_) * double(guess), gicp.hpp:450-460
+  // device-driven loop (k_solve): the loop's knobs (gicp.h:119-130) and where the per-iteration trace goes (device memory, nullable)
+  int max_iterations, max_inner_iterations;
+  double rotation_epsilon, transformation_epsilon;
+  lh_gicp_trace* trace;
 };
 
 struct SweepJob {  // dynamic per-launch part
@@ -49,6 +55,11 @@ struct SweepArgs {
   int max_depth;   // deepest target tree among the jobs (sizes the LDS traversal stack)
   int pad;
   SweepJob job[MAX_JOBS];
+};
+
+struct SolveArgs {   // k_solve: one workgroup (one wave) per listed slot
+  int njobs;
+  int slot[MAX_JOBS];
 };
 
 struct CostJob {
@@ -108,8 +119,14 @@ void launch_index_trees(const IndexDesc* descs, int n_clouds, int max_n, const T
 // ---- K4 / K5 ---------------------------------------------------------------------------------------
 void launch_sweep(const PairDesc* descs, SweepArgs& a, int max_n, hipStream_t s);
 // cost_mode 1: sweep + 74-moment reduction in one kernel (one partial per 256-point workgroup), then the final sum
-void launch_sweep_fused(const PairDesc* descs, SweepArgs& a, int max_n, double* partials_dev, int partials_stride, hipStream_t s);
-void launch_moments_final(const PairDesc* descs, const CostArgs& a, double* partials_dev, int partials_stride, double* out, hipStream_t s);
+// states == nullptr: host-driven loop (the jobs' transforms come with the launch); otherwise the pairs' device states (k_solve's)
+void launch_sweep_fused(const PairDesc* descs, SweepArgs& a, int max_n, double* partials_dev, int partials_stride, const OuterState* states,
+                        hipStream_t s);
+void launch_moments_final(const PairDesc* descs, const CostArgs& a, double* partials_dev, int partials_stride, double* out, const OuterState* states,
+                          hipStream_t s);
+// the BFGS solve + convergence test of one outer iteration, on the device (cost_mode 1): reads the FINAL_CHUNKS x MOM_ROW chunk
+// sums k_moments_final left at chunks[slot * chunk_stride], updates states[slot]
+void launch_solve(const PairDesc* descs, const SolveArgs& a, const double* chunks, int chunk_stride, OuterState* states, hipStream_t s);
 constexpr int FUSED_CHUNK = 64;   // one 74-double partial per WAVE of the fused sweep
 constexpr int FINAL_CHUNKS = 8;   // the final sum leaves FINAL_CHUNKS x 74 chunk sums per job for the host to add (in chunk order)
 // cold-start helper: exact NN of every 8th source point, written as the warm-start candidate of its 8-point group

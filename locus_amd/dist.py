@@ -33,6 +33,22 @@ def gather_poses(local_poses, world, device=None):
     return [o[: int(c.item())].cpu().numpy() for o, c in zip(out, cnts)]
 
 
+def gather_records(raw, world, device=None):
+    """ONE all_gather of fixed-size result records (a ctypes array of lh_gicp_result, 96 B each; every rank holds the same
+    number) on device tensors: the only exchange of the pair-sharded path.  Returns the uint8 tensor of all
+    ranks' records in rank order (left on `device`: nobody needs them on the host inside the timed step)."""
+    import torch
+    import torch.distributed as dist
+    loc = torch.frombuffer(bytearray(raw), dtype=torch.uint8)
+    if device is not None:
+        loc = loc.to(device)
+    if world == 1:
+        return loc
+    allr = torch.empty(world * loc.numel(), dtype=torch.uint8, device=loc.device)
+    dist.all_gather_into_tensor(allr, loc)
+    return allr
+
+
 def max_over_ranks(value, world, device=None):
     import torch
     import torch.distributed as dist

@@ -123,12 +123,13 @@ int main() {
     // the prior is applied in double and rounded once: the source the registration saw is float(prior * double(p))
     PointCloudF::Ptr src = pco.GetQueryTransformed();
     EXPECT(src && src->size() == translated.size());
+    const double px = (double)(float)-0.04, py = (double)(float)-0.05;  // pcl_ros::transformAsMatrix fills a Matrix4f first (:256-259)
     if (src && src->size() == translated.size())
       for (size_t i = 0; i < src->size(); i += 37) {
         EXPECT(src->points[i].x == static_cast<float>(1.0 * (double)translated.points[i].x + 0.0 * (double)translated.points[i].y +
-                                                      0.0 * (double)translated.points[i].z + -0.04));
+                                                      0.0 * (double)translated.points[i].z + px));
         EXPECT(src->points[i].y == static_cast<float>(0.0 * (double)translated.points[i].x + 1.0 * (double)translated.points[i].y +
-                                                      0.0 * (double)translated.points[i].z + -0.05));
+                                                      0.0 * (double)translated.points[i].z + py));
       }
   }
 

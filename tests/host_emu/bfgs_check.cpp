@@ -1,6 +1,10 @@
-// Cross-check of the product's host solver (locus_amd/csrc/lh_bfgs.hpp) against the oracle's BFGS restatement:
+// Cross-check of the product's solver (locus_amd/csrc/lh_bfgs.hpp) against the oracle's BFGS restatement:
 // both minimise the same GICP cost over the same synthetic correspondences; the product side is driven through
-// its CostFn interface with the oracle's lo_cost_fdf supplying the 13 sums (standing in for the device pass).
+// its functor interface with the oracle's lo_cost_fdf supplying the 13 sums (standing in for the device pass).
+//   1. libm flavour (cost_mode 0 on the host): the two restatements follow the same trajectory BIT FOR BIT
+//   2. portable flavour (lh_math.hpp; what k_solve runs on the GPU and the host runs for the sharded pair): same minimum,
+//      and its elementary functions agree with libm to a few ulp
+//   3. the 74-moment model of cost_mode 1 (MomentModel / MomentPass) reproduces the per-point functor's sums
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -12,12 +16,12 @@ extern "C" {
 #include "../../oracle/locus_oracle.h"
 }
 
-struct OracleBackedCost : public lh::CostFn {
+struct OracleBackedPass {
   const float *src, *tgt;
   const int32_t* idx;
   int m;
   const double* maha;
-  void pass(const double x[6], double sums13[13], double* count) override {
+  void operator()(const double x[6], double sums13[13], double* count) {
     double f, g[6];
     lo_cost_fdf(src, tgt, idx, idx, m, maha, x, &f, g, sums13);
     *count = (double)m;
@@ -64,13 +68,16 @@ int main() {
       M[3] = (s[5] * s[6] - s[3] * s[8]) / det; M[4] = (s[0] * s[8] - s[2] * s[6]) / det; M[5] = (s[2] * s[3] - s[0] * s[5]) / det;
       M[6] = (s[3] * s[7] - s[4] * s[6]) / det; M[7] = (s[1] * s[6] - s[0] * s[7]) / det; M[8] = (s[0] * s[4] - s[1] * s[3]) / det;
     }
-    // product solver
-    OracleBackedCost fn;
-    fn.src = src.data(); fn.tgt = tgt.data(); fn.idx = idx.data(); fn.m = n; fn.maha = maha.data();
+    // product solver, libm flavour
+    OracleBackedPass pass;
+    pass.src = src.data(); pass.tgt = tgt.data(); pass.idx = idx.data(); pass.m = n; pass.maha = maha.data();
+    typedef lh::CostEval<OracleBackedPass, lh::LibmMath> FnL;
+    FnL fn;
+    fn.pass = &pass;
     float Tp[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
     int n_inner = 0;
     double f_end = 0;
-    int st = lh::estimate_rigid_bfgs(&fn, 50, Tp, &n_inner, &f_end);
+    int st = lh::estimate_rigid_bfgs<FnL, lh::LibmMath>(&fn, 50, Tp, &n_inner, &f_end);
     // oracle solver on the same correspondences: identical cost numbers => the two BFGS restatements must follow
     // the same trajectory bit for bit
     float To2[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
@@ -84,6 +91,70 @@ int main() {
     printf("trial %d: status %d/%d inner %d/%d fused passes %d (oracle entry-point passes %d) f_end %.9g/%.9g |t-t*| %.3g same=%d\n", trial, st,
            st_o, n_inner, n_inner_o, fn.passes, passes_o, f_end, f_end_o, err, (int)same);
     if (st != 0 || st_o != 0 || !same || n_inner != n_inner_o || f_end != f_end_o || !(err < 5e-3)) bad++;
+    // 2. portable flavour on the same per-point functor: another trajectory (last-bit differences in sin / cos), the same minimum
+    typedef lh::CostEval<OracleBackedPass, lh::PortableMath> FnP;
+    FnP fnp;
+    fnp.pass = &pass;
+    float Tq[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    int n_inner_p = 0;
+    double f_end_p = 0;
+    int st_p = lh::estimate_rigid_bfgs<FnP, lh::PortableMath>(&fnp, 50, Tq, &n_inner_p, &f_end_p);
+    double dpo = 0;
+    for (int k = 0; k < 16; k++) dpo = std::fmax(dpo, std::fabs((double)Tq[k] - (double)Tp[k]));
+    // 3. the moment model about T0 = I: 74 sums of the same correspondences (double T0*p - q, like the fused sweep), then the
+    // whole solve from the model; the first evaluation must reproduce the per-point functor's sums up to that functor's float T*p (1e-5 relative)
+    lh::MomentModel mom;
+    for (int k = 0; k < 74; k++) mom.S[k] = 0.0;
+    for (int k = 0; k < 16; k++) mom.T0[k] = (k % 5 == 0) ? 1.f : 0.f;
+    for (int i = 0; i < n; i++) {
+      const double* Mi = &maha[9 * i];
+      double pt[4] = {src[4 * i], src[4 * i + 1], src[4 * i + 2], 1.0};
+      double a[3] = {pt[0] - tgt[4 * i], pt[1] - tgt[4 * i + 1], pt[2] - tgt[4 * i + 2]};
+      double Ma[3];
+      for (int r = 0; r < 3; r++) Ma[r] = Mi[r * 3] * a[0] + Mi[r * 3 + 1] * a[1] + Mi[r * 3 + 2] * a[2];
+      mom.S[0] += a[0] * Ma[0] + a[1] * Ma[1] + a[2] * Ma[2];
+      for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 4; c++) mom.S[1 + 4 * r + c] += Ma[r] * pt[c];
+      for (int r = 0; r < 3; r++)
+        for (int q = r; q < 3; q++)
+          for (int c = 0; c < 4; c++)
+            for (int e = c; e < 4; e++) mom.S[13 + lh::MomentModel::sym3(r, q) * 10 + lh::MomentModel::sym4(c, e)] += Mi[r * 3 + q] * pt[c] * pt[e];
+      mom.S[73] += 1.0;
+    }
+    mom.prepare();
+    lh::MomentPass<lh::PortableMath> mpass{&mom};
+    double x0[6] = {0.01, -0.02, 0.005, 0.001, -0.002, 0.003}, Sm[13], Sp[13], cm, cp;
+    mpass(x0, Sm, &cm);
+    pass(x0, Sp, &cp);
+    double worst = 0;
+    for (int k = 0; k < 13; k++) worst = std::fmax(worst, std::fabs(Sm[k] - Sp[k]) / (std::fabs(Sp[k]) + 1.0));
+    typedef lh::CostEval<lh::MomentPass<lh::PortableMath>, lh::PortableMath> FnM;
+    FnM fnm;
+    fnm.pass = &mpass;
+    lh::OuterParams OP{20, 50, 2e-3, 1e-3};
+    lh::OuterState os;
+    lh::outer_state_init(&os);
+    lh::outer_step<FnM, lh::PortableMath>(&fnm, OP, &os);
+    double dmo = 0;
+    for (int k = 0; k < 16; k++) dmo = std::fmax(dmo, std::fabs((double)os.T[k] - (double)Tp[k]));
+    printf("         portable: status %d inner %d |T - T_libm| %.3g ; moments: sums rel %.3g, outer_step status %d iter %d |T - T_libm| %.3g\n", st_p,
+           n_inner_p, dpo, worst, os.status, os.iter, dmo);
+    if (st_p != 0 || !(dpo < 2e-4) || !(worst < 2e-4) || os.status != 0 || os.iter != 1 || !(dmo < 2e-4) || cm != (double)n) bad++;
+  }
+  // elementary functions of the portable flavour against libm
+  {
+    std::uniform_real_distribution<double> u(-1.0, 1.0);
+    double ws = 0, wa = 0;
+    for (int i = 0; i < 200000; i++) {
+      double x = (i & 1) ? 0.8 * u(rng) : 12.0 * u(rng), s, c;
+      lh::pm_sincos(x, &s, &c);
+      ws = std::fmax(ws, std::fmax(std::fabs(s - std::sin(x)), std::fabs(c - std::cos(x))));
+      double y = u(rng), z = (i & 2) ? u(rng) : 1e-3 * u(rng);
+      wa = std::fmax(wa, std::fabs(lh::pm_atan2(z, y) - std::atan2(z, y)));
+      wa = std::fmax(wa, std::fabs(lh::pm_asin(z) - std::asin(z)));
+    }
+    printf("portable math: max |sincos - libm| %.3g, max |atan2/asin - libm| %.3g\n", ws, wa);
+    if (!(ws < 3e-16) || !(wa < 1e-15)) bad++;
   }
   printf(bad ? "BFGS_CHECK_FAILED\n" : "BFGS_CHECK_OK\n");
   return bad ? 1 : 0;

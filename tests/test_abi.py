@@ -11,6 +11,14 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _has_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
 def _header_symbols():
     txt = open(os.path.join(ROOT, "include", "locus_hip.h")).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
@@ -27,6 +35,23 @@ def test_library_exports_every_declared_symbol(capi):
     assert L.lh_abi_version() == 1
 
 
+def test_rccl_library_exports_every_declared_symbol(capi):
+    """liblocus_hip_rccl.so (include/locus_hip_rccl.h): loads next to librccl and exports what its header declares"""
+    from locus_amd import rccl
+    txt = open(os.path.join(ROOT, "include", "locus_hip_rccl.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    syms = sorted(set(re.findall(r"\b(lh_rccl_[a-z0-9_]+)\s*\(", txt)))
+    L = rccl.lib()
+    assert len(syms) == 10 and sorted(rccl.EXPORTS) == syms
+    assert not [s for s in syms if not hasattr(L, s)]
+    assert rccl.ID_BYTES == 128
+    if not _has_gpu():   # argument validation happens before any device or RCCL call
+        h = C.c_void_p()
+        assert L.lh_rccl_create(0, b"\0" * 128, 2, 2, C.byref(h)) == capi.LH_EINVAL      # rank outside the world
+        assert L.lh_rccl_create(0, b"\0" * 128, 0, 1, C.byref(h)) == capi.LH_EDEVICE      # no GPU here
+        assert L.lh_rccl_install_sum_hook(None, None) == capi.LH_EINVAL
+
+
 def test_struct_layouts_match_header(capi):
     assert C.sizeof(capi.CloudView) == 32
     assert C.sizeof(capi.GicpParams) == 72
@@ -39,14 +64,6 @@ def test_default_params_are_the_class_defaults(capi):
     assert (p.max_iterations, p.max_inner_iterations, p.k_correspondences) == (200, 20, 20)
     assert (p.corr_dist, p.transformation_epsilon, p.rotation_epsilon, p.gicp_epsilon) == (5.0, 5e-4, 2e-3, 1e-3)
     assert p.recompute_source_cov == 0 and p.recompute_target_cov == 0
-
-
-def _has_gpu():
-    try:
-        import torch
-        return torch.cuda.is_available()
-    except Exception:
-        return False
 
 
 @pytest.mark.skipif(_has_gpu(), reason="only meaningful on a box without a GPU")

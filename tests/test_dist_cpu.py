@@ -67,6 +67,53 @@ def test_two_rank_gather_over_gloo(n_pairs):
     assert np.allclose(traj[-1][:3, :3] @ traj[-1][:3, :3].T, np.eye(3), atol=1e-5)
 
 
+def _records_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from locus_amd import capi
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    n = 3
+    raw = (capi.GicpResult * n)()
+    for i in range(n):
+        for k in range(16):
+            raw[i].T[k] = float(100 * rank + 10 * i + k)
+        raw[i].iterations = 20 - i
+        raw[i].n_correspondences_last = 1000 * rank + i
+        raw[i].fitness = 0.25 * (rank + 1)
+    allr = ldist.gather_records(raw, world)
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, bytes(allr.numpy().tobytes()), bytes(bytearray(raw))))
+
+
+def test_two_rank_result_record_gather_over_gloo():
+    """bench.py --gpus N: the lh_gicp_result records of every rank in ONE all_gather (device tensors under RCCL, host tensors under
+    gloo here): every rank ends with the same table, each rank's block at its own offset, bit for bit"""
+    import ctypes as C
+    import torch.multiprocessing as mp
+    from locus_amd import capi
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_records_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict()
+    for _ in procs:
+        rank, table, mine = q.get(timeout=120)
+        res[rank] = (table, mine)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][0] == res[1][0] == res[0][1] + res[1][1]
+    rec = (capi.GicpResult * 6).from_buffer_copy(res[0][0])
+    assert C.sizeof(capi.GicpResult) == 96 and rec[4].T[3] == 113.0 and rec[4].iterations == 19 and rec[5].n_correspondences_last == 1002
+
+
 def _hook_worker(rank, world, port, q):
     import ctypes as C
     import torch.distributed as dist
