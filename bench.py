@@ -135,12 +135,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--pairs", type=int, default=64, help="scan pairs per GPU per step")
-    ap.add_argument("--in-flight", type=int, default=64)
+    ap.add_argument("--pairs", type=int, default=128, help="scan pairs per GPU per step")
+    ap.add_argument("--in-flight", type=int, default=128)
     ap.add_argument("--rings", type=int, default=64)
     ap.add_argument("--azimuths", type=int, default=1563)  # 64 x 1563 = 100 032 points / scan
     ap.add_argument("--scale", type=float, default=2.0)
     ap.add_argument("--cost-mode", type=int, default=1, help="lh_gicp_params.cost_mode (1 = moments, 0 = per-evaluation passes)")
+    ap.add_argument("--solver", type=int, default=0, help="lh_gicp_params.solver: 0 = outer loop on the device (k_solve), 1 = on the host")
+    ap.add_argument("--quick", action="store_true", help="timed region only: no roofline / mode-0 / natural-convergence / CPU legs (A/B runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single-latency", action="store_true", help="skip the one-pair-at-a-time lh_gicp_align latency leg")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the measured configuration) or gloo (functional check)")
@@ -177,7 +179,7 @@ def main():
     ctx = capi.Context(local_rank)
     # forced 20 outer iterations: eps = 0 would divide by zero in the ratio, use a vanishing eps instead
     P = capi.default_params(max_iterations=20, max_inner_iterations=20, corr_dist=1.0, transformation_epsilon=1e-12,
-                            rotation_epsilon=1e-12, cost_mode=args.cost_mode)
+                            rotation_epsilon=1e-12, cost_mode=args.cost_mode, solver=args.solver)
     S, T, host = make_pairs(ctx, args.pairs, rank, args.rings, args.azimuths, args.scale)
     n_pts = len(S[0])
 
@@ -233,11 +235,16 @@ def main():
         errs.append(np.abs(Tm[:3, 3] - delta[:3, 3]).max())
 
     result = None
+    if rank == 0 and args.quick:
+        print(json.dumps({"value": round(value, 2), "ms_per_step": round(1e3 * elapsed / args.steps, 3), "solver": args.solver,
+                          "iters": [min(iters), float(np.mean(iters)), max(iters)], "env": {k: v for k, v in os.environ.items() if k.startswith("LH_")}}))
+        return
     if rank == 0:
         # ---- roofline leg: the same steps again with HIP-event timing of every launch on the library's stream ----
         # Profiling runs ONE scheduler group so kernels never overlap; to time launches of the same shape as the timed
-        # region's (two half-batches of in_flight/2 pairs each) the leg runs with in_flight/2 pairs per launch.
-        prof_in_flight = max(8, args.in_flight // 2) if args.in_flight >= 16 else args.in_flight
+        # region's (four groups of in_flight/4 pairs each) the leg runs with in_flight/4 pairs per launch.
+        groups = 4 if args.in_flight >= 64 else (2 if args.in_flight >= 16 else 1)   # the scheduler's groups (lh_api.hip run_tasks_device)
+        prof_in_flight = max(8, args.in_flight // groups)
         ctx.profile(True)
         ctx.profile_reset()
         for _ in range(max(1, min(args.steps, 2))):

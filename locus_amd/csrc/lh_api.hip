@@ -183,6 +183,7 @@ struct Workspace {
   double* maha6 = nullptr;
   int32_t* prev_nn = nullptr;
   float4* cert = nullptr;     // NN certificates (see Nn1CertCollector)
+  float4* rec = nullptr;      // the neighbour prev_nn points at, gathered (position, normal): 2 float4 per source point
   unsigned long long* stats = nullptr;  // 2 counters
   float4* out_xyz = nullptr;  // guess * input when guess != I
   int n_pad = 0;
@@ -194,6 +195,12 @@ struct lh_ctx {
   int device = 0;
   HostPool* pool = nullptr;
   hipStream_t stream = nullptr, stream2 = nullptr;  // stream2: second half-batch of the pipelined scheduler
+  hipStream_t stream3 = nullptr, stream4 = nullptr; // further scheduler groups of the device-driven loop
+  void sync_side_streams() {  // everything the scheduler may have queued besides the primary stream
+    if (stream2) (void)hipStreamSynchronize(stream2);
+    if (stream3) (void)hipStreamSynchronize(stream3);
+    if (stream4) (void)hipStreamSynchronize(stream4);
+  }
   // index-build scratch (shared by all clouds of the context; builds are serial on the stream)
   uint32_t *keys0 = nullptr, *keys1 = nullptr, *vals0 = nullptr, *vals1 = nullptr, *bbox = nullptr;
   void* sort_temp = nullptr;
@@ -223,7 +230,7 @@ struct lh_ctx {
   OuterState* states_host = nullptr;   // pinned: upload staging at admission / download target when the host looks
   OuterState* states_init = nullptr;   // pinned: initial states (separate from the download target: uploads and downloads overlap)
   double* chunks_dev = nullptr;        // [n_slots][FINAL_CHUNKS * MOM_ROW]
-  hipEvent_t group_ev[2] = {nullptr, nullptr};
+  hipEvent_t group_ev[4] = {nullptr, nullptr, nullptr, nullptr};
   // batch mode: one workspace per scheduler slot.  They live here (not in a thread-local) so that they are tied to this
   // context's device, reused by every thread that drives the context, and released by lh_destroy.
   std::vector<Workspace> slot_ws;
@@ -388,7 +395,7 @@ static lh_status build_indices(lh_ctx* x, lh_cloud* const* clouds, int n_clouds,
       if (c->n > (1 << 27)) return LH_EINVAL;  // leaf references keep 27 bits of sorted position
       if (c->n > c->index_cap) {
         (void)hipStreamSynchronize(x->stream);
-        if (x->stream2) (void)hipStreamSynchronize(x->stream2);
+        x->sync_side_streams();
         (void)lhFree(c->sorted); (void)lhFree(c->pos); (void)lhFree(c->node_buf);
         c->sorted = nullptr; c->pos = nullptr; c->node_buf = nullptr; c->index_cap = 0;
         HIPCHK(lhMalloc(&c->sorted, sizeof(float4) * ((size_t)c->n + LEAF_CAP)));
@@ -405,7 +412,7 @@ static lh_status build_indices(lh_ctx* x, lh_cloud* const* clouds, int n_clouds,
     if (total > 0x7ffffff0L) return LH_EINVAL;
     if ((int)total > x->idx_cap) {
       (void)hipStreamSynchronize(x->stream);
-      if (x->stream2) (void)hipStreamSynchronize(x->stream2);
+      x->sync_side_streams();
       (void)lhFree(x->k64a); (void)lhFree(x->k64b); (void)lhFree(x->v32a); (void)lhFree(x->v32b); (void)lhFree(x->sort64_temp);
       (void)lhFree(x->tree_tmp); (void)lhFree(x->scan_tmp);
       int cap = round_up((int)std::min<long>(total + total / 4, 0x7fffff00L), 1024);
@@ -475,23 +482,24 @@ static lh_status cloud_ensure_cov(lh_cloud* c, int k, double eps) {
 lh_status Workspace::ensure(lh_ctx* c, int n) {
   if (n <= cap) return LH_OK;
   (void)hipStreamSynchronize(c->stream);  // a slot may belong to either scheduler group: nothing may still use the old buffers
-  if (c->stream2) (void)hipStreamSynchronize(c->stream2);
-  (void)lhFree(corr); (void)lhFree(maha6); (void)lhFree(prev_nn); (void)lhFree(out_xyz); (void)lhFree(cert);
-  corr = nullptr; maha6 = nullptr; prev_nn = nullptr; out_xyz = nullptr; cert = nullptr; cap = 0;
+  c->sync_side_streams();
+  (void)lhFree(corr); (void)lhFree(maha6); (void)lhFree(prev_nn); (void)lhFree(out_xyz); (void)lhFree(cert); (void)lhFree(rec);
+  corr = nullptr; maha6 = nullptr; prev_nn = nullptr; out_xyz = nullptr; cert = nullptr; rec = nullptr; cap = 0;
   int ncap = round_up(n, 256);
   HIPCHK(hipMalloc(&corr, sizeof(float4) * (size_t)ncap));
   HIPCHK(hipMalloc(&maha6, sizeof(double) * 6 * (size_t)ncap));
   HIPCHK(hipMalloc(&prev_nn, sizeof(int32_t) * (size_t)ncap));
   HIPCHK(hipMalloc(&out_xyz, sizeof(float4) * (size_t)ncap));
   HIPCHK(hipMalloc(&cert, sizeof(float4) * (size_t)ncap));
+  HIPCHK(hipMalloc(&rec, sizeof(float4) * 2 * (size_t)ncap));
   if (!stats) { HIPCHK(hipMalloc(&stats, 16)); HIPCHK(hipMemset(stats, 0, 16)); }
   cap = ncap;
   n_pad = ncap;
   return LH_OK;
 }
 void Workspace::release() {
-  (void)lhFree(corr); (void)lhFree(maha6); (void)lhFree(prev_nn); (void)lhFree(out_xyz); (void)lhFree(cert); (void)lhFree(stats);
-  corr = nullptr; maha6 = nullptr; prev_nn = nullptr; out_xyz = nullptr; cert = nullptr; stats = nullptr; cap = 0;
+  (void)lhFree(corr); (void)lhFree(maha6); (void)lhFree(prev_nn); (void)lhFree(out_xyz); (void)lhFree(cert); (void)lhFree(rec); (void)lhFree(stats);
+  corr = nullptr; maha6 = nullptr; prev_nn = nullptr; out_xyz = nullptr; cert = nullptr; rec = nullptr; stats = nullptr; cap = 0;
 }
 
 static lh_status ctx_ensure_slots(lh_ctx* c, int n_slots, int max_n) {
@@ -499,7 +507,7 @@ static lh_status ctx_ensure_slots(lh_ctx* c, int n_slots, int max_n) {
   int mom_stride = ((max_n + 255) / 256) * 4 * MOM_ROW;  // one partial row per wave of every 256-point workgroup of the fused sweep
   if (n_slots <= c->n_slots && per_slot <= c->partials_per_slot && mom_stride <= c->mom_stride) return LH_OK;
   (void)hipStreamSynchronize(c->stream);
-  if (c->stream2) (void)hipStreamSynchronize(c->stream2);
+  c->sync_side_streams();
   n_slots = std::max(n_slots, c->n_slots);
   per_slot = std::max(per_slot, c->partials_per_slot);
   mom_stride = std::max(mom_stride, c->mom_stride);
@@ -517,7 +525,7 @@ static lh_status ctx_ensure_slots(lh_ctx* c, int n_slots, int max_n) {
   HIPCHK(hipMalloc(&c->chunks_dev, sizeof(double) * (size_t)FINAL_CHUNKS * MOM_ROW * n_slots));
   HIPCHK(hipHostMalloc(&c->states_host, sizeof(OuterState) * n_slots, hipHostMallocDefault));
   HIPCHK(hipHostMalloc(&c->states_init, sizeof(OuterState) * n_slots, hipHostMallocDefault));
-  for (int k = 0; k < 2; k++)
+  for (int k = 0; k < 4; k++)
     if (!c->group_ev[k]) HIPCHK(hipEventCreateWithFlags(&c->group_ev[k], hipEventDisableTiming));
   c->mom_stride = mom_stride;
   HIPCHK(hipHostMalloc(&c->descs_host, sizeof(PairDesc) * n_slots, hipHostMallocDefault));
@@ -578,9 +586,9 @@ struct Task {
   // cost_mode 0: one fused device pass per evaluation (gicp.hpp:362-402), reference arithmetic; libm on the host like the oracle
   struct DevicePass {
     Task* t;
-    void operator()(const double x[6], double sums13[13], double* count) {
+    void operator()(const double x[6], const Trig& tg, double sums13[13], double* count) {
       float T16[16];
-      apply_state<LibmMath>(x, T16);  // base_transformation_ = I (gicp.hpp:435, 367-368)
+      apply_state_trig(x, tg, T16);   // base_transformation_ = I (gicp.hpp:435, 367-368)
       T16_to_T12(T16, t->req_T12);
       t->yield(REQ_COST);
       memcpy(sums13, t->res_sums, sizeof(double) * 13);
@@ -620,14 +628,14 @@ struct Task {
         typedef CostEval<Pass, PortableMath> Fn;
         Pass pass{&mom};
         Fn fn;               // new correspondences: a fresh functor cache
-        fn.pass = &pass;
+        fn.pass = pass;
         outer_step<Fn, PortableMath>(&fn, OP, &os);
         k_t = mom.count();
       } else {
         typedef CostEval<DevicePass, LibmMath> Fn;
         DevicePass pass{this};
         Fn fn;
-        fn.pass = &pass;
+        fn.pass = pass;
         outer_step<Fn, LibmMath>(&fn, OP, &os);
         k_t = fn.count();
       }
@@ -704,6 +712,7 @@ static lh_status task_prepare(lh_ctx* c, Task* t, bool rebuild_index) {
   d.tgt_hdr = tgt->hdr();
   d.prev_nn = t->ws->prev_nn;
   d.cert = t->ws->cert;
+  d.rec = t->ws->rec;
   d.stats = t->count_stats ? t->ws->stats : nullptr;
   d.corr = t->ws->corr;
   d.maha6 = t->ws->maha6;
@@ -804,7 +813,10 @@ static lh_status group_launch(lh_ctx* c, Group& g) {
         g.moms.push_back(t);
       }
       ProfScope p(c, "nn_sweep", bytes, st);
-      launch_sweep_fused(c->descs_dev, a, max_n, c->mom_partials_dev, c->mom_stride, nullptr, st);
+      bool normals_only = true;
+      for (int j = 0; j < a.njobs; j++)
+        if (g.sweeps[o + j]->P.recompute_source_cov || g.sweeps[o + j]->P.recompute_target_cov) normals_only = false;
+      launch_sweep_fused(c->descs_dev, a, max_n, c->mom_partials_dev, c->mom_stride, nullptr, normals_only, st);
       launch_moments_final(c->descs_dev, ca, c->mom_partials_dev, c->mom_stride, c->partials_host, nullptr, st);
     } else {
       {
@@ -937,20 +949,41 @@ struct DevGroup {
   std::vector<int> free_slots;
   int slot_lo = 0, slot_hi = 0;  // this group's contiguous slot range
   bool pending = false;          // rounds are enqueued and a state download is in flight behind them
+  std::vector<Task*> to_align;   // retired in this round, output cloud still to be written
 };
+
+// align()'s output clouds (gicp.hpp:586, pcl::transformPointCloud(*input_, output, final_transformation_)) of the pairs that retired
+// together: one launch on the group's stream
+static void dev_write_aligned(lh_ctx* c, DevGroup& g) {
+  for (size_t o = 0; o < g.to_align.size(); o += MAX_XFORM_JOBS) {
+    XformBatchArgs a;
+    a.njobs = (int)std::min<size_t>(MAX_XFORM_JOBS, g.to_align.size() - o);
+    a.pad = 0;
+    int max_n = 0;
+    double bytes = 0;
+    for (int j = 0; j < a.njobs; j++) {
+      Task* t = g.to_align[o + j];
+      XformJob& x = a.job[j];
+      x.in_xyz = t->src->xyz; x.out_xyz = t->aligned->xyz;
+      x.in_nrm = t->aligned->nrm ? t->src->nrm : nullptr; x.out_nrm = t->aligned->nrm;
+      x.in_int = t->aligned->intensity ? t->src->intensity : nullptr; x.out_int = t->aligned->intensity;
+      x.n = t->src->n; x.pad = 0;
+      Task::T16_to_T12(t->result.T, x.T);
+      max_n = std::max(max_n, x.n);
+      bytes += 32.0 * x.n;
+    }
+    ProfScope p(c, "transform", bytes, g.stream);
+    launch_transform_copy_batch(a, max_n, g.stream);
+  }
+  g.to_align.clear();
+}
 
 static lh_status dev_retire(lh_ctx* c, DevGroup& g, Task* t) {
   t->os = c->states_host[t->slot];
   t->finish_result();
   if (c->prof)  // fused K4+K5': algorithmic bytes B_nn + one B_fdf per iteration = 20 N + (232 + 108) K_t
     c->prof_entries[c->prof_entry("nn_sweep")].bytes += 340.0 * t->os.corr_sum;
-  if (t->aligned) {  // pcl::transformPointCloud(*input_, output, final_transformation_) (gicp.hpp:586), on the group's stream
-    float T12[12];
-    Task::T16_to_T12(t->result.T, T12);
-    ProfScope p(c, "transform", 32.0 * t->src->n, g.stream);
-    launch_transform_copy(t->src->xyz, t->aligned->nrm ? t->src->nrm : nullptr, t->aligned->intensity ? t->src->intensity : nullptr, t->src->n, T12,
-                          t->aligned->xyz, t->aligned->nrm, t->aligned->intensity, g.stream);
-  }
+  if (t->aligned) g.to_align.push_back(t);  // its output cloud goes out with the other pairs that retire in this round
   if (t->trace && t->trace_dev) {
     HIPCHK(hipMemcpyAsync(t->trace, t->trace_dev, sizeof(lh_gicp_trace), hipMemcpyDeviceToHost, g.stream));
     HIPCHK(hipStreamSynchronize(g.stream));
@@ -973,6 +1006,7 @@ static lh_status dev_enqueue(lh_ctx* c, DevGroup& g, int rounds) {
       sa.njobs = a.njobs;
       int max_n = 0;
       double bytes = 0;
+      bool normals_only = true;
       SweepArgs seed;
       seed.njobs = 0; seed.max_depth = 0; seed.pad = 0; seed.bpj = 0;
       int smax = 0;
@@ -986,6 +1020,7 @@ static lh_status dev_enqueue(lh_ctx* c, DevGroup& g, int rounds) {
         memcpy(ca.job[j].T, a.job[j].T, sizeof(a.job[j].T));
         sa.slot[j] = t->slot;
         max_n = std::max(max_n, t->src->n);
+        if (t->P.recompute_source_cov || t->P.recompute_target_cov) normals_only = false;
         if (t->enq_iters < t->P.max_iterations) bytes += 20.0 * t->src->n;  // SURVEY 8d B_nn = 20 N + 232 K_t; the K_t terms are added at retirement
         if (t->first_sweep) {  // cold pair: seed pre-pass so its first sweep starts warm
           seed.job[seed.njobs++] = a.job[j];
@@ -1000,7 +1035,7 @@ static lh_status dev_enqueue(lh_ctx* c, DevGroup& g, int rounds) {
       }
       {
         ProfScope p(c, "nn_sweep", bytes, st);
-        launch_sweep_fused(c->descs_dev, a, max_n, c->mom_partials_dev, c->mom_stride, c->states_dev, st);
+        launch_sweep_fused(c->descs_dev, a, max_n, c->mom_partials_dev, c->mom_stride, c->states_dev, normals_only, st);
         launch_moments_final(c->descs_dev, ca, c->mom_partials_dev, c->mom_stride, c->chunks_dev, c->states_dev, st);
       }
       {
@@ -1019,11 +1054,19 @@ static lh_status dev_enqueue(lh_ctx* c, DevGroup& g, int rounds) {
 
 static lh_status run_tasks_device(lh_ctx* c, std::vector<Task*>& tasks, int in_flight, bool rebuild_index, std::vector<Workspace>* slot_ws) {
   static const int rounds_cfg = []() { const char* e = getenv("LH_DEVICE_ROUNDS"); int v = e ? atoi(e) : 4; return v < 1 ? 1 : v; }();
-  const int G = (in_flight >= 16 && !c->prof) ? 2 : 1;  // profiling keeps one group so HIP-event times do not overlap
-  if (G == 2 && !c->stream2) HIPCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
-  DevGroup groups[2];
+  // Groups: a pair's solve (one wave, tens of sequential cost evaluations) takes about as long as its sweep, so with more groups
+  // in flight there is always somebody's sweep to run beside the other groups' solves.  Profiling keeps one group so that the
+  // HIP-event times of the launches do not overlap.
+  static const int groups_cfg = []() { const char* e = getenv("LH_DEVICE_GROUPS"); int v = e ? atoi(e) : 0; return v < 0 ? 0 : (v > 4 ? 4 : v); }();
+  int G = groups_cfg ? groups_cfg : (in_flight >= 64 ? 4 : (in_flight >= 16 ? 2 : 1));
+  if (c->prof) G = 1;
+  G = std::max(1, std::min(G, in_flight));
+  hipStream_t* extra[3] = {&c->stream2, &c->stream3, &c->stream4};
+  for (int gi = 1; gi < G; gi++)
+    if (!*extra[gi - 1]) HIPCHK(hipStreamCreateWithFlags(extra[gi - 1], hipStreamNonBlocking));
+  DevGroup groups[4];
   groups[0].stream = c->stream;
-  groups[1].stream = c->stream2;
+  for (int gi = 1; gi < G; gi++) groups[gi].stream = *extra[gi - 1];
   {
     int per = (in_flight + G - 1) / G, s = 0;
     for (int gi = 0; gi < G; gi++) {
@@ -1037,7 +1080,7 @@ static lh_status run_tasks_device(lh_ctx* c, std::vector<Task*>& tasks, int in_f
   lh_status err = LH_OK;
   auto fail = [&](lh_status st) {
     (void)hipStreamSynchronize(c->stream);
-    if (c->stream2) (void)hipStreamSynchronize(c->stream2);
+    c->sync_side_streams();
     for (Task* t : tasks)
       if (t->trace_dev) { (void)lhFree(t->trace_dev); t->trace_dev = nullptr; }
     return st;
@@ -1065,6 +1108,7 @@ static lh_status run_tasks_device(lh_ctx* c, std::vector<Task*>& tasks, int in_f
           } else
             i++;
         }
+        dev_write_aligned(c, g);
       }
       if (next < tasks.size() && !g.free_slots.empty()) {  // admit: the NN indexes of all newly admitted targets are built together
         std::vector<lh_cloud*> to_build;
@@ -1147,7 +1191,7 @@ static lh_status run_tasks_host(lh_ctx* c, std::vector<Task*>& tasks, int in_fli
   // build, sweeps); nothing may be handed back to the pool, or to the caller, before both streams have drained
   auto fail = [&](lh_status st) {
     (void)hipStreamSynchronize(c->stream);
-    if (c->stream2) (void)hipStreamSynchronize(c->stream2);
+    c->sync_side_streams();
     return st;
   };
   while (next < tasks.size() || busy()) {
@@ -1316,7 +1360,7 @@ void lh_destroy(lh_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
-  if (c->stream2) (void)hipStreamSynchronize(c->stream2);
+  c->sync_side_streams();
   delete c->pool;
   c->pool = nullptr;
   for (auto& w : c->slot_ws) w.release();
@@ -1331,11 +1375,13 @@ void lh_destroy(lh_ctx* c) {
   if (c->idx_copy_done) (void)hipEventDestroy(c->idx_copy_done);
   if (c->idx_build_done) (void)hipEventDestroy(c->idx_build_done);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
+  if (c->stream3) (void)hipStreamDestroy(c->stream3);
+  if (c->stream4) (void)hipStreamDestroy(c->stream4);
   (void)lhFree(c->sort_temp); (void)lhFree(c->bbox); (void)lhFree(c->descs_dev); (void)lhFree(c->mom_partials_dev);
   (void)lhFree(c->states_dev); (void)lhFree(c->chunks_dev);
   if (c->states_host) (void)hipHostFree(c->states_host);
   if (c->states_init) (void)hipHostFree(c->states_init);
-  for (int k = 0; k < 2; k++)
+  for (int k = 0; k < 4; k++)
     if (c->group_ev[k]) (void)hipEventDestroy(c->group_ev[k]);
   if (c->descs_host) (void)hipHostFree(c->descs_host);
   if (c->partials_host) (void)hipHostFree(c->partials_host);
@@ -1734,7 +1780,7 @@ lh_status lh_gicp_align_batch_out(lh_ctx* ctx, const lh_gicp_params* p, int n_pa
   for (int i = 0; i < n_pairs; i++) out[i] = tasks[i].result;
   if (aligned) {  // the output clouds were written on the scheduler streams: complete before the caller touches them
     (void)hipStreamSynchronize(ctx->stream);
-    if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
+    ctx->sync_side_streams();
   }
   return st;
 }

@@ -15,6 +15,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <type_traits>
 
 #include "lh_math.hpp"
 
@@ -34,10 +35,54 @@ LH_FN bool same_bits6(const double* a, const double* b) {  // memcmp of six doub
   return eq;
 }
 
+// ---- the six sine / cosine pairs one state needs ------------------------------------------------------------------------
+// applyState (gicp.hpp:619-634) takes the float half angles (Eigen::AngleAxisf -> Quaternionf), computeRDerivative
+// (gicp.hpp:160-214) the double angles.  One evaluation of the functor needs both, so they are computed once, together:
+// on the host six calls; in k_solve (one wave per pair, every lane holds the same state) six LANES make one call each and the
+// results are broadcast -- the same function on the same arguments either way, hence the same bits.
+struct Trig {
+  double sphi, cphi, sth, cth, spsi, cpsi;  // x[3], x[4], x[5]
+  float shx, chx, shy, chy, shz, chz;       // 0.5f * float(x[3]), 0.5f * float(x[4]), 0.5f * float(x[5])
+};
+#if defined(__HIP_DEVICE_COMPILE__)
+// value of lane `src` for the whole wave (v_readlane_b32 x 2; the wave's control flow is uniform in k_solve)
+__device__ __forceinline__ double wave_bcast(double v, int src) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_readlane(lo, src);
+  hi = __builtin_amdgcn_readlane(hi, src);
+  return __hiloint2double(hi, lo);
+}
+#endif
+template <class M>
+LH_FN void trig_all(const double* x, Trig* t) {
+  const float hx = 0.5f * (float)x[3], hy = 0.5f * (float)x[4], hz = 0.5f * (float)x[5];
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (std::is_same<M, PortableMath>::value) {
+    const int lane = (int)(threadIdx.x & 63u);
+    // PortableMath::sincos_f(h) = float(pm_sincos(double(h))): all six are pm_sincos of a double argument, one per lane
+    double arg = lane == 0 ? x[3] : (lane == 1 ? x[4] : (lane == 2 ? x[5] : (lane == 3 ? (double)hx : (lane == 4 ? (double)hy : (double)hz))));
+    double sn, cs;
+    pm_sincos(arg, &sn, &cs);
+    t->sphi = wave_bcast(sn, 0); t->cphi = wave_bcast(cs, 0);
+    t->sth = wave_bcast(sn, 1); t->cth = wave_bcast(cs, 1);
+    t->spsi = wave_bcast(sn, 2); t->cpsi = wave_bcast(cs, 2);
+    t->shx = (float)wave_bcast(sn, 3); t->chx = (float)wave_bcast(cs, 3);
+    t->shy = (float)wave_bcast(sn, 4); t->chy = (float)wave_bcast(cs, 4);
+    t->shz = (float)wave_bcast(sn, 5); t->chz = (float)wave_bcast(cs, 5);
+    return;
+  }
+#endif
+  M::sincos_d(x[3], &t->sphi, &t->cphi);
+  M::sincos_d(x[4], &t->sth, &t->cth);
+  M::sincos_d(x[5], &t->spsi, &t->cpsi);
+  M::sincos_f(hx, &t->shx, &t->chx);
+  M::sincos_f(hy, &t->shy, &t->chy);
+  M::sincos_f(hz, &t->shz, &t->chz);
+}
+
 // ---- state <-> matrix -------------------------------------------------------------------------------
 // applyState (gicp.hpp:619-634), float quaternion path of Eigen's AngleAxisf products; T = 16 floats column-major
-template <class M>
-LH_FN void apply_state(const double* x, float* T) {
+LH_FN void apply_state_trig(const double* x, const Trig& tg, float* T) {
   struct Q { float w, x, y, z; };
   auto mul = [](Q a, Q b) {
     Q r;
@@ -47,12 +92,7 @@ LH_FN void apply_state(const double* x, float* T) {
     r.z = a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x;
     return r;
   };
-  float hz = 0.5f * (float)x[5], hy = 0.5f * (float)x[4], hx = 0.5f * (float)x[3];
-  float sz, cz, sy, cy, sx, cx;
-  M::sincos_f(hz, &sz, &cz);
-  M::sincos_f(hy, &sy, &cy);
-  M::sincos_f(hx, &sx, &cx);
-  Q qz{cz, 0.f, 0.f, sz}, qy{cy, 0.f, sy, 0.f}, qx{cx, sx, 0.f, 0.f};
+  Q qz{tg.chz, 0.f, 0.f, tg.shz}, qy{tg.chy, 0.f, tg.shy, 0.f}, qx{tg.chx, tg.shx, 0.f, 0.f};
   Q q = mul(mul(qz, qy), qx);
   float tx = 2.0f * q.x, ty = 2.0f * q.y, tz = 2.0f * q.z;
   float twx = tx * q.w, twy = ty * q.w, twz = tz * q.w;
@@ -67,16 +107,17 @@ LH_FN void apply_state(const double* x, float* T) {
   T[3] = T[7] = T[11] = 0.0f;
   T[12] = (float)x[0]; T[13] = (float)x[1]; T[14] = (float)x[2]; T[15] = 1.0f;
 }
+template <class M>
+LH_FN void apply_state(const double* x, float* T) {
+  Trig tg;
+  trig_all<M>(x, &tg);
+  apply_state_trig(x, tg, T);
+}
 inline void apply_state(const double* x, float* T) { apply_state<LibmMath>(x, T); }  // host, libm (reference build)
 
 // computeRDerivative (gicp.hpp:160-214) + matricesInnerProd (gicp.h:361-370); R row-major
-template <class M>
-LH_FN void compute_r_derivative(const double* x, const double* R, double* g) {
-  double phi = x[3], theta = x[4], psi = x[5];
-  double cphi, sphi, cth, sth, cpsi, spsi;
-  M::sincos_d(phi, &sphi, &cphi);
-  M::sincos_d(theta, &sth, &cth);
-  M::sincos_d(psi, &spsi, &cpsi);
+LH_FN void compute_r_derivative_trig(const Trig& tg, const double* R, double* g) {
+  const double cphi = tg.cphi, sphi = tg.sphi, cth = tg.cth, sth = tg.sth, cpsi = tg.cpsi, spsi = tg.spsi;
   double dPhi[9] = {0, sphi * spsi + cphi * cpsi * sth, cphi * spsi - cpsi * sphi * sth,
                     0, -cpsi * sphi + cphi * spsi * sth, -cphi * cpsi - sphi * spsi * sth,
                     0, cphi * cth, -cth * sphi};
@@ -99,39 +140,62 @@ LH_FN void compute_r_derivative(const double* x, const double* R, double* g) {
 }
 
 // f /= m, g_t *= 2/m, R *= 2/m, rotation gradient (gicp.hpp:398-401); S = f, g_t[3], R[9]
-template <class M>
-LH_FN void cost_finish(const double* S, double m, const double* x, double* f, double* g) {
+LH_FN void cost_finish_trig(const double* S, double m, const Trig& tg, double* f, double* g) {
   *f = S[0] / m;
   double s = 2.0 / m;
   g[0] = S[1] * s; g[1] = S[2] * s; g[2] = S[3] * s;
   double R[9];
 #pragma unroll
   for (int i = 0; i < 9; i++) R[i] = S[4 + i] * s;
-  compute_r_derivative<M>(x, R, g);
+  compute_r_derivative_trig(tg, R, g);
 }
-inline void cost_finish(const double* S, double m, const double* x, double* f, double* g) { cost_finish<LibmMath>(S, m, x, f, g); }
+inline void cost_finish(const double* S, double m, const double* x, double* f, double* g) {  // host, libm
+  Trig tg;
+  trig_all<LibmMath>(x, &tg);
+  cost_finish_trig(S, m, tg, f, g);
+}
 
 // ---- functor with a one-entry cache ------------------------------------------------------------------
-// Pass: void operator()(const double x[6], double sums13[13], double* count) -- one fused pass: the 13 sums + correspondence count
+// Pass: void operator()(const double x[6], const Trig& tg, double sums13[13], double* count) -- one fused pass: the 13 sums +
+// correspondence count at the state x (tg = its sines / cosines, shared with the gradient's rotation part)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define LH_EVAL_ATTR __attribute__((noinline))
+#else
+#define LH_EVAL_ATTR
+#endif
+struct EvalOut { double f, g[6], m; };
+// One evaluation, everything by value.  In k_solve this is the ONE out-of-line function (the line search reaches it from six
+// places): arguments and result travel in registers, so the solver's own state (the BFGS vectors, the functor cache) stays
+// in registers too instead of living in scratch memory behind a `this` pointer.
+template <class Pass, class M>
+LH_FN LH_EVAL_ATTR EvalOut eval_state(Pass pass, double x0, double x1, double x2, double x3, double x4, double x5) {
+  const double x[6] = {x0, x1, x2, x3, x4, x5};
+  double S[13];
+  Trig tg;
+  trig_all<M>(x, &tg);
+  EvalOut o;
+  pass(x, tg, S, &o.m);
+  if (o.m > 0) cost_finish_trig(S, o.m, tg, &o.f, o.g);
+  else {
+    o.f = 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) o.g[i] = 0.0;
+  }
+  return o;
+}
 template <class Pass, class M>
 struct CostEval {
-  Pass* pass = nullptr;
+  Pass pass;
   bool have = false;
   double cx[6], cf = 0, cg[6], cm = 0;
   int passes = 0;
   LH_FN void eval(const double x[6], double* f, double* g) {
     if (!have || !same_bits6(x, cx)) {
-      double S[13];
-      (*pass)(x, S, &cm);
+      EvalOut o = eval_state<Pass, M>(pass, x[0], x[1], x[2], x[3], x[4], x[5]);
       passes++;
+      cf = o.f; cm = o.m;
 #pragma unroll
-      for (int i = 0; i < 6; i++) cx[i] = x[i];
-      if (cm > 0) cost_finish<M>(S, cm, x, &cf, cg);
-      else {
-        cf = 0;
-#pragma unroll
-        for (int i = 0; i < 6; i++) cg[i] = 0.0;
-      }
+      for (int i = 0; i < 6; i++) { cx[i] = x[i]; cg[i] = o.g[i]; }
       have = true;
     }
     if (f) *f = cf;
@@ -194,13 +258,40 @@ struct MomentModel {
 
 // the Pass of cost_mode 1: every evaluation of an outer iteration comes from the 74 moments of its sweep.  base_transformation_
 // is the identity here (gicp.hpp:435, 367-368), so T(x) = applyState(x).
+// In k_solve (one wave per pair) lane i mod 12 keeps row i of the 12x12 form and B[i] in registers and computes G[i] -- the same
+// twelve sequential multiply-adds the host does for that row -- and the twelve results are broadcast: 12 steps instead of 144.
 template <class M>
 struct MomentPass {
   const MomentModel* mom;
-  LH_FN void operator()(const double x[6], double sums13[13], double* count) const {
+  LH_FN void operator()(const double x[6], const Trig& tg, double sums13[13], double* count) const {
     float T16[16];
-    apply_state<M>(x, T16);
+    apply_state_trig(x, tg, T16);
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int i_mine = (int)(threadIdx.x & 63u) % 12;
+    const double* row = mom->H12 + 12 * i_mine;
+    double d[12];
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int c = 0; c < 4; c++) d[4 * r + c] = (double)T16[c * 4 + r] - (double)mom->T0[c * 4 + r];
+    double g = 0.0;
+#pragma unroll
+    for (int k = 0; k < 12; k++) g += row[k] * d[k];
+    const double Gmine = mom->S[1 + i_mine] + g;
+    double G[12], f = mom->S[0];
+#pragma unroll
+    for (int i = 0; i < 12; i++) G[i] = wave_bcast(Gmine, i);
+#pragma unroll
+    for (int k = 0; k < 12; k++) f += d[k] * (mom->S[1 + k] + G[k]);
+    sums13[0] = f;
+    sums13[1] = G[3]; sums13[2] = G[7]; sums13[3] = G[11];
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+      for (int b = 0; b < 3; b++) sums13[4 + 3 * a + b] = G[4 * b + a];
+#else
     mom->sums(T16, sums13);
+#endif
     *count = mom->count();
   }
 };

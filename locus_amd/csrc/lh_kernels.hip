@@ -316,10 +316,16 @@ __global__ void __launch_bounds__(256) k_seed(const PairDesc* __restrict__ descs
   Nn1Collector col{INFINITY, 0x7fffffff};
   tree_search(tv, qx, qy, qz, col, lds_stack + threadIdx.x, 256);
   int j = (col.bi == 0x7fffffff) ? -1 : col.bi;
+  float4 rt = make_float4(0.f, 0.f, 0.f, 0.f), rn = rt;
+  if (j >= 0 && d.rec) {
+    rt = d.tgt_xyz[j];
+    if (d.tgt_nrm) rn = d.tgt_nrm[j];
+  }
   for (int e = 0; e < group; e++)
     if (i + e < d.n) {
       d.prev_nn[i + e] = j;
       d.cert[i + e] = make_float4(0.f, 0.f, 0.f, 0.f);  // lower bound 0 => the certificate can never skip the search
+      if (d.rec) { d.rec[2 * (size_t)(i + e)] = rt; d.rec[2 * (size_t)(i + e) + 1] = rn; }  // the record follows prev_nn
     }
 }
 void launch_seed(const PairDesc* descs, SweepArgs& a, int max_n, hipStream_t s) {
@@ -340,12 +346,16 @@ __device__ __forceinline__ bool job_transform(const SweepJob& job, const OuterSt
     for (int k = 0; k < 12; k++) T[k] = job.T[k];
     return true;
   }
-  const OuterState* st = states + job.slot;
-  if (__builtin_amdgcn_readfirstlane(gld(&st->done))) return false;
+  // The state was written by an EARLIER launch (k_solve) and is read-only here, at a wave-uniform address: read it through the
+  // constant address space so that the loads are scalar (s_load_dword*: SGPR results, their own counter -- the wave's vector
+  // loads of the point data are neither delayed by them nor waited for with them).
+  typedef const __attribute__((address_space(4))) OuterState* ConstState;
+  ConstState st = (ConstState)(uintptr_t)(states + job.slot);
+  if (st->done) return false;
 #pragma unroll
   for (int r = 0; r < 3; r++)
 #pragma unroll
-    for (int c = 0; c < 4; c++) T[r * 4 + c] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(gld(&st->T[c * 4 + r]))));
+    for (int c = 0; c < 4; c++) T[r * 4 + c] = st->T[c * 4 + r];
   return true;
 }
 
@@ -358,28 +368,48 @@ struct SweepPoint {
   bool matched;
   bool searched; // the certificate did not cover this query: the tree was walked
 };
+// kRank1 (the fused sweep of cost_mode 1, both covariances from normals): C = I - (1-eps) n n^T / |n|^2 is a rank-one update
+// of the identity, so   R C1 R^T + C2 = (R R^T + I) - k1 u u^T - k2 v v^T,   u = R n1, v = n2, k = (1-eps) / |n|^2
+// -- the same matrix in exact arithmetic for ANY R (float-rounded rotations included), formed with 60 instead of 150 double
+// operations, no square roots, and inverted as a symmetric 3x3 (six cofactors).  Its rounding differs from the reference's
+// order of operations (normalise, two 3x3x3 products) in the last bits of M, which is why only cost_mode 1 -- a bit-different
+// evaluation of the cost anyway -- uses it; k_sweep (cost_mode 0, the debug entry points) keeps the reference order.
+template <bool kRank1 = false>
 __device__ __forceinline__ void sweep_point(const PairDesc& d, const float* __restrict__ T, int i, uint64_t* stack, SweepPoint& o) {
+  // first round of loads: everything whose address only depends on i goes out together (the certificate and, in the fused
+  // kernel, the source normal as well: each was its own dependent memory round behind the candidate before, and the late
+  // sweeps are bound by exactly that chain -- a workgroup lives for two memory latencies instead of three)
   o.p = gld(d.src + i);
+  int w = gld(d.prev_nn + i);
+  const float4 cq = gld(d.cert + i);   // only meaningful when w >= 0; the buffer always holds n entries
+  float4 nn = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 t = make_float4(0.f, 0.f, 0.f, 0.f), tn = make_float4(0.f, 0.f, 0.f, 0.f);
+  if constexpr (kRank1) {
+    nn = gld(d.src_nrm + i);
+    // ... and so does the candidate itself: rec[i] holds the position and normal of target point prev_nn[i] (kept in step with
+    // prev_nn by every writer), so the gather through w -- a second, dependent memory round -- is gone from every sweep
+    t = gld(d.rec + 2 * (size_t)i);
+    tn = gld(d.rec + 2 * (size_t)i + 1);
+  }
   float qx, qy, qz;
   xform_pt(T, o.p.x, o.p.y, o.p.z, qx, qy, qz);  // gicp.hpp:469
   TreeView tv{d.tgt_sorted, d.tgt_nodes, d.tgt_hdr, d.m};
   Nn1CertCollector col{INFINITY, 0x7fffffff, INFINITY};
-  int w = gld(d.prev_nn + i);
   bool need_search = true;
-  float4 t = make_float4(0.f, 0.f, 0.f, 0.f), tn = make_float4(0.f, 0.f, 0.f, 0.f);
   if (w >= 0) {
     // warm start: last sweep's neighbour is a valid candidate => tight initial bound, still exact
-    t = gld(d.tgt_xyz + w);
-    // its normal is fetched in the same round: when the certificate holds (every late sweep) the neighbour is w and the
-    // normal would otherwise be a third dependent memory level; after a walk both are re-read, so neither stays live across it
-    if (d.tgt_nrm) tn = gld(d.tgt_nrm + w);
+    if constexpr (!kRank1) {
+      t = gld(d.tgt_xyz + w);
+      // its normal is fetched in the same round: when the certificate holds (every late sweep) the neighbour is w and the
+      // normal would otherwise be a third dependent memory level; after a walk both are re-read, so neither stays live across it
+      if (d.tgt_nrm) tn = gld(d.tgt_nrm + w);
+    }
     col.bd = d2f(qx, qy, qz, t.x, t.y, t.z);
     col.bi = w;
     // certificate from the last full search at query position cq: every other target point was at squared distance
     // >= cq.w from cq, so it is at distance >= sqrt(cq.w) - |q - cq| from q.  If the candidate is strictly closer
     // (1e-5 relative margin >> float rounding of the d2 evaluations), the traversal cannot change the result.
     // (float arithmetic: sqrtf is correctly rounded to ~1e-7 relative, two orders below the 1e-5 margins)
-    float4 cq = gld(d.cert + i);
     float e = sqrtf(d2f(qx, qy, qz, cq.x, cq.y, cq.z));
     float dw = sqrtf(col.bd), lo = sqrtf(cq.w);
     if (dw * (1.0f + 1e-5f) + e * (1.0f + 1e-5f) + 1e-12f < lo * (1.0f - 1e-5f)) need_search = false;
@@ -396,10 +426,64 @@ __device__ __forceinline__ void sweep_point(const PairDesc& d, const float* __re
   if (need_search && j >= 0) {
     t = gld(d.tgt_xyz + j);
     if (d.tgt_nrm) tn = gld(d.tgt_nrm + j);
+    if constexpr (kRank1) nn = gld(d.src_nrm + i);   // re-read after a walk, so that the normal is not live across it
+    if (j != w && d.rec) {                           // the record follows prev_nn
+      gst(d.rec + 2 * (size_t)i, t);
+      gst(d.rec + 2 * (size_t)i + 1, tn);
+    }
   }
   o.j = j;
   o.matched = j >= 0 && (double)col.bd < d.corr_dist2;  // gicp.hpp:483
   if (o.matched) {
+    // transform_R = double(transformation_) * double(guess), top-left 3x3 (gicp.hpp:450-460); the k = 3 term is T(i,3)*0
+    double R[9];
+    if (d.guess_identity) {  // T * I: every product with an off-diagonal 0 vanishes and x * 1.0 + 0.0 = x exactly
+#pragma unroll
+      for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int cc = 0; cc < 3; cc++) R[r * 3 + cc] = (double)T[r * 4 + cc];
+    } else {
+#pragma unroll
+      for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int cc = 0; cc < 3; cc++)
+          R[r * 3 + cc] = (((double)T[r * 4 + 0] * d.guess3[0 * 3 + cc] + (double)T[r * 4 + 1] * d.guess3[1 * 3 + cc]) +
+                           (double)T[r * 4 + 2] * d.guess3[2 * 3 + cc]) + (double)T[r * 4 + 3] * 0.0;
+    }
+    if constexpr (kRank1) {  // (the launch guarantees that neither cloud of any job carries k-NN covariances)
+      const double kap = 1.0 - d.gicp_eps;
+      double n1[3] = {(double)nn.x, (double)nn.y, (double)nn.z}, v[3] = {(double)tn.x, (double)tn.y, (double)tn.z};
+      double l1 = (n1[0] * n1[0] + n1[1] * n1[1]) + n1[2] * n1[2], l2 = (v[0] * v[0] + v[1] * v[1]) + v[2] * v[2];
+      double k1 = (l1 > 0.0 && l1 < 1.0e300) ? kap / l1 : 0.0;   // zero / non-finite normal => C = I (cov_from_normal)
+      double k2 = (l2 > 0.0 && l2 < 1.0e300) ? kap / l2 : 0.0;
+      double u[3];
+#pragma unroll
+      for (int r = 0; r < 3; r++) u[r] = (R[r * 3 + 0] * n1[0] + R[r * 3 + 1] * n1[1]) + R[r * 3 + 2] * n1[2];
+      double ku[3] = {k1 * u[0], k1 * u[1], k1 * u[2]}, kv[3] = {k2 * v[0], k2 * v[1], k2 * v[2]};
+      // A = R R^T + I - ku u^T - kv v^T, symmetric: (00 01 02 11 12 22)
+      double A[6];
+      {
+        int q = 0;
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+          for (int cc = r; cc < 3; cc++) {
+            double rr = (R[r * 3 + 0] * R[cc * 3 + 0] + R[r * 3 + 1] * R[cc * 3 + 1]) + R[r * 3 + 2] * R[cc * 3 + 2];
+            if (r == cc) rr += 1.0;
+            A[q++] = (rr - ku[r] * u[cc]) - kv[r] * v[cc];
+          }
+      }
+      // symmetric cofactor inverse
+      double c00 = A[3] * A[5] - A[4] * A[4], c01 = A[2] * A[4] - A[1] * A[5], c02 = A[1] * A[4] - A[2] * A[3];
+      double c11 = A[0] * A[5] - A[2] * A[2], c12 = A[1] * A[2] - A[0] * A[4], c22 = A[0] * A[3] - A[1] * A[1];
+      double det = (A[0] * c00 + A[1] * c01) + A[2] * c02;
+      double id = 1.0 / det;
+      o.M[0] = c00 * id; o.M[1] = c01 * id; o.M[2] = c02 * id;
+      o.M[3] = o.M[1];   o.M[4] = c11 * id; o.M[5] = c12 * id;
+      o.M[6] = o.M[2];   o.M[7] = o.M[5];   o.M[8] = c22 * id;
+      o.tgt = t;
+      return;
+    }
     double C1[9], C2[9];
     if (d.src_cov6) {
       double s6[6];
@@ -417,21 +501,6 @@ __device__ __forceinline__ void sweep_point(const PairDesc& d, const float* __re
       sym6_to_mat9(s6, C2);
     } else {
       cov_from_normal(tn.x, tn.y, tn.z, d.gicp_eps, C2);
-    }
-    // transform_R = double(transformation_) * double(guess), top-left 3x3 (gicp.hpp:450-460); the k = 3 term is T(i,3)*0
-    double R[9];
-    if (d.guess_identity) {  // T * I: every product with an off-diagonal 0 vanishes and x * 1.0 + 0.0 = x exactly
-#pragma unroll
-      for (int r = 0; r < 3; r++)
-#pragma unroll
-        for (int cc = 0; cc < 3; cc++) R[r * 3 + cc] = (double)T[r * 4 + cc];
-    } else {
-#pragma unroll
-      for (int r = 0; r < 3; r++)
-#pragma unroll
-        for (int cc = 0; cc < 3; cc++)
-          R[r * 3 + cc] = (((double)T[r * 4 + 0] * d.guess3[0 * 3 + cc] + (double)T[r * 4 + 1] * d.guess3[1 * 3 + cc]) +
-                           (double)T[r * 4 + 2] * d.guess3[2 * 3 + cc]) + (double)T[r * 4 + 3] * 0.0;
     }
     mahalanobis(R, C1, C2, o.M);  // gicp.hpp:488-493
     o.tgt = t;
@@ -541,6 +610,8 @@ __device__ __forceinline__ void wave_reduce_row(uint64_t* lds_base, double* out,
 // one point per thread (78 VGPRs, 6 waves per SIMD).  A variant with 4 points per thread and the 74 moments accumulated in
 // registers (239 VGPRs, 2 waves per SIMD) pays the reduction once per 4 points but was slower even on certificate-only
 // sweeps (142 vs 128 us): with so few waves the dependent src -> neighbour gathers are no longer hidden.
+// kNormals: every job's covariances come from stored normals (the production configuration) -> rank-one Mahalanobis path
+template <bool kNormals>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) k_sweep_fused(const PairDesc* __restrict__ descs, SweepArgs a, double* __restrict__ partials,
                                                      int partials_stride, const OuterState* __restrict__ states) {
   extern __shared__ __attribute__((aligned(16))) uint64_t lds_stack[];  // [entries][256], later reused as double[8][256]
@@ -555,7 +626,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) k
   SweepPoint sp;
   sp.matched = false;
   sp.searched = false;
-  if (i < d.n) sweep_point(d, T, i, lds_stack + threadIdx.x, sp);
+  if (i < d.n) sweep_point<kNormals>(d, T, i, lds_stack + threadIdx.x, sp);
   double M6[6] = {0, 0, 0, 0, 0, 0}, Ma[3] = {0, 0, 0}, pt[4] = {0, 0, 0, 0}, pp[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, aMa = 0.0;
   if (sp.matched) moments_of_point(T, sp, M6, Ma, aMa, pt, pp);
   const double live = sp.matched ? 1.0 : 0.0;
@@ -614,11 +685,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) k
 }
 
 void launch_sweep_fused(const PairDesc* descs, SweepArgs& a, int max_n, double* partials_dev, int partials_stride, const OuterState* states,
-                        hipStream_t s) {
+                        bool normals_only, hipStream_t s) {
   size_t lds = stack_lds_bytes(a.max_depth, 256);
   if (lds < 4 * 8 * 72 * sizeof(double)) lds = 4 * 8 * 72 * sizeof(double);
   a.bpj = (max_n + 255) / 256;
-  hipLaunchKernelGGL(k_sweep_fused, dim3(xcd_grid(a.njobs, a.bpj)), dim3(256), lds, s, descs, a, partials_dev, partials_stride, states);
+  if (normals_only) hipLaunchKernelGGL(k_sweep_fused<true>, dim3(xcd_grid(a.njobs, a.bpj)), dim3(256), lds, s, descs, a, partials_dev, partials_stride, states);
+  else hipLaunchKernelGGL(k_sweep_fused<false>, dim3(xcd_grid(a.njobs, a.bpj)), dim3(256), lds, s, descs, a, partials_dev, partials_stride, states);
 }
 void launch_sweep(const PairDesc* descs, SweepArgs& a, int max_n, hipStream_t s) {
   a.bpj = (max_n + 255) / 256;
@@ -862,9 +934,10 @@ __global__ void __launch_bounds__(64) k_solve(const PairDesc* __restrict__ descs
   OuterState s = *sp;
   typedef MomentPass<PortableMath> Pass;
   typedef CostEval<Pass, PortableMath> Fn;
-  Pass pass{&mom};
+  Pass pass;
+  pass.mom = &mom;
   Fn fn;
-  fn.pass = &pass;
+  fn.pass = pass;
   const int before = s.passes, it = s.iter;
   outer_step<Fn, PortableMath>(&fn, P, &s);
   s.corr_sum += mom.count();
@@ -922,6 +995,21 @@ __global__ void __launch_bounds__(256) k_transform_copy(const float4* __restrict
   out_xyz[i] = make_float4(x, y, z, 1.0f);
   if (in_nrm && out_nrm) out_nrm[i] = in_nrm[i];
   if (in_int && out_int) out_int[i] = in_int[i];
+}
+// the same for all pairs that retire together: one launch, grid.y = pair
+__global__ void __launch_bounds__(256) k_transform_copy_batch(XformBatchArgs a) {
+  const XformJob& j = a.job[blockIdx.y];
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= j.n) return;
+  float4 p = j.in_xyz[i];
+  float x, y, z;
+  xform_pt(j.T, p.x, p.y, p.z, x, y, z);
+  j.out_xyz[i] = make_float4(x, y, z, 1.0f);
+  if (j.in_nrm && j.out_nrm) j.out_nrm[i] = j.in_nrm[i];
+  if (j.in_int && j.out_int) j.out_int[i] = j.in_int[i];
+}
+void launch_transform_copy_batch(const XformBatchArgs& a, int max_n, hipStream_t s) {
+  hipLaunchKernelGGL(k_transform_copy_batch, dim3((max_n + 255) / 256, a.njobs), dim3(256), 0, s, a);
 }
 void launch_transform_copy(const float4* in_xyz, const float4* in_nrm, const float* in_int, int n, const float* T12p, float4* out_xyz,
                            float4* out_nrm, float* out_int, hipStream_t s) {

@@ -29,6 +29,8 @@ struct PairDesc {
   const TreeHeader* tgt_hdr;
   int32_t* prev_nn;         // warm-start NN index per source point                      [n]
   float4* cert;             // (query x,y,z at the last full search, lower bound on the other points' d2) [n]
+  float4* rec;              // per source point the neighbour prev_nn points at, gathered: (tgt xyz, id), (tgt normal, curvature) [2 n]
+                            // -- written whenever prev_nn changes, so a sweep whose certificates hold reads ONE round of loads
   unsigned long long* stats; // [0] += queries that ran the tree traversal, [1] += queries (instrumentation)
   float4* corr;             // per source point: (tgt x, y, z, bitcast tgt idx | -1)     [n]
   double* maha6;            // 6 planes of n_pad doubles: M00 M01 M02 M11 M12 M22
@@ -120,8 +122,9 @@ void launch_index_trees(const IndexDesc* descs, int n_clouds, int max_n, const T
 void launch_sweep(const PairDesc* descs, SweepArgs& a, int max_n, hipStream_t s);
 // cost_mode 1: sweep + 74-moment reduction in one kernel (one partial per 256-point workgroup), then the final sum
 // states == nullptr: host-driven loop (the jobs' transforms come with the launch); otherwise the pairs' device states (k_solve's)
+// normals_only: no job of the launch uses k-NN covariances (recompute_*_cov) -> the rank-one Mahalanobis form
 void launch_sweep_fused(const PairDesc* descs, SweepArgs& a, int max_n, double* partials_dev, int partials_stride, const OuterState* states,
-                        hipStream_t s);
+                        bool normals_only, hipStream_t s);
 void launch_moments_final(const PairDesc* descs, const CostArgs& a, double* partials_dev, int partials_stride, double* out, const OuterState* states,
                           hipStream_t s);
 // the BFGS solve + convergence test of one outer iteration, on the device (cost_mode 1): reads the FINAL_CHUNKS x MOM_ROW chunk
@@ -146,6 +149,15 @@ void launch_transform(const float4* in_xyz, const float4* in_nrm, int n, const f
 // xyz transformed, normals / intensity copied unchanged (pcl::transformPointCloud on a PointXYZINormal cloud)
 void launch_transform_copy(const float4* in_xyz, const float4* in_nrm, const float* in_int, int n, const float* T12, float4* out_xyz,
                            float4* out_nrm, float* out_int, hipStream_t s);
+struct XformJob {
+  const float4* in_xyz; const float4* in_nrm; const float* in_int;
+  float4* out_xyz; float4* out_nrm; float* out_int;
+  int n, pad;
+  float T[12];
+};
+constexpr int MAX_XFORM_JOBS = 32;   // 32 x 104 B of launch arguments
+struct XformBatchArgs { int njobs, pad; XformJob job[MAX_XFORM_JOBS]; };
+void launch_transform_copy_batch(const XformBatchArgs& a, int max_n, hipStream_t s);
 void launch_fill_i32(int32_t* p, int n, int32_t v, hipStream_t s);
 // ungated 1-NN of T*q against a tree; T12 may be null (identity)
 void launch_nn1(const float4* q, int nq, const float* T12, TreeView tree, int32_t* idx, float* d2, hipStream_t s);

@@ -21,7 +21,7 @@ struct OracleBackedPass {
   const int32_t* idx;
   int m;
   const double* maha;
-  void operator()(const double x[6], double sums13[13], double* count) {
+  void operator()(const double x[6], const lh::Trig&, double sums13[13], double* count) {
     double f, g[6];
     lo_cost_fdf(src, tgt, idx, idx, m, maha, x, &f, g, sums13);
     *count = (double)m;
@@ -73,7 +73,7 @@ int main() {
     pass.src = src.data(); pass.tgt = tgt.data(); pass.idx = idx.data(); pass.m = n; pass.maha = maha.data();
     typedef lh::CostEval<OracleBackedPass, lh::LibmMath> FnL;
     FnL fn;
-    fn.pass = &pass;
+    fn.pass = pass;
     float Tp[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
     int n_inner = 0;
     double f_end = 0;
@@ -94,7 +94,7 @@ int main() {
     // 2. portable flavour on the same per-point functor: another trajectory (last-bit differences in sin / cos), the same minimum
     typedef lh::CostEval<OracleBackedPass, lh::PortableMath> FnP;
     FnP fnp;
-    fnp.pass = &pass;
+    fnp.pass = pass;
     float Tq[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
     int n_inner_p = 0;
     double f_end_p = 0;
@@ -124,13 +124,15 @@ int main() {
     mom.prepare();
     lh::MomentPass<lh::PortableMath> mpass{&mom};
     double x0[6] = {0.01, -0.02, 0.005, 0.001, -0.002, 0.003}, Sm[13], Sp[13], cm, cp;
-    mpass(x0, Sm, &cm);
-    pass(x0, Sp, &cp);
+    lh::Trig tg0;
+    lh::trig_all<lh::PortableMath>(x0, &tg0);
+    mpass(x0, tg0, Sm, &cm);
+    pass(x0, tg0, Sp, &cp);
     double worst = 0;
     for (int k = 0; k < 13; k++) worst = std::fmax(worst, std::fabs(Sm[k] - Sp[k]) / (std::fabs(Sp[k]) + 1.0));
     typedef lh::CostEval<lh::MomentPass<lh::PortableMath>, lh::PortableMath> FnM;
     FnM fnm;
-    fnm.pass = &mpass;
+    fnm.pass = mpass;
     lh::OuterParams OP{20, 50, 2e-3, 1e-3};
     lh::OuterState os;
     lh::outer_state_init(&os);

@@ -8,7 +8,8 @@ if os.path.exists(log):
     os.remove(log)
 from locus_amd import capi, synth
 ctx = capi.Context(0)
-P = capi.default_params(max_iterations=20, max_inner_iterations=20, corr_dist=1.0, transformation_epsilon=1e-12, rotation_epsilon=1e-12)
+P = capi.default_params(max_iterations=20, max_inner_iterations=20, corr_dist=1.0, transformation_epsilon=1e-12, rotation_epsilon=1e-12,
+                        solver=int(os.environ.get("LH_PROBE_SOLVER", "0")))
 S, T = [], []
 
 
