@@ -230,8 +230,6 @@ struct lh_ctx {
   OuterState* states_host = nullptr;   // pinned: upload staging at admission / download target when the host looks
   OuterState* states_init = nullptr;   // pinned: initial states (separate from the download target: uploads and downloads overlap)
   double* chunks_dev = nullptr;        // [n_slots][FINAL_CHUNKS * MOM_ROW]
-  uint64_t* wmask_dev = nullptr;       // split sweep: [n_slots][mask_stride] one walker mask per source wave (k_late -> k_walk)
-  int mask_stride = 0;
   hipEvent_t group_ev[4] = {nullptr, nullptr, nullptr, nullptr};
   // batch mode: one workspace per scheduler slot.  They live here (not in a thread-local) so that they are tied to this
   // context's device, reused by every thread that drives the context, and released by lh_destroy.
@@ -506,19 +504,15 @@ void Workspace::release() {
 
 static lh_status ctx_ensure_slots(lh_ctx* c, int n_slots, int max_n) {
   size_t per_slot = std::max<size_t>((size_t)cost_blocks(max_n) * COST_NSUM, (size_t)FINAL_CHUNKS * MOM_ROW);
-  int mom_stride = sweep_rows(max_n, true) * MOM_ROW;  // one partial row per wave of every 256-point workgroup of the fused sweep (+ the walk rows of the split sweep)
-  int mask_stride = sweep_mask_words(max_n);
-  if (n_slots <= c->n_slots && per_slot <= c->partials_per_slot && mom_stride <= c->mom_stride && mask_stride <= c->mask_stride) return LH_OK;
+  int mom_stride = ((max_n + 255) / 256) * 4 * MOM_ROW;  // one partial row per wave of every 256-point workgroup of the fused sweep
+  if (n_slots <= c->n_slots && per_slot <= c->partials_per_slot && mom_stride <= c->mom_stride) return LH_OK;
   (void)hipStreamSynchronize(c->stream);
   c->sync_side_streams();
   n_slots = std::max(n_slots, c->n_slots);
   per_slot = std::max(per_slot, c->partials_per_slot);
   mom_stride = std::max(mom_stride, c->mom_stride);
-  mask_stride = std::max(mask_stride, c->mask_stride);
   (void)lhFree(c->descs_dev);
   (void)lhFree(c->mom_partials_dev);
-  (void)lhFree(c->wmask_dev);
-  c->wmask_dev = nullptr;
   (void)lhFree(c->states_dev);
   (void)lhFree(c->chunks_dev);
   if (c->descs_host) (void)hipHostFree(c->descs_host);
@@ -529,8 +523,6 @@ static lh_status ctx_ensure_slots(lh_ctx* c, int n_slots, int max_n) {
   HIPCHK(hipMalloc(&c->mom_partials_dev, sizeof(double) * (size_t)mom_stride * n_slots));
   HIPCHK(hipMalloc(&c->states_dev, sizeof(OuterState) * n_slots));
   HIPCHK(hipMalloc(&c->chunks_dev, sizeof(double) * (size_t)FINAL_CHUNKS * MOM_ROW * n_slots));
-  HIPCHK(hipMalloc(&c->wmask_dev, sizeof(uint64_t) * (size_t)mask_stride * n_slots));
-  c->mask_stride = mask_stride;
   HIPCHK(hipHostMalloc(&c->states_host, sizeof(OuterState) * n_slots, hipHostMallocDefault));
   HIPCHK(hipHostMalloc(&c->states_init, sizeof(OuterState) * n_slots, hipHostMallocDefault));
   for (int k = 0; k < 4; k++)
@@ -746,20 +738,6 @@ static lh_status task_prepare(lh_ctx* c, Task* t, bool rebuild_index) {
   return LH_OK;
 }
 
-// the fused sweep of cost_mode 1 + the final row sum: two launches (k_late / k_walk) when every job's covariances come from
-// normals (LH_SPLIT_SWEEP=1), the single k_sweep_fused otherwise
-static void launch_fused_and_final(lh_ctx* c, SweepArgs& a, const CostArgs& ca, int max_n, bool normals_only, double* final_out, const OuterState* states,
-                                   hipStream_t st) {
-  static const bool split_cfg = []() { const char* e = getenv("LH_SPLIT_SWEEP"); return e && atoi(e) != 0; }();  // opt-in until it beats the single launch
-  const bool split = split_cfg && normals_only;
-  bool guess_identity = true;
-  for (int j = 0; j < a.njobs; j++)
-    if (!c->descs_host[a.job[j].slot].guess_identity) guess_identity = false;
-  if (split) launch_sweep_split(c->descs_dev, a, max_n, c->mom_partials_dev, c->mom_stride, states, c->wmask_dev, c->mask_stride, guess_identity, st);
-  else launch_sweep_fused(c->descs_dev, a, max_n, c->mom_partials_dev, c->mom_stride, states, normals_only, st);
-  launch_moments_final(c->descs_dev, ca, c->mom_partials_dev, c->mom_stride, final_out, states, split, st);
-}
-
 // ---- scheduler ------------------------------------------------------------------------------------------------
 // In-flight pairs are split into groups (two half-batches when >= 16 pairs are in flight, each with its own HIP
 // stream): while the host delivers results / runs the BFGS solves of one group, the other group's kernels keep the
@@ -838,7 +816,8 @@ static lh_status group_launch(lh_ctx* c, Group& g) {
       bool normals_only = true;
       for (int j = 0; j < a.njobs; j++)
         if (g.sweeps[o + j]->P.recompute_source_cov || g.sweeps[o + j]->P.recompute_target_cov) normals_only = false;
-      launch_fused_and_final(c, a, ca, max_n, normals_only, c->partials_host, nullptr, st);
+      launch_sweep_fused(c->descs_dev, a, max_n, c->mom_partials_dev, c->mom_stride, nullptr, normals_only, st);
+      launch_moments_final(c->descs_dev, ca, c->mom_partials_dev, c->mom_stride, c->partials_host, nullptr, st);
     } else {
       {
         ProfScope p(c, "nn_sweep", bytes, st);
@@ -1056,7 +1035,8 @@ static lh_status dev_enqueue(lh_ctx* c, DevGroup& g, int rounds) {
       }
       {
         ProfScope p(c, "nn_sweep", bytes, st);
-        launch_fused_and_final(c, a, ca, max_n, normals_only, c->chunks_dev, c->states_dev, st);
+        launch_sweep_fused(c->descs_dev, a, max_n, c->mom_partials_dev, c->mom_stride, c->states_dev, normals_only, st);
+        launch_moments_final(c->descs_dev, ca, c->mom_partials_dev, c->mom_stride, c->chunks_dev, c->states_dev, st);
       }
       {
         ProfScope p(c, "bfgs_solve", 0.0, st);
@@ -1398,7 +1378,7 @@ void lh_destroy(lh_ctx* c) {
   if (c->stream3) (void)hipStreamDestroy(c->stream3);
   if (c->stream4) (void)hipStreamDestroy(c->stream4);
   (void)lhFree(c->sort_temp); (void)lhFree(c->bbox); (void)lhFree(c->descs_dev); (void)lhFree(c->mom_partials_dev);
-  (void)lhFree(c->states_dev); (void)lhFree(c->chunks_dev); (void)lhFree(c->wmask_dev);
+  (void)lhFree(c->states_dev); (void)lhFree(c->chunks_dev);
   if (c->states_host) (void)hipHostFree(c->states_host);
   if (c->states_init) (void)hipHostFree(c->states_init);
   for (int k = 0; k < 4; k++)

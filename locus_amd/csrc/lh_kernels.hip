@@ -12,9 +12,6 @@
 //   k_ap                                                              K8  PointCloudLocalization.cc:723-750
 #include <cstdlib>
 
-#include <cstring>
-#include <vector>
-
 #include "lh_kernels.hpp"
 #include "lh_ndt.hpp"
 
@@ -687,305 +684,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) k
   }
 }
 
-// ===== the fused sweep in two launches (cost_mode 1, covariances from normals) ==========================================
-// What bounded k_sweep_fused (SQ counters, profiles/): a wave that has nothing to search -- every wave of the late iterations --
-// still carried the traversal's costs: 24 KB of LDS stack per workgroup (6 waves per SIMD), a workgroup barrier before the
-// reduction (its staging area aliases the stacks), and in the iterations where only a few per cent of the queries still walk,
-// nearly every wave waited a whole tree descent for its one or two walkers.  So the work is split by WHAT A POINT NEEDS:
-//   k_late  every source point, one round of loads (point, normal, certificate, neighbour record), certificate check; the
-//           points whose certificate holds are finished here -- Mahalanobis matrix, 74 moments, Gram reduction per wave with a
-//           wave-PRIVATE staging area: no traversal stack, no workgroup barrier, 64 VGPRs.  The others only leave one bit in the
-//           wave's 64-bit walker mask (deterministic: written, not appended).
-//   k_walk  compacts the walkers of 1024 consecutive source points (16 masks) onto the lanes of one workgroup -- dense waves
-//           whatever the fraction -- runs the exact search (warm start from the previous neighbour), refreshes neighbour,
-//           certificate and record, and reduces their moments into four further rows.  No walkers: zero rows, exit.
-// k_moments_final adds both row sets in fixed order, so results stay bitwise reproducible and independent of batching.
-typedef double v4d __attribute__((ext_vector_type(4)));
-constexpr int GRAM_RS = 15;  // doubles per staged point: a (11), then x, y, z (the ten products b are formed by the reading lanes); odd => conflict-free column writes
-
-// Mahalanobis matrix (rank-one form, see sweep_point<true>) and moment operands of one matched pair of points.
-// kGuessI: every job of the launch aligns with the identity as initial guess (the usual case; transform_R = double(transformation_)):
-// a template parameter because the general form's nine extra doubles cost the late kernel its occupancy
-template <bool kGuessI>
-__device__ __forceinline__ void point_terms(const PairDesc& d, const float* __restrict__ T, const float4& p, const float4& nn, const float4& t,
-                                            const float4& tn, double (&av)[11]) {
-  double R[9];
-  if constexpr (kGuessI) {
-#pragma unroll
-    for (int r = 0; r < 3; r++)
-#pragma unroll
-      for (int cc = 0; cc < 3; cc++) R[r * 3 + cc] = (double)T[r * 4 + cc];
-  } else {
-#pragma unroll
-    for (int r = 0; r < 3; r++)
-#pragma unroll
-      for (int cc = 0; cc < 3; cc++)
-        R[r * 3 + cc] = (((double)T[r * 4 + 0] * d.guess3[0 * 3 + cc] + (double)T[r * 4 + 1] * d.guess3[1 * 3 + cc]) +
-                         (double)T[r * 4 + 2] * d.guess3[2 * 3 + cc]) + (double)T[r * 4 + 3] * 0.0;
-  }
-  const double kap = 1.0 - d.gicp_eps;
-  double n1[3] = {(double)nn.x, (double)nn.y, (double)nn.z}, v[3] = {(double)tn.x, (double)tn.y, (double)tn.z};
-  double l1 = (n1[0] * n1[0] + n1[1] * n1[1]) + n1[2] * n1[2], l2 = (v[0] * v[0] + v[1] * v[1]) + v[2] * v[2];
-  double k1 = (l1 > 0.0 && l1 < 1.0e300) ? kap / l1 : 0.0;   // zero / non-finite normal => C = I (cov_from_normal)
-  double k2 = (l2 > 0.0 && l2 < 1.0e300) ? kap / l2 : 0.0;
-  double u[3];
-#pragma unroll
-  for (int r = 0; r < 3; r++) u[r] = (R[r * 3 + 0] * n1[0] + R[r * 3 + 1] * n1[1]) + R[r * 3 + 2] * n1[2];
-  double ku[3] = {k1 * u[0], k1 * u[1], k1 * u[2]}, kv[3] = {k2 * v[0], k2 * v[1], k2 * v[2]};
-  double A[6];
-  {
-    int q = 0;
-#pragma unroll
-    for (int r = 0; r < 3; r++)
-#pragma unroll
-      for (int cc = r; cc < 3; cc++) {
-        double rr = (R[r * 3 + 0] * R[cc * 3 + 0] + R[r * 3 + 1] * R[cc * 3 + 1]) + R[r * 3 + 2] * R[cc * 3 + 2];
-        if (r == cc) rr += 1.0;
-        A[q++] = (rr - ku[r] * u[cc]) - kv[r] * v[cc];
-      }
-  }
-  double c00 = A[3] * A[5] - A[4] * A[4], c01 = A[2] * A[4] - A[1] * A[5], c02 = A[1] * A[4] - A[2] * A[3];
-  double c11 = A[0] * A[5] - A[2] * A[2], c12 = A[1] * A[2] - A[0] * A[4], c22 = A[0] * A[3] - A[1] * A[1];
-  double det = (A[0] * c00 + A[1] * c01) + A[2] * c02;
-  double id = 1.0 / det;
-  const double M6[6] = {c00 * id, c01 * id, c02 * id, c11 * id, c12 * id, c22 * id};
-  // residual about T0 = T (double), M a, a^T M a, and the ten products of (x, y, z, 1)
-  double pt[4] = {(double)p.x, (double)p.y, (double)p.z, 1.0};
-  double a0 = ((((double)T[0] * pt[0] + (double)T[1] * pt[1]) + (double)T[2] * pt[2]) + (double)T[3]) - (double)t.x;
-  double a1 = ((((double)T[4] * pt[0] + (double)T[5] * pt[1]) + (double)T[6] * pt[2]) + (double)T[7]) - (double)t.y;
-  double a2 = ((((double)T[8] * pt[0] + (double)T[9] * pt[1]) + (double)T[10] * pt[2]) + (double)T[11]) - (double)t.z;
-  double Ma0 = (M6[0] * a0 + M6[1] * a1) + M6[2] * a2;
-  double Ma1 = (M6[1] * a0 + M6[3] * a1) + M6[4] * a2;
-  double Ma2 = (M6[2] * a0 + M6[4] * a1) + M6[5] * a2;
-#pragma unroll
-  for (int k = 0; k < 6; k++) av[k] = M6[k];
-  av[6] = Ma0; av[7] = Ma1; av[8] = Ma2;
-  av[9] = (a0 * Ma0 + a1 * Ma1) + a2 * Ma2;
-  av[10] = 1.0;
-}
-
-// D += sum over the wave's 64 lanes of a_i b_i^T (see k_sweep_fused): operands through the wave's own staging rows `wl`
-// (32 rows of GRAM_RS doubles), half a wave at a time, sixteen v_mfma_f64_16x16x4_f64.  A lane stages a (11 values) and its
-// point (x, y, z); the lane that feeds column j of B forms b_j = u_c u_e, u = (x, y, z, 1), itself -- the same product the
-// writer would have made, without ten more doubles per lane in registers and in LDS.  `on` = the lane has a matched point
-// (otherwise it stages zeros).  Wave-synchronous: no workgroup barrier.
-__device__ __forceinline__ void gram_accumulate(double* wl, const double (&av)[11], const float4& p, bool on, v4d& acc) {
-  const int lane = threadIdx.x & 63;
-  const int E = lane & 15;
-  // column j = E of b: (c, e) in the order xx xy xz x yy yz y zz z 1
-  const int bc = E < 4 ? 0 : (E < 7 ? 1 : (E < 9 ? 2 : 3));
-  const int be = E < 4 ? E : (E < 7 ? E - 3 : (E < 9 ? E - 5 : 3));
-#pragma unroll
-  for (int half = 0; half < 2; half++) {
-    if ((lane >> 5) == half) {
-      double* row = wl + (lane & 31) * GRAM_RS;
-#pragma unroll
-      for (int e = 0; e < 11; e++) row[e] = av[e];
-      row[11] = on ? (double)p.x : 0.0;
-      row[12] = on ? (double)p.y : 0.0;
-      row[13] = on ? (double)p.z : 0.0;
-      row[14] = on ? 1.0 : 0.0;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int m = 0; m < 8; m++) {
-      const double* row = wl + (4 * m + (lane >> 4)) * GRAM_RS;
-      double A = (E < 11) ? row[E] : 0.0;
-      double B = (E < 10) ? row[11 + bc] * row[11 + be] : 0.0;   // u_3 = the staged 1.0 (0.0 for an idle lane: its whole row is zero)
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A, B, acc, 0, 0, 0);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-  }
-}
-// D[row = (lane >> 4) + 4 r][col = lane & 15] is acc[r] (the f64 C/D map) -> the wave's 76-double row
-__device__ __forceinline__ void gram_store(const v4d& acc, double* out, double walks) {
-  const int lane = threadIdx.x & 63, j = lane & 15;
-#pragma unroll
-  for (int r = 0; r < 4; r++) {
-    const int i = (lane >> 4) + 4 * r;
-    int k = -1;
-    if (i < 6 && j < 10) k = 13 + i * 10 + j;
-    else if (i < 9 && i >= 6 && (j == 3 || j == 6 || j == 8 || j == 9)) k = 1 + (i - 6) * 4 + (j == 3 ? 0 : (j == 6 ? 1 : (j == 8 ? 2 : 3)));
-    else if (i == 9 && j == 9) k = 0;
-    else if (i == 10 && j == 9) k = 73;
-    if (k >= 0) out[k] = acc[r];
-  }
-  if (lane < MOM_ROW - MOM_NSUM) out[MOM_NSUM + lane] = lane == 0 ? walks : 0.0;
-}
-
-template <bool kGuessI>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) k_late(const PairDesc* __restrict__ descs, SweepArgs a, double* __restrict__ partials,
-                                                                                   int partials_stride, const OuterState* __restrict__ states,
-                                                                                   uint64_t* __restrict__ wmask, int mask_stride_in) {
-  int mask_stride = mask_stride_in;
-  extern __shared__ __attribute__((aligned(16))) double lds_gram[];  // [4 waves][32 rows][GRAM_RS]
-  int jb, blk;
-  if (!xcd_job_map(a.njobs, a.bpj, jb, blk)) return;
-  const SweepJob& job = a.job[jb];
-  const PairDesc d = descs[job.slot];
-  if (blk * 256 >= d.n) return;
-  float T[12];
-  if (!job_transform(job, states, T)) return;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int i = blk * 256 + tid;
-  bool walker = false, matched = false;
-  float4 p = make_float4(0.f, 0.f, 0.f, 0.f), nn = p, t = p, tn = p;
-  if (i < d.n) {
-    // ONE round of loads: the point, its normal, its neighbour's index, the certificate of the last search and the neighbour itself
-    p = gld(d.src + i);
-    const int w = gld(d.prev_nn + i);
-    const float4 cq = gld(d.cert + i);
-    nn = gld(d.src_nrm + i);
-    t = gld(d.rec + 2 * (size_t)i);
-    tn = gld(d.rec + 2 * (size_t)i + 1);
-    float qx, qy, qz;
-    xform_pt(T, p.x, p.y, p.z, qx, qy, qz);  // gicp.hpp:469
-    bool ok = false;
-    float bd = 0.f;
-    if (w >= 0) {  // the certificate test of sweep_point: the neighbour of the last search is provably still the nearest
-      bd = d2f(qx, qy, qz, t.x, t.y, t.z);
-      float e = sqrtf(d2f(qx, qy, qz, cq.x, cq.y, cq.z));
-      float dw = sqrtf(bd), lo = sqrtf(cq.w);
-      ok = dw * (1.0f + 1e-5f) + e * (1.0f + 1e-5f) + 1e-12f < lo * (1.0f - 1e-5f);
-    }
-    walker = !ok;
-    matched = ok && (double)bd < d.corr_dist2;  // gicp.hpp:483
-  }
-  const int exp_code = mask_stride >> 24;  // EXPERIMENT ONLY
-  mask_stride &= 0xffffff;
-  const unsigned long long mask = __ballot(walker);
-  if (lane == 0) wmask[(size_t)job.slot * mask_stride + blk * 4 + wave] = mask;
-  double av[11];
-  if (matched && !(exp_code & 1)) point_terms<kGuessI>(d, T, p, nn, t, tn, av);  // gicp.hpp:488-498
-  else {
-#pragma unroll
-    for (int k = 0; k < 11; k++) av[k] = (exp_code & 1) ? (double)(p.x + nn.x + t.x + tn.x) : 0.0;
-  }
-  v4d acc = {0.0, 0.0, 0.0, 0.0};
-  if (!(exp_code & 2)) gram_accumulate(lds_gram + wave * (32 * GRAM_RS), av, p, matched, acc);
-  else { acc[0] = av[0]; acc[1] = av[3]; acc[2] = av[6]; acc[3] = av[9]; }
-  if (exp_code & 4) { if (acc[0] == 12345.678) partials[0] = acc[1]; return; }
-  gram_store(acc, partials + (size_t)job.slot * partials_stride + ((size_t)blk * 4 + wave) * MOM_ROW, (double)__popcll(mask));
-}
-
-__device__ __forceinline__ int nth_set_bit(unsigned long long m, int r) {  // position of the r-th (0-based) set bit
-  uint32_t x = (uint32_t)m;
-  int pos = 0, c = __popc(x);
-  if (r >= c) { r -= c; pos = 32; x = (uint32_t)(m >> 32); }
-#pragma unroll
-  for (int sh = 16; sh >= 1; sh >>= 1) {
-    c = __popc(x & ((1u << sh) - 1u));
-    if (r >= c) { r -= c; pos += sh; x >>= sh; }
-  }
-  return pos;
-}
-
-constexpr int WALK_SPAN = 1024;  // source points whose walkers one k_walk workgroup takes (16 wave masks)
-template <bool kGuessI>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) k_walk(const PairDesc* __restrict__ descs, SweepArgs a, double* __restrict__ partials,
-                                                                                   int partials_stride, const OuterState* __restrict__ states,
-                                                                                   const uint64_t* __restrict__ wmask, int mask_stride) {
-  extern __shared__ __attribute__((aligned(16))) uint64_t lds_stack[];  // [entries][256]; between the walks: the Gram staging rows
-  __shared__ unsigned long long m16[16];
-  __shared__ int pre[17];
-  int jb, blk;
-  if (!xcd_job_map(a.njobs, a.bpj, jb, blk)) return;
-  const SweepJob& job = a.job[jb];
-  const PairDesc d = descs[job.slot];
-  if (blk * WALK_SPAN >= d.n) return;
-  float T[12];
-  if (!job_transform(job, states, T)) return;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int n_words = ((d.n + 255) / 256) * 4;
-  if (tid < 16) {
-    int wi = blk * 16 + tid;
-    m16[tid] = wi < n_words ? wmask[(size_t)job.slot * mask_stride + wi] : 0ull;
-  }
-  __syncthreads();
-  if (tid == 0) {
-    int s = 0;
-    for (int k = 0; k < 16; k++) { pre[k] = s; s += __popcll(m16[k]); }
-    pre[16] = s;
-  }
-  __syncthreads();
-  const int total = pre[16];
-  double* out = partials + (size_t)job.slot * partials_stride + ((size_t)n_words + (size_t)blk * 4 + wave) * MOM_ROW;  // after the late rows
-  if (total == 0) {  // nobody here needs a search (every late iteration): zero rows, so that the final sum needs no flags
-    out[lane] = 0.0;
-    if (lane < MOM_ROW - 64) out[64 + lane] = 0.0;
-    return;
-  }
-  v4d acc = {0.0, 0.0, 0.0, 0.0};
-  TreeView tv{d.tgt_sorted, d.tgt_nodes, d.tgt_hdr, d.m};
-  for (int base = 0; base < total; base += 256) {
-    const int r = base + tid;
-    bool matched = false;
-    float4 p = make_float4(0.f, 0.f, 0.f, 0.f), nn = p, t = p, tn = p;
-    if (r < total) {
-      int k = 0;
-#pragma unroll
-      for (int q = 1; q < 16; q++) k += (r >= pre[q]) ? 1 : 0;      // the mask word that holds the r-th walker
-      const int i = (blk * 16 + k) * 64 + nth_set_bit(m16[k], r - pre[k]);
-      p = gld(d.src + i);
-      const int w = gld(d.prev_nn + i);
-      float qx, qy, qz;
-      xform_pt(T, p.x, p.y, p.z, qx, qy, qz);
-      Nn1CertCollector col{INFINITY, 0x7fffffff, INFINITY};
-      if (w >= 0) {  // warm start: the previous neighbour is a valid candidate => tight initial bound, still exact
-        const float4 t0 = gld(d.rec + 2 * (size_t)i);
-        col.bd = d2f(qx, qy, qz, t0.x, t0.y, t0.z);
-        col.bi = w;
-      }
-      tree_search(tv, qx, qy, qz, col, lds_stack + tid, 256);
-      gst(d.cert + i, make_float4(qx, qy, qz, col.lb));
-      const int j = (col.bi == 0x7fffffff) ? -1 : col.bi;
-      if (j != w) gst(d.prev_nn + i, j);
-      if (j >= 0) {
-        t = gld(d.tgt_xyz + j);
-        tn = gld(d.tgt_nrm + j);
-        nn = gld(d.src_nrm + i);
-        p = gld(d.src + i);   // re-read (a cache hit) rather than kept in registers across the walk
-        if (j != w) { gst(d.rec + 2 * (size_t)i, t); gst(d.rec + 2 * (size_t)i + 1, tn); }  // the record follows prev_nn
-        matched = (double)col.bd < d.corr_dist2;  // gicp.hpp:483
-      }
-    }
-    double av[11];
-    if (matched) point_terms<kGuessI>(d, T, p, nn, t, tn, av);
-    else {
-#pragma unroll
-      for (int k = 0; k < 11; k++) av[k] = 0.0;
-    }
-    __syncthreads();  // every lane of the workgroup is done with its traversal stack: the staging rows alias it
-    gram_accumulate(reinterpret_cast<double*>(lds_stack) + wave * (32 * GRAM_RS), av, p, matched, acc);
-    __syncthreads();  // ... and every wave with its staging rows before the next batch of walks
-  }
-  gram_store(acc, out, 0.0);   // (the late rows already carry the walker counts)
-}
-
-void launch_sweep_split(const PairDesc* descs, SweepArgs& a, int max_n, double* partials_dev, int partials_stride, const OuterState* states,
-                        uint64_t* wmask, int mask_stride, bool guess_identity, hipStream_t s) {
-  const size_t lds_late = sizeof(double) * 4 * 32 * GRAM_RS;
-  a.bpj = (max_n + 255) / 256;
-  // EXPERIMENT ONLY (LH_EXP_LATE="1,2,3"): shadow launches of k_late with parts removed, BEFORE the real one (which then overwrites
-  // their rows and masks), so that the variants are timed on the real state of every iteration
-  static const std::vector<int> exp_codes = []() {
-    std::vector<int> v;
-    const char* e = getenv("LH_EXP_LATE");
-    while (e && *e) { v.push_back(atoi(e)); e = strchr(e, ','); if (e) e++; }
-    return v;
-  }();
-  for (int code : exp_codes)
-    hipLaunchKernelGGL(k_late<true>, dim3(xcd_grid(a.njobs, a.bpj)), dim3(256), lds_late, s, descs, a, partials_dev, partials_stride, states, wmask, mask_stride | (code << 24));
-  const int mask_stride_k = mask_stride;
-  if (guess_identity) hipLaunchKernelGGL(k_late<true>, dim3(xcd_grid(a.njobs, a.bpj)), dim3(256), lds_late, s, descs, a, partials_dev, partials_stride, states, wmask, mask_stride_k);
-  else hipLaunchKernelGGL(k_late<false>, dim3(xcd_grid(a.njobs, a.bpj)), dim3(256), lds_late, s, descs, a, partials_dev, partials_stride, states, wmask, mask_stride_k);
-  a.bpj = (max_n + WALK_SPAN - 1) / WALK_SPAN;
-  if (guess_identity) hipLaunchKernelGGL(k_walk<true>, dim3(xcd_grid(a.njobs, a.bpj)), dim3(256), stack_lds_bytes(0, 256), s, descs, a, partials_dev, partials_stride, states, wmask, mask_stride);
-  else hipLaunchKernelGGL(k_walk<false>, dim3(xcd_grid(a.njobs, a.bpj)), dim3(256), stack_lds_bytes(0, 256), s, descs, a, partials_dev, partials_stride, states, wmask, mask_stride);
-}
-
 void launch_sweep_fused(const PairDesc* descs, SweepArgs& a, int max_n, double* partials_dev, int partials_stride, const OuterState* states,
                         bool normals_only, hipStream_t s) {
   size_t lds = stack_lds_bytes(a.max_depth, 256);
@@ -1165,13 +863,12 @@ __global__ void __launch_bounds__(256) k_moments(const PairDesc* __restrict__ de
 constexpr int FINAL_SUB = 4;
 __global__ void __launch_bounds__(FINAL_SUB * MOM_ROW) k_moments_final(const PairDesc* __restrict__ descs, CostArgs a, const double* __restrict__ partials,
                                                                       int partials_stride, int ppb, int rpb, double* __restrict__ out,
-                                                                      const OuterState* __restrict__ states, int ppb2) {
+                                                                      const OuterState* __restrict__ states) {
   const CostJob& job = a.job[blockIdx.y];
   if (states && states[job.slot].done) return;  // device-driven loop: the pair's sweep did not run either
   const int c = blockIdx.x;
   int n = descs[job.slot].n;
   int nb = ((n + ppb - 1) / ppb) * rpb;
-  if (ppb2) nb += ((n + ppb2 - 1) / ppb2) * rpb;  // split sweep: the walk rows follow the late rows
   int v = threadIdx.x % MOM_ROW, sub = threadIdx.x / MOM_ROW;
   int per = (nb + FINAL_CHUNKS - 1) / FINAL_CHUNKS;
   int b0 = c * per, b1 = min(nb, b0 + per);
@@ -1201,15 +898,12 @@ void launch_moments(const PairDesc* descs, const CostArgs& a, int max_n, double*
                     hipStream_t s) {
   hipLaunchKernelGGL(k_moments, dim3(mom_blocks(max_n), a.njobs), dim3(256), 0, s, descs, a, partials_dev, partials_stride);
   hipLaunchKernelGGL(k_moments_final, dim3(FINAL_CHUNKS, a.njobs), dim3(FINAL_SUB * MOM_ROW), 0, s, descs, a, partials_dev, partials_stride, MOM_CHUNK, 1, out,
-                     (const OuterState*)nullptr, 0);
+                     (const OuterState*)nullptr);
 }
 void launch_moments_final(const PairDesc* descs, const CostArgs& a, double* partials_dev, int partials_stride, double* out, const OuterState* states,
-                          bool split_rows, hipStream_t s) {
-  hipLaunchKernelGGL(k_moments_final, dim3(FINAL_CHUNKS, a.njobs), dim3(FINAL_SUB * MOM_ROW), 0, s, descs, a, partials_dev, partials_stride, 256, 4, out, states,
-                     split_rows ? WALK_SPAN : 0);
+                          hipStream_t s) {
+  hipLaunchKernelGGL(k_moments_final, dim3(FINAL_CHUNKS, a.njobs), dim3(FINAL_SUB * MOM_ROW), 0, s, descs, a, partials_dev, partials_stride, 256, 4, out, states);
 }
-int sweep_rows(int n, bool split) { return ((n + 255) / 256) * 4 + (split ? ((n + WALK_SPAN - 1) / WALK_SPAN) * 4 : 0); }
-int sweep_mask_words(int n) { return (((n + 255) / 256) * 4 + 15) & ~15; }
 
 // ===== the solve of one outer iteration on the device (cost_mode 1) =========================================
 // One wave per pair runs the part of computeTransformation's loop body that follows the sweep (gicp.hpp:518-568): the whole BFGS

@@ -126,14 +126,7 @@ void launch_sweep(const PairDesc* descs, SweepArgs& a, int max_n, hipStream_t s)
 void launch_sweep_fused(const PairDesc* descs, SweepArgs& a, int max_n, double* partials_dev, int partials_stride, const OuterState* states,
                         bool normals_only, hipStream_t s);
 void launch_moments_final(const PairDesc* descs, const CostArgs& a, double* partials_dev, int partials_stride, double* out, const OuterState* states,
-                          bool split_rows, hipStream_t s);
-// the fused sweep as two launches (every job's covariances from normals): k_late finishes the points whose certificate holds and
-// leaves one 64-bit walker mask per wave in wmask[slot * mask_stride + ...]; k_walk compacts and searches the rest.  Rows:
-// sweep_rows(n, true) per job (late rows, then walk rows); mask words per job: sweep_mask_words(n)
-void launch_sweep_split(const PairDesc* descs, SweepArgs& a, int max_n, double* partials_dev, int partials_stride, const OuterState* states,
-                        uint64_t* wmask, int mask_stride, bool guess_identity /* of every job */, hipStream_t s);
-int sweep_rows(int n, bool split);
-int sweep_mask_words(int n);
+                          hipStream_t s);
 // the BFGS solve + convergence test of one outer iteration, on the device (cost_mode 1): reads the FINAL_CHUNKS x MOM_ROW chunk
 // sums k_moments_final left at chunks[slot * chunk_stride], updates states[slot]
 void launch_solve(const PairDesc* descs, const SolveArgs& a, const double* chunks, int chunk_stride, OuterState* states, hipStream_t s);
