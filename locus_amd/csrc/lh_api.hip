@@ -209,6 +209,8 @@ struct lh_ctx {
   // batched index build scratch
   uint64_t *k64a = nullptr, *k64b = nullptr;
   uint32_t *v32a = nullptr, *v32b = nullptr, *idx_bbox = nullptr;
+  uint64_t *k32a = nullptr, *k32b = nullptr;   // the build's radix sort: (key, index) pairs in flight between its passes
+  uint32_t* rs_hist = nullptr;                 // ... and its per-tile digit tables
   void* sort64_temp = nullptr;
   size_t sort64_temp_bytes = 0;
   char* tree_tmp = nullptr;        // TreeScratch arrays (TREE_SCRATCH_BYTES_PER_POINT per point)
@@ -379,7 +381,7 @@ static lh_status build_indices(lh_ctx* x, lh_cloud* const* clouds, int n_clouds,
   for (int o = 0; o < n_clouds; o += MAX_INDEX_BATCH) {
     int nb = std::min(MAX_INDEX_BATCH, n_clouds - o);
     long total = 0;
-    int max_n = 0;
+    int max_n = 0, tile0 = 0;
     if (!x->idx_descs_dev) {
       HIPCHK(hipMalloc(&x->idx_descs_dev, sizeof(IndexDesc) * MAX_INDEX_BATCH));
       HIPCHK(hipHostMalloc(&x->idx_descs_host, sizeof(IndexDesc) * MAX_INDEX_BATCH, hipHostMallocDefault));
@@ -406,6 +408,8 @@ static lh_status build_indices(lh_ctx* x, lh_cloud* const* clouds, int n_clouds,
       IndexDesc& d = x->idx_descs_host[k];
       d.xyz = c->xyz; d.sorted = c->sorted; d.nodes = c->nodes(); d.hdr = c->hdr(); d.pos = c->pos;
       d.n = c->n; d.offset = (int)total;
+      d.tile0 = tile0; d.pad = 0;
+      tile0 += segsort_tiles(c->n);
       total += c->n;
       max_n = std::max(max_n, c->n);
     }
@@ -414,12 +418,15 @@ static lh_status build_indices(lh_ctx* x, lh_cloud* const* clouds, int n_clouds,
       (void)hipStreamSynchronize(x->stream);
       x->sync_side_streams();
       (void)lhFree(x->k64a); (void)lhFree(x->k64b); (void)lhFree(x->v32a); (void)lhFree(x->v32b); (void)lhFree(x->sort64_temp);
-      (void)lhFree(x->tree_tmp); (void)lhFree(x->scan_tmp);
+      (void)lhFree(x->tree_tmp); (void)lhFree(x->scan_tmp); (void)lhFree(x->k32a); (void)lhFree(x->k32b); (void)lhFree(x->rs_hist);
       int cap = round_up((int)std::min<long>(total + total / 4, 0x7fffff00L), 1024);
       HIPCHK(hipMalloc(&x->k64a, sizeof(uint64_t) * (size_t)cap));
       HIPCHK(hipMalloc(&x->k64b, sizeof(uint64_t) * (size_t)cap));
       HIPCHK(hipMalloc(&x->v32a, sizeof(uint32_t) * (size_t)cap));
       HIPCHK(hipMalloc(&x->v32b, sizeof(uint32_t) * (size_t)cap));
+      HIPCHK(hipMalloc(&x->k32a, sizeof(uint64_t) * (size_t)cap));
+      HIPCHK(hipMalloc(&x->k32b, sizeof(uint64_t) * (size_t)cap));
+      HIPCHK(hipMalloc(&x->rs_hist, sizeof(uint32_t) * segsort_hist_elems(cap, MAX_INDEX_BATCH)));
       x->sort64_temp_bytes = sort64_temp_bytes(cap);
       HIPCHK(hipMalloc(&x->sort64_temp, x->sort64_temp_bytes ? x->sort64_temp_bytes : 16));
       HIPCHK(hipMalloc(&x->tree_tmp, TREE_SCRATCH_BYTES_PER_POINT * ((size_t)cap + 16) + 4096));
@@ -449,8 +456,40 @@ static lh_status build_indices(lh_ctx* x, lh_cloud* const* clouds, int n_clouds,
     int id_bits = 0;
     while ((1 << id_bits) < nb) id_bits++;
     { ProfScope p(x, "index_bbox_keys", 16.0 * total * 2, s); launch_index_keys(x->idx_descs_dev, nb, max_n, x->idx_bbox, x->k64a, x->v32a, s); }
-    { ProfScope p(x, "index_radix_sort", 12.0 * total * 2 * 4, s);
-      sort_pairs_u64(x->sort64_temp, x->sort64_temp_bytes, x->k64a, x->k64b, x->v32a, x->v32b, (int)total, 32 + id_bits, s); }
+    {
+      // LH_SORT=rocprim: the library's 64-bit sort (A/B); LH_SORT=check: both, compared element by element (tests)
+      static const int sort_cfg = []() { const char* e = getenv("LH_SORT"); return !e ? 0 : (strcmp(e, "rocprim") == 0 ? 1 : (strcmp(e, "check") == 0 ? 2 : 0)); }();
+      if (sort_cfg == 1) {
+        ProfScope p(x, "index_radix_sort", 12.0 * total * 2 * 4, s);
+        sort_pairs_u64(x->sort64_temp, x->sort64_temp_bytes, x->k64a, x->k64b, x->v32a, x->v32b, (int)total, 32 + id_bits, s);
+      } else {
+        std::vector<uint64_t> kref;
+        std::vector<uint32_t> vref;
+        if (sort_cfg == 2) {  // reference first (segsort clobbers v32a)
+          sort_pairs_u64(x->sort64_temp, x->sort64_temp_bytes, x->k64a, x->k64b, x->v32a, x->v32b, (int)total, 32 + id_bits, s);
+          kref.resize(total); vref.resize(total);
+          HIPCHK(hipMemcpyAsync(kref.data(), x->k64b, sizeof(uint64_t) * total, hipMemcpyDeviceToHost, s));
+          HIPCHK(hipMemcpyAsync(vref.data(), x->v32b, sizeof(uint32_t) * total, hipMemcpyDeviceToHost, s));
+          HIPCHK(hipStreamSynchronize(s));
+        }
+        { ProfScope p(x, "index_radix_sort", 8.0 * total * 3 * 3, s);
+          segsort_pairs(x->idx_descs_dev, nb, max_n, x->k64a, x->k64b, x->v32a, x->v32b, x->k32a, x->k32b, x->rs_hist, s); }
+        if (sort_cfg == 2) {
+          std::vector<uint64_t> kk(total);
+          std::vector<uint32_t> vv(total);
+          HIPCHK(hipMemcpyAsync(kk.data(), x->k64b, sizeof(uint64_t) * total, hipMemcpyDeviceToHost, s));
+          HIPCHK(hipMemcpyAsync(vv.data(), x->v32b, sizeof(uint32_t) * total, hipMemcpyDeviceToHost, s));
+          HIPCHK(hipStreamSynchronize(s));
+          long bad = 0;
+          for (long i = 0; i < total; i++)
+            if (kk[i] != kref[i] || vv[i] != vref[i]) bad++;
+          if (bad) {
+            fprintf(stderr, "[locus_hip] LH_SORT=check: %ld of %ld sorted elements differ from the library sort\n", bad, total);
+            return LH_EDEVICE;
+          }
+        }
+      }
+    }
     { ProfScope p(x, "index_leaves_scan", 8.0 * total * 3, s);
       launch_index_leaves(ts, s);
       inclusive_scan_u32(x->scan_tmp, x->scan_tmp_bytes, ts.flag, ts.lid, (int)total, s); }
@@ -1369,7 +1408,7 @@ void lh_destroy(lh_ctx* c) {
   for (auto e : c->ev_pool) (void)hipEventDestroy(e);
   (void)lhFree(c->keys0); (void)lhFree(c->keys1); (void)lhFree(c->vals0); (void)lhFree(c->vals1);
   (void)lhFree(c->k64a); (void)lhFree(c->k64b); (void)lhFree(c->v32a); (void)lhFree(c->v32b); (void)lhFree(c->sort64_temp);
-  (void)lhFree(c->tree_tmp); (void)lhFree(c->scan_tmp);
+  (void)lhFree(c->tree_tmp); (void)lhFree(c->scan_tmp); (void)lhFree(c->k32a); (void)lhFree(c->k32b); (void)lhFree(c->rs_hist);
   (void)lhFree(c->idx_bbox); (void)lhFree(c->idx_descs_dev);
   if (c->idx_descs_host) (void)hipHostFree(c->idx_descs_host);
   if (c->idx_copy_done) (void)hipEventDestroy(c->idx_copy_done);

@@ -90,6 +90,7 @@ struct IndexDesc {
   TreeHeader* hdr;
   int32_t* pos;       // original index -> position in `sorted`
   int n, offset;      // offset = start of this cloud in the concatenated key/value arrays
+  int tile0, pad;     // first tile of this cloud in the sort's histogram table (sum of segsort_tiles of the clouds before it)
 };
 // build scratch shared by the clouds of a batch (capacity = total points of the batch + 1)
 struct TreeScratch {
@@ -107,6 +108,11 @@ struct TreeScratch {
 };
 constexpr size_t TREE_SCRATCH_BYTES_PER_POINT = 4 + 4 + 8 + 4 + 32 + 2 + 8 + 8;  // flag lid lkey lstart lbox a1+a2 ichild irange
 constexpr int MAX_INDEX_BATCH = 64;
+// the build's own sort (lh_radix.hip): segmented 3 x 10-bit LSD radix sort of the 30-bit keys, every cloud inside its segment
+int segsort_tiles(int n);
+size_t segsort_hist_elems(long total_points, int n_clouds);
+void segsort_pairs(const IndexDesc* descs, int n_clouds, int max_n, const uint64_t* keys_in, uint64_t* keys_out, const uint32_t* vals_in,
+                   uint32_t* vals_out, uint64_t* kv_a, uint64_t* kv_b, uint32_t* hist, hipStream_t s);
 size_t sort64_temp_bytes(int n);
 void sort_pairs_u64(void* temp, size_t temp_bytes, const uint64_t* keys_in, uint64_t* keys_out, const uint32_t* vals_in,
                     uint32_t* vals_out, int n, int end_bit, hipStream_t s);

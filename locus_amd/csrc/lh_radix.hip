@@ -1,0 +1,178 @@
+// lh_radix.hip -- the sort of the batched index build (K2): a hand-written SEGMENTED least-significant-digit radix sort.
+//
+// The build sorts (cloud id << 32 | 30-bit Hilbert key) -> point index for all targets admitted together.  The cloud id only
+// says which segment of the concatenated array an element belongs to, and the segments are already in id order, so the
+// library sort's 37-bit passes over one long array are replaced by three 10-bit passes over 30-bit keys INSIDE each segment
+// (grid.y = cloud): 32-bit keys in flight instead of 64-bit ones, three passes instead of five, nothing shared between clouds.
+// A pass is three launches:
+//   k_rs_hist     a workgroup counts the digits of its tile (4096 consecutive elements) in LDS -> hist[cloud][tile][digit]
+//   k_rs_scan     one 1024-thread workgroup per cloud, thread = digit: exclusive offsets in (digit, tile) order
+//   k_rs_scatter  the tile again: a wave ranks 64 consecutive elements at a time with wave64 ballots (ten ballots give every
+//                 lane the mask of the lanes that hold its digit; rank = popcount of the lower lanes), running per-wave digit
+//                 counters in LDS, then the waves' counters are prefixed in wave order -> stable positions
+// Stable, deterministic, and identical in output to a stable library sort of the 64-bit keys (equal keys keep ascending point
+// index), which tests/test_gpu_kernels.py::test_index_sort_matches_library_sort checks through LH_SORT=check.
+#include "lh_kernels.hpp"
+
+namespace lh {
+
+constexpr int RS_BITS = 10, RS_BINS = 1 << RS_BITS, RS_TILE = 4096, RS_PER_THREAD = RS_TILE / 256;
+
+// Elements in flight between the passes are (key, point index) PAIRS in one 8-byte word: an LSD pass scatters every element
+// to its own place (the low Hilbert digits of neighbouring points are unrelated), so what counts is the number of isolated
+// stores, and a pair costs one instead of two.  Pass 0 reads the build's u64 keys + u32 indices, pass 2 writes them again.
+template <bool kFirst>
+__device__ __forceinline__ uint32_t rs_key(const void* keys, size_t g) {
+  if constexpr (kFirst) return (uint32_t)reinterpret_cast<const uint64_t*>(keys)[g];   // low word = the 30-bit key
+  else return reinterpret_cast<const uint2*>(keys)[g].x;
+}
+
+template <bool kFirst>
+__global__ void __launch_bounds__(256) k_rs_hist(const IndexDesc* __restrict__ descs, const void* __restrict__ keys, int shift,
+                                                 uint32_t* __restrict__ hist) {
+  __shared__ uint32_t h[RS_BINS];
+  const int cloud = blockIdx.y, tile = blockIdx.x;
+  const int n = descs[cloud].n, off = descs[cloud].offset;
+  if (tile * RS_TILE >= n) return;
+  for (int b = threadIdx.x; b < RS_BINS; b += 256) h[b] = 0;
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < RS_PER_THREAD; r++) {
+    int i = tile * RS_TILE + r * 256 + threadIdx.x;
+    if (i < n) atomicAdd(&h[(rs_key<kFirst>(keys, (size_t)off + i) >> shift) & (RS_BINS - 1)], 1u);
+  }
+  __syncthreads();
+  uint32_t* out = hist + ((size_t)descs[cloud].tile0 + tile) * RS_BINS;
+  for (int b = threadIdx.x; b < RS_BINS; b += 256) out[b] = h[b];
+}
+
+// thread = digit: offsets[tile][digit] = (elements of smaller digits) + (elements of this digit in earlier tiles)
+__global__ void __launch_bounds__(RS_BINS) k_rs_scan(const IndexDesc* __restrict__ descs, uint32_t* __restrict__ hist) {
+  __shared__ uint32_t wave_tot[RS_BINS / 64];
+  const int cloud = blockIdx.x, b = threadIdx.x, lane = b & 63, wave = b >> 6;
+  const int tiles = (descs[cloud].n + RS_TILE - 1) / RS_TILE;
+  uint32_t* h = hist + (size_t)descs[cloud].tile0 * RS_BINS;
+  uint32_t tot = 0;
+  int t0 = 0;
+  for (; t0 + 8 <= tiles; t0 += 8) {   // eight independent loads in flight
+    uint32_t v[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) v[k] = h[(size_t)(t0 + k) * RS_BINS + b];
+#pragma unroll
+    for (int k = 0; k < 8; k++) tot += v[k];
+  }
+  for (; t0 < tiles; t0++) tot += h[(size_t)t0 * RS_BINS + b];
+  uint32_t inc = tot;   // inclusive scan over the 1024 digit totals: inside the wave, then across the 16 waves
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    uint32_t v = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += v;
+  }
+  if (lane == 63) wave_tot[wave] = inc;
+  __syncthreads();
+  uint32_t base = 0;
+  for (int w = 0; w < wave; w++) base += wave_tot[w];
+  uint32_t run = base + inc - tot;
+  t0 = 0;
+  for (; t0 + 8 <= tiles; t0 += 8) {
+    uint32_t v[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) v[k] = h[(size_t)(t0 + k) * RS_BINS + b];
+#pragma unroll
+    for (int k = 0; k < 8; k++) { h[(size_t)(t0 + k) * RS_BINS + b] = run; run += v[k]; }
+  }
+  for (; t0 < tiles; t0++) {
+    uint32_t c = h[(size_t)t0 * RS_BINS + b];
+    h[(size_t)t0 * RS_BINS + b] = run;
+    run += c;
+  }
+}
+
+template <bool kFirst, bool kLast>
+__global__ void __launch_bounds__(256) k_rs_scatter(const IndexDesc* __restrict__ descs, const void* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+                                                    int shift, const uint32_t* __restrict__ offs, void* __restrict__ keys_out,
+                                                    uint32_t* __restrict__ vals_out) {
+  __shared__ uint32_t cnt[4][RS_BINS];   // per-wave running digit counters, then the waves' base positions
+  const int cloud = blockIdx.y, tile = blockIdx.x;
+  const int n = descs[cloud].n, off = descs[cloud].offset;
+  if (tile * RS_TILE >= n) return;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  for (int b = tid; b < 4 * RS_BINS; b += 256) (&cnt[0][0])[b] = 0;
+  __syncthreads();
+  // wave w owns elements [w * 512, (w + 1) * 512) of the tile, 64 consecutive ones per batch: (wave, batch, lane) is tile order
+  uint32_t key[RS_PER_THREAD], val[RS_PER_THREAD], rank[RS_PER_THREAD];
+  const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int r = 0; r < RS_PER_THREAD; r++) {
+    const int i = tile * RS_TILE + wave * (RS_TILE / 4) + r * 64 + lane;
+    const bool live = i < n;
+    key[r] = 0xffffffffu; val[r] = 0;
+    if (live) {
+      if constexpr (kFirst) { key[r] = rs_key<true>(keys_in, (size_t)off + i); val[r] = vals_in[(size_t)off + i]; }
+      else { const uint2 kv = reinterpret_cast<const uint2*>(keys_in)[(size_t)off + i]; key[r] = kv.x; val[r] = kv.y; }
+    }
+    const uint32_t dig = live ? ((key[r] >> shift) & (RS_BINS - 1)) : RS_BINS;   // bit 10 set: idle lanes match only each other
+    unsigned long long m = ~0ull;
+#pragma unroll
+    for (int bit = 0; bit <= RS_BITS; bit++) {
+      const unsigned long long bal = __ballot((dig >> bit) & 1u);
+      m &= ((dig >> bit) & 1u) ? bal : ~bal;
+    }
+    // the lowest lane of every digit group advances the wave's counter of that digit and hands the old value to its group
+    const int leader = __ffsll((long long)m) - 1;
+    uint32_t old = 0;
+    if (live && lane == leader) { old = cnt[wave][dig]; cnt[wave][dig] = old + (uint32_t)__popcll(m); }
+    old = __shfl(old, leader, 64);
+    rank[r] = old + (uint32_t)__popcll(m & below);
+  }
+  __syncthreads();
+  // cnt[w][d] = elements of digit d in wave w -> position of wave w's first such element
+  const uint32_t* o = offs + ((size_t)descs[cloud].tile0 + tile) * RS_BINS;
+  for (int b = tid; b < RS_BINS; b += 256) {
+    uint32_t run = o[b];
+#pragma unroll
+    for (int w = 0; w < 4; w++) { uint32_t c = cnt[w][b]; cnt[w][b] = run; run += c; }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < RS_PER_THREAD; r++) {
+    const int i = tile * RS_TILE + wave * (RS_TILE / 4) + r * 64 + lane;
+    if (i < n) {
+      const uint32_t dig = (key[r] >> shift) & (RS_BINS - 1);
+      const size_t pos = (size_t)off + cnt[wave][dig] + rank[r];
+      if constexpr (kLast) {
+        reinterpret_cast<uint64_t*>(keys_out)[pos] = ((uint64_t)(uint32_t)cloud << 32) | key[r];
+        vals_out[pos] = val[r];
+      } else
+        reinterpret_cast<uint2*>(keys_out)[pos] = make_uint2(key[r], val[r]);
+    }
+  }
+}
+
+int segsort_tiles(int n) { return (n + RS_TILE - 1) / RS_TILE; }   // IndexDesc::tile0 = sum of the previous clouds' tiles
+size_t segsort_hist_elems(long total_points, int n_clouds) { return (size_t)(total_points / RS_TILE + n_clouds) * RS_BINS; }
+
+// keys_in: (cloud << 32 | 30-bit key) of all clouds, concatenated in cloud order (descs[c].offset / .n); vals_in: point indices.
+// kv_a / kv_b: two scratch arrays of (total points) 8-byte pairs.  On return keys_out / vals_out hold every cloud's segment
+// sorted by key, ties in ascending input position.
+void segsort_pairs(const IndexDesc* descs, int n_clouds, int max_n, const uint64_t* keys_in, uint64_t* keys_out, const uint32_t* vals_in,
+                   uint32_t* vals_out, uint64_t* kv_a, uint64_t* kv_b, uint32_t* hist, hipStream_t s) {
+  const int tiles = (max_n + RS_TILE - 1) / RS_TILE;
+  const dim3 grid(tiles, n_clouds), blk(256);
+  // pass 0: (u64 key, u32 index) in, pairs out
+  hipLaunchKernelGGL(k_rs_hist<true>, grid, blk, 0, s, descs, (const void*)keys_in, 0, hist);
+  hipLaunchKernelGGL(k_rs_scan, dim3(n_clouds), dim3(RS_BINS), 0, s, descs, hist);
+  hipLaunchKernelGGL((k_rs_scatter<true, false>), grid, blk, 0, s, descs, (const void*)keys_in, vals_in, 0, (const uint32_t*)hist, (void*)kv_a, (uint32_t*)nullptr);
+  // pass 1: pairs -> pairs
+  hipLaunchKernelGGL(k_rs_hist<false>, grid, blk, 0, s, descs, (const void*)kv_a, RS_BITS, hist);
+  hipLaunchKernelGGL(k_rs_scan, dim3(n_clouds), dim3(RS_BINS), 0, s, descs, hist);
+  hipLaunchKernelGGL((k_rs_scatter<false, false>), grid, blk, 0, s, descs, (const void*)kv_a, (const uint32_t*)nullptr, RS_BITS, (const uint32_t*)hist, (void*)kv_b,
+                     (uint32_t*)nullptr);
+  // pass 2: pairs in, (cloud << 32 | key) and index out
+  hipLaunchKernelGGL(k_rs_hist<false>, grid, blk, 0, s, descs, (const void*)kv_b, 2 * RS_BITS, hist);
+  hipLaunchKernelGGL(k_rs_scan, dim3(n_clouds), dim3(RS_BINS), 0, s, descs, hist);
+  hipLaunchKernelGGL((k_rs_scatter<false, true>), grid, blk, 0, s, descs, (const void*)kv_b, (const uint32_t*)nullptr, 2 * RS_BITS, (const uint32_t*)hist, (void*)keys_out,
+                     vals_out);
+}
+
+}  // namespace lh

@@ -329,3 +329,43 @@ def test_p2plane_information_kat_and_oracle(ctx, capi, oracle):
     Ao = oracle.p2plane_Ap(oracle.normalize_cloud(oracle.xyz4(src)), oracle.nrm4(nrms), corr)
     # the reference/oracle normalisation sums sequentially in float; the HIP path sums in double -> 1e-4 relative
     assert np.allclose(Ap, Ao, rtol=2e-4, atol=2e-4 * np.abs(Ao).max())
+
+
+def test_index_sort_matches_library_sort():
+    """K2's hand-written segmented radix sort (lh_radix.hip) against a stable library sort of the same (cloud id << 32 | Hilbert key)
+    array: LH_SORT=check runs both inside every index build and fails the call on the first differing element.  Ragged batches,
+    tiny clouds, runs of identical keys (ties must keep ascending point index), a 300 k-point cloud (147 tiles)."""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import numpy as np, sys
+sys.path.insert(0, %r)
+from locus_amd import capi, synth
+ctx = capi.Context(0)
+rng = np.random.default_rng(5)
+clouds = []
+for n in (1, 2, 7, 63, 64, 65, 2047, 2048, 2049, 5000, 100032, 300000):
+    pts = rng.uniform(-30, 30, size=(n, 3)).astype(np.float32)
+    clouds.append(pts)
+dup = np.repeat(rng.uniform(-5, 5, size=(40, 3)).astype(np.float32), 100, axis=0)   # 40 points x 100 copies: long runs of equal keys
+clouds.append(dup)
+clouds.append(synth.scan(rings=32, azimuths=900, scale=2.0, seed=8))
+C = [capi.Cloud(ctx, c) for c in clouds]
+for c in C:
+    c.build_index()                     # one cloud per build
+# batched builds (one sort for all targets of a batch): ragged sizes, more clouds than one launch of 64
+S, T = [], []
+for k in range(70):
+    src, tgt, _ = synth.scan_pair(n_rings=4 + k %% 13, n_az=100 + 37 * (k %% 7), scale=1.0, noise=0.01, seed=700 + k)
+    cs, ct = capi.Cloud(ctx, src), capi.Cloud(ctx, tgt)
+    cs.normals_knn(5); ct.normals_knn(5); ct.drop_index()
+    S.append(cs); T.append(ct)
+out = capi.align_batch(ctx, capi.default_params(max_iterations=3, corr_dist=1.0), S, T, max_in_flight=70)
+assert all(o["status"] == 0 for o in out)
+print("SORT_CHECK_OK")
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LH_SORT="check")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and "SORT_CHECK_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
