@@ -60,6 +60,30 @@ PARITY_TOL_R = max(1e-4, 1.3e-4)
 PARITY_TYPICAL_T = max(1e-4, 2.4e-4)
 
 
+class _Roctx:
+    """roctx ranges around the legs of the run, so that a rocprofv3 --kernel-trace --marker-trace of this command can be
+    sliced per leg (tools/trace_leg_summary.py): the rocprof summary of the profile leg must agree with roofline.avg_launch_us.
+    Silently a no-op when the marker library is not there."""
+
+    def __init__(self):
+        self.lib = None
+        for name in ("librocprofiler-sdk-roctx.so", "libroctx64.so"):
+            try:
+                self.lib = C.CDLL(name)
+                self.lib.roctxRangePushA.argtypes = [C.c_char_p]
+                break
+            except OSError:
+                self.lib = None
+
+    def push(self, name):
+        if self.lib:
+            self.lib.roctxRangePushA(name.encode())
+
+    def pop(self):
+        if self.lib:
+            self.lib.roctxRangePop()
+
+
 def physical_cores():
     try:
         import psutil
@@ -208,14 +232,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    roctx = _Roctx()
     for _ in range(args.warmup):
         out = step()
     barrier()
+    roctx.push("timed_region")
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
     barrier()
     elapsed = time.perf_counter() - t0
+    roctx.pop()
     elapsed = ldist.max_over_ranks(elapsed, world, device=ddev)
     if world > 1:   # the gathered table holds this rank's records at its own offset, bit for bit
         mine = bytes(bytearray(out))
@@ -247,9 +274,13 @@ def main():
         prof_in_flight = max(8, args.in_flight // groups)
         ctx.profile(True)
         ctx.profile_reset()
+        ctx.synchronize()
+        roctx.push("profile_leg")
         for _ in range(max(1, min(args.steps, 2))):
             step(prof_in_flight, exchange=False)  # rank 0 only: no collective may be called here
         stats = ctx.profile_get()
+        ctx.synchronize()
+        roctx.pop()
         ctx.profile(False)
         dom = max(stats.items(), key=lambda kv: kv[1]["ms"])
         name, st = dom
