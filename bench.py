@@ -165,7 +165,7 @@ def main():
     ap.add_argument("--azimuths", type=int, default=1563)  # 64 x 1563 = 100 032 points / scan
     ap.add_argument("--scale", type=float, default=2.0)
     ap.add_argument("--cost-mode", type=int, default=1, help="lh_gicp_params.cost_mode (1 = moments, 0 = per-evaluation passes)")
-    ap.add_argument("--solver", type=int, default=0, help="lh_gicp_params.solver: 0 = outer loop on the device (k_solve), 1 = on the host")
+    ap.add_argument("--solver", type=int, default=0, help="lh_gicp_params.solver: 0 = auto (device loop for batches), 1 = host loop, 2 = device loop")
     ap.add_argument("--quick", action="store_true", help="timed region only: no roofline / mode-0 / natural-convergence / CPU legs (A/B runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single-latency", action="store_true", help="skip the one-pair-at-a-time lh_gicp_align latency leg")

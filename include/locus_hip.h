@@ -72,9 +72,11 @@ typedef struct {
                                         so ONE 74-moment reduction per outer iteration serves every BFGS evaluation (double
                                         T*p instead of float: differs from mode 0 by the reference's own float rounding noise) */
   int solver;                    /* where the loop between two sweeps runs in cost_mode 1 (the BFGS solve on the 74 moments, the convergence
-                                    test): 0 = (default) on the device, k_solve -- the host only enqueues iterations and looks at the pairs'
-                                    states every few rounds; 1 = on the host, one sync per outer iteration (the path the source-sharded
-                                    pair takes anyway, lh_set_allreduce).  Same code, same arithmetic (lh_math.hpp): identical results. */
+                                    test): 2 = on the device (k_solve: the host only enqueues iterations and looks at the pairs' states
+                                    every few rounds); 1 = on the host, one sync per outer iteration (the path the source-sharded pair
+                                    takes anyway, lh_set_allreduce); 0 = (default) device for batches of >= 8 pairs in flight, host for
+                                    fewer (lower latency for one pair at a time).  Same code, same arithmetic (lh_math.hpp): the
+                                    results are bit-identical either way. */
 } lh_gicp_params;
 
 typedef struct {
@@ -173,7 +175,7 @@ lh_status lh_knn_cloud(lh_cloud* target, const lh_cloud* q, int k, int32_t* idx,
    src[p] -> tgt[p].  The NN index of every target is (re)built inside the call, like align() does. */
 lh_status lh_gicp_align_batch(lh_ctx* ctx, const lh_gicp_params* p, int n_pairs, lh_cloud* const* src,
                               lh_cloud* const* tgt, const float* guesses /* n_pairs*16 or NULL */,
-                              lh_gicp_result* out, int max_in_flight /* 0 = default */);
+                              lh_gicp_result* out, int max_in_flight /* 0 = default (64) */);
 /* the same, plus align()'s output cloud of every pair (gicp.hpp:586, pcl::transformPointCloud(*input_, output,
    final_transformation_)): aligned[i] = final T * src[i], xyz transformed and every other field copied, written on the device
    as the pair retires.  aligned[i] == NULL on entry: a new device cloud is created (the caller destroys it); otherwise an

@@ -1278,12 +1278,21 @@ static lh_status run_tasks_host(lh_ctx* c, std::vector<Task*>& tasks, int in_fli
   return err;
 }
 
-// cost_mode 1 runs the loop on the device unless something needs the host inside it: the source-sharded pair's SUM hook
-// (its sums cross ranks through a host callback), a debug-statistics sweep, or an explicit request (lh_gicp_params.solver = 1)
+// Where the loop between two sweeps runs in cost_mode 1 (lh_gicp_params.solver): on the device (k_solve) the host is out of the
+// loop and throughput no longer depends on it -- the choice for batches; on the host one outer iteration costs a sync and a
+// few microseconds of BFGS on a CPU core, against ~3 us per cost evaluation on a single GPU wave -- the choice for one pair at
+// a time (measured: 1.2 ms vs 2.5 ms per 100k-point pair at 20 iterations).  solver = 0 picks by the number of pairs in
+// flight.  The host loop is also taken when something needs the host inside the loop: the source-sharded pair's SUM hook (its
+// sums cross ranks through a host callback) and the debug-statistics sweeps.  Both loops give bit-identical results.
+constexpr int DEVICE_LOOP_MIN_IN_FLIGHT = 8;
 static lh_status run_tasks(lh_ctx* c, std::vector<Task*>& tasks, int in_flight, bool rebuild_index, std::vector<Workspace>* slot_ws = nullptr) {
   bool device_loop = !c->reduce_fn;
-  for (Task* t : tasks)
+  bool forced = false;
+  for (Task* t : tasks) {
     if (t->P.cost_mode != 1 || t->P.solver == 1 || t->count_stats || t->P.max_iterations < 1) device_loop = false;
+    if (t->P.solver == 2) forced = true;
+  }
+  if (device_loop && !forced && std::min<size_t>(in_flight, tasks.size()) < (size_t)DEVICE_LOOP_MIN_IN_FLIGHT) device_loop = false;
   return device_loop ? run_tasks_device(c, tasks, in_flight, rebuild_index, slot_ws) : run_tasks_host(c, tasks, in_flight, rebuild_index, slot_ws);
 }
 
@@ -1783,7 +1792,7 @@ lh_status lh_gicp_align_batch_out(lh_ctx* ctx, const lh_gicp_params* p, int n_pa
   if (!ctx || !p || n_pairs < 0 || !src || !tgt || !out) return LH_EINVAL;
   if (n_pairs == 0) return LH_OK;
   HIPCHK(hipSetDevice(ctx->device));
-  int in_flight = max_in_flight > 0 ? max_in_flight : 16;
+  int in_flight = max_in_flight > 0 ? max_in_flight : 64;  // default: enough pairs in flight for four scheduler groups
   in_flight = std::min(in_flight, n_pairs);
   int max_n = 1;
   for (int i = 0; i < n_pairs; i++) {
