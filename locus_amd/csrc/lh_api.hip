@@ -226,6 +226,8 @@ struct lh_ctx {
   double* partials_host = nullptr; // pinned, device-visible: [n_slots][max_cost_blocks][COST_NSUM]
   size_t partials_per_slot = 0;    // doubles
   double* mom_partials_dev = nullptr;  // [n_slots][mom_stride] per-block moment partials (device)
+  unsigned long long* wmask_dev = nullptr;  // [n_slots][mask_stride] walker masks of the two-launch sweep (one 64-bit word per wave of source points)
+  int mask_stride = 0;
   int mom_stride = 0;
   // device-driven loop (cost_mode 1, k_solve): per-slot loop state, the chunk sums k_moments_final leaves for k_solve
   OuterState* states_dev = nullptr;    // [n_slots]
@@ -543,15 +545,18 @@ void Workspace::release() {
 
 static lh_status ctx_ensure_slots(lh_ctx* c, int n_slots, int max_n) {
   size_t per_slot = std::max<size_t>((size_t)cost_blocks(max_n) * COST_NSUM, (size_t)FINAL_CHUNKS * MOM_ROW);
-  int mom_stride = ((max_n + 255) / 256) * 4 * MOM_ROW;  // one partial row per wave of every 256-point workgroup of the fused sweep
+  int mom_stride = sweep_rows(max_n) * MOM_ROW;  // one partial row per wave of every 256-point workgroup of the fused sweep + the walk rows
+  int mask_stride = ((max_n + 255) / 256) * 4;
   if (n_slots <= c->n_slots && per_slot <= c->partials_per_slot && mom_stride <= c->mom_stride) return LH_OK;
   (void)hipStreamSynchronize(c->stream);
   c->sync_side_streams();
   n_slots = std::max(n_slots, c->n_slots);
   per_slot = std::max(per_slot, c->partials_per_slot);
   mom_stride = std::max(mom_stride, c->mom_stride);
+  mask_stride = std::max(mask_stride, c->mask_stride);
   (void)lhFree(c->descs_dev);
   (void)lhFree(c->mom_partials_dev);
+  (void)lhFree(c->wmask_dev);
   (void)lhFree(c->states_dev);
   (void)lhFree(c->chunks_dev);
   if (c->descs_host) (void)hipHostFree(c->descs_host);
@@ -560,6 +565,7 @@ static lh_status ctx_ensure_slots(lh_ctx* c, int n_slots, int max_n) {
   if (c->states_init) (void)hipHostFree(c->states_init);
   HIPCHK(hipMalloc(&c->descs_dev, sizeof(PairDesc) * n_slots));
   HIPCHK(hipMalloc(&c->mom_partials_dev, sizeof(double) * (size_t)mom_stride * n_slots));
+  HIPCHK(hipMalloc(&c->wmask_dev, sizeof(unsigned long long) * (size_t)mask_stride * n_slots));
   HIPCHK(hipMalloc(&c->states_dev, sizeof(OuterState) * n_slots));
   HIPCHK(hipMalloc(&c->chunks_dev, sizeof(double) * (size_t)FINAL_CHUNKS * MOM_ROW * n_slots));
   HIPCHK(hipHostMalloc(&c->states_host, sizeof(OuterState) * n_slots, hipHostMallocDefault));
@@ -567,6 +573,7 @@ static lh_status ctx_ensure_slots(lh_ctx* c, int n_slots, int max_n) {
   for (int k = 0; k < 4; k++)
     if (!c->group_ev[k]) HIPCHK(hipEventCreateWithFlags(&c->group_ev[k], hipEventDisableTiming));
   c->mom_stride = mom_stride;
+  c->mask_stride = mask_stride;
   HIPCHK(hipHostMalloc(&c->descs_host, sizeof(PairDesc) * n_slots, hipHostMallocDefault));
   HIPCHK(hipHostMalloc(&c->partials_host, sizeof(double) * per_slot * n_slots, hipHostMallocDefault));
   c->n_slots = n_slots;
@@ -606,6 +613,7 @@ struct Task {
   // device-driven loop
   lh_gicp_trace* trace_dev = nullptr;
   int enq_iters = 0;         // outer iterations enqueued so far
+  int sweeps_done = 0;       // host-driven loop: sweeps launched so far (the device-driven loop counts enq_iters)
   // the loop's state (host-driven: advanced by run(); device-driven: the last download of the pair's device state)
   OuterState os;
   // outputs
@@ -708,6 +716,7 @@ struct Task {
     g_boot_task = this;
     req = REQ_NONE;
     first_sweep = true;
+    sweeps_done = 0;
     resume();  // runs until the first request
   }
 };
@@ -789,6 +798,13 @@ struct Group {
   bool inflight = false;
 };
 
+// Is the pair's k-th sweep (0-based) launched in the two-launch form (k_late + k_walk)?  A fixed rule of the pair's own
+// parameters and k, so that both loop flavours, any batching and any number of GPUs add the same partial rows in the same order.
+static bool sweep_is_split(const Task* t, int k) {
+  return t->P.cost_mode == 1 && !t->P.recompute_source_cov && !t->P.recompute_target_cov && t->guess_is_identity && t->src->nrm &&
+         t->tgt->nrm && t->ws->rec && k >= sweep_split_from();
+}
+
 static lh_status group_launch(lh_ctx* c, Group& g) {
   hipStream_t st = g.stream;
   g.sweeps.clear(); g.moms.clear(); g.costs.clear();
@@ -853,9 +869,14 @@ static lh_status group_launch(lh_ctx* c, Group& g) {
       }
       ProfScope p(c, "nn_sweep", bytes, st);
       bool normals_only = true;
-      for (int j = 0; j < a.njobs; j++)
-        if (g.sweeps[o + j]->P.recompute_source_cov || g.sweeps[o + j]->P.recompute_target_cov) normals_only = false;
-      launch_sweep_fused(c->descs_dev, a, max_n, c->mom_partials_dev, c->mom_stride, nullptr, normals_only, st);
+      uint32_t split_mask = 0u;
+      for (int j = 0; j < a.njobs; j++) {
+        Task* t = g.sweeps[o + j];
+        if (t->P.recompute_source_cov || t->P.recompute_target_cov) normals_only = false;
+        if (sweep_is_split(t, t->sweeps_done)) split_mask |= 1u << j;
+        t->sweeps_done++;
+      }
+      launch_sweep_fused(c->descs_dev, a, split_mask, max_n, c->mom_partials_dev, c->mom_stride, nullptr, normals_only, c->wmask_dev, c->mask_stride, st);
       launch_moments_final(c->descs_dev, ca, c->mom_partials_dev, c->mom_stride, c->partials_host, nullptr, st);
     } else {
       {
@@ -1046,6 +1067,7 @@ static lh_status dev_enqueue(lh_ctx* c, DevGroup& g, int rounds) {
       int max_n = 0;
       double bytes = 0;
       bool normals_only = true;
+      uint32_t split_mask = 0u;
       SweepArgs seed;
       seed.njobs = 0; seed.max_depth = 0; seed.pad = 0; seed.bpj = 0;
       int smax = 0;
@@ -1066,6 +1088,7 @@ static lh_status dev_enqueue(lh_ctx* c, DevGroup& g, int rounds) {
           smax = std::max(smax, t->src->n);
           t->first_sweep = false;
         }
+        if (sweep_is_split(t, t->enq_iters)) split_mask |= 1u << j;
         t->enq_iters++;
       }
       if (seed.njobs > 0) {
@@ -1074,7 +1097,7 @@ static lh_status dev_enqueue(lh_ctx* c, DevGroup& g, int rounds) {
       }
       {
         ProfScope p(c, "nn_sweep", bytes, st);
-        launch_sweep_fused(c->descs_dev, a, max_n, c->mom_partials_dev, c->mom_stride, c->states_dev, normals_only, st);
+        launch_sweep_fused(c->descs_dev, a, split_mask, max_n, c->mom_partials_dev, c->mom_stride, c->states_dev, normals_only, c->wmask_dev, c->mask_stride, st);
         launch_moments_final(c->descs_dev, ca, c->mom_partials_dev, c->mom_stride, c->chunks_dev, c->states_dev, st);
       }
       {
@@ -1425,7 +1448,7 @@ void lh_destroy(lh_ctx* c) {
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
   if (c->stream3) (void)hipStreamDestroy(c->stream3);
   if (c->stream4) (void)hipStreamDestroy(c->stream4);
-  (void)lhFree(c->sort_temp); (void)lhFree(c->bbox); (void)lhFree(c->descs_dev); (void)lhFree(c->mom_partials_dev);
+  (void)lhFree(c->sort_temp); (void)lhFree(c->bbox); (void)lhFree(c->descs_dev); (void)lhFree(c->mom_partials_dev); (void)lhFree(c->wmask_dev);
   (void)lhFree(c->states_dev); (void)lhFree(c->chunks_dev);
   if (c->states_host) (void)hipHostFree(c->states_host);
   if (c->states_init) (void)hipHostFree(c->states_init);

@@ -414,6 +414,89 @@ LH_HD void tree_search(const TreeView& t, float qx, float qy, float qz, Collecto
   }
 }
 
+// The same traversal cut into steps for a caller that drives the loop itself (k_walk's persistent lanes: a lane starts its next
+// query while the others are in the middle of theirs).  WalkStack = tree_search's stack (first N entries in LDS at
+// base[entry * stride], deeper ones in private memory); node_visit = one iteration of tree_search's inner loop: the child to
+// descend into, or the next stacked subtree that can still matter, or NO_CHILD when the search has ended.  Same keys, same order,
+// same pruning rule, same skip() calls as tree_search, so a collector ends with the same state.
+template <int N>
+struct WalkStack {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __attribute__((address_space(3))) uint64_t* base;
+#else
+  uint64_t* base;
+#endif
+  int stride;
+  int sp;
+  uint64_t spill[SPILL_MAX + LDS_STACK - N];
+#if defined(__HIP_DEVICE_COMPILE__)
+  LH_HD WalkStack(uint64_t* b, int st) : base((__attribute__((address_space(3))) uint64_t*)b), stride(st), sp(0) {}
+#else
+  LH_HD WalkStack(uint64_t* b, int st) : base(b), stride(st), sp(0) {}
+#endif
+  LH_HD void push(uint32_t key, int32_t ref) {
+    uint64_t e = ((uint64_t)key << 32) | (uint32_t)ref;
+    if (sp < N) base[sp * stride] = e;
+    else spill[sp - N] = e;
+    sp++;
+  }
+  template <class Collector>
+  LH_HD int32_t pop(Collector& col) {
+    for (;;) {
+      if (sp == 0) return NO_CHILD;
+      --sp;
+      uint64_t e;
+      if (sp < N) e = base[sp * stride];
+      else e = spill[sp - N];
+      float dk = u2f((uint32_t)(e >> 32) & ~3u);
+      if (dk <= col.bound()) return (int32_t)(uint32_t)e;
+      col.skip(dk);
+    }
+  }
+};
+template <class Collector, class Stack>
+LH_HD int32_t node_visit(const NodeX& nd, const GridQuery& gq, float scl2, Collector& col, Stack& stk) {
+  const uint32_t NONE = 0xffffffffu;
+  const float INF = inf_f();
+  col.count_node(0);
+  const uint4 a = gload16<uint4>(nd.lo_xy);
+  const uint4 b = gload16<uint4>(nd.hi_xy);
+  const uint4 c = gload16<uint4>(nd.z_lohi);
+  const int4 ch = gload16<int4>(nd.child);
+  float d0 = boxd2_q(gq, a.x, b.x, c.x, scl2);
+  float d1 = boxd2_q(gq, a.y, b.y, c.y, scl2);
+  float d2 = boxd2_q(gq, a.z, b.z, c.z, scl2);
+  float d3 = boxd2_q(gq, a.w, b.w, c.w, scl2);
+  d1 = ch.y == NO_CHILD ? INF : d1;
+  d2 = ch.z == NO_CHILD ? INF : d2;
+  d3 = ch.w == NO_CHILD ? INF : d3;
+  const float bd = col.bound();
+  const bool v0 = d0 <= bd && d0 < INF, v1 = d1 <= bd && d1 < INF, v2 = d2 <= bd && d2 < INF, v3 = d3 <= bd && d3 < INF;
+  uint32_t k0 = v0 ? ((f2u(d0) & ~3u) | 0u) : NONE;
+  uint32_t k1 = v1 ? ((f2u(d1) & ~3u) | 1u) : NONE;
+  uint32_t k2 = v2 ? ((f2u(d2) & ~3u) | 2u) : NONE;
+  uint32_t k3 = v3 ? ((f2u(d3) & ~3u) | 3u) : NONE;
+  col.skip(v0 ? INF : d0); col.skip(v1 ? INF : d1); col.skip(v2 ? INF : d2); col.skip(v3 ? INF : d3);
+  uint32_t x, y;
+  x = k0 < k1 ? k0 : k1; y = k0 < k1 ? k1 : k0; k0 = x; k1 = y;
+  x = k2 < k3 ? k2 : k3; y = k2 < k3 ? k3 : k2; k2 = x; k3 = y;
+  x = k0 < k2 ? k0 : k2; y = k0 < k2 ? k2 : k0; k0 = x; k2 = y;
+  x = k1 < k3 ? k1 : k3; y = k1 < k3 ? k3 : k1; k1 = x; k3 = y;
+  x = k1 < k2 ? k1 : k2; y = k1 < k2 ? k2 : k1; k1 = x; k2 = y;
+  auto child_of = [&](uint32_t k) -> int32_t {
+    uint32_t sl = k & 3u;
+    return sl == 0 ? ch.x : (sl == 1 ? ch.y : (sl == 2 ? ch.z : ch.w));
+  };
+  if (k1 != NONE) {
+    if (k2 != NONE) {
+      if (k3 != NONE) stk.push(k3, child_of(k3));
+      stk.push(k2, child_of(k2));
+    }
+    stk.push(k1, child_of(k1));
+  }
+  return (k0 != NONE) ? child_of(k0) : stk.pop(col);
+}
+
 // ---- index build, per-element steps shared by the build kernels and the host-side check ---------------------------------
 // sorted keys: (cloud id << 32) | 30-bit Hilbert key, so a batch of clouds is one sorted array and no cell spans two clouds
 constexpr int KEY_PREFIX_MIN = 34;  // 64 - 30: shortest prefix that still pins the cloud id (and the two unused bits)

@@ -607,6 +607,97 @@ __device__ __forceinline__ void wave_reduce_row(uint64_t* lds_base, double* out,
   if (lane < ROW - NV) out[NV + lane] = lane == 0 ? extra : 0.0;  // the rest of the row: one extra value (e.g. tree walks), zeros
 }
 
+// ---- the 74 moments of a wave as a Gram matrix on the FP64 matrix pipe -----------------------------------------------------
+// The 74 sums of a wave's 64 points are D = sum_i a_i b_i^T with
+//   a_i = (M00 M01 M02 M11 | M12 M22 Ma0 Ma1 | Ma2 aMa live 0)        b_i = (x y z 1 | xx xy xz yy | yz zz 0 0)
+// cut into 4x4 tiles: H = M6 x all ten columns (row tiles R0, R1 x column tiles C0, C1, C2), B = Ma x (x y z 1) (R1, R2 x C0),
+// c0 = aMa * 1 and the count = live * 1 (R2 x C0): seven tiles.  v_mfma_f64_4x4x4_4b_f64 multiplies FOUR independent 4x4x4 blocks
+// per instruction in 20 cycles (measured, tools/micro/mfma_f64_rate.hip; the 16x16x4 form takes 64 and 57 % of its 16x16 tile is
+// unused here): the four blocks take four different groups of four points of the same tile, so 64 points cost 7 x 4 = 28
+// instructions = 560 cycles of the matrix pipe instead of 16 x 64 = 1024.  Lane map (probed, tools/micro/mfma_f64_4x4_map.hip):
+// A lane 16 k + 4 b + i = A_b[i][k], B lane 16 k + 4 b + j = B_b[k][j], D lane 16 i + 4 b + j = D_b[i][j].
+// Operands go through LDS once (lane = point -> lane = (k, block, element)), half a wave at a time: 32 rows of GRAM_RS doubles.
+// A lane stages a (11 values), its point (x, y, z) and a 1.0; the reading lane forms the products of b itself -- the same
+// products the writer would have made, without ten more doubles per lane in registers and in LDS.  Wave-synchronous: no barrier.
+struct GramAcc { double t[7]; };   // R0C0 R0C1 R0C2 R1C0 R1C1 R1C2 R2C0, summed over the block's point groups
+constexpr int GRAM_RS = 15;        // doubles per staged point; odd => conflict-free column writes
+__device__ __forceinline__ void gram_zero(GramAcc& g) {
+#pragma unroll
+  for (int k = 0; k < 7; k++) g.t[k] = 0.0;
+}
+// `on` = the lane has a matched point (otherwise it stages zeros)
+__device__ __forceinline__ void gram_accumulate(double* wl, const double (&av)[11], const float4& p, bool on, GramAcc& g) {
+  const int lane = threadIdx.x & 63;
+  const int kk = lane >> 4, b = (lane >> 2) & 3, ij = lane & 3;
+#pragma unroll
+  for (int half = 0; half < 2; half++) {
+    if ((lane >> 5) == half) {
+      double* row = wl + (lane & 31) * GRAM_RS;
+#pragma unroll
+      for (int e = 0; e < 11; e++) row[e] = av[e];
+      row[11] = on ? (double)p.x : 0.0;
+      row[12] = on ? (double)p.y : 0.0;
+      row[13] = on ? (double)p.z : 0.0;
+      row[14] = on ? 1.0 : 0.0;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int s = 0; s < 2; s++) {  // sixteen points per step: block b takes points 16 s + 4 b .. + 3
+      const double* row = wl + (16 * s + 4 * b + kk) * GRAM_RS;
+      const double A0 = row[ij], A1 = row[4 + ij], A2 = (ij < 3) ? row[8 + ij] : 0.0;
+      const double x = row[11], y = row[12], z = row[13], o = row[14];
+      const double u = ij == 0 ? x : (ij == 1 ? y : (ij == 2 ? z : o));     // C0: x y z 1
+      const double B1 = (ij == 3 ? y : x) * (ij == 3 ? y : u);             // C1: xx xy xz yy
+      const double B2 = ij == 0 ? y * z : (ij == 1 ? z * z : 0.0);         // C2: yz zz 0 0
+      g.t[0] = __builtin_amdgcn_mfma_f64_4x4x4f64(A0, u, g.t[0], 0, 0, 0);
+      g.t[1] = __builtin_amdgcn_mfma_f64_4x4x4f64(A0, B1, g.t[1], 0, 0, 0);
+      g.t[2] = __builtin_amdgcn_mfma_f64_4x4x4f64(A0, B2, g.t[2], 0, 0, 0);
+      g.t[3] = __builtin_amdgcn_mfma_f64_4x4x4f64(A1, u, g.t[3], 0, 0, 0);
+      g.t[4] = __builtin_amdgcn_mfma_f64_4x4x4f64(A1, B1, g.t[4], 0, 0, 0);
+      g.t[5] = __builtin_amdgcn_mfma_f64_4x4x4f64(A1, B2, g.t[5], 0, 0, 0);
+      g.t[6] = __builtin_amdgcn_mfma_f64_4x4x4f64(A2, u, g.t[6], 0, 0, 0);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+// the four blocks' tiles are added in a fixed tree ((b0 + b1) + (b2 + b3)) and written to the wave's 76-double row:
+// S[0] = c0, S[1 + 4 r + c] = B[r][c], S[13 + 10 m + q] = H[m][q] (q: xx xy xz x yy yz y zz z 1), S[73] = count, S[74] = walks
+__device__ __forceinline__ void gram_store(const GramAcc& g, double* out, double walks) {
+  const int lane = threadIdx.x & 63, i = lane >> 4, b = (lane >> 2) & 3, j = lane & 3;
+  double v[7];
+#pragma unroll
+  for (int k = 0; k < 7; k++) {
+    double s = g.t[k];
+    s += __shfl_xor(s, 4);
+    s += __shfl_xor(s, 8);
+    v[k] = s;
+  }
+  if (b == 0) {
+    const int q0 = j == 0 ? 3 : (j == 1 ? 6 : (j == 2 ? 8 : 9));   // C0: x y z 1
+    const int q1 = j == 3 ? 4 : j;                                  // C1: xx xy xz yy
+    const int q2 = j == 0 ? 5 : 7;                                  // C2: yz zz
+    // R0: M00 M01 M02 M11 = M6[i]
+    out[13 + 10 * i + q0] = v[0];
+    out[13 + 10 * i + q1] = v[1];
+    if (j < 2) out[13 + 10 * i + q2] = v[2];
+    // R1: M12 M22 Ma0 Ma1
+    if (i < 2) {
+      out[13 + 10 * (4 + i) + q0] = v[3];
+      out[13 + 10 * (4 + i) + q1] = v[4];
+      if (j < 2) out[13 + 10 * (4 + i) + q2] = v[5];
+    } else {
+      out[1 + 4 * (i - 2) + j] = v[3];
+    }
+    // R2: Ma2 aMa live 0
+    if (i == 0) out[1 + 8 + j] = v[6];
+    if (i == 1 && j == 3) out[0] = v[6];
+    if (i == 2 && j == 3) out[73] = v[6];
+  }
+  if (lane < MOM_ROW - MOM_NSUM) out[MOM_NSUM + lane] = lane == 0 ? walks : 0.0;
+}
+
 // one point per thread (78 VGPRs, 6 waves per SIMD).  A variant with 4 points per thread and the 74 moments accumulated in
 // registers (239 VGPRs, 2 waves per SIMD) pays the reduction once per 4 points but was slower even on certificate-only
 // sweeps (142 vs 128 us): with so few waves the dependent src -> neighbour gathers are no longer hidden.
@@ -633,64 +724,328 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) k
   const int walks = __popcll(__ballot(sp.searched));
   double* out = partials + (size_t)job.slot * partials_stride + ((size_t)blk * 4 + (threadIdx.x >> 6)) * MOM_ROW;
   {
-    // The 74 moments of a wave are one 16x16 Gram matrix over its 64 points: D = sum_i a_i b_i^T with
-    //   a_i = (M00 M01 M02 M11 M12 M22 | Ma0 Ma1 Ma2 | aMa | live)   b_i = (xx xy xz x yy yz y zz z 1)
-    // (H = rows 0-5 x cols 0-9, B = rows 6-8 x cols {3,6,8,9}, c0 = D[9][9], count = D[10][9]).  v_mfma_f64_16x16x4_f64 adds four
-    // points per instruction on the matrix pipe, which runs beside the VALU: the products, the cross-lane adds and most of the
-    // LDS traffic of the shuffle reduction disappear from the vector pipe.  Operands go through LDS once (lane = point ->
-    // lane = (element, point)), half a wave at a time so that the staging fits the traversal-stack region.
-    typedef double v4d __attribute__((ext_vector_type(4)));
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    constexpr int RS = 21;  // doubles per staged point: a (11) then b (10); odd => conflict-free column writes
-    double* wl = reinterpret_cast<double*>(lds_stack) + wave * (32 * RS);
+    // the 74 moments of the wave on the matrix pipe (gram_accumulate above); the staging rows alias the traversal stacks
+    const int wave = threadIdx.x >> 6;
     const double av[11] = {M6[0], M6[1], M6[2], M6[3], M6[4], M6[5], Ma[0], Ma[1], Ma[2], aMa, live};
-    v4d acc = {0.0, 0.0, 0.0, 0.0};
+    GramAcc acc;
+    gram_zero(acc);
     __syncthreads();  // every lane of the workgroup is done with its traversal stack
-#pragma unroll
-    for (int half = 0; half < 2; half++) {
-      if ((lane >> 5) == half) {
-        double* row = wl + (lane & 31) * RS;
-#pragma unroll
-        for (int e = 0; e < 11; e++) row[e] = av[e];
-#pragma unroll
-        for (int e = 0; e < 10; e++) row[11 + e] = pp[e];
-      }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-      __builtin_amdgcn_wave_barrier();
-      const int E = lane & 15;
-#pragma unroll
-      for (int m = 0; m < 8; m++) {  // points 4m .. 4m+3 of this half: A[i = lane & 15][k = lane >> 4], B[k = lane >> 4][j = lane & 15]
-        const double* row = wl + (4 * m + (lane >> 4)) * RS;
-        double A = (E < 11) ? row[E] : 0.0;
-        double B = (E < 10) ? row[11 + E] : 0.0;
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A, B, acc, 0, 0, 0);
-      }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-      __builtin_amdgcn_wave_barrier();
-    }
-    // D[row = (lane >> 4) + 4 r][col = lane & 15] is acc[r] (the f64 C/D map)
-    const int j = lane & 15;
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const int i = (lane >> 4) + 4 * r;
-      int k = -1;
-      if (i < 6 && j < 10) k = 13 + i * 10 + j;
-      else if (i < 9 && i >= 6 && (j == 3 || j == 6 || j == 8 || j == 9)) k = 1 + (i - 6) * 4 + (j == 3 ? 0 : (j == 6 ? 1 : (j == 8 ? 2 : 3)));
-      else if (i == 9 && j == 9) k = 0;
-      else if (i == 10 && j == 9) k = 73;
-      if (k >= 0) out[k] = acc[r];
-    }
-    if (lane < MOM_ROW - MOM_NSUM) out[MOM_NSUM + lane] = lane == 0 ? (double)walks : 0.0;
+    gram_accumulate(reinterpret_cast<double*>(lds_stack) + wave * (32 * GRAM_RS), av, sp.p, sp.matched, acc);
+    gram_store(acc, out, (double)walks);
+  }
+  // every job has one more row per `span` source points (k_walk's, below); a job swept by this kernel leaves them zero, so that the
+  // final sum adds the same rows in the same order whichever way the sweep was launched
+  if (a.span > 0) {
+    const int bps = a.span >> 8;
+    if (blk % bps == 0 && threadIdx.x < MOM_ROW)
+      partials[(size_t)job.slot * partials_stride + ((size_t)((d.n + 255) / 256) * 4 + blk / bps) * MOM_ROW + threadIdx.x] = 0.0;
   }
 }
 
-void launch_sweep_fused(const PairDesc* descs, SweepArgs& a, int max_n, double* partials_dev, int partials_stride, const OuterState* states,
-                        bool normals_only, hipStream_t s) {
-  size_t lds = stack_lds_bytes(a.max_depth, 256);
-  if (lds < 4 * 8 * 72 * sizeof(double)) lds = 4 * 8 * 72 * sizeof(double);
-  a.bpj = (max_n + 255) / 256;
-  if (normals_only) hipLaunchKernelGGL(k_sweep_fused<true>, dim3(xcd_grid(a.njobs, a.bpj)), dim3(256), lds, s, descs, a, partials_dev, partials_stride, states);
-  else hipLaunchKernelGGL(k_sweep_fused<false>, dim3(xcd_grid(a.njobs, a.bpj)), dim3(256), lds, s, descs, a, partials_dev, partials_stride, states);
+// ===== the same sweep in two launches (cost_mode 1, covariances from normals, guess = I) =======================================
+// What bounds k_sweep_fused once most certificates hold (SQ counters, profiles/): a wave that has nothing to search still carries
+// the traversal's costs -- 24 KB of LDS stack per workgroup (6 waves per SIMD), a workgroup barrier in front of the reduction (its
+// staging area aliases the stacks) -- and in the iterations where a few per cent of the queries still walk, nearly every wave
+// executes a whole tree descent for its one or two walkers (measured 3-13 of 64 lanes active).  So the work is split by WHAT A
+// POINT NEEDS:
+//   k_late  every source point, one round of loads (point, normal, certificate, neighbour record), certificate test; the points
+//           whose certificate holds are finished here -- Mahalanobis matrix, 74 moments, Gram reduction per wave with a
+//           wave-PRIVATE staging area: no traversal stack, no workgroup barrier, 8 waves per SIMD.  The others only leave one
+//           bit in the wave's 64-bit walker mask (written, not appended: deterministic).
+//   k_walk  one WAVE per `span` consecutive source points: queues the span's walkers and runs their exact searches with
+//           PERSISTENT LANES -- a lane whose search has ended takes the next walker from the queue (once `refill` lanes are idle),
+//           so the wave's lanes stay busy whatever the fraction of walkers and however unequal the walks; then refreshes
+//           neighbour, certificate and record and reduces the walkers' moments into one more row per span.  No walkers: zero
+//           row, exit.
+// k_moments_final adds both row sets in fixed order, so results stay bitwise reproducible and independent of batching.
+// Mahalanobis matrix (rank-one form, see sweep_point<true>) and moment operands of one matched pair of points; guess = I
+__device__ __forceinline__ void point_terms(const PairDesc& d, const float* __restrict__ T, const float4& p, const float4& nn, const float4& t,
+                                            const float4& tn, double (&av)[11]) {
+  double R[9];
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int cc = 0; cc < 3; cc++) R[r * 3 + cc] = (double)T[r * 4 + cc];
+  const double kap = 1.0 - d.gicp_eps;
+  double n1[3] = {(double)nn.x, (double)nn.y, (double)nn.z}, v[3] = {(double)tn.x, (double)tn.y, (double)tn.z};
+  double l1 = (n1[0] * n1[0] + n1[1] * n1[1]) + n1[2] * n1[2], l2 = (v[0] * v[0] + v[1] * v[1]) + v[2] * v[2];
+  double k1 = (l1 > 0.0 && l1 < 1.0e300) ? kap / l1 : 0.0;   // zero / non-finite normal => C = I (cov_from_normal)
+  double k2 = (l2 > 0.0 && l2 < 1.0e300) ? kap / l2 : 0.0;
+  double u[3];
+#pragma unroll
+  for (int r = 0; r < 3; r++) u[r] = (R[r * 3 + 0] * n1[0] + R[r * 3 + 1] * n1[1]) + R[r * 3 + 2] * n1[2];
+  double ku[3] = {k1 * u[0], k1 * u[1], k1 * u[2]}, kv[3] = {k2 * v[0], k2 * v[1], k2 * v[2]};
+  double A[6];
+  {
+    int q = 0;
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int cc = r; cc < 3; cc++) {
+        double rr = (R[r * 3 + 0] * R[cc * 3 + 0] + R[r * 3 + 1] * R[cc * 3 + 1]) + R[r * 3 + 2] * R[cc * 3 + 2];
+        if (r == cc) rr += 1.0;
+        A[q++] = (rr - ku[r] * u[cc]) - kv[r] * v[cc];
+      }
+  }
+  double c00 = A[3] * A[5] - A[4] * A[4], c01 = A[2] * A[4] - A[1] * A[5], c02 = A[1] * A[4] - A[2] * A[3];
+  double c11 = A[0] * A[5] - A[2] * A[2], c12 = A[1] * A[2] - A[0] * A[4], c22 = A[0] * A[3] - A[1] * A[1];
+  double det = (A[0] * c00 + A[1] * c01) + A[2] * c02;
+  double id = 1.0 / det;
+  const double M6[6] = {c00 * id, c01 * id, c02 * id, c11 * id, c12 * id, c22 * id};
+  // residual about T0 = T (double), M a, a^T M a
+  double pt[3] = {(double)p.x, (double)p.y, (double)p.z};
+  double a0 = ((((double)T[0] * pt[0] + (double)T[1] * pt[1]) + (double)T[2] * pt[2]) + (double)T[3]) - (double)t.x;
+  double a1 = ((((double)T[4] * pt[0] + (double)T[5] * pt[1]) + (double)T[6] * pt[2]) + (double)T[7]) - (double)t.y;
+  double a2 = ((((double)T[8] * pt[0] + (double)T[9] * pt[1]) + (double)T[10] * pt[2]) + (double)T[11]) - (double)t.z;
+  double Ma0 = (M6[0] * a0 + M6[1] * a1) + M6[2] * a2;
+  double Ma1 = (M6[1] * a0 + M6[3] * a1) + M6[4] * a2;
+  double Ma2 = (M6[2] * a0 + M6[4] * a1) + M6[5] * a2;
+#pragma unroll
+  for (int k = 0; k < 6; k++) av[k] = M6[k];
+  av[6] = Ma0; av[7] = Ma1; av[8] = Ma2;
+  av[9] = (a0 * Ma0 + a1 * Ma1) + a2 * Ma2;
+  av[10] = 1.0;
+}
+
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) k_late(const PairDesc* __restrict__ descs, SweepArgs a, double* __restrict__ partials,
+                                                                                   int partials_stride, const OuterState* __restrict__ states,
+                                                                                   unsigned long long* __restrict__ wmask, int mask_stride) {
+  extern __shared__ __attribute__((aligned(16))) double lds_gram[];  // [4 waves][32 rows][GRAM_RS]
+  int jb, blk;
+  if (!xcd_job_map(a.njobs, a.bpj, jb, blk)) return;
+  const SweepJob& job = a.job[jb];
+  const PairDesc d = descs[job.slot];
+  if (blk * 256 >= d.n) return;
+  float T[12];
+  if (!job_transform(job, states, T)) return;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int i = blk * 256 + tid;
+  bool walker = false, matched = false;
+  float4 p = make_float4(0.f, 0.f, 0.f, 0.f), nn = p, t = p, tn = p;
+  if (i < d.n) {
+    // ONE round of loads: the point, its normal, its neighbour's index, the certificate of the last search and the neighbour itself
+    p = gld(d.src + i);
+    const int w = gld(d.prev_nn + i);
+    const float4 cq = gld(d.cert + i);
+    nn = gld(d.src_nrm + i);
+    t = gld(d.rec + 2 * (size_t)i);
+    tn = gld(d.rec + 2 * (size_t)i + 1);
+    float qx, qy, qz;
+    xform_pt(T, p.x, p.y, p.z, qx, qy, qz);  // gicp.hpp:469
+    bool ok = false;
+    float bd = 0.f;
+    if (w >= 0) {  // the certificate test of sweep_point: the neighbour of the last search is provably still the nearest
+      bd = d2f(qx, qy, qz, t.x, t.y, t.z);
+      float e = sqrtf(d2f(qx, qy, qz, cq.x, cq.y, cq.z));
+      float dw = sqrtf(bd), lo = sqrtf(cq.w);
+      ok = dw * (1.0f + 1e-5f) + e * (1.0f + 1e-5f) + 1e-12f < lo * (1.0f - 1e-5f);
+    }
+    walker = !ok;
+    matched = ok && (double)bd < d.corr_dist2;  // gicp.hpp:483
+  }
+  const unsigned long long mask = __ballot(walker);
+  if (lane == 0) wmask[(size_t)job.slot * mask_stride + blk * 4 + wave] = mask;
+  double* out = partials + (size_t)job.slot * partials_stride + ((size_t)blk * 4 + wave) * MOM_ROW;
+  if (__ballot(matched) == 0ull) {  // nothing to add (every point of this wave walks: the first sweeps): a zero row, no math, no MFMA
+    out[lane] = 0.0;
+    if (lane < MOM_ROW - 64) out[64 + lane] = (lane == MOM_NSUM - 64) ? (double)__popcll(mask) : 0.0;
+    return;
+  }
+  double av[11];
+  if (matched) point_terms(d, T, p, nn, t, tn, av);  // gicp.hpp:488-498
+  else {
+#pragma unroll
+    for (int k = 0; k < 11; k++) av[k] = 0.0;
+  }
+  GramAcc acc;
+  gram_zero(acc);
+  gram_accumulate(lds_gram + wave * (32 * GRAM_RS), av, p, matched, acc);
+  gram_store(acc, out, (double)__popcll(mask));
+}
+
+constexpr int WALK_STACK = 8;        // traversal-stack entries a lane keeps in LDS (warm walks rarely go deeper; the rest spills to private memory)
+constexpr int WALK_SPAN_MAX = 1024;  // source points per k_walk wave, at most
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) k_walk(const PairDesc* __restrict__ descs, SweepArgs a, double* __restrict__ partials, int partials_stride,
+                                             const OuterState* __restrict__ states, const unsigned long long* __restrict__ wmask, int mask_stride) {
+  __shared__ __attribute__((aligned(16))) uint64_t lds_stack[WALK_STACK * 64];  // [entry][lane]; after the walks: the Gram staging rows (32 x 15 doubles)
+  __shared__ uint16_t queue[WALK_SPAN_MAX];
+  static_assert(WALK_STACK * 64 >= 32 * GRAM_RS, "the staging rows alias the stack");
+  int jb, blk;
+  if (!xcd_job_map(a.njobs, a.bpj, jb, blk)) return;
+  const SweepJob& job = a.job[jb];
+  const PairDesc d = descs[job.slot];
+  const int span = a.span;
+  if (blk * span >= d.n) return;
+  float T[12];
+  if (!job_transform(job, states, T)) return;
+  const int lane = threadIdx.x;
+  const int n_words = ((d.n + 255) / 256) * 4;
+  const int wps = span >> 6;   // mask words per span (<= 16)
+  unsigned long long m = 0ull;
+  if (lane < wps && blk * wps + lane < n_words) m = wmask[(size_t)job.slot * mask_stride + blk * wps + lane];
+  const int cnt = __popcll(m);
+  int pre = cnt;   // inclusive prefix over the first 16 lanes
+#pragma unroll
+  for (int off = 1; off < 16; off <<= 1) {
+    int v = __shfl_up(pre, off);
+    if (lane >= off) pre += v;
+  }
+  const int total = __builtin_amdgcn_readlane(pre, 15);   // (lanes >= wps hold empty masks)
+  pre -= cnt;
+  double* out = partials + (size_t)job.slot * partials_stride + ((size_t)n_words + blk) * MOM_ROW;
+  if (total == 0) {  // nobody here needs a search (every late iteration): zero row, so that the final sum needs no flags
+    out[lane] = 0.0;
+    if (lane < MOM_ROW - 64) out[64 + lane] = 0.0;
+    return;
+  }
+  for (int k = 0; k < wps; k++) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)m, k), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(m >> 32), k);
+    const unsigned long long mk = ((unsigned long long)hi << 32) | lo;
+    const int pk = __builtin_amdgcn_readlane(pre, k);
+    if ((mk >> lane) & 1ull) queue[pk + __popcll(mk & ((1ull << lane) - 1ull))] = (uint16_t)(k * 64 + lane);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  const int i0 = blk * span;
+  {
+    // ---- the walks: tree_search's loop (lh_device.hpp) as a state machine, so that a lane can start its next query while
+    // the others are in the middle of theirs.  Same visiting rule, same collector => same neighbours and certificates.
+    TreeView tv{d.tgt_sorted, d.tgt_nodes, d.tgt_hdr, d.m};
+    TreeHeader h;
+    h.root = gld(&tv.hdr->root);
+    h.org[0] = gld(&tv.hdr->org[0]); h.org[1] = gld(&tv.hdr->org[1]); h.org[2] = gld(&tv.hdr->org[2]);
+    h.inv = gld(&tv.hdr->inv); h.scl2 = gld(&tv.hdr->scl2);
+    const int32_t root = h.root;
+    const int32_t DONE = NO_CHILD;
+    WalkStack<WALK_STACK> stk(lds_stack + lane, 64);
+    Nn1CertCollector col{INFINITY, 0x7fffffff, INFINITY};
+    GridQuery gq{0u, 0u, 0u, 0.f};
+    float qx = 0.f, qy = 0.f, qz = 0.f;
+    int qi = -1;
+    int32_t ref = DONE;
+    int head = 0;
+    const int refill = a.refill;
+    for (;;) {
+      const bool idle = ref == DONE;
+      const unsigned long long im = __ballot(idle);
+      const int nidle = __popcll(im);
+      if (nidle == 64 || (head < total && nidle >= refill)) {
+        if (idle) {
+          if (qi >= 0) {  // the search that has just ended: its neighbour and certificate
+            const int i = i0 + qi;
+            gst(d.cert + i, make_float4(qx, qy, qz, col.lb));
+            gst(d.prev_nn + i, (col.bi == 0x7fffffff) ? -1 : col.bi);
+            qi = -1;
+          }
+          const int slot = head + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(im >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)im, 0u));
+          if (slot < total) {
+            qi = queue[slot];
+            const int i = i0 + qi;
+            const float4 p = gld(d.src + i);
+            const int w = gld(d.prev_nn + i);
+            xform_pt(T, p.x, p.y, p.z, qx, qy, qz);  // gicp.hpp:469
+            col = Nn1CertCollector{INFINITY, 0x7fffffff, INFINITY};
+            if (w >= 0) {  // warm start: the previous neighbour is a valid candidate => tight initial bound, still exact
+              const float4 t0 = gld(d.rec + 2 * (size_t)i);
+              col.bd = d2f(qx, qy, qz, t0.x, t0.y, t0.z);
+              col.bi = w;
+            }
+            gq = grid_query(h, qx, qy, qz);
+            stk.sp = 0;
+            ref = root;
+          }
+        }
+        head = min(total, head + nidle);
+        if (__ballot(ref != DONE) == 0ull) break;
+      }
+      while (ref >= 0 && ref != DONE) ref = node_visit(tv.nodes[ref], gq, h.scl2, col, stk);
+      if (ref < 0) {
+        scan_leaf(tv, ref, qx, qy, qz, col);
+        ref = stk.pop(col);
+      }
+    }
+  }
+  // ---- the walkers' moments: their new neighbours are in prev_nn (written by lanes of this wave: workgroup-scope visibility)
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  GramAcc acc;
+  gram_zero(acc);
+  for (int base = 0; base < total; base += 64) {
+    const int r = base + lane;
+    bool matched = false;
+    float4 p = make_float4(0.f, 0.f, 0.f, 0.f), nn = p, t = p, tn = p;
+    if (r < total) {
+      const int i = i0 + queue[r];
+      p = gld(d.src + i);
+      nn = gld(d.src_nrm + i);
+      const int j = gld(d.prev_nn + i);
+      if (j >= 0) {
+        t = gld(d.tgt_xyz + j);
+        tn = gld(d.tgt_nrm + j);
+        gst(d.rec + 2 * (size_t)i, t);   // the record follows prev_nn
+        gst(d.rec + 2 * (size_t)i + 1, tn);
+        float qx, qy, qz;
+        xform_pt(T, p.x, p.y, p.z, qx, qy, qz);
+        matched = (double)d2f(qx, qy, qz, t.x, t.y, t.z) < d.corr_dist2;  // gicp.hpp:483 (the same float the search ended with)
+      }
+    }
+    // the transform's doubles must be re-made from the scalar floats in every round: hoisted out of the loop they would cost 40
+    // vector registers (and the kernel three of its seven waves per SIMD)
+    float Tl[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) {
+      Tl[k] = T[k];
+      asm volatile("" : "+s"(Tl[k]));
+    }
+    double av[11];
+    if (matched) point_terms(d, Tl, p, nn, t, tn, av);
+    else {
+#pragma unroll
+      for (int k = 0; k < 11; k++) av[k] = 0.0;
+    }
+    gram_accumulate(reinterpret_cast<double*>(lds_stack), av, p, matched, acc);
+  }
+  gram_store(acc, out, 0.0);   // (the late rows carry the walker counts)
+}
+
+static void split_jobs(const SweepArgs& a, uint32_t split_mask, SweepArgs& f, SweepArgs& sp) {
+  f = a; sp = a;
+  f.njobs = 0; sp.njobs = 0;
+  for (int j = 0; j < a.njobs; j++) {
+    if ((split_mask >> j) & 1u) sp.job[sp.njobs++] = a.job[j];
+    else f.job[f.njobs++] = a.job[j];
+  }
+}
+int sweep_walk_span() {
+  static const int span = []() { const char* e = getenv("LH_WALK_SPAN"); int v = e ? atoi(e) : 512; v = (v / 256) * 256; return v < 256 ? 256 : (v > WALK_SPAN_MAX ? WALK_SPAN_MAX : v); }();
+  return span;
+}
+int sweep_split_from() {
+  static const int from = []() { const char* e = getenv("LH_SPLIT_FROM"); int v = e ? atoi(e) : 3; return v < 0 ? 0 : v; }();
+  return from;
+}
+
+void launch_sweep_fused(const PairDesc* descs, SweepArgs& a, uint32_t split_mask, int max_n, double* partials_dev, int partials_stride,
+                        const OuterState* states, bool normals_only, unsigned long long* wmask, int mask_stride, hipStream_t s) {
+  static const int refill = []() { const char* e = getenv("LH_WALK_REFILL"); int v = e ? atoi(e) : 16; return v < 1 ? 1 : (v > 64 ? 64 : v); }();
+  a.span = sweep_walk_span();
+  a.refill = refill;
+  SweepArgs f, sp;
+  split_jobs(a, wmask ? split_mask : 0u, f, sp);
+  if (f.njobs > 0) {
+    size_t lds = stack_lds_bytes(f.max_depth, 256);
+    if (lds < 4 * 8 * 72 * sizeof(double)) lds = 4 * 8 * 72 * sizeof(double);
+    f.bpj = (max_n + 255) / 256;
+    if (normals_only) hipLaunchKernelGGL(k_sweep_fused<true>, dim3(xcd_grid(f.njobs, f.bpj)), dim3(256), lds, s, descs, f, partials_dev, partials_stride, states);
+    else hipLaunchKernelGGL(k_sweep_fused<false>, dim3(xcd_grid(f.njobs, f.bpj)), dim3(256), lds, s, descs, f, partials_dev, partials_stride, states);
+  }
+  if (sp.njobs > 0) {
+    sp.bpj = (max_n + 255) / 256;
+    hipLaunchKernelGGL(k_late, dim3(xcd_grid(sp.njobs, sp.bpj)), dim3(256), sizeof(double) * 4 * 32 * GRAM_RS, s, descs, sp, partials_dev, partials_stride, states,
+                       wmask, mask_stride);
+    sp.bpj = (max_n + sp.span - 1) / sp.span;
+    hipLaunchKernelGGL(k_walk, dim3(xcd_grid(sp.njobs, sp.bpj)), dim3(64), 0, s, descs, sp, partials_dev, partials_stride, states, wmask, mask_stride);
+  }
 }
 void launch_sweep(const PairDesc* descs, SweepArgs& a, int max_n, hipStream_t s) {
   a.bpj = (max_n + 255) / 256;
@@ -862,13 +1217,14 @@ __global__ void __launch_bounds__(256) k_moments(const PairDesc* __restrict__ de
 // rows of a job = ceil(n / ppb) * rpb  (ppb points per workgroup of the producing kernel, rpb rows per workgroup)
 constexpr int FINAL_SUB = 4;
 __global__ void __launch_bounds__(FINAL_SUB * MOM_ROW) k_moments_final(const PairDesc* __restrict__ descs, CostArgs a, const double* __restrict__ partials,
-                                                                      int partials_stride, int ppb, int rpb, double* __restrict__ out,
+                                                                      int partials_stride, int ppb, int rpb, int extra_ppr, double* __restrict__ out,
                                                                       const OuterState* __restrict__ states) {
   const CostJob& job = a.job[blockIdx.y];
   if (states && states[job.slot].done) return;  // device-driven loop: the pair's sweep did not run either
   const int c = blockIdx.x;
   int n = descs[job.slot].n;
   int nb = ((n + ppb - 1) / ppb) * rpb;
+  if (extra_ppr > 0) nb += (n + extra_ppr - 1) / extra_ppr;   // the fused / split sweep's walk rows (one per extra_ppr source points)
   int v = threadIdx.x % MOM_ROW, sub = threadIdx.x / MOM_ROW;
   int per = (nb + FINAL_CHUNKS - 1) / FINAL_CHUNKS;
   int b0 = c * per, b1 = min(nb, b0 + per);
@@ -897,12 +1253,12 @@ __global__ void __launch_bounds__(FINAL_SUB * MOM_ROW) k_moments_final(const Pai
 void launch_moments(const PairDesc* descs, const CostArgs& a, int max_n, double* partials_dev, int partials_stride, double* out,
                     hipStream_t s) {
   hipLaunchKernelGGL(k_moments, dim3(mom_blocks(max_n), a.njobs), dim3(256), 0, s, descs, a, partials_dev, partials_stride);
-  hipLaunchKernelGGL(k_moments_final, dim3(FINAL_CHUNKS, a.njobs), dim3(FINAL_SUB * MOM_ROW), 0, s, descs, a, partials_dev, partials_stride, MOM_CHUNK, 1, out,
+  hipLaunchKernelGGL(k_moments_final, dim3(FINAL_CHUNKS, a.njobs), dim3(FINAL_SUB * MOM_ROW), 0, s, descs, a, partials_dev, partials_stride, MOM_CHUNK, 1, 0, out,
                      (const OuterState*)nullptr);
 }
 void launch_moments_final(const PairDesc* descs, const CostArgs& a, double* partials_dev, int partials_stride, double* out, const OuterState* states,
                           hipStream_t s) {
-  hipLaunchKernelGGL(k_moments_final, dim3(FINAL_CHUNKS, a.njobs), dim3(FINAL_SUB * MOM_ROW), 0, s, descs, a, partials_dev, partials_stride, 256, 4, out, states);
+  hipLaunchKernelGGL(k_moments_final, dim3(FINAL_CHUNKS, a.njobs), dim3(FINAL_SUB * MOM_ROW), 0, s, descs, a, partials_dev, partials_stride, 256, 4, sweep_walk_span(), out, states);
 }
 
 // ===== the solve of one outer iteration on the device (cost_mode 1) =========================================

@@ -177,6 +177,30 @@ static int run_case(int n, int nq, int k, unsigned seed, int dup) {
     Nn1Collector c2{bd[w], w};
     tree_search(tv, q.x, q.y, q.z, c2, stk.data(), 1);
     if (c2.bi != ord[0] || c2.bd != bd[ord[0]]) bad++;
+    {  // the step-wise form of the same traversal (WalkStack + node_visit: what k_walk's persistent lanes run) must leave the
+       // certificate collector in the same state as tree_search, warm (any valid candidate) or cold
+      for (int warm = 0; warm < 2; warm++) {
+        Nn1CertCollector ca{warm ? bd[w] : inf_f(), warm ? w : 0x7fffffff, inf_f()}, cb = ca;
+        tree_search(tv, q.x, q.y, q.z, ca, stk.data(), 1);
+        TreeHeader h = *tv.hdr;
+        GridQuery gq = grid_query(h, q.x, q.y, q.z);
+        std::vector<uint64_t> st2(4);
+        WalkStack<4> ws(st2.data(), 1);   // a short in-"LDS" part so that the spill path is exercised too
+        int32_t ref = h.root;
+        for (;;) {
+          while (ref >= 0 && ref != NO_CHILD) ref = node_visit(tv.nodes[ref], gq, h.scl2, cb, ws);
+          if (ref == NO_CHILD) break;
+          scan_leaf(tv, ref, q.x, q.y, q.z, cb);
+          ref = ws.pop(cb);
+        }
+        if (ca.bi != cb.bi || ca.bd != cb.bd || ca.bi != ord[0]) bad++;
+        // the certificate bound: tree_search's cold start makes a greedy descent first, which may examine (and so bound) other
+        // points than the plain loop; warm walks are the same sequence of visits => the same bound, bit for bit
+        if (warm && ca.lb != cb.lb) bad++;
+        if (n > 1 && !(cb.lb >= bd[ord[0]]) ) bad++;   // a valid lower bound on every other point is never below the winner's distance
+        if (n > 1 && cb.lb > bd[ord[1]]) bad++;        // ... and never above the true runner-up
+      }
+    }
     KnnCollector ck{kd.data(), ki.data(), kk, 1, 0};
     tree_search(tv, q.x, q.y, q.z, ck, stk.data(), 1);
     if (ck.cnt != kk) bad++;
