@@ -10,6 +10,7 @@
 #include <ucontext.h>
 
 #include <algorithm>
+#include <chrono>
 #include <atomic>
 #include <condition_variable>
 #include <functional>
@@ -566,6 +567,7 @@ static lh_status ctx_ensure_slots(lh_ctx* c, int n_slots, int max_n) {
   HIPCHK(hipMalloc(&c->descs_dev, sizeof(PairDesc) * n_slots));
   HIPCHK(hipMalloc(&c->mom_partials_dev, sizeof(double) * (size_t)mom_stride * n_slots));
   HIPCHK(hipMalloc(&c->wmask_dev, sizeof(unsigned long long) * (size_t)mask_stride * n_slots));
+  HIPCHK(hipMemset(c->wmask_dev, 0, sizeof(unsigned long long) * (size_t)mask_stride * n_slots));
   HIPCHK(hipMalloc(&c->states_dev, sizeof(OuterState) * n_slots));
   HIPCHK(hipMalloc(&c->chunks_dev, sizeof(double) * (size_t)FINAL_CHUNKS * MOM_ROW * n_slots));
   HIPCHK(hipHostMalloc(&c->states_host, sizeof(OuterState) * n_slots, hipHostMallocDefault));
@@ -877,7 +879,7 @@ static lh_status group_launch(lh_ctx* c, Group& g) {
         t->sweeps_done++;
       }
       launch_sweep_fused(c->descs_dev, a, split_mask, max_n, c->mom_partials_dev, c->mom_stride, nullptr, normals_only, c->wmask_dev, c->mask_stride, st);
-      launch_moments_final(c->descs_dev, ca, c->mom_partials_dev, c->mom_stride, c->partials_host, nullptr, st);
+      launch_moments_final(c->descs_dev, ca, c->mom_partials_dev, c->mom_stride, c->partials_host, nullptr, c->wmask_dev, c->mask_stride, st);
     } else {
       {
         ProfScope p(c, "nn_sweep", bytes, st);
@@ -958,6 +960,10 @@ static lh_status group_collect(lh_ctx* c, Group& g) {
       walks += part[ch * MOM_ROW + MOM_NSUM];
     }
     t->last_walks = (long)walks;
+    {  // LH_WALK_LOG=1: tree walks of every sweep of every pair (stderr; instrumentation)
+      static const bool wlog = []() { const char* e = getenv("LH_WALK_LOG"); return e && atoi(e) != 0; }();
+      if (wlog) fprintf(stderr, "[lh walks] slot %d sweep %d walks %ld\n", t->slot, t->sweeps_done - 1, t->last_walks);
+    }
     if (c->reduce_fn && c->reduce_fn(t->mom.S, MOM_NSUM, c->reduce_user) != 0) return LH_EDEVICE;
     for (int r = 0; r < 3; r++)
       for (int cc = 0; cc < 4; cc++) t->mom.T0[cc * 4 + r] = t->req_T12[r * 4 + cc];
@@ -1098,7 +1104,7 @@ static lh_status dev_enqueue(lh_ctx* c, DevGroup& g, int rounds) {
       {
         ProfScope p(c, "nn_sweep", bytes, st);
         launch_sweep_fused(c->descs_dev, a, split_mask, max_n, c->mom_partials_dev, c->mom_stride, c->states_dev, normals_only, c->wmask_dev, c->mask_stride, st);
-        launch_moments_final(c->descs_dev, ca, c->mom_partials_dev, c->mom_stride, c->chunks_dev, c->states_dev, st);
+        launch_moments_final(c->descs_dev, ca, c->mom_partials_dev, c->mom_stride, c->chunks_dev, c->states_dev, c->wmask_dev, c->mask_stride, st);
       }
       {
         ProfScope p(c, "bfgs_solve", 0.0, st);
@@ -1138,6 +1144,11 @@ static lh_status run_tasks_device(lh_ctx* c, std::vector<Task*>& tasks, int in_f
       groups[gi].slot_hi = s;
     }
   }
+  // LH_HOST_PROF=1: where the scheduling thread's time goes (stderr, per batch): waiting for the GPU vs feeding it
+  static const bool host_prof = []() { const char* e = getenv("LH_HOST_PROF"); return e && atoi(e) != 0; }();
+  double hp_wait = 0, hp_retire = 0, hp_admit = 0, hp_enq = 0;
+  auto hp_now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double hp_t0 = hp_now();
   size_t next = 0;
   lh_status err = LH_OK;
   auto fail = [&](lh_status st) {
@@ -1156,8 +1167,11 @@ static lh_status run_tasks_device(lh_ctx* c, std::vector<Task*>& tasks, int in_f
     for (int gi = 0; gi < G; gi++) {
       DevGroup& g = groups[gi];
       lh_status st;
+      double hp_a = hp_now();
       if (g.pending) {  // wait for THIS group's rounds; the other group's are still queued / running
         HIPCHK(hipEventSynchronize(g.ev));
+        hp_wait += hp_now() - hp_a;
+        hp_a = hp_now();
         g.pending = false;
         for (size_t i = 0; i < g.active.size();) {
           Task* t = g.active[i];
@@ -1171,7 +1185,9 @@ static lh_status run_tasks_device(lh_ctx* c, std::vector<Task*>& tasks, int in_f
             i++;
         }
         dev_write_aligned(c, g);
+        hp_retire += hp_now() - hp_a;
       }
+      hp_a = hp_now();
       if (next < tasks.size() && !g.free_slots.empty()) {  // admit: the NN indexes of all newly admitted targets are built together
         std::vector<lh_cloud*> to_build;
         size_t nn = next;
@@ -1218,6 +1234,8 @@ static lh_status run_tasks_device(lh_ctx* c, std::vector<Task*>& tasks, int in_f
           g.active.push_back(t);
         }
       }
+      hp_admit += hp_now() - hp_a;
+      hp_a = hp_now();
       if (!g.active.empty()) {
         // how many iterations before the host looks again: no pair needs more than what is left of its max_iterations
         int need = 0;
@@ -1225,8 +1243,12 @@ static lh_status run_tasks_device(lh_ctx* c, std::vector<Task*>& tasks, int in_f
         st = dev_enqueue(c, g, std::max(1, std::min(rounds_cfg, need)));
         if (st) return fail(st);
       }
+      hp_enq += hp_now() - hp_a;
     }
   }
+  if (host_prof)
+    fprintf(stderr, "[lh host] %zu pairs, %d groups: total %.3f ms = wait %.3f + retire %.3f + admit %.3f + enqueue %.3f\n", tasks.size(), G,
+            1e3 * (hp_now() - hp_t0), 1e3 * hp_wait, 1e3 * hp_retire, 1e3 * hp_admit, 1e3 * hp_enq);
   return err;
 }
 

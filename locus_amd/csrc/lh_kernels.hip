@@ -375,7 +375,7 @@ struct SweepPoint {
 // order of operations (normalise, two 3x3x3 products) in the last bits of M, which is why only cost_mode 1 -- a bit-different
 // evaluation of the cost anyway -- uses it; k_sweep (cost_mode 0, the debug entry points) keeps the reference order.
 template <bool kRank1 = false>
-__device__ __forceinline__ void sweep_point(const PairDesc& d, const float* __restrict__ T, int i, uint64_t* stack, SweepPoint& o) {
+__device__ __forceinline__ void sweep_point(const PairDesc& d, const float* __restrict__ T, int i, uint64_t* stack, SweepPoint& o, float cm) {
   // first round of loads: everything whose address only depends on i goes out together (the certificate and, in the fused
   // kernel, the source normal as well: each was its own dependent memory round behind the candidate before, and the late
   // sweeps are bound by exactly that chain -- a workgroup lives for two memory latencies instead of three)
@@ -412,7 +412,7 @@ __device__ __forceinline__ void sweep_point(const PairDesc& d, const float* __re
     // (float arithmetic: sqrtf is correctly rounded to ~1e-7 relative, two orders below the 1e-5 margins)
     float e = sqrtf(d2f(qx, qy, qz, cq.x, cq.y, cq.z));
     float dw = sqrtf(col.bd), lo = sqrtf(cq.w);
-    if (dw * (1.0f + 1e-5f) + e * (1.0f + 1e-5f) + 1e-12f < lo * (1.0f - 1e-5f)) need_search = false;
+    if (dw * (1.0f + cm) + e * (1.0f + cm) + 1e-12f < lo * (1.0f - cm)) need_search = false;
   }
   o.searched = need_search;
   if (need_search) {
@@ -516,7 +516,7 @@ __global__ void __launch_bounds__(256) k_sweep(const PairDesc* __restrict__ desc
   int i = blk * 256 + threadIdx.x;
   if (i >= d.n) return;
   SweepPoint sp;
-  sweep_point(d, job.T, i, lds_stack + threadIdx.x, sp);
+  sweep_point(d, job.T, i, lds_stack + threadIdx.x, sp, a.cert_rel);
   float4 c = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
   if (sp.matched) {
     d.maha6[(size_t)0 * d.n_pad + i] = sp.M[0];
@@ -717,7 +717,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) k
   SweepPoint sp;
   sp.matched = false;
   sp.searched = false;
-  if (i < d.n) sweep_point<kNormals>(d, T, i, lds_stack + threadIdx.x, sp);
+  if (i < d.n) sweep_point<kNormals>(d, T, i, lds_stack + threadIdx.x, sp, a.cert_rel);
   double M6[6] = {0, 0, 0, 0, 0, 0}, Ma[3] = {0, 0, 0}, pt[4] = {0, 0, 0, 0}, pp[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, aMa = 0.0;
   if (sp.matched) moments_of_point(T, sp, M6, Ma, aMa, pt, pp);
   const double live = sp.matched ? 1.0 : 0.0;
@@ -750,14 +750,24 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) k
 // POINT NEEDS:
 //   k_late  every source point, one round of loads (point, normal, certificate, neighbour record), certificate test; the points
 //           whose certificate holds are finished here -- Mahalanobis matrix, 74 moments, Gram reduction per wave with a
-//           wave-PRIVATE staging area: no traversal stack, no workgroup barrier, 8 waves per SIMD.  The others only leave one
+//           wave-PRIVATE staging area: no traversal stack, no workgroup barrier, 7 waves per SIMD.  The others only leave one
 //           bit in the wave's 64-bit walker mask (written, not appended: deterministic).
-//   k_walk  one WAVE per `span` consecutive source points: queues the span's walkers and runs their exact searches with
-//           PERSISTENT LANES -- a lane whose search has ended takes the next walker from the queue (once `refill` lanes are idle),
-//           so the wave's lanes stay busy whatever the fraction of walkers and however unequal the walks; then refreshes
-//           neighbour, certificate and record and reduces the walkers' moments into one more row per span.  No walkers: zero
-//           row, exit.
+//   k_walk  one WAVE per `span` consecutive source points (four independent waves per workgroup): looks at the span's masks
+//           first and ends if nobody walks (most spans of most iterations); otherwise queues the walkers and runs their exact
+//           searches with PERSISTENT LANES -- a lane whose search has ended takes the next walker from the queue (once `refill`
+//           lanes are idle), so the wave's lanes stay busy whatever the fraction of walkers and however unequal the walks;
+//           then refreshes neighbour, certificate and record and reduces the walkers' moments into one more row per span.
 // k_moments_final adds both row sets in fixed order, so results stay bitwise reproducible and independent of batching.
+// Measured (32 x 100 k points, MI355X): iterations with 25 / 7 / 2 % walkers 300 / 203 / 145 us against 310 / 255 / 170 fused; in
+// the iterations where (nearly) everything walks the fused kernel is faster (its walks overlap the other waves' streaming), so
+// the first LH_SPLIT_FROM (3) sweeps of a pair stay fused.  Certificate-only iterations: 62 + 24 + 10 us (k_late, k_walk, final
+// sum) against 80 + 10 in isolation -- k_walk's 24 us are the latency of ONE search plus its moments (two dozen dependent memory
+// round trips of a lone wave: a pair of 100 k points nearly always has one or two points whose two nearest neighbours tie to
+// within the certificate's safety margin; a k_walk whose waves all end after the mask test takes 2 us); with several scheduler
+// groups in flight that latency overlaps other streams' kernels and the step gets 3-6 % faster, one pair alone pays it
+// (1.2 -> 1.5 ms for 20 iterations).  Tried and dropped: the walks inside k_late by the last wave of a span to finish (a device-wide counter
+// needs agent-scope release/acquire = L2 write-back: 1.4 ms per launch; a workgroup-wide one keeps the workgroup's LDS and
+// registers while one wave walks: walking iterations 40 % slower).
 // Mahalanobis matrix (rank-one form, see sweep_point<true>) and moment operands of one matched pair of points; guess = I
 __device__ __forceinline__ void point_terms(const PairDesc& d, const float* __restrict__ T, const float4& p, const float4& nn, const float4& t,
                                             const float4& tn, double (&av)[11]) {
@@ -838,13 +848,20 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))
       bd = d2f(qx, qy, qz, t.x, t.y, t.z);
       float e = sqrtf(d2f(qx, qy, qz, cq.x, cq.y, cq.z));
       float dw = sqrtf(bd), lo = sqrtf(cq.w);
-      ok = dw * (1.0f + 1e-5f) + e * (1.0f + 1e-5f) + 1e-12f < lo * (1.0f - 1e-5f);
+      ok = dw * (1.0f + a.cert_rel) + e * (1.0f + a.cert_rel) + 1e-12f < lo * (1.0f - a.cert_rel);
     }
     walker = !ok;
     matched = ok && (double)bd < d.corr_dist2;  // gicp.hpp:483
   }
   const unsigned long long mask = __ballot(walker);
-  if (lane == 0) wmask[(size_t)job.slot * mask_stride + blk * 4 + wave] = mask;
+  if (lane == 0) {
+    wmask[(size_t)job.slot * mask_stride + blk * 4 + wave] = mask;
+  }
+  {  // the span's walk row starts as zeros (k_walk overwrites it if the span has walkers)
+    const int bps = a.span >> 8;
+    if (blk % bps == 0 && tid < MOM_ROW)
+      partials[(size_t)job.slot * partials_stride + ((size_t)((d.n + 255) / 256) * 4 + blk / bps) * MOM_ROW + tid] = 0.0;
+  }
   double* out = partials + (size_t)job.slot * partials_stride + ((size_t)blk * 4 + wave) * MOM_ROW;
   if (__ballot(matched) == 0ull) {  // nothing to add (every point of this wave walks: the first sweeps): a zero row, no math, no MFMA
     out[lane] = 0.0;
@@ -864,40 +881,45 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))
 }
 
 constexpr int WALK_STACK = 8;        // traversal-stack entries a lane keeps in LDS (warm walks rarely go deeper; the rest spills to private memory)
-constexpr int WALK_SPAN_MAX = 1024;  // source points per k_walk wave, at most
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) k_walk(const PairDesc* __restrict__ descs, SweepArgs a, double* __restrict__ partials, int partials_stride,
+constexpr int WALK_SPAN_MAX = 512;   // source points per k_walk wave, at most
+// Four INDEPENDENT waves per workgroup, each with its own span (no barrier anywhere): one-wave workgroups cost 25 us per launch in
+// workgroup dispatch alone (6 000 of them, each with its LDS allocation), whether or not anybody walks.
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) k_walk(const PairDesc* __restrict__ descs, SweepArgs a, double* __restrict__ partials, int partials_stride,
                                              const OuterState* __restrict__ states, const unsigned long long* __restrict__ wmask, int mask_stride) {
-  __shared__ __attribute__((aligned(16))) uint64_t lds_stack[WALK_STACK * 64];  // [entry][lane]; after the walks: the Gram staging rows (32 x 15 doubles)
-  __shared__ uint16_t queue[WALK_SPAN_MAX];
+  __shared__ __attribute__((aligned(16))) uint64_t lds_stack_all[4][WALK_STACK * 64];  // per wave [entry][lane]; after the walks: the Gram staging rows (32 x 15 doubles)
+  __shared__ uint16_t queue_all[4][WALK_SPAN_MAX];
   static_assert(WALK_STACK * 64 >= 32 * GRAM_RS, "the staging rows alias the stack");
-  int jb, blk;
-  if (!xcd_job_map(a.njobs, a.bpj, jb, blk)) return;
+  int jb, blk4;
+  if (!xcd_job_map(a.njobs, a.bpj, jb, blk4)) return;
   const SweepJob& job = a.job[jb];
-  const PairDesc d = descs[job.slot];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int span = a.span;
+  const int blk = blk4 * 4 + wv;   // this wave's span
+  const int wps = span >> 6;       // mask words per span (<= 8)
+  // The masks FIRST, straight from the launch arguments (slot, stride): most spans of most iterations have no walker, and their
+  // waves must not pay the chain descriptor -> state -> transform before they find out (24 us per launch when they did).
+  unsigned long long m = 0ull;
+  if (lane < wps && blk * wps + lane < mask_stride) m = wmask[(size_t)job.slot * mask_stride + blk * wps + lane];
+  if (__ballot(m != 0ull) == 0ull) return;  // nobody in this span needs a search: k_late left a zero row
+  uint64_t* const lds_stack = lds_stack_all[wv];
+  uint16_t* const queue = queue_all[wv];
+  const PairDesc d = descs[job.slot];
   if (blk * span >= d.n) return;
   float T[12];
   if (!job_transform(job, states, T)) return;
-  const int lane = threadIdx.x;
   const int n_words = ((d.n + 255) / 256) * 4;
-  const int wps = span >> 6;   // mask words per span (<= 16)
-  unsigned long long m = 0ull;
-  if (lane < wps && blk * wps + lane < n_words) m = wmask[(size_t)job.slot * mask_stride + blk * wps + lane];
+  if (blk * wps + lane >= n_words) m = 0ull;   // (words past this pair's last workgroup may be a former, larger pair's)
   const int cnt = __popcll(m);
-  int pre = cnt;   // inclusive prefix over the first 16 lanes
+  int pre = cnt;   // inclusive prefix over the first 8 lanes
 #pragma unroll
-  for (int off = 1; off < 16; off <<= 1) {
+  for (int off = 1; off < 8; off <<= 1) {
     int v = __shfl_up(pre, off);
     if (lane >= off) pre += v;
   }
-  const int total = __builtin_amdgcn_readlane(pre, 15);   // (lanes >= wps hold empty masks)
+  const int total = __builtin_amdgcn_readlane(pre, 7);   // (lanes >= wps hold empty masks)
   pre -= cnt;
+  if (total == 0) return;
   double* out = partials + (size_t)job.slot * partials_stride + ((size_t)n_words + blk) * MOM_ROW;
-  if (total == 0) {  // nobody here needs a search (every late iteration): zero row, so that the final sum needs no flags
-    out[lane] = 0.0;
-    if (lane < MOM_ROW - 64) out[64 + lane] = 0.0;
-    return;
-  }
   for (int k = 0; k < wps; k++) {
     const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)m, k), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(m >> 32), k);
     const unsigned long long mk = ((unsigned long long)hi << 32) | lo;
@@ -1008,6 +1030,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) k_
   gram_store(acc, out, 0.0);   // (the late rows carry the walker counts)
 }
 
+// relative safety margin of the certificate test (sweep_point, k_late): the float evaluations of the three distances in it are
+// each within 3e-7 relative of the true values, so 1e-5 leaves a factor of 30
+static float cert_margin() {
+  static const float m = []() { const char* e = getenv("LH_CERT_REL"); float v = e ? (float)atof(e) : 1e-5f; return (v >= 1e-6f && v <= 1e-3f) ? v : 1e-5f; }();
+  return m;
+}
 static void split_jobs(const SweepArgs& a, uint32_t split_mask, SweepArgs& f, SweepArgs& sp) {
   f = a; sp = a;
   f.njobs = 0; sp.njobs = 0;
@@ -1017,7 +1045,7 @@ static void split_jobs(const SweepArgs& a, uint32_t split_mask, SweepArgs& f, Sw
   }
 }
 int sweep_walk_span() {
-  static const int span = []() { const char* e = getenv("LH_WALK_SPAN"); int v = e ? atoi(e) : 512; v = (v / 256) * 256; return v < 256 ? 256 : (v > WALK_SPAN_MAX ? WALK_SPAN_MAX : v); }();
+  static const int span = []() { const char* e = getenv("LH_WALK_SPAN"); int v = e ? atoi(e) : 512; v = v >= 512 ? 512 : 256; return v; }();
   return span;
 }
 int sweep_split_from() {
@@ -1029,6 +1057,8 @@ void launch_sweep_fused(const PairDesc* descs, SweepArgs& a, uint32_t split_mask
                         const OuterState* states, bool normals_only, unsigned long long* wmask, int mask_stride, hipStream_t s) {
   static const int refill = []() { const char* e = getenv("LH_WALK_REFILL"); int v = e ? atoi(e) : 16; return v < 1 ? 1 : (v > 64 ? 64 : v); }();
   a.span = sweep_walk_span();
+  a.cert_rel = cert_margin();
+  a.pad2 = 0;
   a.refill = refill;
   SweepArgs f, sp;
   split_jobs(a, wmask ? split_mask : 0u, f, sp);
@@ -1043,11 +1073,12 @@ void launch_sweep_fused(const PairDesc* descs, SweepArgs& a, uint32_t split_mask
     sp.bpj = (max_n + 255) / 256;
     hipLaunchKernelGGL(k_late, dim3(xcd_grid(sp.njobs, sp.bpj)), dim3(256), sizeof(double) * 4 * 32 * GRAM_RS, s, descs, sp, partials_dev, partials_stride, states,
                        wmask, mask_stride);
-    sp.bpj = (max_n + sp.span - 1) / sp.span;
-    hipLaunchKernelGGL(k_walk, dim3(xcd_grid(sp.njobs, sp.bpj)), dim3(64), 0, s, descs, sp, partials_dev, partials_stride, states, wmask, mask_stride);
+    sp.bpj = ((max_n + sp.span - 1) / sp.span + 3) / 4;
+    hipLaunchKernelGGL(k_walk, dim3(xcd_grid(sp.njobs, sp.bpj)), dim3(256), 0, s, descs, sp, partials_dev, partials_stride, states, wmask, mask_stride);
   }
 }
 void launch_sweep(const PairDesc* descs, SweepArgs& a, int max_n, hipStream_t s) {
+  a.cert_rel = cert_margin();
   a.bpj = (max_n + 255) / 256;
   hipLaunchKernelGGL(k_sweep, dim3(xcd_grid(a.njobs, a.bpj)), dim3(256), stack_lds_bytes(a.max_depth, 256), s, descs, a);
 }
@@ -1218,7 +1249,7 @@ __global__ void __launch_bounds__(256) k_moments(const PairDesc* __restrict__ de
 constexpr int FINAL_SUB = 4;
 __global__ void __launch_bounds__(FINAL_SUB * MOM_ROW) k_moments_final(const PairDesc* __restrict__ descs, CostArgs a, const double* __restrict__ partials,
                                                                       int partials_stride, int ppb, int rpb, int extra_ppr, double* __restrict__ out,
-                                                                      const OuterState* __restrict__ states) {
+                                                                      const OuterState* __restrict__ states, unsigned long long* __restrict__ wmask, int mask_stride) {
   const CostJob& job = a.job[blockIdx.y];
   if (states && states[job.slot].done) return;  // device-driven loop: the pair's sweep did not run either
   const int c = blockIdx.x;
@@ -1254,11 +1285,12 @@ void launch_moments(const PairDesc* descs, const CostArgs& a, int max_n, double*
                     hipStream_t s) {
   hipLaunchKernelGGL(k_moments, dim3(mom_blocks(max_n), a.njobs), dim3(256), 0, s, descs, a, partials_dev, partials_stride);
   hipLaunchKernelGGL(k_moments_final, dim3(FINAL_CHUNKS, a.njobs), dim3(FINAL_SUB * MOM_ROW), 0, s, descs, a, partials_dev, partials_stride, MOM_CHUNK, 1, 0, out,
-                     (const OuterState*)nullptr);
+                     (const OuterState*)nullptr, (unsigned long long*)nullptr, 0);
 }
 void launch_moments_final(const PairDesc* descs, const CostArgs& a, double* partials_dev, int partials_stride, double* out, const OuterState* states,
-                          hipStream_t s) {
-  hipLaunchKernelGGL(k_moments_final, dim3(FINAL_CHUNKS, a.njobs), dim3(FINAL_SUB * MOM_ROW), 0, s, descs, a, partials_dev, partials_stride, 256, 4, sweep_walk_span(), out, states);
+                          unsigned long long* wmask, int mask_stride, hipStream_t s) {
+  hipLaunchKernelGGL(k_moments_final, dim3(FINAL_CHUNKS, a.njobs), dim3(FINAL_SUB * MOM_ROW), 0, s, descs, a, partials_dev, partials_stride, 256, 4, sweep_walk_span(), out, states,
+                     wmask, mask_stride);
 }
 
 // ===== the solve of one outer iteration on the device (cost_mode 1) =========================================

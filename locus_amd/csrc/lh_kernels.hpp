@@ -58,6 +58,8 @@ struct SweepArgs {
   int pad;
   int span;        // source points per walk row / per k_walk wave (set by launch_sweep_fused)
   int refill;      // k_walk: idle lanes that trigger a refill from the walker queue
+  float cert_rel;  // relative safety margin of the certificate test (set by the launch functions)
+  int pad2;
   SweepJob job[MAX_JOBS];
 };
 
@@ -132,14 +134,14 @@ void launch_sweep(const PairDesc* descs, SweepArgs& a, int max_n, hipStream_t s)
 // states == nullptr: host-driven loop (the jobs' transforms come with the launch); otherwise the pairs' device states (k_solve's)
 // normals_only: no job of the launch uses k-NN covariances (recompute_*_cov) -> the rank-one Mahalanobis form
 // split_mask: bit j set = job j is swept by the two-launch form (k_late + k_walk; needs covariances from normals, guess = I and
-// wmask: one 64-bit walker mask per wave of 64 source points, mask_stride words per slot); the others by the fused kernel
+// wmask: one 64-bit walker mask per wave of 64 source points, mask_stride words per slot, zero-initialised); the others by the fused kernel
 void launch_sweep_fused(const PairDesc* descs, SweepArgs& a, uint32_t split_mask, int max_n, double* partials_dev, int partials_stride,
                         const OuterState* states, bool normals_only, unsigned long long* wmask, int mask_stride, hipStream_t s);
 int sweep_walk_span();    // source points per walk row (LH_WALK_SPAN, default 512)
 int sweep_split_from();   // first outer iteration (0-based) swept in two launches (LH_SPLIT_FROM)
 inline int sweep_rows(int n) { return ((n + 255) / 256) * 4 + (n + sweep_walk_span() - 1) / sweep_walk_span(); }   // partial rows of one job
 void launch_moments_final(const PairDesc* descs, const CostArgs& a, double* partials_dev, int partials_stride, double* out, const OuterState* states,
-                          hipStream_t s);
+                          unsigned long long* wmask, int mask_stride, hipStream_t s);
 // the BFGS solve + convergence test of one outer iteration, on the device (cost_mode 1): reads the FINAL_CHUNKS x MOM_ROW chunk
 // sums k_moments_final left at chunks[slot * chunk_stride], updates states[slot]
 void launch_solve(const PairDesc* descs, const SolveArgs& a, const double* chunks, int chunk_stride, OuterState* states, hipStream_t s);

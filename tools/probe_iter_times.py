@@ -24,7 +24,8 @@ def morton_order(pts, bits=10):
     return np.argsort(key, kind="stable")
 
 
-for p in range(32):
+NP = int(os.environ.get("LH_PROBE_PAIRS", "32"))
+for p in range(NP):
     src, tgt, _ = synth.scan_pair(n_rings=64, n_az=1563, scale=2.0, noise=0.02, seed=10 + 2 * p)
     if os.environ.get("LH_PROBE_SORT") == "1":
         src = src[morton_order(src)]
@@ -33,11 +34,11 @@ for p in range(32):
     cs, ct = capi.Cloud(ctx, src), capi.Cloud(ctx, tgt)
     cs.normals_knn(20); ct.normals_knn(20); ct.drop_index()
     S.append(cs); T.append(ct)
-capi.align_batch(ctx, P, S, T, max_in_flight=32)   # warm-up
+capi.align_batch(ctx, P, S, T, max_in_flight=NP)   # warm-up
 for t in T:
     t.drop_index()
 ctx.profile(True); ctx.profile_reset()
-capi.align_batch(ctx, P, S, T, max_in_flight=32)
+capi.align_batch(ctx, P, S, T, max_in_flight=NP)
 st = ctx.profile_get()
 ctx.profile(False)
 rows = [l.split() for l in open(log)]
