@@ -209,6 +209,12 @@ lh_status lh_cov_knn(lh_cloud* c, int k, double gicp_epsilon, double* cov9_out);
    tgt_idx[n] (-1 unmatched), maha9 [n][9] row-major (entries of unmatched points are unspecified).
    Consecutive calls without changing the clouds are warm (previous neighbours + certificates), like align()'s sweeps. */
 lh_status lh_gicp_debug_sweep(lh_gicp* g, const float T[16], const float guess[16], int32_t* tgt_idx, double* maha9);
+/* one sweep of the cost_mode 1 kernels (the fused sweep for the first sweeps of a pair, k_late + k_walk afterwards: sweep_index
+   selects exactly as align() would) with explicit transformation_; guess = identity, covariances from the clouds' normals.
+   tgt_idx[n] = neighbour of every source point (-1 none) -- the state the certificates and second-chance tests maintain, so a
+   test can hold it against a brute-force search after every sweep; *walks = queries that ran the tree traversal; sums74 = the 74
+   moment sums of the sweep (nullable).  sweep_index 0 starts cold (seed pass); later calls are warm like align()'s sweeps. */
+lh_status lh_gicp_debug_sweep_fused(lh_gicp* g, const float T[16], int sweep_index, int32_t* tgt_idx, uint64_t* walks, double* sums74);
 /* instrumentation: out[0] = source points whose sweep ran the tree traversal, out[1] = source points swept (cumulative) */
 lh_status lh_gicp_debug_stats(lh_gicp* g, uint64_t out[2], int reset);
 /* instrumentation of the tree traversal (1-NN of T*q; cand = optional warm-start candidate per query, leaf_prescan = look at

@@ -106,7 +106,7 @@ EXPORTS = [
     "lh_cloud_download", "lh_cloud_transform", "lh_cloud_slice", "lh_cloud_concat", "lh_gicp_create", "lh_gicp_destroy", "lh_gicp_set_params",
     "lh_gicp_set_source", "lh_gicp_set_target", "lh_gicp_set_source_cloud", "lh_gicp_set_target_cloud",
     "lh_gicp_promote_source_to_target", "lh_gicp_align", "lh_gicp_fitness", "lh_set_allreduce", "lh_nn1", "lh_nn1_cloud", "lh_knn_cloud",
-    "lh_gicp_align_batch", "lh_gicp_align_batch_out", "lh_device_count", "lh_gicp_align_batch_multi", "lh_gicp_align_batch_multi_views", "lh_cov_knn", "lh_gicp_debug_sweep", "lh_gicp_debug_stats", "lh_debug_traversal_stats", "lh_gicp_debug_cost", "lh_p2plane_information",
+    "lh_gicp_align_batch", "lh_gicp_align_batch_out", "lh_device_count", "lh_gicp_align_batch_multi", "lh_gicp_align_batch_multi_views", "lh_cov_knn", "lh_gicp_debug_sweep", "lh_gicp_debug_sweep_fused", "lh_gicp_debug_stats", "lh_debug_traversal_stats", "lh_gicp_debug_cost", "lh_p2plane_information",
     "lh_icp_covariance", "lh_voxel_grid", "lh_cloud_voxel_grid", "lh_cloud_voxel_grid_pointf", "lh_cloud_nearest_neighbors", "lh_cloud_crop_box", "lh_default_ndt_params", "lh_ndt_create", "lh_ndt_destroy", "lh_ndt_set_params",
     "lh_ndt_set_source", "lh_ndt_set_target", "lh_ndt_set_source_cloud", "lh_ndt_set_target_cloud", "lh_ndt_align", "lh_ndt_debug_cells",
     "lh_ndt_debug_derivatives", "lh_map_create", "lh_map_destroy", "lh_map_insert", "lh_map_refresh", "lh_map_cloud", "lh_map_size", "lh_normals_knn", "lh_normals_knn_cloud",
@@ -169,6 +169,7 @@ def lib():
                                                       C.POINTER(GicpResult), i32]
         L.lh_cov_knn.argtypes = [vp, i32, dbl, vp]
         L.lh_gicp_debug_sweep.argtypes = [vp, vp, vp, vp, vp]
+        L.lh_gicp_debug_sweep_fused.argtypes = [vp, vp, C.c_int, vp, vp, vp]
         L.lh_gicp_debug_stats.argtypes = [vp, vp, i32]
         L.lh_debug_traversal_stats.argtypes = [vp, vp, vp, vp, i32, vp]
         L.lh_gicp_debug_cost.argtypes = [vp, vp, C.POINTER(dbl), vp, vp, C.POINTER(i32)]
@@ -711,6 +712,15 @@ class Gicp:
         maha = np.zeros((n_src, 3, 3), np.float64)
         _check(lib().lh_gicp_debug_sweep(self.h, _ptr(T), _ptr(g), _ptr(idx), _ptr(maha)), "lh_gicp_debug_sweep")
         return idx, maha
+
+    def debug_sweep_fused(self, T16, n_src, sweep_index):
+        """one sweep of the cost_mode 1 kernels (fused / k_late + k_walk by sweep_index): neighbour indices, tree walks, 74 sums"""
+        T = np.ascontiguousarray(T16, np.float32).reshape(16)
+        idx = np.empty(n_src, np.int32)
+        walks = np.zeros(1, np.uint64)
+        sums = np.zeros(74, np.float64)
+        _check(lib().lh_gicp_debug_sweep_fused(self.h, _ptr(T), int(sweep_index), _ptr(idx), _ptr(walks), _ptr(sums)), "lh_gicp_debug_sweep_fused")
+        return idx, int(walks[0]), sums
 
     def debug_stats(self, reset=True):
         out = np.zeros(2, np.uint64)

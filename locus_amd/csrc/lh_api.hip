@@ -2036,6 +2036,53 @@ lh_status lh_gicp_debug_sweep(lh_gicp* g, const float T[16], const float guess[1
   return LH_OK;
 }
 
+lh_status lh_gicp_debug_sweep_fused(lh_gicp* g, const float T[16], int sweep_index, int32_t* tgt_idx, uint64_t* walks, double* sums74) {
+  if (!g || !g->src || !g->tgt || !T || sweep_index < 0) return LH_EINVAL;
+  if (!g->src->nrm || !g->tgt->nrm) return LH_EINVAL;   // the cost_mode 1 kernels of the production configuration: covariances from normals
+  lh_ctx* c = g->ctx;
+  HIPCHK(hipSetDevice(c->device));
+  lh_status st = ctx_ensure_slots(c, 1, g->src->n);
+  if (st) return st;
+  Task& t = g->task;
+  t.P = g->P; t.P.cost_mode = 1; t.P.recompute_source_cov = 0; t.P.recompute_target_cov = 0;
+  t.src = g->src; t.tgt = g->tgt; t.ws = &g->ws; t.trace = nullptr; t.slot = 0;
+  memcpy(t.guess, I16, sizeof(I16));
+  t.count_stats = false;
+  t.stream = nullptr;
+  if (sweep_index == 0 || !g->dbg_prepared) {  // cold: descriptor, index, and the seed pass below
+    st = task_prepare(c, &t, !g->tgt->has_index);
+    if (st) return st;
+    g->dbg_prepared = true;
+  }
+  SweepArgs a;
+  a.njobs = 1; a.bpj = 0; a.max_depth = 0; a.pad = 0; a.job[0].slot = 0; a.job[0].pad = 0;
+  Task::T16_to_T12(T, a.job[0].T);
+  if (sweep_index == 0) {
+    SweepArgs sa = a;
+    launch_seed(c->descs_dev, sa, g->src->n, c->stream);
+  }
+  CostArgs ca;
+  ca.njobs = 1; ca.pad = 0; ca.job[0].slot = 0; ca.job[0].out_offset = 0;
+  memcpy(ca.job[0].T, a.job[0].T, sizeof(a.job[0].T));
+  launch_sweep_fused(c->descs_dev, a, sweep_is_split(&t, sweep_index) ? 1u : 0u, g->src->n, c->mom_partials_dev, c->mom_stride, nullptr, true, c->wmask_dev,
+                     c->mask_stride, c->stream);
+  launch_moments_final(c->descs_dev, ca, c->mom_partials_dev, c->mom_stride, c->partials_host, nullptr, c->wmask_dev, c->mask_stride, c->stream);
+  HIPCHK(hipGetLastError());
+  if (tgt_idx) HIPCHK(hipMemcpyAsync(tgt_idx, g->ws.prev_nn, sizeof(int32_t) * (size_t)g->src->n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  double w = 0.0;
+  for (int ch = 0; ch < FINAL_CHUNKS; ch++) w += c->partials_host[ch * MOM_ROW + MOM_NSUM];
+  if (walks) *walks = (uint64_t)w;
+  if (sums74)
+    for (int k = 0; k < MOM_NSUM; k++) {
+      double v = 0.0;
+      for (int ch = 0; ch < FINAL_CHUNKS; ch++) v += c->partials_host[ch * MOM_ROW + k];
+      sums74[k] = v;
+    }
+  g->dbg_ready = false;   // (the correspondence buffers of lh_gicp_debug_sweep were not written)
+  return LH_OK;
+}
+
 lh_status lh_gicp_debug_stats(lh_gicp* g, uint64_t out[2], int reset) {
   if (!g || !out) return LH_EINVAL;
   out[0] = out[1] = 0;

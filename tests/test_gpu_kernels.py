@@ -168,6 +168,46 @@ def test_warm_sweeps_with_certificates_stay_bit_exact(ctx, capi, oracle):
     assert fracs[0] == 1.0 and fracs[8] < 0.01  # a repeated transform needs (almost) no traversal
 
 
+def test_mode1_sweeps_keep_exact_neighbours(ctx, capi, oracle):
+    # the cost_mode 1 kernels keep their neighbour state across sweeps with certificates and, from the fourth sweep on, the
+    # two-launch form (k_late + k_walk with persistent lanes).  Whatever path a point takes, after EVERY sweep its neighbour must
+    # be the exhaustive search's (lowest index among equals), and the matched count must be the gate's.
+    src, tgt, delta = synth.scan_pair(n_rings=32, n_az=700, scale=2.0, noise=0.02, seed=29)
+    ttree = oracle.Tree(oracle.xyz4(tgt))
+    nt = oracle.normals_knn(oracle.xyz4(tgt), 20, threads=4, tree=ttree)
+    ns = oracle.normals_knn(oracle.xyz4(src), 20, threads=4)
+    g = capi.Gicp(ctx, capi.default_params(corr_dist=1.0))
+    g.set_source(capi.make_pointf(src, ns))
+    g.set_target(capi.make_pointf(tgt, nt))
+    x_true = np.array([delta[0, 3], delta[1, 3], delta[2, 3], 0.0, 0.0, np.arctan2(delta[1, 0], delta[0, 0])])
+    # a GICP-like sequence: identity, a big first step, converging iterates down to float noise, repeats, a jump back, converging again
+    scales = [0.0, 0.9, 0.97, 0.99, 0.997, 0.999, 0.9997, 0.9999, 0.99997, 0.99999, 1.0, 1.0, 1.0 + 1e-6, 0.5, 0.98, 0.995, 0.999, 0.9999, 1.0, 1.0]
+    walks_log = []
+    for k, sc in enumerate(scales):
+        T16 = oracle.apply_state(x_true * sc)
+        idx, walks, sums = g.debug_sweep_fused(T16, src.shape[0], k)
+        q = oracle.transform(oracle.xyz4(src), T16)
+        io, do = ttree.nn1(q, threads=4)
+        assert (idx == io).all(), (k, sc, int((idx != io).sum()))
+        assert sums[73] == float((do.astype(np.float64) < 1.0).sum()), (k, sums[73])
+        walks_log.append(walks)
+    print("tree walks per sweep:", walks_log)
+    n = src.shape[0]
+    assert walks_log[0] == n                      # cold
+    assert walks_log[11] <= 30 and walks_log[19] <= 30  # a repeated transform: only the near-ties (within the test's safety margin) walk
+    # and again from a cold start with every sweep in the two-launch form from the start of the warm phase (sweep_index >= 3 only
+    # selects the kernels): same neighbours
+    g2 = capi.Gicp(ctx, capi.default_params(corr_dist=1.0))
+    g2.set_source(capi.make_pointf(src, ns))
+    g2.set_target(capi.make_pointf(tgt, nt))
+    for k, sc in enumerate([0.0, 0.9, 0.99, 0.999, 1.0]):
+        T16 = oracle.apply_state(x_true * sc)
+        idx, walks, _ = g2.debug_sweep_fused(T16, src.shape[0], 0 if k == 0 else 3 + k)
+        q = oracle.transform(oracle.xyz4(src), T16)
+        io, _ = ttree.nn1(q, threads=4)
+        assert (idx == io).all(), ("two-launch", k, int((idx != io).sum()))
+
+
 def test_sweep_queries_outside_the_target_box_stay_bit_exact(ctx, capi, oracle):
     # node boxes are 16-bit fixed point on the target's own grid; a query outside that grid is clamped onto it and carries
     # its overshoot as a separate term.  Shift the source a little, a lot and absurdly far out of the target's bounding box:
