@@ -447,6 +447,7 @@ static lh_status build_indices(lh_ctx* x, lh_cloud* const* clouds, int n_clouds,
       ts.a2box = reinterpret_cast<float4*>(p); p += 32 * (cap / 1024 + 16);
       ts.ichild = reinterpret_cast<int32_t*>(p); p += 8 * cap;
       ts.irange = reinterpret_cast<int32_t*>(p); p += 8 * cap;
+      ts.iparent = reinterpret_cast<int32_t*>(p); p += 4 * cap;
       ts.flag = reinterpret_cast<uint32_t*>(p); p += 4 * cap;
       ts.lid = reinterpret_cast<uint32_t*>(p); p += 4 * cap;
       ts.lstart = reinterpret_cast<uint32_t*>(p); p += 4 * cap;

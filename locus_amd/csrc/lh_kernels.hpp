@@ -108,9 +108,10 @@ struct TreeScratch {
   float4* a2box;          // boxes of 1024 consecutive leaves
   int32_t* ichild;        // binary children of internal node i [2]: >= 0 internal, < 0 leaf ~index
   int32_t* irange;        // covered leaf range [2]
+  int32_t* iparent;       // binary parent of internal node i (undefined for a root)
   int total;
 };
-constexpr size_t TREE_SCRATCH_BYTES_PER_POINT = 4 + 4 + 8 + 4 + 32 + 2 + 8 + 8;  // flag lid lkey lstart lbox a1+a2 ichild irange
+constexpr size_t TREE_SCRATCH_BYTES_PER_POINT = 4 + 4 + 8 + 4 + 32 + 2 + 8 + 8 + 4;  // flag lid lkey lstart lbox a1+a2 ichild irange iparent
 constexpr int MAX_INDEX_BATCH = 64;
 // the build's own sort (lh_radix.hip): segmented 3 x 10-bit LSD radix sort of the 30-bit keys, every cloud inside its segment
 int segsort_tiles(int n);
