@@ -479,6 +479,7 @@ __device__ __forceinline__ void sweep_point(const PairDesc& d, const float* __re
                            (double)T[r * 4 + 2] * d.guess3[2 * 3 + cc]) + (double)T[r * 4 + 3] * 0.0;
     }
     if constexpr (kRank1) {  // (the launch guarantees that neither cloud of any job carries k-NN covariances)
+#pragma clang fp contract(fast)   // see point_terms
       const double kap = 1.0 - d.gicp_eps;
       double n1[3] = {(double)nn.x, (double)nn.y, (double)nn.z}, v[3] = {(double)tn.x, (double)tn.y, (double)tn.z};
       double l1 = (n1[0] * n1[0] + n1[1] * n1[1]) + n1[2] * n1[2], l2 = (v[0] * v[0] + v[1] * v[1]) + v[2] * v[2];
@@ -570,6 +571,7 @@ __device__ __forceinline__ double mom_value(int k, const double* M6, const doubl
 }
 // the moment contributions of one matched point, added to acc[0..73] (acc must be zero-initialised by the caller)
 __device__ __forceinline__ void moments_of_point(const float* __restrict__ T, const SweepPoint& sp, double* M6, double* Ma, double& aMa, double* pt, double* pp) {
+#pragma clang fp contract(fast)   // see point_terms (cost_mode 1 only)
   pt[0] = (double)sp.p.x; pt[1] = (double)sp.p.y; pt[2] = (double)sp.p.z; pt[3] = 1.0;
   double T0[12];
 #pragma unroll
@@ -799,6 +801,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) k
 // Mahalanobis matrix (rank-one form, see sweep_point<true>) and moment operands of one matched pair of points; guess = I
 __device__ __forceinline__ void point_terms(const PairDesc& d, const float* __restrict__ T, const float4& p, const float4& nn, const float4& t,
                                             const float4& tn, double (&av)[11]) {
+  // (the translation unit is compiled without FMA contraction because the float NN distances must round like the oracle's; this
+  // double-precision evaluation exists only here, in cost_mode 1, whose parity bar is the reference's own FMA / non-FMA floor:
+  // fused multiply-adds are a quarter fewer vector instructions in a kernel that sits at 70 % of its VALU bound)
+#pragma clang fp contract(fast)
   double R[9];
 #pragma unroll
   for (int r = 0; r < 3; r++)
