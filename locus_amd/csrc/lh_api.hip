@@ -547,7 +547,7 @@ void Workspace::release() {
 
 static lh_status ctx_ensure_slots(lh_ctx* c, int n_slots, int max_n) {
   size_t per_slot = std::max<size_t>((size_t)cost_blocks(max_n) * COST_NSUM, (size_t)FINAL_CHUNKS * MOM_ROW);
-  int mom_stride = sweep_rows(max_n) * MOM_ROW;  // one partial row per wave of every 256-point workgroup of the fused sweep + the walk rows
+  int mom_stride = sweep_rows(max_n) * MOM_ROW;  // one partial row per 256-point workgroup of the sweep + the walk rows
   int mask_stride = ((max_n + 255) / 256) * 4;
   if (n_slots <= c->n_slots && per_slot <= c->partials_per_slot && mom_stride <= c->mom_stride) return LH_OK;
   (void)hipStreamSynchronize(c->stream);

@@ -728,6 +728,15 @@ __device__ __forceinline__ void gram_store(const GramAcc& g, double* out, double
   if (lane < MOM_ROW - MOM_NSUM) out[MOM_NSUM + lane] = lane == 0 ? walks : 0.0;
 }
 
+// One row per WORKGROUP: every wave leaves its 76-double row in its own (now free) staging region, and after a barrier -- at the very
+// end, the waves have nothing left to do -- 76 threads add the four in a fixed tree.  A row per wave was 9.5 bytes of stores per
+// source point and made the final sum read 34 MB per 32-pair launch (10 us of every iteration).
+__device__ __forceinline__ void wg_row_sum(const double* lds_rows, int wave_stride, double* __restrict__ out) {
+  __syncthreads();
+  const int t = threadIdx.x;
+  if (t < MOM_ROW) out[t] = (lds_rows[t] + lds_rows[wave_stride + t]) + (lds_rows[2 * wave_stride + t] + lds_rows[3 * wave_stride + t]);
+}
+
 // one point per thread (78 VGPRs, 6 waves per SIMD).  A variant with 4 points per thread and the 74 moments accumulated in
 // registers (239 VGPRs, 2 waves per SIMD) pays the reduction once per 4 points but was slower even on certificate-only
 // sweeps (142 vs 128 us): with so few waves the dependent src -> neighbour gathers are no longer hidden.
@@ -752,7 +761,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) k
   if (sp.matched) moments_of_point(T, sp, M6, Ma, aMa, pt, pp);
   const double live = sp.matched ? 1.0 : 0.0;
   const int walks = __popcll(__ballot(sp.searched));
-  double* out = partials + (size_t)job.slot * partials_stride + ((size_t)blk * 4 + (threadIdx.x >> 6)) * MOM_ROW;
+  double* out = partials + (size_t)job.slot * partials_stride + (size_t)blk * MOM_ROW;   // one row per workgroup
   {
     // the 74 moments of the wave on the matrix pipe (gram_accumulate above); the staging rows alias the traversal stacks
     const int wave = threadIdx.x >> 6;
@@ -760,15 +769,17 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) k
     GramAcc acc;
     gram_zero(acc);
     __syncthreads();  // every lane of the workgroup is done with its traversal stack
-    gram_accumulate(reinterpret_cast<double*>(lds_stack) + wave * (32 * GRAM_RS), av, sp.p, sp.matched, acc);
-    gram_store(acc, out, (double)walks);
+    double* wl = reinterpret_cast<double*>(lds_stack) + wave * (32 * GRAM_RS);
+    gram_accumulate(wl, av, sp.p, sp.matched, acc);
+    gram_store(acc, wl, (double)walks);
+    wg_row_sum(reinterpret_cast<double*>(lds_stack), 32 * GRAM_RS, out);
   }
   // every job has one more row per `span` source points (k_walk's, below); a job swept by this kernel leaves them zero, so that the
   // final sum adds the same rows in the same order whichever way the sweep was launched
   if (a.span > 0) {
     const int bps = a.span >> 8;
     if (blk % bps == 0 && threadIdx.x < MOM_ROW)
-      partials[(size_t)job.slot * partials_stride + ((size_t)((d.n + 255) / 256) * 4 + blk / bps) * MOM_ROW + threadIdx.x] = 0.0;
+      partials[(size_t)job.slot * partials_stride + ((size_t)((d.n + 255) / 256) + blk / bps) * MOM_ROW + threadIdx.x] = 0.0;
   }
 }
 
@@ -894,24 +905,26 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))
   {  // the span's walk row starts as zeros (k_walk overwrites it if the span has walkers)
     const int bps = a.span >> 8;
     if (blk % bps == 0 && tid < MOM_ROW)
-      partials[(size_t)job.slot * partials_stride + ((size_t)((d.n + 255) / 256) * 4 + blk / bps) * MOM_ROW + tid] = 0.0;
+      partials[(size_t)job.slot * partials_stride + ((size_t)((d.n + 255) / 256) + blk / bps) * MOM_ROW + tid] = 0.0;
   }
-  double* out = partials + (size_t)job.slot * partials_stride + ((size_t)blk * 4 + wave) * MOM_ROW;
+  double* out = partials + (size_t)job.slot * partials_stride + (size_t)blk * MOM_ROW;   // one row per workgroup
+  double* myrow = lds_gram + wave * (32 * GRAM_RS);
   if (__ballot(matched) == 0ull) {  // nothing to add (every point of this wave walks: the first sweeps): a zero row, no math, no MFMA
-    out[lane] = 0.0;
-    if (lane < MOM_ROW - 64) out[64 + lane] = (lane == MOM_NSUM - 64) ? (double)__popcll(mask) : 0.0;
-    return;
-  }
-  double av[11];
-  if (matched) point_terms(d, T, p, nn, t, tn, av);  // gicp.hpp:488-498
-  else {
+    myrow[lane] = 0.0;
+    if (lane < MOM_ROW - 64) myrow[64 + lane] = (lane == MOM_NSUM - 64) ? (double)__popcll(mask) : 0.0;
+  } else {
+    double av[11];
+    if (matched) point_terms(d, T, p, nn, t, tn, av);  // gicp.hpp:488-498
+    else {
 #pragma unroll
-    for (int k = 0; k < 11; k++) av[k] = 0.0;
+      for (int k = 0; k < 11; k++) av[k] = 0.0;
+    }
+    GramAcc acc;
+    gram_zero(acc);
+    gram_accumulate(myrow, av, p, matched, acc);
+    gram_store(acc, myrow, (double)__popcll(mask));
   }
-  GramAcc acc;
-  gram_zero(acc);
-  gram_accumulate(lds_gram + wave * (32 * GRAM_RS), av, p, matched, acc);
-  gram_store(acc, out, (double)__popcll(mask));
+  wg_row_sum(lds_gram, 32 * GRAM_RS, out);
 }
 
 constexpr int WALK_STACK = 8;        // traversal-stack entries a lane keeps in LDS (warm walks rarely go deeper; the rest spills to private memory)
@@ -953,7 +966,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) k
   const int total = __builtin_amdgcn_readlane(pre, 7);   // (lanes >= wps hold empty masks)
   pre -= cnt;
   if (total == 0) return;
-  double* out = partials + (size_t)job.slot * partials_stride + ((size_t)n_words + blk) * MOM_ROW;
+  double* out = partials + (size_t)job.slot * partials_stride + ((size_t)(n_words >> 2) + blk) * MOM_ROW;   // behind the pair's workgroup rows
   for (int k = 0; k < wps; k++) {
     const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)m, k), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(m >> 32), k);
     const unsigned long long mk = ((unsigned long long)hi << 32) | lo;
@@ -1323,7 +1336,7 @@ void launch_moments(const PairDesc* descs, const CostArgs& a, int max_n, double*
 }
 void launch_moments_final(const PairDesc* descs, const CostArgs& a, double* partials_dev, int partials_stride, double* out, const OuterState* states,
                           unsigned long long* wmask, int mask_stride, hipStream_t s) {
-  hipLaunchKernelGGL(k_moments_final, dim3(FINAL_CHUNKS, a.njobs), dim3(FINAL_SUB * MOM_ROW), 0, s, descs, a, partials_dev, partials_stride, 256, 4, sweep_walk_span(), out, states,
+  hipLaunchKernelGGL(k_moments_final, dim3(FINAL_CHUNKS, a.njobs), dim3(FINAL_SUB * MOM_ROW), 0, s, descs, a, partials_dev, partials_stride, 256, 1, sweep_walk_span(), out, states,
                      wmask, mask_stride);
 }
 

@@ -140,7 +140,7 @@ void launch_sweep_fused(const PairDesc* descs, SweepArgs& a, uint32_t split_mask
                         const OuterState* states, bool normals_only, unsigned long long* wmask, int mask_stride, hipStream_t s);
 int sweep_walk_span();    // source points per walk row (LH_WALK_SPAN, default 512)
 int sweep_split_from();   // first outer iteration (0-based) swept in two launches (LH_SPLIT_FROM)
-inline int sweep_rows(int n) { return ((n + 255) / 256) * 4 + (n + sweep_walk_span() - 1) / sweep_walk_span(); }   // partial rows of one job
+inline int sweep_rows(int n) { return (n + 255) / 256 + (n + sweep_walk_span() - 1) / sweep_walk_span(); }   // partial rows of one job: one per 256-point workgroup + the walk rows
 void launch_moments_final(const PairDesc* descs, const CostArgs& a, double* partials_dev, int partials_stride, double* out, const OuterState* states,
                           unsigned long long* wmask, int mask_stride, hipStream_t s);
 // the BFGS solve + convergence test of one outer iteration, on the device (cost_mode 1): reads the FINAL_CHUNKS x MOM_ROW chunk
