@@ -725,7 +725,7 @@ struct Task {
 };
 
 // prepare device state of one pair in its slot: index, covariances, output cloud, descriptor
-static lh_status task_prepare(lh_ctx* c, Task* t, bool rebuild_index) {
+static lh_status task_prepare(lh_ctx* c, Task* t, bool rebuild_index, bool upload_desc = true) {
   lh_cloud *src = t->src, *tgt = t->tgt;
   if (!src || !tgt || src->n <= 0 || tgt->n <= 0) return LH_EINVAL;
   const lh_gicp_params& P = t->P;
@@ -784,7 +784,7 @@ static lh_status task_prepare(lh_ctx* c, Task* t, bool rebuild_index) {
   d.rotation_epsilon = P.rotation_epsilon;
   d.transformation_epsilon = P.transformation_epsilon;
   d.trace = t->trace_dev;
-  HIPCHK(hipMemcpyAsync(&c->descs_dev[t->slot], &d, sizeof(PairDesc), hipMemcpyHostToDevice, ts));
+  if (upload_desc) HIPCHK(hipMemcpyAsync(&c->descs_dev[t->slot], &d, sizeof(PairDesc), hipMemcpyHostToDevice, ts));   // (the device-driven scheduler uploads a group's descriptors in one copy)
   HIPCHK(hipGetLastError());
   return LH_OK;
 }
@@ -1201,6 +1201,7 @@ static lh_status run_tasks_device(lh_ctx* c, std::vector<Task*>& tasks, int in_f
           st = build_indices(c, to_build.data(), (int)to_build.size(), g.stream);
           if (st) return fail(st);
         }
+        std::vector<int> admitted;
         while (next < tasks.size() && !g.free_slots.empty()) {
           Task* t = tasks[next++];
           t->slot = g.free_slots.back();
@@ -1214,11 +1215,10 @@ static lh_status run_tasks_device(lh_ctx* c, std::vector<Task*>& tasks, int in_f
             else if (hipMemsetAsync(t->trace_dev, 0, sizeof(int), g.stream) != hipSuccess) st = LH_EDEVICE;  // n_iters = 0
             t->trace->n_iters = 0;
           }
-          if (!st) st = task_prepare(c, t, false);
-          if (!st) {  // the pair's loop state: transformation_ = I, nothing done yet (pcl::Registration::align)
-            OuterState* init = &c->states_init[t->slot];
-            outer_state_init(init);
-            if (hipMemcpyAsync(&c->states_dev[t->slot], init, sizeof(OuterState), hipMemcpyHostToDevice, g.stream) != hipSuccess) st = LH_EDEVICE;
+          if (!st) st = task_prepare(c, t, false, false);
+          if (!st) {  // the pair's loop state: transformation_ = I, nothing done yet (pcl::Registration::align); uploaded below with the others
+            outer_state_init(&c->states_init[t->slot]);
+            admitted.push_back(t->slot);
           }
           if (st) {
             if (t->trace_dev) { (void)lhFree(t->trace_dev); t->trace_dev = nullptr; }
@@ -1233,6 +1233,22 @@ static lh_status run_tasks_device(lh_ctx* c, std::vector<Task*>& tasks, int in_f
           t->first_sweep = true;
           t->enq_iters = 0;
           g.active.push_back(t);
+        }
+        if (!admitted.empty()) {
+          // ONE copy for the group's descriptors (the host copies of the slots that keep running are unchanged) and one per run of
+          // admitted slots for the loop states: a copy is a small kernel on the group's stream, and three per pair were 840 per step
+          if (hipMemcpyAsync(&c->descs_dev[g.slot_lo], &c->descs_host[g.slot_lo], sizeof(PairDesc) * (size_t)(g.slot_hi - g.slot_lo), hipMemcpyHostToDevice,
+                             g.stream) != hipSuccess)
+            return fail(LH_EDEVICE);
+          std::sort(admitted.begin(), admitted.end());
+          for (size_t a0 = 0; a0 < admitted.size();) {
+            size_t a1 = a0 + 1;
+            while (a1 < admitted.size() && admitted[a1] == admitted[a1 - 1] + 1) a1++;
+            if (hipMemcpyAsync(&c->states_dev[admitted[a0]], &c->states_init[admitted[a0]], sizeof(OuterState) * (a1 - a0), hipMemcpyHostToDevice, g.stream) !=
+                hipSuccess)
+              return fail(LH_EDEVICE);
+            a0 = a1;
+          }
         }
       }
       hp_admit += hp_now() - hp_a;

@@ -1,0 +1,24 @@
+# lane utilisation of the walking kernels: SQ_THREAD_CYCLES_VALU / SQ_INSTS_VALU per dispatch (the average number of
+# active lanes of a vector instruction) for the fused sweep and for k_walk, plus VALU busy.  Program: tools/probe_iter_times.py.
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+mkdir -p $R/gpurun_out/pmc
+rm -rf /tmp/pmcl
+timeout 250 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES SQ_WAVE_CYCLES -d /tmp/pmcl -o run --output-format csv -- python $R/tools/probe_iter_times.py > /tmp/pmcl.log 2>&1
+f=$(find /tmp/pmcl -name "*counter_collection.csv" | head -1)
+python - "$f" <<'PY' | tee $R/gpurun_out/pmc/lanes.txt
+import csv, sys, collections
+rows = collections.defaultdict(lambda: collections.defaultdict(float)); tag = {}
+for r in csv.DictReader(open(sys.argv[1])):
+    for p in ("k_sweep_fused", "k_late", "k_walk", "k_seed"):
+        if p in r["Kernel_Name"]:
+            rows[int(r["Dispatch_Id"])][r["Counter_Name"]] += float(r["Counter_Value"]); tag[int(r["Dispatch_Id"])] = p
+per = collections.defaultdict(list)
+for k in sorted(rows):
+    per[tag[k]].append(rows[k])
+for p, v in per.items():
+    v = v[len(v) // 2:]      # the profiled alignment (second half of the program's launches)
+    print(p, "dispatches (profiled alignment):", len(v))
+    print("   active lanes per VALU instruction:", " ".join("%.1f" % (d["SQ_THREAD_CYCLES_VALU"] / max(d["SQ_INSTS_VALU"], 1.0)) for d in v))
+    print("   VALU instructions per wave       :", " ".join("%.0f" % (d["SQ_INSTS_VALU"] / max(d["SQ_WAVES"], 1.0)) for d in v))
+PY

@@ -15,38 +15,61 @@ done
 python - <<'PY'
 import csv, json, os, collections
 R = os.environ["GRAFT_REPO_ROOT"]
-def load(path, pat):
+def load(path, pats):
+    """per dispatch (in launch order) of the kernels matching any pattern: (kernel tag, counters)"""
     rows = collections.defaultdict(lambda: collections.defaultdict(float))
+    tag = {}
     for r in csv.DictReader(open(path)):
-        if pat in r["Kernel_Name"]:
-            rows[int(r["Dispatch_Id"])][r["Counter_Name"]] += float(r["Counter_Value"])
-    return [rows[k] for k in sorted(rows)]
+        for p in pats:
+            if p in r["Kernel_Name"]:
+                rows[int(r["Dispatch_Id"])][r["Counter_Name"]] += float(r["Counter_Value"])
+                tag[int(r["Dispatch_Id"])] = p
+    return [(tag[k], rows[k]) for k in sorted(rows)]
+def rbytes(d):
+    other = d["TCC_EA0_RDREQ_sum"] - d["TCC_EA0_RDREQ_32B_sum"] - d["TCC_EA0_RDREQ_64B_sum"] - d["TCC_EA0_RDREQ_128B_sum"]
+    return 128 * d["TCC_EA0_RDREQ_128B_sum"] + 64 * d["TCC_EA0_RDREQ_64B_sum"] + 32 * d["TCC_EA0_RDREQ_32B_sum"] + 64 * max(other, 0.0)
+def wbytes(d):
+    return 64 * d["TCC_EA0_WRREQ_64B_sum"] + 32 * (d["TCC_EA0_WRREQ_sum"] - d["TCC_EA0_WRREQ_64B_sum"])
 out = {}
-for pat, name in (("k_sweep_fused", "nn_sweep"), ("k_seed", "nn_seed"), ("k_moments_final", "moments_final")):
-    rd, wr = load(R + "/gpurun_out/pmc/traffic_pass1.csv", pat), load(R + "/gpurun_out/pmc/traffic_pass2.csv", pat)
-    def rbytes(d):
-        other = d["TCC_EA0_RDREQ_sum"] - d["TCC_EA0_RDREQ_32B_sum"] - d["TCC_EA0_RDREQ_64B_sum"] - d["TCC_EA0_RDREQ_128B_sum"]
-        return 128 * d["TCC_EA0_RDREQ_128B_sum"] + 64 * d["TCC_EA0_RDREQ_64B_sum"] + 32 * d["TCC_EA0_RDREQ_32B_sum"] + 64 * max(other, 0.0)
-    def wbytes(d):
-        return 64 * d["TCC_EA0_WRREQ_64B_sum"] + 32 * (d["TCC_EA0_WRREQ_sum"] - d["TCC_EA0_WRREQ_64B_sum"])
+# ---- the sweep ("nn_sweep" in bench.py's profile): k_sweep_fused for the first sweeps of a pair, k_late + k_walk afterwards.
+# The profiled alignment is the LAST of the program: its 20 sweeps = the last F fused launches + the last L (k_late, k_walk) pairs.
+SW = ("k_sweep_fused", "k_late", "k_walk")
+rd, wr = load(R + "/gpurun_out/pmc/traffic_pass1.csv", SW), load(R + "/gpurun_out/pmc/traffic_pass2.csv", SW)
+if rd and wr and len(rd) == len(wr):
+    # walk the launches backwards until 20 sweeps are collected (a sweep = one k_sweep_fused launch, or one k_late launch with the k_walk behind it)
+    seq = [(t, rbytes(a), wbytes(b), b["TCC_HIT_sum"], b["TCC_MISS_sum"]) for (t, a), (_, b) in zip(rd, wr)]
+    prof = collections.defaultdict(list)
+    sweeps = 0
+    for t, r, w, h, m in reversed(seq):
+        if sweeps == 20 and t != "k_walk":
+            break
+        prof[t].insert(0, (r, w, h, m))
+        if t in ("k_sweep_fused", "k_late"):
+            sweeps += 1
+        if sweeps == 20 and t in ("k_sweep_fused", "k_late"):
+            break
+    F, L = len(prof["k_sweep_fused"]), len(prof["k_late"])
+    prof["k_walk"] = prof["k_walk"][-L:] if L else []
+    tot = sum(r + w for v in prof.values() for r, w, _, _ in v)
+    late = [(prof["k_late"][i][0] + prof["k_late"][i][1]) + (prof["k_walk"][i][0] + prof["k_walk"][i][1]) for i in range(max(0, L - 10), L)] if L else []
+    hit = sum(h for v in prof.values() for _, _, h, _ in v); miss = sum(m for v in prof.values() for _, _, _, m in v)
+    out["nn_sweep"] = {"jobs_per_launch": 32, "sweeps_profiled_alignment": sweeps, "fused_launches": F, "late_walk_launch_pairs": L,
+                       "hbm_bytes_per_launch": tot / max(sweeps, 1),
+                       "fused_bytes_per_launch": [round(r + w) for r, w, _, _ in prof.get("k_sweep_fused", [])],
+                       "k_late_bytes_per_launch": [round(r + w) for r, w, _, _ in prof.get("k_late", [])],
+                       "k_walk_bytes_per_launch": [round(r + w) for r, w, _, _ in prof.get("k_walk", [])],
+                       "late_sweep_bytes": (sum(late) / len(late)) if late else None,
+                       "l2_hit_rate_profiled_alignment": hit / max(hit + miss, 1.0)}
+for pat, name in (("k_seed", "nn_seed"), ("k_moments_final", "moments_final")):
+    rd, wr = load(R + "/gpurun_out/pmc/traffic_pass1.csv", (pat,)), load(R + "/gpurun_out/pmc/traffic_pass2.csv", (pat,))
     n = min(len(rd), len(wr))
     if n == 0:
         continue
-    per = [rbytes(rd[k]) + wbytes(wr[k]) for k in range(n)]
-    prof = per[-20:] if name == "nn_sweep" else per[-1:]      # the profiled alignment's launches (32 jobs each)
-    ent = {"dispatches": n, "jobs_per_launch": 32, "hbm_bytes_per_launch": sum(prof) / len(prof),
-           "per_launch_bytes_profiled_alignment": [round(v) for v in prof]}
-    if name == "nn_sweep":
-        late = per[-10:]
-        ent["late_sweep_bytes"] = sum(late) / len(late)
-        ent["late_read_bytes"] = sum(rbytes(d) for d in rd[-10:]) / 10
-        ent["late_write_bytes"] = sum(wbytes(d) for d in wr[-10:]) / 10
-        hit = sum(d["TCC_HIT_sum"] for d in wr[-20:]); miss = sum(d["TCC_MISS_sum"] for d in wr[-20:])
-        ent["l2_hit_rate_profiled_alignment"] = hit / max(hit + miss, 1.0)
-    out[name] = ent
-out["_method"] = ("rocprofv3 --kernel-trace --output-format csv --pmc <set> (two separate passes, no sys/hip traces) on tools/probe_iter_times.py; bytes = "
+    per = [rbytes(rd[k][1]) + wbytes(wr[k][1]) for k in range(n)]
+    out[name] = {"dispatches": n, "jobs_per_launch": 32, "hbm_bytes_per_launch": per[-1]}
+out["_method"] = ("rocprofv3 --kernel-trace --output-format csv --pmc <set> (two separate passes, no sys/hip traces) on tools/probe_iter_times.py (32 pairs, one scheduler group); bytes = "
                   "128*RDREQ_128B + 64*RDREQ_64B + 32*RDREQ_32B + 64*(other reads) + 64*WRREQ_64B + 32*(WRREQ - WRREQ_64B), TCC_EA0 counters summed over the XCDs; "
-                  "hbm_bytes_per_launch = mean over the 20 sweep launches (32 jobs each) of the profiled alignment")
+                  "nn_sweep.hbm_bytes_per_launch = all bytes of k_sweep_fused + k_late + k_walk of the profiled alignment / its 20 sweeps (32 jobs each)")
 json.dump(out, open(R + "/gpurun_out/pmc/traffic.json", "w"), indent=1)
-print(json.dumps({k: {kk: vv for kk, vv in v.items() if kk != "per_launch_bytes_profiled_alignment"} if isinstance(v, dict) else v for k, v in out.items()}, indent=1)[:2500])
+print(json.dumps(out, indent=1)[:3000])
 PY
