@@ -208,6 +208,32 @@ def test_mode1_sweeps_keep_exact_neighbours(ctx, capi, oracle):
         assert (idx == io).all(), ("two-launch", k, int((idx != io).sum()))
 
 
+@pytest.mark.parametrize("n_src", [1, 2, 63, 64, 65, 255, 256, 257, 511, 513, 1000, 1025, 2049])
+def test_mode1_sweeps_ragged_sizes(ctx, capi, oracle, n_src):
+    # source sizes around every granularity of the two-launch sweep (64-point waves, 256-point workgroups, 512-point spans, four spans
+    # per k_walk workgroup): neighbours after a cold sweep, a warm fused sweep and three k_late + k_walk sweeps must be the exhaustive
+    # search's, and the matched count the gate's
+    rng = np.random.default_rng(1000 + n_src)
+    tgt = synth.scan(rings=16, azimuths=300, scale=1.0, seed=5)[:, :3].astype(np.float32)
+    pick = rng.choice(tgt.shape[0], n_src, replace=n_src > tgt.shape[0])
+    src = (tgt[pick] + rng.normal(0, 0.03, (n_src, 3))).astype(np.float32)
+    ttree = oracle.Tree(oracle.xyz4(tgt))
+    nt = oracle.normals_knn(oracle.xyz4(tgt), 20, threads=4, tree=ttree)
+    ns = np.tile(np.array([0.0, 0.0, 1.0, 0.0], np.float32), (n_src, 1))      # any finite normals do: the neighbours do not depend on them
+    g = capi.Gicp(ctx, capi.default_params(corr_dist=0.5))
+    g.set_source(capi.make_pointf(src, ns))
+    g.set_target(capi.make_pointf(tgt, nt))
+    x = np.array([0.2, -0.1, 0.05, 0.01, -0.02, 0.03])
+    for k, (sc, sweep_index) in enumerate([(0.0, 0), (0.8, 1), (0.97, 3), (0.999, 4), (1.0, 5), (1.0, 6)]):
+        T16 = oracle.apply_state(x * sc)
+        idx, walks, sums = g.debug_sweep_fused(T16, n_src, sweep_index)
+        q = oracle.transform(oracle.xyz4(src), T16)
+        io, do = ttree.nn1(q, threads=1)
+        assert (idx == io).all(), (n_src, k, int((idx != io).sum()))
+        assert sums[73] == float((do.astype(np.float64) < 0.25).sum()), (n_src, k, sums[73])
+        assert walks <= n_src
+
+
 def test_sweep_queries_outside_the_target_box_stay_bit_exact(ctx, capi, oracle):
     # node boxes are 16-bit fixed point on the target's own grid; a query outside that grid is clamped onto it and carries
     # its overshoot as a separate term.  Shift the source a little, a lot and absurdly far out of the target's bounding box:
