@@ -34,20 +34,35 @@ from locus_amd import dist as ldist  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
 
-def make_pairs(ctx, n_pairs, rank, rings, az, scale):
-    """Synthetic consecutive-scan pairs: distinct seeds per rank and pair.  Normals are
-    computed on the GPU with the K3 kernel (k=20), like the NormalComputation nodelet upstream of GICP."""
-    S, T, host = [], [], []
-    for p in range(n_pairs):
-        seed = 1000 * rank + 10 + 2 * p
-        src, tgt, delta = synth.scan_pair(n_rings=rings, n_az=az, scale=scale, noise=0.02, seed=seed)
+def _gen_pair(a):
+    seed, rings, az, scale = a
+    return synth.scan_pair(n_rings=rings, n_az=az, scale=scale, noise=0.02, seed=seed)
+
+
+def gen_pairs_host(n_pairs, rank, rings, az, scale):
+    """the synthetic scans (consecutive-scan pairs, distinct seeds per rank and pair) on the host.  Ray casting
+    a 100 k-point scan in numpy takes ~0.13 s, so a few hundred pairs are spread over worker processes -- started BEFORE any GPU
+    runtime is initialised in this process (fork)."""
+    jobs = [(1000 * rank + 10 + 2 * p, rings, az, scale) for p in range(n_pairs)]
+    workers = max(1, min(16, (os.cpu_count() or 1) // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))), n_pairs // 8))
+    if workers <= 1:
+        return [_gen_pair(j) for j in jobs]
+    import multiprocessing as mp
+    with mp.get_context("fork").Pool(workers) as pool:
+        return pool.map(_gen_pair, jobs, chunksize=4)
+
+
+def make_pairs(ctx, host):
+    """device clouds of the pairs.  Normals are computed on the GPU with the K3 kernel (k=20), like the NormalComputation nodelet
+    upstream of GICP."""
+    S, T = [], []
+    for src, tgt, _ in host:
         cs, ct = capi.Cloud(ctx, src), capi.Cloud(ctx, tgt)
         cs.normals_knn(20)
         ct.normals_knn(20)
         ct.drop_index()
         S.append(cs)
         T.append(ct)
-        host.append((src, tgt, delta))
     return S, T, host
 
 
@@ -159,8 +174,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--pairs", type=int, default=128, help="scan pairs per GPU per step")
-    ap.add_argument("--in-flight", type=int, default=128)
+    ap.add_argument("--pairs", type=int, default=512, help="scan pairs per GPU per step")
+    ap.add_argument("--in-flight", type=int, default=512, help="pairs in flight on the GPU (one scheduler group = stream per 32)")
     ap.add_argument("--rings", type=int, default=64)
     ap.add_argument("--azimuths", type=int, default=1563)  # 64 x 1563 = 100 032 points / scan
     ap.add_argument("--scale", type=float, default=2.0)
@@ -178,6 +193,8 @@ def main():
     # safety net: a rank that stops making progress dumps every thread's Python stack and exits instead of hanging the box
     import faulthandler
     faulthandler.dump_traceback_later(float(os.environ.get("LH_BENCH_WATCHDOG_S", "1500")), exit=True)
+
+    host_pairs = gen_pairs_host(args.pairs, int(os.environ.get("RANK", "0")), args.rings, args.azimuths, args.scale)   # (before any GPU runtime: worker processes)
 
     import torch
     import torch.distributed as dist
@@ -204,7 +221,7 @@ def main():
     # forced 20 outer iterations: eps = 0 would divide by zero in the ratio, use a vanishing eps instead
     P = capi.default_params(max_iterations=20, max_inner_iterations=20, corr_dist=1.0, transformation_epsilon=1e-12,
                             rotation_epsilon=1e-12, cost_mode=args.cost_mode, solver=args.solver)
-    S, T, host = make_pairs(ctx, args.pairs, rank, args.rings, args.azimuths, args.scale)
+    S, T, host = make_pairs(ctx, host_pairs)
     n_pts = len(S[0])
 
     # align()'s output clouds (gicp.hpp:586) are part of every alignment: lh_gicp_align_batch_out writes them on the device as the
@@ -270,7 +287,7 @@ def main():
         # ---- roofline leg: the same steps again with HIP-event timing of every launch on the library's stream ----
         # Profiling runs ONE scheduler group so kernels never overlap; to time launches of the same shape as the timed
         # region's (four groups of in_flight/4 pairs each) the leg runs with in_flight/4 pairs per launch.
-        groups = 4 if args.in_flight >= 64 else (2 if args.in_flight >= 16 else 1)   # the scheduler's groups (lh_api.hip run_tasks_device)
+        groups = min(32, args.in_flight // 32) if args.in_flight >= 64 else (2 if args.in_flight >= 16 else 1)   # the scheduler's groups (lh_api.hip run_tasks_device)
         prof_in_flight = max(8, args.in_flight // groups)
         ctx.profile(True)
         ctx.profile_reset()

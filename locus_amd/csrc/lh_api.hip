@@ -197,10 +197,14 @@ struct lh_ctx {
   HostPool* pool = nullptr;
   hipStream_t stream = nullptr, stream2 = nullptr;  // stream2: second half-batch of the pipelined scheduler
   hipStream_t stream3 = nullptr, stream4 = nullptr; // further scheduler groups of the device-driven loop
+  static constexpr int MAX_GROUPS = 32;
+  hipStream_t stream_more[MAX_GROUPS - 4] = {};   // groups 5..32
   void sync_side_streams() {  // everything the scheduler may have queued besides the primary stream
     if (stream2) (void)hipStreamSynchronize(stream2);
     if (stream3) (void)hipStreamSynchronize(stream3);
     if (stream4) (void)hipStreamSynchronize(stream4);
+    for (hipStream_t s : stream_more)
+      if (s) (void)hipStreamSynchronize(s);
   }
   // index-build scratch (shared by all clouds of the context; builds are serial on the stream)
   uint32_t *keys0 = nullptr, *keys1 = nullptr, *vals0 = nullptr, *vals1 = nullptr, *bbox = nullptr;
@@ -218,8 +222,11 @@ struct lh_ctx {
   void* scan_tmp = nullptr;
   size_t scan_tmp_bytes = 0;
   int idx_cap = 0;
-  IndexDesc *idx_descs_dev = nullptr, *idx_descs_host = nullptr;
-  hipEvent_t idx_copy_done = nullptr, idx_build_done = nullptr;
+  static constexpr int IDX_STAGE = 40;   // staging ring of the batched index build's descriptors: more than the scheduler's groups, so a build never waits for an older upload
+  IndexDesc *idx_descs_dev = nullptr, *idx_descs_host = nullptr;   // host: IDX_STAGE x MAX_INDEX_BATCH entries (pinned)
+  hipEvent_t idx_copy_done[IDX_STAGE] = {};
+  hipEvent_t idx_build_done = nullptr;
+  int idx_stage = 0;
   // pair slots
   PairDesc* descs_dev = nullptr;   // [n_slots]
   PairDesc* descs_host = nullptr;  // pinned staging
@@ -235,7 +242,7 @@ struct lh_ctx {
   OuterState* states_host = nullptr;   // pinned: upload staging at admission / download target when the host looks
   OuterState* states_init = nullptr;   // pinned: initial states (separate from the download target: uploads and downloads overlap)
   double* chunks_dev = nullptr;        // [n_slots][FINAL_CHUNKS * MOM_ROW]
-  hipEvent_t group_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t group_ev[MAX_GROUPS] = {};
   // batch mode: one workspace per scheduler slot.  They live here (not in a thread-local) so that they are tied to this
   // context's device, reused by every thread that drives the context, and released by lh_destroy.
   std::vector<Workspace> slot_ws;
@@ -387,13 +394,18 @@ static lh_status build_indices(lh_ctx* x, lh_cloud* const* clouds, int n_clouds,
     int max_n = 0, tile0 = 0;
     if (!x->idx_descs_dev) {
       HIPCHK(hipMalloc(&x->idx_descs_dev, sizeof(IndexDesc) * MAX_INDEX_BATCH));
-      HIPCHK(hipHostMalloc(&x->idx_descs_host, sizeof(IndexDesc) * MAX_INDEX_BATCH, hipHostMallocDefault));
+      HIPCHK(hipHostMalloc(&x->idx_descs_host, sizeof(IndexDesc) * MAX_INDEX_BATCH * lh_ctx::IDX_STAGE, hipHostMallocDefault));
       HIPCHK(hipMalloc(&x->idx_bbox, sizeof(uint32_t) * 8 * MAX_INDEX_BATCH));
-      HIPCHK(hipEventCreateWithFlags(&x->idx_copy_done, hipEventDisableTiming));
+      for (int k = 0; k < lh_ctx::IDX_STAGE; k++) HIPCHK(hipEventCreateWithFlags(&x->idx_copy_done[k], hipEventDisableTiming));
       HIPCHK(hipEventCreateWithFlags(&x->idx_build_done, hipEventDisableTiming));
-    } else {
-      HIPCHK(hipEventSynchronize(x->idx_copy_done));  // the previous batch's descriptor upload left the staging buffer
     }
+    // The descriptors are staged in a ring: the upload of a build is queued behind the previous build on the GPU (shared scratch), so
+    // waiting for the PREVIOUS upload before refilling one staging buffer tied the scheduling thread to the GPU's index builds
+    // (1.6 ms per group of 32 with sixteen groups in flight: 25 of a 60-ms step).  Only the upload IDX_STAGE builds ago is waited for.
+    const int stage = x->idx_stage;
+    x->idx_stage = (x->idx_stage + 1) % lh_ctx::IDX_STAGE;
+    IndexDesc* const stage_host = x->idx_descs_host + (size_t)stage * MAX_INDEX_BATCH;
+    HIPCHK(hipEventSynchronize(x->idx_copy_done[stage]));   // (an event that was never recorded is complete)
     for (int k = 0; k < nb; k++) {
       lh_cloud* c = clouds[o + k];
       if (!c || c->n <= 0 || c->ctx != x) return LH_EINVAL;
@@ -408,7 +420,7 @@ static lh_status build_indices(lh_ctx* x, lh_cloud* const* clouds, int n_clouds,
         HIPCHK(lhMalloc(&c->node_buf, sizeof(NodeX) * ((size_t)c->n + 1)));  // worst case: every point its own leaf
         c->index_cap = c->n;
       }
-      IndexDesc& d = x->idx_descs_host[k];
+      IndexDesc& d = stage_host[k];
       d.xyz = c->xyz; d.sorted = c->sorted; d.nodes = c->nodes(); d.hdr = c->hdr(); d.pos = c->pos;
       d.n = c->n; d.offset = (int)total;
       d.tile0 = tile0; d.pad = 0;
@@ -455,8 +467,8 @@ static lh_status build_indices(lh_ctx* x, lh_cloud* const* clouds, int n_clouds,
       ts.total = (int)total;
     }
     HIPCHK(hipStreamWaitEvent(s, x->idx_build_done, 0));  // the shared build scratch may still be in use on the other stream
-    HIPCHK(hipMemcpyAsync(x->idx_descs_dev, x->idx_descs_host, sizeof(IndexDesc) * nb, hipMemcpyHostToDevice, s));
-    HIPCHK(hipEventRecord(x->idx_copy_done, s));
+    HIPCHK(hipMemcpyAsync(x->idx_descs_dev, stage_host, sizeof(IndexDesc) * nb, hipMemcpyHostToDevice, s));
+    HIPCHK(hipEventRecord(x->idx_copy_done[stage], s));
     int id_bits = 0;
     while ((1 << id_bits) < nb) id_bits++;
     { ProfScope p(x, "index_bbox_keys", 16.0 * total * 2, s); launch_index_keys(x->idx_descs_dev, nb, max_n, x->idx_bbox, x->k64a, x->v32a, s); }
@@ -573,7 +585,7 @@ static lh_status ctx_ensure_slots(lh_ctx* c, int n_slots, int max_n) {
   HIPCHK(hipMalloc(&c->chunks_dev, sizeof(double) * (size_t)FINAL_CHUNKS * MOM_ROW * n_slots));
   HIPCHK(hipHostMalloc(&c->states_host, sizeof(OuterState) * n_slots, hipHostMallocDefault));
   HIPCHK(hipHostMalloc(&c->states_init, sizeof(OuterState) * n_slots, hipHostMallocDefault));
-  for (int k = 0; k < 4; k++)
+  for (int k = 0; k < lh_ctx::MAX_GROUPS; k++)
     if (!c->group_ev[k]) HIPCHK(hipEventCreateWithFlags(&c->group_ev[k], hipEventDisableTiming));
   c->mom_stride = mom_stride;
   c->mask_stride = mask_stride;
@@ -1126,14 +1138,17 @@ static lh_status run_tasks_device(lh_ctx* c, std::vector<Task*>& tasks, int in_f
   // Groups: a pair's solve (one wave, tens of sequential cost evaluations) takes about as long as its sweep, so with more groups
   // in flight there is always somebody's sweep to run beside the other groups' solves.  Profiling keeps one group so that the
   // HIP-event times of the launches do not overlap.
-  static const int groups_cfg = []() { const char* e = getenv("LH_DEVICE_GROUPS"); int v = e ? atoi(e) : 0; return v < 0 ? 0 : (v > 4 ? 4 : v); }();
-  int G = groups_cfg ? groups_cfg : (in_flight >= 64 ? 4 : (in_flight >= 16 ? 2 : 1));
+  static const int groups_cfg = []() { const char* e = getenv("LH_DEVICE_GROUPS"); int v = e ? atoi(e) : 0; return v < 0 ? 0 : (v > lh_ctx::MAX_GROUPS ? lh_ctx::MAX_GROUPS : v); }();
+  // one group per MAX_JOBS (32) pairs in flight -- a group's launch covers all its pairs -- up to 32 groups = streams: with 256 in
+  // flight, eight groups of 32 ran 14 % more pairs/s than four of 64 (each chain is half latency: solve, start-up, lone searches)
+  int G = groups_cfg ? groups_cfg : (in_flight >= 64 ? std::min(lh_ctx::MAX_GROUPS, in_flight / MAX_JOBS) : (in_flight >= 16 ? 2 : 1));
   if (c->prof) G = 1;
   G = std::max(1, std::min(G, in_flight));
-  hipStream_t* extra[3] = {&c->stream2, &c->stream3, &c->stream4};
+  hipStream_t* extra[lh_ctx::MAX_GROUPS - 1] = {&c->stream2, &c->stream3, &c->stream4};
+  for (int k = 0; k < lh_ctx::MAX_GROUPS - 4; k++) extra[3 + k] = &c->stream_more[k];
   for (int gi = 1; gi < G; gi++)
     if (!*extra[gi - 1]) HIPCHK(hipStreamCreateWithFlags(extra[gi - 1], hipStreamNonBlocking));
-  DevGroup groups[4];
+  DevGroup groups[lh_ctx::MAX_GROUPS];
   groups[0].stream = c->stream;
   for (int gi = 1; gi < G; gi++) groups[gi].stream = *extra[gi - 1];
   {
@@ -1147,7 +1162,7 @@ static lh_status run_tasks_device(lh_ctx* c, std::vector<Task*>& tasks, int in_f
   }
   // LH_HOST_PROF=1: where the scheduling thread's time goes (stderr, per batch): waiting for the GPU vs feeding it
   static const bool host_prof = []() { const char* e = getenv("LH_HOST_PROF"); return e && atoi(e) != 0; }();
-  double hp_wait = 0, hp_retire = 0, hp_admit = 0, hp_enq = 0;
+  double hp_wait = 0, hp_retire = 0, hp_admit = 0, hp_enq = 0, hp_build = 0, hp_prep = 0;
   auto hp_now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double hp_t0 = hp_now();
   size_t next = 0;
@@ -1204,9 +1219,12 @@ static lh_status run_tasks_device(lh_ctx* c, std::vector<Task*>& tasks, int in_f
             to_build.push_back(tg);
         }
         if (!to_build.empty()) {
+          const double hb = hp_now();
           st = build_indices(c, to_build.data(), (int)to_build.size(), g.stream);
           if (st) return fail(st);
+          hp_build += hp_now() - hb;
         }
+        const double hpp = hp_now();
         std::vector<int> admitted;
         while (next < tasks.size() && !g.free_slots.empty()) {
           Task* t = tasks[next++];
@@ -1240,6 +1258,7 @@ static lh_status run_tasks_device(lh_ctx* c, std::vector<Task*>& tasks, int in_f
           t->enq_iters = 0;
           g.active.push_back(t);
         }
+        hp_prep += hp_now() - hpp;
         if (!admitted.empty()) {
           // ONE copy for the group's descriptors (the host copies of the slots that keep running are unchanged) and one per run of
           // admitted slots for the loop states: a copy is a small kernel on the group's stream, and three per pair were 840 per step
@@ -1270,8 +1289,8 @@ static lh_status run_tasks_device(lh_ctx* c, std::vector<Task*>& tasks, int in_f
     }
   }
   if (host_prof)
-    fprintf(stderr, "[lh host] %zu pairs, %d groups: total %.3f ms = wait %.3f + retire %.3f + admit %.3f + enqueue %.3f\n", tasks.size(), G,
-            1e3 * (hp_now() - hp_t0), 1e3 * hp_wait, 1e3 * hp_retire, 1e3 * hp_admit, 1e3 * hp_enq);
+    fprintf(stderr, "[lh host] %zu pairs, %d groups: total %.3f ms = wait %.3f + retire %.3f + admit %.3f (index builds %.3f, pair set-up %.3f) + enqueue %.3f\n", tasks.size(), G,
+            1e3 * (hp_now() - hp_t0), 1e3 * hp_wait, 1e3 * hp_retire, 1e3 * hp_admit, 1e3 * hp_build, 1e3 * hp_prep, 1e3 * hp_enq);
   return err;
 }
 
@@ -1488,16 +1507,19 @@ void lh_destroy(lh_ctx* c) {
   (void)lhFree(c->tree_tmp); (void)lhFree(c->scan_tmp); (void)lhFree(c->k32a); (void)lhFree(c->k32b); (void)lhFree(c->rs_hist);
   (void)lhFree(c->idx_bbox); (void)lhFree(c->idx_descs_dev);
   if (c->idx_descs_host) (void)hipHostFree(c->idx_descs_host);
-  if (c->idx_copy_done) (void)hipEventDestroy(c->idx_copy_done);
+  for (hipEvent_t e : c->idx_copy_done)
+    if (e) (void)hipEventDestroy(e);
   if (c->idx_build_done) (void)hipEventDestroy(c->idx_build_done);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
   if (c->stream3) (void)hipStreamDestroy(c->stream3);
   if (c->stream4) (void)hipStreamDestroy(c->stream4);
+  for (hipStream_t s : c->stream_more)
+    if (s) (void)hipStreamDestroy(s);
   (void)lhFree(c->sort_temp); (void)lhFree(c->bbox); (void)lhFree(c->descs_dev); (void)lhFree(c->mom_partials_dev); (void)lhFree(c->wmask_dev);
   (void)lhFree(c->states_dev); (void)lhFree(c->chunks_dev);
   if (c->states_host) (void)hipHostFree(c->states_host);
   if (c->states_init) (void)hipHostFree(c->states_init);
-  for (int k = 0; k < 4; k++)
+  for (int k = 0; k < lh_ctx::MAX_GROUPS; k++)
     if (c->group_ev[k]) (void)hipEventDestroy(c->group_ev[k]);
   if (c->descs_host) (void)hipHostFree(c->descs_host);
   if (c->partials_host) (void)hipHostFree(c->partials_host);
