@@ -6,7 +6,7 @@
 // (grid.y = cloud): 32-bit keys in flight instead of 64-bit ones, three passes instead of five, nothing shared between clouds.
 // A pass is three launches:
 //   k_rs_hist     a workgroup counts the digits of its tile (4096 consecutive elements) in LDS -> hist[cloud][tile][digit]
-//   k_rs_scan     one 1024-thread workgroup per cloud, thread = digit: exclusive offsets in (digit, tile) order
+//   k_rs_scan     one 256-thread workgroup per cloud, four digits per thread: exclusive offsets in (digit, tile) order
 //   k_rs_scatter  the tile again: a wave ranks 64 consecutive elements at a time with wave64 ballots (ten ballots give every
 //                 lane the mask of the lanes that hold its digit; rank = popcount of the lower lanes), running per-wave digit
 //                 counters in LDS, then the waves' counters are prefixed in wave order -> stable positions
@@ -47,22 +47,27 @@ __global__ void __launch_bounds__(256) k_rs_hist(const IndexDesc* __restrict__ d
 }
 
 // thread = digit: offsets[tile][digit] = (elements of smaller digits) + (elements of this digit in earlier tiles)
-__global__ void __launch_bounds__(RS_BINS) k_rs_scan(const IndexDesc* __restrict__ descs, uint32_t* __restrict__ hist) {
-  __shared__ uint32_t wave_tot[RS_BINS / 64];
+// 256 threads, four digits each (one 16-byte load per tile row): a 1024-thread workgroup has to wait until a whole CU's worth of wave
+// slots is free, and beside sixteen streams of sweeps that took 100-600 us for 6 us of work -- on the critical path of every group's
+// index build (rocprofv3, timed region of the bench).
+__global__ void __launch_bounds__(256) k_rs_scan(const IndexDesc* __restrict__ descs, uint32_t* __restrict__ hist) {
+  __shared__ uint32_t wave_tot[4];
   const int cloud = blockIdx.x, b = threadIdx.x, lane = b & 63, wave = b >> 6;
   const int tiles = (descs[cloud].n + RS_TILE - 1) / RS_TILE;
-  uint32_t* h = hist + (size_t)descs[cloud].tile0 * RS_BINS;
-  uint32_t tot = 0;
+  uint4* h = reinterpret_cast<uint4*>(hist + (size_t)descs[cloud].tile0 * RS_BINS) + b;   // row stride RS_BINS / 4 uint4
+  constexpr int RS = RS_BINS / 4;
+  uint4 tot = make_uint4(0u, 0u, 0u, 0u);
   int t0 = 0;
-  for (; t0 + 8 <= tiles; t0 += 8) {   // eight independent loads in flight
-    uint32_t v[8];
+  for (; t0 + 4 <= tiles; t0 += 4) {   // four independent loads in flight
+    uint4 v[4];
 #pragma unroll
-    for (int k = 0; k < 8; k++) v[k] = h[(size_t)(t0 + k) * RS_BINS + b];
+    for (int k = 0; k < 4; k++) v[k] = h[(size_t)(t0 + k) * RS];
 #pragma unroll
-    for (int k = 0; k < 8; k++) tot += v[k];
+    for (int k = 0; k < 4; k++) { tot.x += v[k].x; tot.y += v[k].y; tot.z += v[k].z; tot.w += v[k].w; }
   }
-  for (; t0 < tiles; t0++) tot += h[(size_t)t0 * RS_BINS + b];
-  uint32_t inc = tot;   // inclusive scan over the 1024 digit totals: inside the wave, then across the 16 waves
+  for (; t0 < tiles; t0++) { uint4 v = h[(size_t)t0 * RS]; tot.x += v.x; tot.y += v.y; tot.z += v.z; tot.w += v.w; }
+  const uint32_t mine = tot.x + tot.y + tot.z + tot.w;
+  uint32_t inc = mine;   // inclusive scan over the 256 four-digit totals: inside the wave, then across the 4 waves
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
     uint32_t v = __shfl_up(inc, o, 64);
@@ -72,19 +77,26 @@ __global__ void __launch_bounds__(RS_BINS) k_rs_scan(const IndexDesc* __restrict
   __syncthreads();
   uint32_t base = 0;
   for (int w = 0; w < wave; w++) base += wave_tot[w];
-  uint32_t run = base + inc - tot;
+  uint4 run;
+  run.x = base + inc - mine;
+  run.y = run.x + tot.x;
+  run.z = run.y + tot.y;
+  run.w = run.z + tot.z;
   t0 = 0;
-  for (; t0 + 8 <= tiles; t0 += 8) {
-    uint32_t v[8];
+  for (; t0 + 4 <= tiles; t0 += 4) {
+    uint4 v[4];
 #pragma unroll
-    for (int k = 0; k < 8; k++) v[k] = h[(size_t)(t0 + k) * RS_BINS + b];
+    for (int k = 0; k < 4; k++) v[k] = h[(size_t)(t0 + k) * RS];
 #pragma unroll
-    for (int k = 0; k < 8; k++) { h[(size_t)(t0 + k) * RS_BINS + b] = run; run += v[k]; }
+    for (int k = 0; k < 4; k++) {
+      h[(size_t)(t0 + k) * RS] = run;
+      run.x += v[k].x; run.y += v[k].y; run.z += v[k].z; run.w += v[k].w;
+    }
   }
   for (; t0 < tiles; t0++) {
-    uint32_t c = h[(size_t)t0 * RS_BINS + b];
-    h[(size_t)t0 * RS_BINS + b] = run;
-    run += c;
+    uint4 c = h[(size_t)t0 * RS];
+    h[(size_t)t0 * RS] = run;
+    run.x += c.x; run.y += c.y; run.z += c.z; run.w += c.w;
   }
 }
 
@@ -161,16 +173,16 @@ void segsort_pairs(const IndexDesc* descs, int n_clouds, int max_n, const uint64
   const dim3 grid(tiles, n_clouds), blk(256);
   // pass 0: (u64 key, u32 index) in, pairs out
   hipLaunchKernelGGL(k_rs_hist<true>, grid, blk, 0, s, descs, (const void*)keys_in, 0, hist);
-  hipLaunchKernelGGL(k_rs_scan, dim3(n_clouds), dim3(RS_BINS), 0, s, descs, hist);
+  hipLaunchKernelGGL(k_rs_scan, dim3(n_clouds), dim3(256), 0, s, descs, hist);
   hipLaunchKernelGGL((k_rs_scatter<true, false>), grid, blk, 0, s, descs, (const void*)keys_in, vals_in, 0, (const uint32_t*)hist, (void*)kv_a, (uint32_t*)nullptr);
   // pass 1: pairs -> pairs
   hipLaunchKernelGGL(k_rs_hist<false>, grid, blk, 0, s, descs, (const void*)kv_a, RS_BITS, hist);
-  hipLaunchKernelGGL(k_rs_scan, dim3(n_clouds), dim3(RS_BINS), 0, s, descs, hist);
+  hipLaunchKernelGGL(k_rs_scan, dim3(n_clouds), dim3(256), 0, s, descs, hist);
   hipLaunchKernelGGL((k_rs_scatter<false, false>), grid, blk, 0, s, descs, (const void*)kv_a, (const uint32_t*)nullptr, RS_BITS, (const uint32_t*)hist, (void*)kv_b,
                      (uint32_t*)nullptr);
   // pass 2: pairs in, (cloud << 32 | key) and index out
   hipLaunchKernelGGL(k_rs_hist<false>, grid, blk, 0, s, descs, (const void*)kv_b, 2 * RS_BITS, hist);
-  hipLaunchKernelGGL(k_rs_scan, dim3(n_clouds), dim3(RS_BINS), 0, s, descs, hist);
+  hipLaunchKernelGGL(k_rs_scan, dim3(n_clouds), dim3(256), 0, s, descs, hist);
   hipLaunchKernelGGL((k_rs_scatter<false, true>), grid, blk, 0, s, descs, (const void*)kv_b, (const uint32_t*)nullptr, 2 * RS_BITS, (const uint32_t*)hist, (void*)keys_out,
                      vals_out);
 }
