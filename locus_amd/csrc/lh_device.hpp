@@ -304,6 +304,38 @@ LH_HD void scan_leaf(const TreeView& t, int32_t ref, float qx, float qy, float q
   }
 }
 
+// Nearest-child descent to ONE leaf and a scan of it: a good candidate, not the neighbour (nothing is stacked, nothing pruned).  What a
+// cold search starts with anyway (tree_search's kGreedy phase); on its own it is a seed: any target point is a valid warm-start candidate.
+template <class Collector>
+LH_HD void tree_descend(const TreeView& t, float qx, float qy, float qz, Collector& col) {
+  const float INF = inf_f();
+  TreeHeader h;
+  h.root = gld(&t.hdr->root);
+  h.org[0] = gld(&t.hdr->org[0]); h.org[1] = gld(&t.hdr->org[1]); h.org[2] = gld(&t.hdr->org[2]);
+  h.inv = gld(&t.hdr->inv); h.scl2 = gld(&t.hdr->scl2);
+  const GridQuery gq = grid_query(h, qx, qy, qz);
+  const float scl2 = h.scl2;
+  int32_t r = h.root;
+  while (r >= 0) {
+    const NodeX& nd = t.nodes[r];
+    const uint4 a = gload16<uint4>(nd.lo_xy);
+    const uint4 b = gload16<uint4>(nd.hi_xy);
+    const uint4 c = gload16<uint4>(nd.z_lohi);
+    const int4 ch = gload16<int4>(nd.child);
+    float d0 = boxd2_q(gq, a.x, b.x, c.x, scl2), d1 = boxd2_q(gq, a.y, b.y, c.y, scl2);
+    float d2 = boxd2_q(gq, a.z, b.z, c.z, scl2), d3 = boxd2_q(gq, a.w, b.w, c.w, scl2);
+    d1 = ch.y == NO_CHILD ? INF : d1;
+    d2 = ch.z == NO_CHILD ? INF : d2;
+    d3 = ch.w == NO_CHILD ? INF : d3;
+    float dm = d0; int32_t rm = ch.x;          // child 0 always exists
+    if (d1 < dm) { dm = d1; rm = ch.y; }
+    if (d2 < dm) { dm = d2; rm = ch.z; }
+    if (d3 < dm) { dm = d3; rm = ch.w; }
+    r = rm;
+  }
+  scan_leaf(t, r, qx, qy, qz, col);
+}
+
 template <class Collector>
 LH_HD void tree_search(const TreeView& t, float qx, float qy, float qz, Collector& col, uint64_t* stack, int stride) {
   const uint32_t NONE = 0xffffffffu;

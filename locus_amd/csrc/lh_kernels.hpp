@@ -148,9 +148,9 @@ void launch_moments_final(const PairDesc* descs, const CostArgs& a, double* part
 void launch_solve(const PairDesc* descs, const SolveArgs& a, const double* chunks, int chunk_stride, OuterState* states, hipStream_t s);
 constexpr int FUSED_CHUNK = 64;   // one 74-double partial per WAVE of the fused sweep
 constexpr int FINAL_CHUNKS = 8;   // the final sum leaves FINAL_CHUNKS x 74 chunk sums per job for the host to add (in chunk order)
-// cold-start helper: exact NN of every 8th source point, written as the warm-start candidate of its 8-point group
+// cold-start helper: the nearest point of the leaf nearest to every 4th source point, written as the warm-start candidate of its group
 void launch_seed(const PairDesc* descs, SweepArgs& a, int max_n, hipStream_t s);
-constexpr int SEED_GROUP = 8;
+constexpr int SEED_GROUP = 4;
 void launch_cost(const PairDesc* descs, const CostArgs& a, int max_n, double* out, hipStream_t s);
 inline int cost_blocks(int n) { return (n + COST_CHUNK - 1) / COST_CHUNK; }
 // second-order moments of the cost about T0 = job.T (see lh_bfgs.hpp MomentModel): per-block partials on the device,
