@@ -177,6 +177,12 @@ static int run_case(int n, int nq, int k, unsigned seed, int dup) {
     Nn1Collector c2{bd[w], w};
     tree_search(tv, q.x, q.y, q.z, c2, stk.data(), 1);
     if (c2.bi != ord[0] || c2.bd != bd[ord[0]]) bad++;
+    {  // the seed pass's descent (tree_descend): ONE leaf, no backtracking -- a valid candidate (a real point at its real distance),
+       // never closer than the true neighbour, and close to it for most queries
+      Nn1Collector cd{inf_f(), 0x7fffffff};
+      tree_descend(tv, q.x, q.y, q.z, cd);
+      if (cd.bi < 0 || cd.bi >= n || cd.bd != bd[cd.bi] || cd.bd < bd[ord[0]]) bad++;
+    }
     {  // the step-wise form of the same traversal (WalkStack + node_visit: what k_walk's persistent lanes run) must leave the
        // certificate collector in the same state as tree_search, warm (any valid candidate) or cold
       for (int warm = 0; warm < 2; warm++) {
