@@ -36,7 +36,9 @@ int lh_rccl_sum_hook(double* sums, int n, void* user);
 lh_status lh_rccl_install_sum_hook(lh_ctx* ctx, lh_rccl* r);
 
 /* every rank contributes n_local results (the counts may differ); `all` (capacity `cap` records) receives the concatenation
-   in rank order on every rank, counts[world] (nullable) the per-rank counts.  LH_EINVAL if cap is too small. */
+   in rank order on every rank, counts[world] (nullable) the per-rank counts.  LH_EINVAL -- on EVERY rank, before the record
+   exchange -- if the total exceeds the smallest `cap` any rank passed (the capacities travel with the counts, so the decision
+   is collective and no rank is left waiting in the second all-gather). */
 lh_status lh_rccl_allgather_results(lh_rccl* r, const lh_gicp_result* local, int n_local, lh_gicp_result* all, int cap, int* counts);
 /* max over the ranks (the timed region of a multi-rank run) and a barrier */
 lh_status lh_rccl_max_double(lh_rccl* r, double* v);

@@ -689,7 +689,7 @@ class Gicp:
                                      aligned_out.dtype.itemsize, f["x"][1])
         else:
             st = lib().lh_gicp_align(self.h, _ptr(g), C.byref(r), C.byref(tr) if tr is not None else None, None, 0, 0)
-        if raise_on_error and st not in (LH_OK, LH_ETOO_FEW_CORR, LH_ESOLVER):
+        if raise_on_error and st not in (LH_OK, LH_ETOO_FEW_CORR, LH_ESOLVER, LH_ENO_NN):
             raise LocusHipError(st, "lh_gicp_align")
         return _result_dict(r, tr)
 
@@ -745,7 +745,7 @@ def align_batch(ctx, params, src_clouds, tgt_clouds, guesses=None, max_in_flight
     out = (GicpResult * n)()
     g = np.ascontiguousarray(guesses, np.float32).reshape(n * 16) if guesses is not None else None
     st = lib().lh_gicp_align_batch(ctx.h, C.byref(params), n, S, T, _ptr(g), out, max_in_flight)
-    if st not in (LH_OK, LH_ETOO_FEW_CORR, LH_ESOLVER):
+    if st not in (LH_OK, LH_ETOO_FEW_CORR, LH_ESOLVER, LH_ENO_NN):
         raise LocusHipError(st, "lh_gicp_align_batch")
     return [_result_dict(out[i]) for i in range(n)]
 
@@ -761,7 +761,7 @@ def align_batch_out(ctx, params, src_clouds, tgt_clouds, guesses=None, max_in_fl
     out = (GicpResult * n)()
     g = np.ascontiguousarray(guesses, np.float32).reshape(n * 16) if guesses is not None else None
     st = lib().lh_gicp_align_batch_out(ctx.h, C.byref(params), n, S, T, _ptr(g), out, A, max_in_flight)
-    if st not in (LH_OK, LH_ETOO_FEW_CORR, LH_ESOLVER):
+    if st not in (LH_OK, LH_ETOO_FEW_CORR, LH_ESOLVER, LH_ENO_NN):
         raise LocusHipError(st, "lh_gicp_align_batch_out")
     clouds = []
     for i in range(n):
@@ -786,7 +786,7 @@ def align_batch_multi(ctxs, params, src_clouds, tgt_clouds, guesses=None, max_in
     out = (GicpResult * n)()
     g = np.ascontiguousarray(guesses, np.float32).reshape(n * 16) if guesses is not None else None
     st = lib().lh_gicp_align_batch_multi(len(ctxs), X, C.byref(params), n, S, T, _ptr(g), out, None, max_in_flight)
-    if st not in (LH_OK, LH_ETOO_FEW_CORR, LH_ESOLVER):
+    if st not in (LH_OK, LH_ETOO_FEW_CORR, LH_ESOLVER, LH_ENO_NN):
         raise LocusHipError(st, "lh_gicp_align_batch_multi")
     return [_result_dict(out[i]) for i in range(n)]
 
@@ -805,6 +805,6 @@ def align_batch_multi_views(ctxs, params, src_points, tgt_points, guesses=None, 
     out = (GicpResult * n)()
     g = np.ascontiguousarray(guesses, np.float32).reshape(n * 16) if guesses is not None else None
     st = lib().lh_gicp_align_batch_multi_views(len(ctxs), X, C.byref(params), n, SV, TV, _ptr(g), out, max_in_flight)
-    if st not in (LH_OK, LH_ETOO_FEW_CORR, LH_ESOLVER):
+    if st not in (LH_OK, LH_ETOO_FEW_CORR, LH_ESOLVER, LH_ENO_NN):
         raise LocusHipError(st, "lh_gicp_align_batch_multi_views")
     return [_result_dict(out[i]) for i in range(n)]

@@ -252,6 +252,7 @@ struct lh_ctx {
   // source-sharded single pair: in-place sum of the cost/moment sums over the ranks that hold the other shards
   lh_allreduce_fn reduce_fn = nullptr;
   void* reduce_user = nullptr;
+  uint64_t epoch = 0;          // one per scheduler run (run_tasks_*): see lh_cloud::built_epoch
   // profiling
   bool prof = false;
   std::vector<ProfEntry> prof_entries;
@@ -327,6 +328,8 @@ struct lh_cloud {
   double* cov6 = nullptr;
   int cov_k = 0;
   double cov_eps = 0;
+  uint64_t built_epoch = 0;    // the batch call (lh_ctx::epoch) that last built this cloud's index: a target shared by pairs of several
+                               // scheduler groups is rebuilt ONCE per call, not once per group admission under the other groups' sweeps
   TreeView view() const { return TreeView{sorted, nodes(), hdr(), n}; }
 };
 
@@ -672,7 +675,12 @@ struct Task {
     result.iterations = os.iter;
     result.n_correspondences_last = os.n_corr_last;
     result.cost_passes = os.passes;
-    result.status = os.status == 0 ? LH_OK : (os.status == -4 ? LH_ETOO_FEW_CORR : LH_ESOLVER);  // the exception the reference caught (gicp.hpp:542-547)
+    result.status = os.status == 0 ? LH_OK : (os.status == -4 ? LH_ETOO_FEW_CORR : (os.status == -6 ? LH_ENO_NN : LH_ESOLVER));  // the exception the reference caught (gicp.hpp:542-547)
+    if (os.status == -6) {  // a source point without a nearest neighbour: computeTransformation returned at gicp.hpp:504-506 and
+      memcpy(result.T, I16, sizeof(I16));   // final_transformation_ is still what pcl::Registration::align reset it to, converged_ false
+      result.converged = 0;
+      result.n_correspondences_last = 0;
+    }
   }
 
   // computeTransformation (gicp.hpp:406-617), host-driven; covariances / index were prepared by the caller
@@ -1167,6 +1175,7 @@ static lh_status run_tasks_device(lh_ctx* c, std::vector<Task*>& tasks, int in_f
   const double hp_t0 = hp_now();
   size_t next = 0;
   lh_status err = LH_OK;
+  const uint64_t epoch = ++c->epoch;
   auto fail = [&](lh_status st) {
     (void)hipStreamSynchronize(c->stream);
     c->sync_side_streams();
@@ -1185,7 +1194,7 @@ static lh_status run_tasks_device(lh_ctx* c, std::vector<Task*>& tasks, int in_f
       lh_status st;
       double hp_a = hp_now();
       if (g.pending) {  // wait for THIS group's rounds; the other group's are still queued / running
-        HIPCHK(hipEventSynchronize(g.ev));
+        if (hipEventSynchronize(g.ev) != hipSuccess) return fail(LH_EDEVICE);   // (through fail(): the other groups' streams drain, the device traces are handed back)
         hp_wait += hp_now() - hp_a;
         hp_a = hp_now();
         g.pending = false;
@@ -1213,16 +1222,24 @@ static lh_status run_tasks_device(lh_ctx* c, std::vector<Task*>& tasks, int in_f
       if (next < tasks.size() && !g.free_slots.empty() && (admit_by_slot || g.active.empty())) {  // admit: the NN indexes of all newly admitted targets are built together
         std::vector<lh_cloud*> to_build;
         size_t nn = next;
+        bool built_elsewhere = false;
         for (size_t k = 0; k < g.free_slots.size() && nn < tasks.size(); k++, nn++) {
           lh_cloud* tg = tasks[nn]->tgt;
-          if (tg && tg->n > 0 && (rebuild_index || !tg->has_index) && std::find(to_build.begin(), to_build.end(), tg) == to_build.end())
-            to_build.push_back(tg);
+          if (!tg || tg->n <= 0) continue;
+          // a target is (re)built once per call: a cloud shared by pairs of several groups (a scan-to-submap batch) was built by the
+          // first group that admitted one of its pairs -- rebuilding it in place here would rewrite the tree under that group's sweeps
+          if (tg->built_epoch == epoch && tg->has_index) { built_elsewhere = true; continue; }
+          if ((rebuild_index || !tg->has_index) && std::find(to_build.begin(), to_build.end(), tg) == to_build.end()) to_build.push_back(tg);
         }
         if (!to_build.empty()) {
           const double hb = hp_now();
           st = build_indices(c, to_build.data(), (int)to_build.size(), g.stream);
           if (st) return fail(st);
+          for (lh_cloud* tg : to_build) tg->built_epoch = epoch;
           hp_build += hp_now() - hb;
+        } else if (built_elsewhere && c->idx_build_done) {
+          // builds are chained through idx_build_done (shared scratch), so the latest record covers every earlier build of this call
+          if (hipStreamWaitEvent(g.stream, c->idx_build_done, 0) != hipSuccess) return fail(LH_EDEVICE);
         }
         const double hpp = hp_now();
         std::vector<int> admitted;
@@ -1308,6 +1325,7 @@ static lh_status run_tasks_host(lh_ctx* c, std::vector<Task*>& tasks, int in_fli
   }
   size_t next = 0;
   lh_status err = LH_OK;
+  const uint64_t epoch = ++c->epoch;
   auto busy = [&]() {
     for (int gi = 0; gi < G; gi++)
       if (!groups[gi].active.empty() || groups[gi].inflight) return true;
@@ -1329,14 +1347,19 @@ static lh_status run_tasks_host(lh_ctx* c, std::vector<Task*>& tasks, int in_fli
       if (next < tasks.size() && !g.free_slots.empty()) {
         std::vector<lh_cloud*> to_build;
         size_t nn = next;
+        bool built_elsewhere = false;
         for (size_t k = 0; k < g.free_slots.size() && nn < tasks.size(); k++, nn++) {
           lh_cloud* tg = tasks[nn]->tgt;
-          if (tg && tg->n > 0 && (rebuild_index || !tg->has_index) && std::find(to_build.begin(), to_build.end(), tg) == to_build.end())
-            to_build.push_back(tg);
+          if (!tg || tg->n <= 0) continue;
+          if (tg->built_epoch == epoch && tg->has_index) { built_elsewhere = true; continue; }   // built by the other group in this call (see run_tasks_device)
+          if ((rebuild_index || !tg->has_index) && std::find(to_build.begin(), to_build.end(), tg) == to_build.end()) to_build.push_back(tg);
         }
         if (!to_build.empty()) {
           st = build_indices(c, to_build.data(), (int)to_build.size(), g.stream);
           if (st) return fail(st);
+          for (lh_cloud* tg : to_build) tg->built_epoch = epoch;
+        } else if (built_elsewhere && c->idx_build_done) {
+          if (hipStreamWaitEvent(g.stream, c->idx_build_done, 0) != hipSuccess) return fail(LH_EDEVICE);
         }
         while (next < tasks.size() && !g.free_slots.empty()) {
           Task* t = tasks[next++];
@@ -1769,7 +1792,8 @@ lh_status lh_gicp_align(lh_gicp* g, const float guess[16], lh_gicp_result* out, 
   g->dbg_ready = true;
   if (aligned_out) {  // pcl::transformPointCloud(*input_, output, final_transformation_) (gicp.hpp:586)
     float T12[12];
-    fill_T12(out->T, T12);
+    // (on the no-neighbour return of gicp.hpp:504-506 line 586 is never reached: `output` is still guess * input from line 440)
+    fill_T12(out->status == LH_ENO_NN ? t.guess : out->T, T12);
     { ProfScope p(c, "transform", 32.0 * g->src->n); launch_transform(g->src->xyz, nullptr, g->src->n, T12, g->ws.out_xyz, nullptr, c->stream); }
     std::vector<float> host((size_t)g->src->n * 4);
     HIPCHK(hipMemcpyAsync(host.data(), g->ws.out_xyz, sizeof(float) * host.size(), hipMemcpyDeviceToHost, c->stream));
@@ -1890,6 +1914,9 @@ lh_status lh_gicp_align_batch_out(lh_ctx* ctx, const lh_gicp_params* p, int n_pa
     if (aligned && aligned[i] && (aligned[i]->ctx != ctx || aligned[i]->n != src[i]->n || aligned[i] == src[i] || aligned[i] == tgt[i])) return LH_EINVAL;
     max_n = std::max(max_n, src[i]->n);
   }
+  if (aligned)  // a caller-supplied output cloud is overwritten: whatever index / covariances it carried describe the OLD coordinates
+    for (int i = 0; i < n_pairs; i++)
+      if (aligned[i]) { aligned[i]->has_index = false; aligned[i]->cov_k = 0; }
   lh_status st = ctx_ensure_slots(ctx, in_flight, max_n);
   if (st) return st;
   if ((int)ctx->slot_ws.size() < in_flight) ctx->slot_ws.resize(in_flight);  // grow-only, reused across calls, freed by lh_destroy
@@ -2070,7 +2097,7 @@ lh_status lh_gicp_debug_sweep(lh_gicp* g, const float T[16], const float guess[1
   for (int i = 0; i < n; i++) {
     int32_t j;
     memcpy(&j, &corr[4 * (size_t)i + 3], 4);
-    if (tgt_idx) tgt_idx[i] = j;
+    if (tgt_idx) tgt_idx[i] = j < 0 ? -1 : j;   // (-2 marks "no neighbour at all" for the cost kernels; unmatched either way)
     if (maha9) {
       double s6[6];
       for (int q = 0; q < 6; q++) s6[q] = planes[(size_t)q * g->ws.n_pad + i];

@@ -22,6 +22,9 @@
 namespace lh {
 
 enum { BFGS_RUNNING = -1, BFGS_SUCCESS = 0, BFGS_NOPROGRESS = 1 };
+// A source point without ANY nearest neighbour (non-finite query) adds this to its sweep's correspondence count instead of 1
+// (lh_kernels.hip nn_index): 2^40, exact in a double next to any real count.  The reference gives the alignment up (gicp.hpp:471-478, 504-506).
+constexpr double NO_NN_MARK = 1099511627776.0;
 
 LH_FN bool same_bits6(const double* a, const double* b) {  // memcmp of six doubles
   bool eq = true;
@@ -514,7 +517,7 @@ struct Bfgs {
 };
 
 // estimateRigidTransformationBFGS (gicp.hpp:218-287).  T16 column-major in/out.
-// returns 0 ok, -4 too few correspondences, -5 solver failure
+// returns 0 ok, -4 too few correspondences, -5 solver failure, -6 a source point without a nearest neighbour
 template <class Fn, class M>
 LH_FN int estimate_rigid_bfgs(Fn* fn, int max_inner, float* T16, int* n_inner, double* f_end) {
   auto TM = [&](int r, int c) { return (double)T16[c * 4 + r]; };
@@ -523,6 +526,7 @@ LH_FN int estimate_rigid_bfgs(Fn* fn, int max_inner, float* T16, int* n_inner, d
   Bfgs<Fn> b;
   int inner = 0, result;
   b.init(fn, x);
+  if (fn->count() >= NO_NN_MARK) return -6;  // `failure` of the NN loop (gicp.hpp:471-478): computeTransformation returns before the solve (:504-506)
   if (fn->count() < 4) return -4;  // gicp.hpp:225 (the count is known after the first fused pass)
   do {
     inner++;
@@ -549,7 +553,7 @@ struct OuterState {
   float prev[16];   // previous_transformation_: what final_transformation_ is composed from (gicp.hpp:583)
   int iter;         // nr_iterations_
   int done;         // the loop has ended: converged_, or an exception was caught (gicp.hpp:542-547)
-  int converged, status;       // status: 0, -4 (NotEnoughPointsException) or -5 (SolverDidntConvergeException)
+  int converged, status;       // status: 0, -4 (NotEnoughPointsException), -5 (SolverDidntConvergeException) or -6 (a query without a neighbour)
   int n_corr_last, passes, n_inner, pad;
   double f_end, delta;
   double corr_sum;  // correspondences summed over the iterations (instrumentation: the algorithmic bytes of SURVEY 8d scale with it)
@@ -569,11 +573,12 @@ LH_FN void outer_step(Fn* fn, const OuterParams& P, OuterState* s) {
   int n_inner = 0;
   double f_end = 0.0;
   int st = estimate_rigid_bfgs<Fn, M>(fn, P.max_inner_iterations, s->T, &n_inner, &f_end);
-  s->n_corr_last = (int)fn->count();
+  s->n_corr_last = st == -6 ? 0 : (int)fn->count();
   s->passes += fn->passes - before;
   s->n_inner = n_inner;
   s->f_end = f_end;
   if (st != 0) {  // exception caught -> break (gicp.hpp:542-547): final_transformation_ comes from previous_transformation_
+                  // (st == -6: the plain `return` of gicp.hpp:504-506 -- final_transformation_ stays what align() reset it to)
     s->status = st;
     s->done = 1;
     return;
@@ -584,7 +589,7 @@ LH_FN void outer_step(Fn* fn, const OuterParams& P, OuterState* s) {
 #pragma unroll
     for (int l = 0; l < 4; l++) {
       double ratio = (k < 3 && l < 3) ? 1. / P.rotation_epsilon : 1. / P.transformation_epsilon;
-      double c_delta = ratio * fabs((double)s->prev[l * 4 + k] - (double)s->T[l * 4 + k]);
+      double c_delta = ratio * (double)fabsf(s->prev[l * 4 + k] - s->T[l * 4 + k]);  // two Matrix4f entries: a FLOAT subtraction (gicp.hpp:535-536)
       if (c_delta > delta) delta = c_delta;
     }
   s->delta = delta;

@@ -387,6 +387,13 @@ __device__ __forceinline__ bool job_transform(const SweepJob& job, const OuterSt
   return true;
 }
 
+// The neighbour a search ended with, or -1 for "none": a query finds no neighbour when it is not finite (NaN: nothing compares
+// closer; Inf: every distance is +inf) -- pcl::KdTreeFLANN's point_representation_->isValid(query) -- and the reference then
+// sets `failure` and gives the whole alignment up (gicp.hpp:471-478, 504-506).  Such a point adds NO_NN_MARK to the
+// correspondence count of its sweep (every other sum untouched): integers stay exact in a double, the mark survives every
+// fixed-order reduction and the SUM hook of the source-sharded pair, and the solver (lh_bfgs.hpp) sees it with the first count.
+__device__ __forceinline__ int nn_index(int bi, float bd) { return (bi == 0x7fffffff || !(bd < INFINITY)) ? -1 : bi; }
+
 // one source point of a sweep: exact NN (warm start + certificate) and, if gated in, M = (R C1 R^T + C2)^-1
 struct SweepPoint {
   float4 p;      // source point
@@ -395,6 +402,7 @@ struct SweepPoint {
   int j;         // target index or -1
   bool matched;
   bool searched; // the certificate did not cover this query: the tree was walked
+  bool nonn;     // the query has NO nearest neighbour (a non-finite query point): searchForNeighbors false, gicp.hpp:471-478
 };
 // kRank1 (the fused sweep of cost_mode 1, both covariances from normals): C = I - (1-eps) n n^T / |n|^2 is a rank-one update
 // of the identity, so   R C1 R^T + C2 = (R R^T + I) - k1 u u^T - k2 v v^T,   u = R n1, v = n2, k = (1-eps) / |n|^2
@@ -449,7 +457,8 @@ __device__ __forceinline__ void sweep_point(const PairDesc& d, const float* __re
     if (d.stats) atomicAdd(&d.stats[0], 1ull);  // instrumentation only (lh_gicp_debug_sweep): contended atomics
   }
   if (d.stats) atomicAdd(&d.stats[1], 1ull);
-  int j = (col.bi == 0x7fffffff) ? -1 : col.bi;
+  int j = nn_index(col.bi, col.bd);
+  o.nonn = j < 0;
   if (j != w) gst(d.prev_nn + i, j);
   if (need_search && j >= 0) {
     t = gld(d.tgt_xyz + j);
@@ -546,7 +555,7 @@ __global__ void __launch_bounds__(256) k_sweep(const PairDesc* __restrict__ desc
   if (i >= d.n) return;
   SweepPoint sp;
   sweep_point(d, job.T, i, lds_stack + threadIdx.x, sp, a.cert_rel);
-  float4 c = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
+  float4 c = make_float4(0.f, 0.f, 0.f, __int_as_float(sp.nonn ? -2 : -1));   // -1: gated out; -2: no neighbour at all (the failure path)
   if (sp.matched) {
     d.maha6[(size_t)0 * d.n_pad + i] = sp.M[0];
     d.maha6[(size_t)1 * d.n_pad + i] = sp.M[1];
@@ -656,7 +665,7 @@ __device__ __forceinline__ void gram_zero(GramAcc& g) {
   for (int k = 0; k < 7; k++) g.t[k] = 0.0;
 }
 // `on` = the lane has a matched point (otherwise it stages zeros)
-__device__ __forceinline__ void gram_accumulate(double* wl, const double (&av)[11], const float4& p, bool on, GramAcc& g) {
+__device__ __forceinline__ void gram_accumulate(double* wl, const double (&av)[11], const float4& p, bool on, GramAcc& g, bool mark = false) {
   const int lane = threadIdx.x & 63;
   const int kk = lane >> 4, b = (lane >> 2) & 3, ij = lane & 3;
 #pragma unroll
@@ -668,7 +677,7 @@ __device__ __forceinline__ void gram_accumulate(double* wl, const double (&av)[1
       row[11] = on ? (double)p.x : 0.0;
       row[12] = on ? (double)p.y : 0.0;
       row[13] = on ? (double)p.z : 0.0;
-      row[14] = on ? 1.0 : 0.0;
+      row[14] = (on || mark) ? 1.0 : 0.0;   // mark: a no-neighbour lane -- av[10] = NO_NN_MARK reaches the count, its (maybe NaN) point nothing
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
@@ -756,10 +765,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) k
   SweepPoint sp;
   sp.matched = false;
   sp.searched = false;
+  sp.nonn = false;
   if (i < d.n) sweep_point<kNormals>(d, T, i, lds_stack + threadIdx.x, sp, a.cert_rel);
   double M6[6] = {0, 0, 0, 0, 0, 0}, Ma[3] = {0, 0, 0}, pt[4] = {0, 0, 0, 0}, pp[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, aMa = 0.0;
   if (sp.matched) moments_of_point(T, sp, M6, Ma, aMa, pt, pp);
-  const double live = sp.matched ? 1.0 : 0.0;
+  const double live = sp.matched ? 1.0 : (sp.nonn ? NO_NN_MARK : 0.0);
   const int walks = __popcll(__ballot(sp.searched));
   double* out = partials + (size_t)job.slot * partials_stride + (size_t)blk * MOM_ROW;   // one row per workgroup
   {
@@ -770,7 +780,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) k
     gram_zero(acc);
     __syncthreads();  // every lane of the workgroup is done with its traversal stack
     double* wl = reinterpret_cast<double*>(lds_stack) + wave * (32 * GRAM_RS);
-    gram_accumulate(wl, av, sp.p, sp.matched, acc);
+    gram_accumulate(wl, av, sp.p, sp.matched, acc, sp.nonn);
     gram_store(acc, wl, (double)walks);
     wg_row_sum(reinterpret_cast<double*>(lds_stack), 32 * GRAM_RS, out);
   }
@@ -1003,7 +1013,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) k
           if (qi >= 0) {  // the search that has just ended: its neighbour and certificate
             const int i = i0 + qi;
             gst(d.cert + i, make_float4(qx, qy, qz, col.lb));
-            gst(d.prev_nn + i, (col.bi == 0x7fffffff) ? -1 : col.bi);
+            gst(d.prev_nn + i, nn_index(col.bi, col.bd));
             qi = -1;
           }
           const int slot = head + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(im >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)im, 0u));
@@ -1041,13 +1051,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) k
   gram_zero(acc);
   for (int base = 0; base < total; base += 64) {
     const int r = base + lane;
-    bool matched = false;
+    bool matched = false, nonn = false;
     float4 p = make_float4(0.f, 0.f, 0.f, 0.f), nn = p, t = p, tn = p;
     if (r < total) {
       const int i = i0 + queue[r];
       p = gld(d.src + i);
       nn = gld(d.src_nrm + i);
       const int j = gld(d.prev_nn + i);
+      nonn = j < 0;   // the search found nothing (a non-finite query): gicp.hpp:471-478
       if (j >= 0) {
         t = gld(d.tgt_xyz + j);
         tn = gld(d.tgt_nrm + j);
@@ -1071,8 +1082,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) k
     else {
 #pragma unroll
       for (int k = 0; k < 11; k++) av[k] = 0.0;
+      if (nonn) av[10] = NO_NN_MARK;
     }
-    gram_accumulate(reinterpret_cast<double*>(lds_stack), av, p, matched, acc);
+    gram_accumulate(reinterpret_cast<double*>(lds_stack), av, p, matched, acc, nonn);
   }
   gram_store(acc, out, 0.0);   // (the late rows carry the walker counts)
 }
@@ -1161,8 +1173,9 @@ __global__ void __launch_bounds__(256) k_cost(const PairDesc* __restrict__ descs
         acc[4] += p0 * t0; acc[5] += p0 * t1; acc[6] += p0 * t2;          // :396
         acc[7] += p1 * t0; acc[8] += p1 * t1; acc[9] += p1 * t2;
         acc[10] += p2 * t0; acc[11] += p2 * t1; acc[12] += p2 * t2;
-        acc[13] += 1.0;
       }
+      // the correspondence count; a query without a neighbour (index -2, gicp.hpp:471-478) adds the failure mark instead: see nn_index
+      acc[13] += __float_as_int(c.w) >= 0 ? 1.0 : (__float_as_int(c.w) == -2 ? NO_NN_MARK : 0.0);
     }
   }
   // fixed-shape reduction: wave64 shuffle tree, then the 4 waves in order => bitwise reproducible
@@ -1207,16 +1220,18 @@ __global__ void __launch_bounds__(256) k_moments(const PairDesc* __restrict__ de
   for (int k = 0; k < 12; k++) T0[k] = (double)job.T[k];
   // software-pipelined: the next point's 80 bytes are requested before the current point's ~110 double FMAs, so the
   // single resident wave per SIMD (148 accumulator VGPRs) still overlaps HBM latency with arithmetic
-  struct Raw { float4 c, p; double m[6]; bool ok; };
+  struct Raw { float4 c, p; double m[6]; bool ok, nonn; };
   auto load = [&](int i) {
     Raw r;
     r.ok = false;
+    r.nonn = false;
     r.c = make_float4(0.f, 0.f, 0.f, 0.f); r.p = r.c;
 #pragma unroll
     for (int k = 0; k < 6; k++) r.m[k] = 0.0;
     if (i < d.n) {
       r.c = d.corr[i];
       r.ok = __float_as_int(r.c.w) >= 0;
+      r.nonn = __float_as_int(r.c.w) == -2;
       r.p = d.src[i];
       if (r.ok) {
 #pragma unroll
@@ -1255,6 +1270,8 @@ __global__ void __launch_bounds__(256) k_moments(const PairDesc* __restrict__ de
 #pragma unroll
         for (int ce = 0; ce < 10; ce++) acc[13 + rs * 10 + ce] += M6[rs] * pp[ce];
       acc[73] += 1.0;
+    } else if (cur.nonn) {
+      acc[73] += NO_NN_MARK;
     }
     cur = nxt;
   }
@@ -1471,7 +1488,7 @@ __global__ void __launch_bounds__(256) k_nn1(const float4* __restrict__ q, int n
   if (has_T) xform_pt(T.v, p.x, p.y, p.z, x, y, z);
   Nn1Collector col{INFINITY, 0x7fffffff};
   tree_search(tv, x, y, z, col, lds_stack + threadIdx.x, 256);
-  idx[i] = (col.bi == 0x7fffffff) ? -1 : col.bi;
+  idx[i] = nn_index(col.bi, col.bd);   // a non-finite query has no neighbour (pcl::KdTreeFLANN: isValid(query))
   d2[i] = col.bd;
 }
 void launch_nn1(const float4* q, int nq, const float* T12p, TreeView tree, int32_t* idx, float* d2, hipStream_t s) {

@@ -115,21 +115,29 @@ lh_status lh_rccl_allgather_results(lh_rccl* r, const lh_gicp_result* local, int
   if (!r || n_local < 0 || (n_local > 0 && !local) || !all) return LH_EINVAL;
   RCHK(hipSetDevice(r->device));
   const int W = r->world;
-  // 1) the per-rank counts (they may differ by one when the pairs do not divide evenly)
-  lh_status st = ensure(r, sizeof(int) * (size_t)W * 2);
+  // 1) the per-rank counts (they may differ by one when the pairs do not divide evenly) AND every rank's capacity: the decision to
+  //    go on is taken from the gathered table, i.e. identically on every rank -- a rank that left between the two collectives on
+  //    its own (a smaller `cap`) would leave the others waiting in the second all-gather
+  lh_status st = ensure(r, sizeof(int) * 2 * (size_t)(W + 1));
   if (st) return st;
   int* hc = reinterpret_cast<int*>(r->host);
   hc[0] = n_local;
-  RCHK(hipMemcpyAsync(r->dev, hc, sizeof(int), hipMemcpyHostToDevice, r->stream));
-  NCHK(ncclAllGather(r->dev, r->dev + sizeof(int) * (size_t)W, 1, ncclInt32, r->comm, r->stream));
-  RCHK(hipMemcpyAsync(hc, r->dev + sizeof(int) * (size_t)W, sizeof(int) * (size_t)W, hipMemcpyDeviceToHost, r->stream));
+  hc[1] = cap;
+  RCHK(hipMemcpyAsync(r->dev, hc, sizeof(int) * 2, hipMemcpyHostToDevice, r->stream));
+  NCHK(ncclAllGather(r->dev, r->dev + sizeof(int) * 2, 2, ncclInt32, r->comm, r->stream));
+  RCHK(hipMemcpyAsync(hc, r->dev + sizeof(int) * 2, sizeof(int) * 2 * (size_t)W, hipMemcpyDeviceToHost, r->stream));
   RCHK(hipStreamSynchronize(r->stream));
-  std::vector<int> cnt(hc, hc + W);
-  int kmax = 0;
+  std::vector<int> cnt(W);
+  int kmax = 0, min_cap = cap;
   long total = 0;
-  for (int c : cnt) { kmax = std::max(kmax, c); total += c; }
+  for (int k = 0; k < W; k++) {
+    cnt[k] = hc[2 * k];
+    kmax = std::max(kmax, cnt[k]);
+    total += cnt[k];
+    min_cap = std::min(min_cap, hc[2 * k + 1]);
+  }
   if (counts) memcpy(counts, cnt.data(), sizeof(int) * (size_t)W);
-  if (total > cap) return LH_EINVAL;
+  if (total > min_cap) return LH_EINVAL;   // on EVERY rank: nobody enters the second collective
   if (kmax == 0) return LH_OK;
   // 2) ONE all-gather of the records, padded to the largest block
   const size_t blk = sizeof(lh_gicp_result) * (size_t)kmax;

@@ -67,7 +67,7 @@ public:
     output.stamp = src_->stamp;
     lh_gicp_result r;
     lh_status st = lh_gicp_align(g_, guess, &r, nullptr, output.points.data(), sizeof(PointF), offsetof(PointF, x));
-    if (st != LH_OK && st != LH_ETOO_FEW_CORR && st != LH_ESOLVER) check(st, "align");
+    if (st != LH_OK && st != LH_ETOO_FEW_CORR && st != LH_ESOLVER && st != LH_ENO_NN) check(st, "align");   // (the reference catches / returns on these: gicp.hpp:504-506, 542-547)
     for (int i = 0; i < 16; i++) final_[i] = r.T[i];
     converged_ = r.converged != 0;
     iterations_ = r.iterations;

@@ -199,7 +199,9 @@ static void nn1_one(const lo_tree* t, const float* q, int32_t* idx, float* d2) {
   float bd = INFINITY;
   int bi = 0x7fffffff;
   if (t->n > 0) nn1_rec(t, 0, q, &bd, &bi);
-  *idx = (t->n > 0 && bi != 0x7fffffff) ? bi : -1;
+  /* no neighbour for a query that is not finite (NaN: nothing compares closer; Inf: every distance is +inf) -- the query
+     pcl::KdTreeFLANN::nearestKSearch's point_representation_->isValid() rejects */
+  *idx = (t->n > 0 && bi != 0x7fffffff && bd < INFINITY) ? bi : -1;
   *d2 = bd;
 }
 
@@ -449,11 +451,12 @@ static void mat3_inv(const double* m, double* inv) {
     for (int j = 0; j < 3; j++) inv[i * 3 + j] = cof3(m, j, i) * invdet;
 }
 
-void lo_nn_mahalanobis(const float* out_xyz4, int n, const lo_tree* tgt_tree, const double* cov_src9,
-                       const double* cov_tgt9, const float* T16, const double* R9, double corr_dist,
-                       int32_t* tgt_idx, double* maha9, int threads) {
+int lo_nn_mahalanobis(const float* out_xyz4, int n, const lo_tree* tgt_tree, const double* cov_src9,
+                      const double* cov_tgt9, const float* T16, const double* R9, double corr_dist,
+                      int32_t* tgt_idx, double* maha9, int threads) {
   const double dist_threshold = corr_dist * corr_dist; /* gicp.hpp:438 */
   if (threads < 1) threads = 1;
+  int failure = 0; /* gicp.hpp:461: a plain int written from the OMP loop (a benign race: only ever set to 1) */
 #pragma omp parallel for schedule(dynamic, 1) num_threads(threads) if (threads > 1)
   for (int i = 0; i < n; i++) {
     float q[4];
@@ -462,7 +465,12 @@ void lo_nn_mahalanobis(const float* out_xyz4, int n, const lo_tree* tgt_tree, co
     float d;
     nn1_one(tgt_tree, q, &j, &d);
     tgt_idx[i] = -1;
-    if (j >= 0 && (double)d < dist_threshold) { /* gicp.hpp:483 */
+    if (j < 0) { /* searchForNeighbors returned false (gicp.hpp:471-478): no neighbour -- here: a non-finite query */
+#pragma omp atomic write
+      failure = 1;
+      continue;
+    }
+    if ((double)d < dist_threshold) { /* gicp.hpp:483 */
       double M[9], tmp[9];
       mat3_mul(R9, cov_src9 + 9 * (size_t)i, M);      /* M = R*C1            gicp.hpp:488 */
       mat3_mul_bt(M, R9, tmp);                        /* temp = M*R^T        gicp.hpp:490 */
@@ -472,6 +480,7 @@ void lo_nn_mahalanobis(const float* out_xyz4, int n, const lo_tree* tgt_tree, co
       tgt_idx[i] = j;
     }
   }
+  return failure;
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -1044,8 +1053,15 @@ int lo_gicp_align(const float* src_xyz4, const float* src_nrm4, int n, const flo
         }
       double R9[9] = {TR[0], TR[1], TR[2], TR[4], TR[5], TR[6], TR[8], TR[9], TR[10]};
       t0 = now_s();
-      lo_nn_mahalanobis(output, n, tree, cov_src, cov_tgt, transformation, R9, P->corr_dist, tgt_idx_full, maha, threads);
+      int failure = lo_nn_mahalanobis(output, n, tree, cov_src, cov_tgt, transformation, R9, P->corr_dist, tgt_idx_full, maha, threads);
       res->t_nn += now_s() - t0;
+      if (failure) { /* gicp.hpp:504-506: return; final_transformation_ keeps what pcl::Registration::align reset it to (identity),
+                        converged_ stays false, nr_iterations_ is what it was */
+        res->status = LO_ENO_NN;
+        res->converged = 0;
+        res->iterations = nr_iterations;
+        goto done;
+      }
       int cnt = 0; /* compaction gicp.hpp:509-514 */
       for (int i = 0; i < n; i++)
         if (tgt_idx_full[i] >= 0) { src_idx[cnt] = i; tgt_idx[cnt] = tgt_idx_full[i]; cnt++; }
@@ -1066,7 +1082,8 @@ int lo_gicp_align(const float* src_xyz4, const float* src_nrm4, int n, const flo
       for (int k = 0; k < 4; k++)
         for (int l = 0; l < 4; l++) {
           double ratio = (k < 3 && l < 3) ? 1.0 / P->rotation_epsilon : 1.0 / P->transformation_epsilon;
-          double c_delta = ratio * fabs((double)previous[l * 4 + k] - (double)transformation[l * 4 + k]);
+          /* fabs(previous_transformation_(k, l) - transformation_(k, l)): two Matrix4f entries, a FLOAT subtraction (gicp.hpp:535-536) */
+          double c_delta = ratio * (double)fabsf(previous[l * 4 + k] - transformation[l * 4 + k]);
           if (c_delta > delta) delta = c_delta;
         }
       if (trace && nr_iterations < LO_MAX_TRACE) {

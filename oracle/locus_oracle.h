@@ -89,7 +89,7 @@ int lo_cov_knn(const float* xyz4, int n, const lo_tree* t, int k, double eps, do
 
 /* K4: one NN + Mahalanobis sweep (gicp.hpp:464-498). T16 = transformation_ (float, col-major),
    R9 = row-major double 3x3 of transformation_*guess.  out: tgt_idx[n] (-1 = unmatched), maha9[n][9]. */
-void lo_nn_mahalanobis(const float* out_xyz4, int n, const lo_tree* tgt_tree, const double* cov_src9,
+int lo_nn_mahalanobis(const float* out_xyz4, int n, const lo_tree* tgt_tree, const double* cov_src9,
                        const double* cov_tgt9, const float* T16, const double* R9, double corr_dist,
                        int32_t* tgt_idx, double* maha9, int threads);
 

@@ -12,6 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_HERE, "liblocus_oracle.so")
 LO_MAX_TRACE = 256
+LO_OK, LO_EINVAL, LO_ENOMEM, LO_ETOO_FEW, LO_ESOLVER, LO_ENO_NN = 0, -1, -2, -4, -5, -6   # locus_oracle.h
 
 
 class LoParams(C.Structure):

@@ -390,3 +390,67 @@ def test_empty_and_invalid_inputs(ctx, capi):
     with pytest.raises(capi.LocusHipError):
         g.fitness()
     assert capi.align_batch(ctx, capi.default_params(), [], []) == []
+
+
+@pytest.mark.parametrize("cost_mode,solver", [(0, 0), (1, 1), (1, 2)])
+@pytest.mark.parametrize("bad", ["nan", "inf"])
+def test_non_finite_source_point_is_the_no_neighbour_failure(ctx, capi, oracle, cost_mode, solver, bad):
+    """gicp.hpp:471-478, 504-506: a query for which searchForNeighbors finds nothing sets `failure`, and computeTransformation
+    returns before the solve -- final_transformation_ stays the identity pcl::Registration::align reset it to, converged_ false.
+    A non-finite source point is such a query (pcl::KdTreeFLANN: isValid).  Status LH_ENO_NN, in every loop flavour (reference
+    arithmetic on the host, moment model on the host, moment model in k_solve), first sweep or a later one, alone or in a batch."""
+    src, ns, tgt, nt, _ = _pair_with_normals(oracle, 91, rings=16, az=300)
+    kw = dict(max_iterations=20, corr_dist=1.0, transformation_epsilon=1e-3)
+    P = capi.default_params(cost_mode=cost_mode, solver=solver, **kw)
+    bad_src = src.copy()
+    bad_src[1234, 1] = np.nan if bad == "nan" else np.inf
+    g = capi.Gicp(ctx, P)
+    g.set_source(capi.make_pointf(bad_src, ns))
+    g.set_target(capi.make_pointf(tgt, nt))
+    r = g.align()
+    ro = oracle.gicp_align(oracle.xyz4(bad_src), ns, oracle.xyz4(tgt), nt, oracle.default_params(num_threads=4, **kw))
+    assert ro["status"] == oracle.LO_ENO_NN and ro["converged"] == 0 and ro["iterations"] == 0
+    assert (oracle.T_to_mat(ro["T"]) == np.eye(4)).all()
+    assert r["status"] == capi.LH_ENO_NN and r["converged"] == 0 and r["iterations"] == 0, r
+    assert (oracle.T_to_mat(r["T"]) == np.eye(4)).all()
+    # inside a batch: only that pair fails, its neighbours are untouched (and equal their one-at-a-time results)
+    good = capi.Gicp(ctx, P)
+    good.set_source(capi.make_pointf(src, ns))
+    good.set_target(capi.make_pointf(tgt, nt))
+    rg = good.align(want_trace=False)
+    assert rg["status"] == 0
+    S = [capi.Cloud(ctx, capi.make_pointf(src if k != 3 else bad_src, ns)) for k in range(9)]
+    T = [capi.Cloud(ctx, capi.make_pointf(tgt, nt)) for _ in range(9)]
+    out = capi.align_batch(ctx, P, S, T, max_in_flight=9)
+    for k, o in enumerate(out):
+        if k == 3:
+            assert o["status"] == capi.LH_ENO_NN and o["converged"] == 0 and (oracle.T_to_mat(o["T"]) == np.eye(4)).all()
+        else:
+            assert o["status"] == 0 and (o["T"] == rg["T"]).all() and o["iterations"] == rg["iterations"]
+    # a point that only becomes non-finite... cannot: T is finite.  But a target cloud of non-finite points gives every query no neighbour
+    nan_tgt = np.full_like(tgt[:64], np.nan)
+    g2 = capi.Gicp(ctx, P)
+    g2.set_source(capi.make_pointf(src, ns))
+    g2.set_target(capi.make_pointf(nan_tgt, nt[:64]))
+    assert g2.align(want_trace=False)["status"] == capi.LH_ENO_NN
+
+
+def test_reused_output_cloud_drops_its_stale_index(ctx, capi, oracle):
+    """lh_gicp_align_batch_out overwrites a caller-supplied aligned[i]: an index (or k-NN covariances) built on its OLD coordinates
+    must not survive, or a later search would walk a stale tree (round-2 advisor finding)."""
+    pairs = [_pair_with_normals(oracle, 95 + i, rings=16, az=260) for i in range(2)]
+    P = capi.default_params(max_iterations=20, corr_dist=1.0, transformation_epsilon=1e-3)
+    S = [capi.Cloud(ctx, capi.make_pointf(p[0], p[1])) for p in pairs]
+    T = [capi.Cloud(ctx, capi.make_pointf(p[2], p[3])) for p in pairs]
+    _, A = capi.align_batch_out(ctx, P, S, T, max_in_flight=2)
+    q = capi.Cloud(ctx, pairs[0][2][:500])
+    A[0].nn1(q)                                   # builds an index on the first result
+    A[0].cov_knn(10)                              # ... and k-NN covariances
+    guesses = np.stack([oracle.mat_to_T(synth.pose_matrix(0.4, -0.3, 0.1, 0, 0, 0.2).astype(np.float32))] * 2)
+    res2, A2 = capi.align_batch_out(ctx, P, S, T, guesses=guesses, max_in_flight=2, aligned=A)
+    assert A2[0] is A[0]
+    d = A[0].download()
+    now = np.stack([d["x"], d["y"], d["z"]], 1)
+    idx, d2 = A[0].nn1(q)                         # must search the NEW coordinates
+    io, do = oracle.nn1_brute(oracle.xyz4(now), oracle.xyz4(pairs[0][2][:500]))
+    assert (idx == io).all() and (d2 == do).all()

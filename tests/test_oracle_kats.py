@@ -345,3 +345,26 @@ def test_config1_plumbing_chain_on_oracle(oracle):
     c1 = mod.chain(threads=1)
     assert (np.array(c1["result"]["T"]) == np.array(r["T"])).all()
 
+
+
+def test_oracle_no_neighbour_failure_path(oracle):
+    """gicp.hpp:471-478, 504-506: a query without a nearest neighbour (here: a non-finite source point) sets `failure`;
+    computeTransformation returns before the solve, so final_transformation_ is still the identity align() reset it to."""
+    from locus_amd import synth
+    src, tgt, _ = synth.scan_pair(n_rings=8, n_az=200, scale=1.0, noise=0.01, seed=5)
+    ns = oracle.normals_knn(oracle.xyz4(src), 10, threads=2)
+    nt = oracle.normals_knn(oracle.xyz4(tgt), 10, threads=2)
+    P = oracle.default_params(num_threads=2, max_iterations=20, corr_dist=1.0, transformation_epsilon=1e-3)
+    ok = oracle.gicp_align(oracle.xyz4(src), ns, oracle.xyz4(tgt), nt, P)
+    assert ok["status"] == oracle.LO_OK and ok["iterations"] >= 1
+    for bad in (np.nan, np.inf, -np.inf):
+        s2 = src.copy()
+        s2[37, 2] = bad
+        r = oracle.gicp_align(oracle.xyz4(s2), ns, oracle.xyz4(tgt), nt, P)
+        assert r["status"] == oracle.LO_ENO_NN and r["converged"] == 0 and r["iterations"] == 0
+        assert (oracle.T_to_mat(r["T"]) == np.eye(4)).all()
+    # the kd-tree and the exhaustive search agree that such a query has no neighbour
+    q = oracle.xyz4(np.array([[np.nan, 0, 0], [np.inf, 0, 0], [0.1, 0.2, 0.3]], np.float32))
+    it, _ = oracle.Tree(oracle.xyz4(tgt)).nn1(q, threads=1)
+    ib, _ = oracle.nn1_brute(oracle.xyz4(tgt), q)
+    assert list(it[:2]) == [-1, -1] and list(ib[:2]) == [-1, -1] and it[2] == ib[2] >= 0
