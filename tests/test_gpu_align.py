@@ -239,27 +239,113 @@ def test_batch_multi_contexts_and_views(ctx, capi, oracle):
 # typical pair inside its 15-of-16 value.
 FLOOR_T_MAX, FLOOR_R_MAX, FLOOR_T_TYPICAL = 2.5e-3, 1.3e-4, 2.4e-4
 ITERATE_SANITY = 2e-2   # intermediate iterates (a line search that stopped elsewhere on the valley floor): order-of-magnitude check only
-BENCH_SEEDS = (10, 12, 14, 16)   # bench.py make_pairs(), rank 0, pairs 0..3
+N_BENCH_PAIRS = 32
+BENCH_SEEDS = tuple(10 + 2 * p for p in range(N_BENCH_PAIRS))   # bench.py gen_pairs_host(), rank 0, pairs 0..31
+# Quantile bars of the benched mode over those pairs (profiles/r03_fullsize_parity.json: the same table over 64 pairs, next to the
+# distance between the reference's own two builds): the typical pair meets SURVEY 8d's 1e-4 m, nine in ten are within 2.5e-4 m,
+# and a pair beyond that is accepted only if the reference ITSELF moves by more than 2.5e-4 m on that pair when its float
+# product is contracted (its line search stalls elsewhere on the valley floor), and never beyond HARD_T.
+Q_MEDIAN_T, Q_P90_T, HARD_T = 1e-4, 2.5e-4, 5e-3
+
+
+def _oracle_inputs(cloud_s, cloud_t, oracle, src, tgt):
+    a, b = cloud_s.download(), cloud_t.download()
+    ns = oracle.nrm4(np.stack([a["normal_x"], a["normal_y"], a["normal_z"]], 1))
+    nt = oracle.nrm4(np.stack([b["normal_x"], b["normal_y"], b["normal_z"]], 1))
+    return oracle.xyz4(src), ns, oracle.xyz4(tgt), nt
 
 
 @pytest.fixture(scope="module")
 def bench_pairs(ctx, capi, oracle):
+    """the bench's own first 32 pairs at full size, with the oracle's alignment of each (trace included).  The oracle runs are
+    independent: they go through a thread pool (ctypes releases the GIL; 4 OMP threads each, like LOCUS on a Husky)."""
     import os
-    threads = os.cpu_count() or 4
-    out = []
+    from concurrent.futures import ThreadPoolExecutor
     kw = dict(max_iterations=20, max_inner_iterations=20, corr_dist=1.0, transformation_epsilon=1e-12, rotation_epsilon=1e-12)
+    out = []
     for seed in BENCH_SEEDS:
         src, tgt, delta = synth.scan_pair(n_rings=64, n_az=1563, scale=2.0, noise=0.02, seed=seed)
         cs, ct = capi.Cloud(ctx, src), capi.Cloud(ctx, tgt)
         cs.normals_knn(20)   # k = 20 normals from the K3 kernel, exactly as bench.py prepares its inputs
         ct.normals_knn(20)
-        a, b = cs.download(), ct.download()
-        ns = oracle.nrm4(np.stack([a["normal_x"], a["normal_y"], a["normal_z"]], 1))
-        nt = oracle.nrm4(np.stack([b["normal_x"], b["normal_y"], b["normal_z"]], 1))
-        ro = oracle.gicp_align(oracle.xyz4(src), ns, oracle.xyz4(tgt), nt, oracle.default_params(num_threads=threads, **kw))
-        fo = oracle.fitness(oracle.xyz4(src), ro["T"], oracle.Tree(oracle.xyz4(tgt)), threads=threads)
-        out.append(dict(seed=seed, cs=cs, ct=ct, ro=ro, fo=fo, delta=delta))
+        out.append(dict(seed=seed, cs=cs, ct=ct, delta=delta, inputs=_oracle_inputs(cs, ct, oracle, src, tgt)))
+    omp = 4
+    workers = max(1, min(len(out), (os.cpu_count() or 4) // omp))
+
+    def run(p):
+        a = p["inputs"]
+        ro = oracle.gicp_align(a[0], a[1], a[2], a[3], oracle.default_params(num_threads=omp, **kw))
+        fo = oracle.fitness(a[0], ro["T"], oracle.Tree(a[2]), threads=omp)
+        return ro, fo
+    with ThreadPoolExecutor(workers) as ex:
+        for p, (ro, fo) in zip(out, ex.map(run, out)):
+            p["ro"], p["fo"] = ro, fo
     return out, kw
+
+
+def test_bench_pairs_device_loop_32_in_flight_vs_oracle(ctx, capi, oracle, bench_pairs):
+    """The path bench.py times -- lh_gicp_align_batch_out, cost_mode 1, the DEVICE-driven loop (k_solve, group admission, two
+    scheduler streams at 32 pairs in flight) -- on 32 of the bench's own 100 032-point pairs against the oracle
+    (gicp.hpp:445-568): every pose, every iteration count, the cost at the end of the last solve; and the bridge at this size:
+    device loop == host loop, bit for bit."""
+    pairs, kw = bench_pairs
+    S, T = [p["cs"] for p in pairs], [p["ct"] for p in pairs]
+    P = capi.default_params(cost_mode=1, **kw)            # solver 0: the device loop from 8 pairs in flight on
+    res, A = capi.align_batch_out(ctx, P, S, T, max_in_flight=32)
+    host = capi.align_batch(ctx, capi.default_params(cost_mode=1, solver=1, **kw), S, T, max_in_flight=32)
+    dts, drs, its = [], [], []
+    for p, r, h, a in zip(pairs, res, host, A):
+        ro = p["ro"]
+        assert r["status"] == 0 and ro["status"] == 0
+        assert (r["T"] == h["T"]).all() and r["iterations"] == h["iterations"] and r["n_corr_last"] == h["n_corr_last"], p["seed"]   # device loop == host loop
+        g = capi.Gicp(ctx, capi.default_params(cost_mode=1, solver=2, **kw))   # the same pair alone through k_solve, for its trace
+        g.set_source(p["cs"])
+        g.set_target(p["ct"])
+        r1 = g.align()
+        assert (r1["T"] == r["T"]).all() and r1["iterations"] == r["iterations"], p["seed"]   # batching / admission never change results
+        dt, dR = _pose_err(r["T"], ro["T"], oracle)
+        dts.append(dt)
+        drs.append(dR)
+        its.append((r["iterations"], ro["iterations"]))
+        assert r1["trace"]["n_corr"][0] == ro["trace"]["n_corr"][0]          # first sweep: identical inputs => identical correspondences
+        assert abs(r["n_corr_last"] - ro["n_corr_last"]) <= 2e-3 * ro["n_corr_last"]
+        assert abs(r1["trace"]["f_end"][-1] - ro["trace"]["f_end"][-1]) <= 2e-3 * ro["trace"]["f_end"][-1]   # the same valley floor
+        assert r["iterations"] >= 4 and (r["iterations"] == 20 or r["converged"] == 1)
+        # align()'s output cloud, written by the device loop as the pair retired (gicp.hpp:586)
+        want, got = p["cs"].transform(r["T"]).download(), a.download()
+        assert (got["x"] == want["x"]).all() and (got["y"] == want["y"]).all() and (got["z"] == want["z"]).all()
+        Tm = oracle.T_to_mat(r["T"])
+        assert np.abs(Tm[:3, 3] - p["delta"][:3, 3]).max() < 0.02
+    dts, drs = np.array(dts), np.array(drs)
+    print("device loop, %d bench pairs vs oracle: |dt| median %.2e p90 %.2e max %.2e | |dR| max %.2e | iterations (gpu, oracle) %s"
+          % (len(pairs), np.median(dts), np.quantile(dts, 0.9), dts.max(), drs.max(), its))
+    assert np.median(dts) <= Q_MEDIAN_T, np.median(dts)
+    assert np.quantile(dts, 0.9) <= Q_P90_T, np.quantile(dts, 0.9)
+    assert drs.max() <= max(TOL_R, FLOOR_R_MAX), drs.max()
+    # pairs beyond the p90 bar: only where the reference's own two builds part by more than that on the SAME pair
+    L = oracle.lib()
+    import os
+    for k in np.nonzero(dts > Q_P90_T)[0]:
+        a = pairs[k]["inputs"]
+        L.lo_set_cost_variant(1)
+        try:
+            rf = oracle.gicp_align(a[0], a[1], a[2], a[3], oracle.default_params(num_threads=os.cpu_count() or 4, **kw), want_trace=False)
+        finally:
+            L.lo_set_cost_variant(0)
+        floor_k, _ = _pose_err(rf["T"], pairs[k]["ro"]["T"], oracle)
+        print("  pair seed %d: |dt| %.2e, reference FMA / non-FMA distance on this pair %.2e" % (pairs[k]["seed"], dts[k], floor_k))
+        assert floor_k > Q_P90_T and dts[k] <= HARD_T, (pairs[k]["seed"], dts[k], floor_k)
+
+
+def test_bench_pairs_reference_arithmetic_32_pairs(ctx, capi, oracle, bench_pairs):
+    """cost_mode 0 (every per-point operation as in gicp.hpp:362-402) on the same 32 pairs as one batch: SURVEY 8d's 1e-4 on every
+    pair, and the oracle's iteration and correspondence counts."""
+    pairs, kw = bench_pairs
+    out = capi.align_batch(ctx, capi.default_params(cost_mode=0, **kw), [p["cs"] for p in pairs], [p["ct"] for p in pairs], max_in_flight=32)
+    for p, r in zip(pairs, out):
+        dt, dR = _pose_err(r["T"], p["ro"]["T"], oracle)
+        assert r["status"] == 0 and dt <= TOL_T and dR <= TOL_R, (p["seed"], dt, dR)
+        assert r["iterations"] == p["ro"]["iterations"] and r["n_corr_last"] == p["ro"]["n_corr_last"], p["seed"]
 
 
 @pytest.mark.parametrize("cost_mode", [0, 1])
@@ -268,6 +354,7 @@ def test_bench_pairs_full_size_vs_oracle(ctx, capi, oracle, bench_pairs, cost_mo
     per-iteration trace (T, n_corr, f_end) of lh_gicp_align_batch / lh_gicp_align against oracle.gicp_align
     (gicp.hpp:445-568)."""
     pairs, kw = bench_pairs
+    pairs = pairs[:4]   # with their per-iteration traces, one at a time (the other tests take all of them as a batch)
     P = capi.default_params(cost_mode=cost_mode, **kw)
     batch = capi.align_batch(ctx, P, [p["cs"] for p in pairs], [p["ct"] for p in pairs], max_in_flight=4)
     dts, drs = [], []

@@ -61,28 +61,47 @@ def test_config1_plumbing_chain(ctx, capi, oracle):
     assert np.abs(A[:3, 3] - c["delta"][:3, 3]).max() < 0.01
 
 
-def test_config3_scan_to_submap_2M(ctx, capi, oracle):
-    # map = union of scans along a 20 m path, voxelised at 0.05 m; localization parameters
+MAP_POINTS = 2_000_000
+
+
+def _submap_2M(ctx, capi):
+    """the union of 40 scans along a 20 m path, voxelised at 0.05 m, truncated / padded to EXACTLY 2 000 000
+    points.  The voxelised shell of this scene holds fewer than 2 M voxels, so it is padded with a seeded sample of the raw union
+    (distinct returns on the same surfaces); were it larger it would be cut to a seeded subset."""
     scans = []
-    for i in range(24):
-        pose = synth.pose_matrix(tx=-8.0 + 16.0 * i / 23.0, ty=1.5 * np.sin(i / 4.0), yaw=0.05 * np.cos(i / 3.0))
+    for i in range(40):
+        pose = synth.pose_matrix(tx=-10.0 + 20.0 * i / 39.0, ty=1.5 * np.sin(i / 4.0), yaw=0.05 * np.cos(i / 3.0))
         pts = synth.scan(pose, 64, 1563, (-25.0, 15.0), 2.0, 0.01, seed=200 + i)
         scans.append((pts.astype(np.float64) @ pose[:3, :3].T + pose[:3, 3]).astype(np.float32))
     allpts = np.concatenate(scans)
-    mpts = _voxel(ctx, capi, allpts, 0.05)
-    assert 1_000_000 < mpts.shape[0] < 2_600_000, mpts.shape
+    vox = _voxel(ctx, capi, allpts, 0.05)
+    rng = np.random.default_rng(2_000_000)
+    if vox.shape[0] >= MAP_POINTS:
+        mpts = vox[np.sort(rng.choice(vox.shape[0], MAP_POINTS, replace=False))]
+    else:
+        mpts = np.concatenate([vox, allpts[rng.choice(allpts.shape[0], MAP_POINTS - vox.shape[0], replace=False)]])
+    return np.ascontiguousarray(mpts, np.float32), vox.shape[0]
+
+
+def test_config3_scan_to_submap_2M(ctx, capi, oracle):
+    """BASELINE configs[2] at its stated size: one 100 032-point scan against a 2 000 000-point local map under the localization
+    parameters (corr_dist 0.2, 50 inner BFGS iterations, tf_eps 1e-5: PointCloudLocalization.cc:234-240), the whole alignment
+    against the oracle's (MeasurementUpdate's icp_->align, PointCloudLocalization.cc:306-313; gicp.hpp:445-568)."""
+    import os
+    mpts, n_vox = _submap_2M(ctx, capi)
+    assert mpts.shape[0] == MAP_POINTS, (mpts.shape, n_vox)
     cmap = capi.Cloud(ctx, mpts)
     cmap.normals_knn(20)
     true_pose = synth.pose_matrix(tx=0.7, ty=0.2, yaw=0.03)
     q = synth.scan(true_pose, 64, 1563, (-25.0, 15.0), 2.0, 0.01, seed=777)
     cq = capi.Cloud(ctx, q)
     cq.normals_knn(20)
-    # sampled bit-exact NN against the oracle's kd-tree on the 2M-point map (index: depth-9 tree)
-    sel = np.random.default_rng(0).choice(q.shape[0], 3000, replace=False)
+    # bit-exact NN of every scan point against the oracle's kd-tree on the 2M-point map
     guess = synth.pose_matrix(tx=0.7 + 0.1, ty=0.2 - 0.05, yaw=0.03 + 0.01)
-    qs = (q[sel].astype(np.float64) @ guess[:3, :3].T + guess[:3, 3]).astype(np.float32)
+    qs = (q.astype(np.float64) @ guess[:3, :3].T + guess[:3, 3]).astype(np.float32)
     idx, d2 = cmap.nn1(capi.Cloud(ctx, qs))
-    io, do = oracle.Tree(oracle.xyz4(mpts)).nn1(oracle.xyz4(qs), threads=8)
+    otree = oracle.Tree(oracle.xyz4(mpts))
+    io, do = otree.nn1(oracle.xyz4(qs), threads=os.cpu_count() or 8)
     assert (idx == io).all() and (d2 == do).all()
     # the LOCUS flow (Locus.cc:474-489): scan -> fixed frame -> mapper neighbours (one map point per scan point) -> sensor
     # frame -> MeasurementUpdate against those neighbours
@@ -94,24 +113,49 @@ def test_config3_scan_to_submap_2M(ctx, capi, oracle):
     nidx, _ = cmap.nn1(in_fixed)
     assert (np.stack([nd["x"], nd["y"], nd["z"]], 1) == mpts[nidx]).all()
     neigh_s = neigh.transform(oracle.mat_to_T(np.linalg.inv(guess)), with_normals=True)
-    gl = capi.Gicp(ctx, capi.default_params(max_iterations=20, max_inner_iterations=50, corr_dist=0.2, transformation_epsilon=1e-5))
+    kw = dict(max_iterations=20, max_inner_iterations=50, corr_dist=0.2, transformation_epsilon=1e-5)
+    gl = capi.Gicp(ctx, capi.default_params(**kw))
     gl.set_source(cq)
     gl.set_target(neigh_s)
     rl = gl.align()
     Tl = guess @ oracle.T_to_mat(rl["T"])  # pose correction composed with the prior
     assert rl["status"] == 0 and np.abs(Tl[:3, 3] - true_pose[:3, 3]).max() < 0.05
-    # MeasurementUpdate-style alignment: corr_dist 0.2, inner 50, tf_eps 1e-5 (point_cloud_localization yaml)
-    P = capi.default_params(max_iterations=20, max_inner_iterations=50, corr_dist=0.2, transformation_epsilon=1e-5)
-    g = capi.Gicp(ctx, P)
-    g.set_source(cq)
-    g.set_target(cmap)
-    r = g.align(guess=oracle.mat_to_T(guess))
-    assert r["status"] == 0 and r["n_corr_last"] > 0.5 * q.shape[0]
-    T = oracle.T_to_mat(r["T"])
-    assert np.abs(T[:3, 3] - true_pose[:3, 3]).max() < 0.02 and np.abs(T[:3, :3] - true_pose[:3, :3]).max() < 2e-3
-    f = r["trace"]["f_end"]
-    assert f[-1] <= f[0]
-    assert g.fitness() < 0.01
+    # MeasurementUpdate-style alignment of the scan against the WHOLE map, both cost modes, against the oracle on identical inputs
+    # (the device's k = 20 normals downloaded for it)
+    a, b = cq.download(), cmap.download()
+    ro = oracle.gicp_align(oracle.xyz4(q), oracle.nrm4(np.stack([a["normal_x"], a["normal_y"], a["normal_z"]], 1)),
+                           oracle.xyz4(mpts), oracle.nrm4(np.stack([b["normal_x"], b["normal_y"], b["normal_z"]], 1)),
+                           oracle.default_params(num_threads=os.cpu_count() or 8, **kw), guess=oracle.mat_to_T(guess))
+    assert ro["status"] == 0
+    for mode in (0, 1):
+        g = capi.Gicp(ctx, capi.default_params(cost_mode=mode, **kw))
+        g.set_source(cq)
+        g.set_target(cmap)
+        r = g.align(guess=oracle.mat_to_T(guess))
+        A, B = oracle.T_to_mat(r["T"]), oracle.T_to_mat(ro["T"])
+        dt, dR = np.abs(A[:3, 3] - B[:3, 3]).max(), np.abs(A[:3, :3] - B[:3, :3]).max()
+        k = min(len(r["trace"]["n_corr"]), len(ro["trace"]["n_corr"]))
+        print("config 3 (100 032 pts vs %d-pt map, %d of them voxel centroids), cost_mode %d: |dt| %.2e |dR| %.2e, iterations %d / %d, n_corr trace %s / %s"
+              % (MAP_POINTS, n_vox, mode, dt, dR, r["iterations"], ro["iterations"], list(r["trace"]["n_corr"][:k]), list(ro["trace"]["n_corr"][:k])))
+        assert r["status"] == 0 and r["n_corr_last"] > 0.5 * q.shape[0]
+        assert r["trace"]["n_corr"][0] == ro["trace"]["n_corr"][0]      # first sweep: identical inputs => identical correspondences
+        if mode == 0:   # reference arithmetic: SURVEY 8d's bar and the whole per-iteration trace
+            assert dt <= 1e-4 and dR <= 1e-4, (dt, dR)
+            assert r["iterations"] == ro["iterations"] and r["converged"] == ro["converged"]
+            assert (r["trace"]["n_corr"][:k] == ro["trace"]["n_corr"][:k]).all()
+            assert np.abs(r["trace"]["T"][:k] - ro["trace"]["T"][:k]).max() <= 1e-4
+        else:           # moment model: inside the reference's own noise floor (tf_eps 1e-5: the loop runs to its fixed point)
+            assert dt <= 2.5e-4 and dR <= 1.3e-4, (dt, dR)
+            assert np.abs(r["trace"]["n_corr"][:k].astype(np.int64) - ro["trace"]["n_corr"][:k]).max() <= 2e-3 * q.shape[0]
+        T = A
+        assert np.abs(T[:3, 3] - true_pose[:3, 3]).max() < 0.02 and np.abs(T[:3, :3] - true_pose[:3, :3]).max() < 2e-3
+        f = r["trace"]["f_end"]
+        assert f[-1] <= f[0]
+        fit = g.fitness()
+        assert fit < 0.01
+        if mode == 0:
+            fo = oracle.fitness(oracle.xyz4(q), ro["T"], otree, threads=os.cpu_count() or 8)
+            assert abs(fit - fo) <= 1e-4 * fo
 
 
 def test_config5_merged_1M_full_pipeline(ctx, capi, oracle):
@@ -153,6 +197,25 @@ def test_config5_merged_1M_full_pipeline(ctx, capi, oracle):
     assert r["status"] == 0 and r["converged"] == 1
     T = oracle.T_to_mat(r["T"])
     assert np.abs(T[:3, 3] - delta[:3, 3]).max() < 0.03 and np.abs(T[:3, :3] - delta[:3, :3]).max() < 3e-3
+    # ... and it is the reference's alignment of that voxelised pair: the oracle on identical inputs (the device's voxels and normals)
+    import os
+    a1, a0 = c1.download(), c0.download()
+    kw = dict(max_iterations=20, corr_dist=1.0, transformation_epsilon=1e-3)
+    ro = oracle.gicp_align(oracle.xyz4(np.stack([a1["x"], a1["y"], a1["z"]], 1)), oracle.nrm4(np.stack([a1["normal_x"], a1["normal_y"], a1["normal_z"]], 1)),
+                           oracle.xyz4(np.stack([a0["x"], a0["y"], a0["z"]], 1)), oracle.nrm4(np.stack([a0["normal_x"], a0["normal_y"], a0["normal_z"]], 1)),
+                           oracle.default_params(num_threads=os.cpu_count() or 8, **kw))
+    for mode, tol_t, tol_r in ((0, 1e-4, 1e-4), (1, 2e-3, 2.5e-3)):   # mode 1 under the reference's own stopping rule: the stopping scale (test_gpu_align.py)
+        gm = capi.Gicp(ctx, capi.default_params(cost_mode=mode, **kw))
+        gm.set_source(c1)
+        gm.set_target(c0)
+        rm = gm.align()
+        A, B = oracle.T_to_mat(rm["T"]), oracle.T_to_mat(ro["T"])
+        dt, dR = np.abs(A[:3, 3] - B[:3, 3]).max(), np.abs(A[:3, :3] - B[:3, :3]).max()
+        print("config 5 (%d vs %d voxelised points), cost_mode %d: |dt| %.2e |dR| %.2e, iterations %d / %d" % (len(c1), len(c0), mode, dt, dR, rm["iterations"], ro["iterations"]))
+        assert rm["status"] == 0 and rm["converged"] == ro["converged"] == 1 and dt <= tol_t and dR <= tol_r, (mode, dt, dR)
+        assert rm["trace"]["n_corr"][0] == ro["trace"]["n_corr"][0]
+        if mode == 0:
+            assert rm["iterations"] == ro["iterations"] and rm["n_corr_last"] == ro["n_corr_last"]
     # the raw 1 M-point frames also register directly (no voxel grid)
     cr0, cr1 = capi.Cloud(ctx, f0), capi.Cloud(ctx, f1)
     cr0.normals_knn(20)
