@@ -4,7 +4,10 @@
 // the CPU against brute force; the product only ever calls them from HIP kernels (lh_kernels.hip).
 //
 // NN index ("K2", replaces the FLANN kd-tree built by tree_->setInputCloud in pcl::Registration::initCompute):
-//   * target points are sorted by a 30-bit Hilbert-curve index (10 bits per axis of a cubic grid over the cloud's box)
+//   * target points are sorted by a 30-bit Morton (Z-order) index (10 bits per axis of a cubic grid over the cloud's box): a key
+//     PREFIX is then an axis-aligned box whose extent can be read off the prefix length -- what the bottom-up search's
+//     termination test needs (tree_search, NodeUp).  (Round 1-2 sorted along a Hilbert curve, which mattered for the first
+//     layout's equal-count runs; the cell-aligned leaves below are the same sets of grid cells under either curve.)
 //   * LEAVES are cells of that grid hierarchy: the largest key-prefix cell around a point that holds <= LEAF_CAP points
 //     (runs of > LEAF_CAP identical keys are cut into chunks).  A key prefix is an aligned box, so leaves are DISJOINT in
 //     space; equal-count runs of the curve (the previous layout) overlap their neighbours at every level and cost 2-3x
@@ -87,11 +90,27 @@ struct TreeHeader {
   int32_t pad[8];
 };
 static_assert(sizeof(TreeHeader) == 64, "TreeHeader occupies one NodeX slot in front of the nodes");
+// The way UP from a node (the bottom-up search of the GICP sweeps, tree_search<..., kUp>): its 4-ary parent and its CELL -- the
+// key-prefix box every point of the subtree lies in and NO other point of the cloud does (leaves are disjoint cells).  Stored
+// rounded INWARDS on the 16-bit grid of the node boxes: a query strictly inside it at d_out steps from the nearest face is at
+// least d_out steps from every point outside the subtree, so once d_out^2 exceeds the best distance found in the subtree the
+// search is over without ever having seen the levels above.  A face on the grid's own boundary is stored as 0 / 65535 and
+// counts as infinitely far: no point of the cloud lies beyond it.  A node that only separates identical keys has no cell of its
+// own: lo > hi, the test never holds.
+struct alignas(16) NodeUp {
+  uint32_t in_lo_xy;   // lox | loy << 16
+  uint32_t in_hi_xy;   // hix | hiy << 16
+  uint32_t in_z;       // loz | hiz << 16
+  int32_t parent;      // cloud-local 4-ary node index; -1: this node is the root
+};
+static_assert(sizeof(NodeUp) == 16, "one 16-B load per level climbed");
 struct TreeView {
   const float4* pts;        // sorted points (+ LEAF_CAP padding entries of +inf / id INT_MAX)
   const NodeX* nodes;       // internal nodes, cloud-local indices
   const TreeHeader* hdr;    // written by the build kernels (device memory)
   int n_points;
+  const NodeUp* up = nullptr;      // per internal node (same index as `nodes`); only the bottom-up searches read it
+  const int32_t* lpar = nullptr;   // [first sorted position of a leaf] -> the 4-ary node that holds the leaf as a child (-1: the leaf is the root)
 };
 LH_HD int32_t leaf_ref(uint32_t first_pos, int count) { return ~(int32_t)((first_pos << 4) | (uint32_t)(count - 1)); }
 
@@ -256,7 +275,57 @@ LH_HD uint32_t spatial_key30(float px, float py, float pz, float lx, float ly, f
   ix = ix < 0 ? 0 : (ix > 1023 ? 1023 : ix);
   iy = iy < 0 ? 0 : (iy > 1023 ? 1023 : iy);
   iz = iz < 0 ? 0 : (iz > 1023 ? 1023 : iz);
-  return hilbert30((uint32_t)ix, (uint32_t)iy, (uint32_t)iz);
+  return morton30((uint32_t)ix, (uint32_t)iy, (uint32_t)iz);
+}
+LH_HD uint32_t compact10(uint32_t v) {  // every third bit -> 10 bits (inverse of expand10)
+  v &= 0x09249249u;
+  v = (v | (v >> 2)) & 0x030C30C3u;
+  v = (v | (v >> 4)) & 0x0300F00Fu;
+  v = (v | (v >> 8)) & 0x030000FFu;
+  v = (v | (v >> 16)) & 0x000003FFu;
+  return v;
+}
+// The cell of a key prefix: `common` = number of leading bits of the 30-bit key shared by every key of the subtree (0..30).
+// Morton order interleaves x, y, z from the top, so the prefix fixes ceil(common / 3), ceil((common - 1) / 3), ceil((common - 2) / 3)
+// leading bits of the three cell coordinates: an aligned box of 10-bit cells [c0[a], c1[a]] per axis.
+LH_HD void morton_cell(uint32_t key30, int common, uint32_t c0[3], uint32_t c1[3]) {
+  const uint32_t cell[3] = {compact10(key30 >> 2), compact10(key30 >> 1), compact10(key30)};
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    int nb = (common - a + 2) / 3;           // bits of this axis inside the prefix
+    nb = nb < 0 ? 0 : (nb > 10 ? 10 : nb);
+    const uint32_t free_bits = 10u - (uint32_t)nb;
+    c0[a] = (cell[a] >> free_bits) << free_bits;
+    c1[a] = c0[a] + ((1u << free_bits) - 1u);
+  }
+}
+// NodeUp of a node whose keys share `common` leading bits (common >= 30 with > 1 leaf below: identical keys, no cell of its own).
+// Cell a of the 10-bit key grid starts at (a / 1023.999) of the cloud's largest extent = a * (65532 / 1023.999) steps of the
+// 16-bit grid (spatial_key30 / quant_frame: both measure from the same origin).  The key of a point is the truncation of a
+// FLOAT product, so the true boundary can sit a few 1e-7 relative (< 0.02 step) off that value: the faces are moved inwards by
+// a whole step beyond the rounding.  Faces on the grid's boundary (cell 0 / 1023) are marked 0 / 65535: nothing lies beyond.
+LH_HD NodeUp node_up(uint32_t key30, int common, bool has_cell, int32_t parent) {
+  NodeUp u;
+  u.parent = parent;
+  if (!has_cell) {
+    u.in_lo_xy = 0xffffffffu; u.in_hi_xy = 0u; u.in_z = 0x0000ffffu;   // lo = 65535 > hi = 0 on every axis
+    return u;
+  }
+  uint32_t c0[3], c1[3], lo[3], hi[3];
+  morton_cell(key30, common > 30 ? 30 : common, c0, c1);
+  const double steps_per_cell = 65532.0 / 1023.999;
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    double l = ceil((double)c0[a] * steps_per_cell) + 1.0, h = floor((double)(c1[a] + 1u) * steps_per_cell) - 1.0;
+    l = l < 1.0 ? 1.0 : (l > 65534.0 ? 65534.0 : l);     // 0 and 65535 are reserved for the grid's own boundary
+    h = h < 1.0 ? 1.0 : (h > 65534.0 ? 65534.0 : h);
+    lo[a] = c0[a] == 0u ? 0u : (uint32_t)l;
+    hi[a] = c1[a] == 1023u ? 65535u : (uint32_t)h;
+  }
+  u.in_lo_xy = lo[0] | (lo[1] << 16);
+  u.in_hi_xy = hi[0] | (hi[1] << 16);
+  u.in_z = lo[2] | (hi[2] << 16);
+  return u;
 }
 
 LH_HD void cswap(uint64_t& a, uint64_t& b) {
