@@ -766,7 +766,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) k
   sp.matched = false;
   sp.searched = false;
   sp.nonn = false;
-  if (i < d.n) sweep_point<kNormals>(d, T, i, lds_stack + threadIdx.x, sp, a.cert_rel);
+  // LH_EXP_LANES (timing experiments only, results are wrong; tools/ab_lanes.sh): 1 = only every 2nd lane searches, 2 = only every 4th --
+  // does a sweep's time follow the number of LANES that walk (request-bound) or the number of WAVES that do (bound per wave step)?
+  // Measured (round 3): a quarter of the lanes -> 25 / 13 / 14 % less time in the three all-walk sweeps: per wave step.
+  const bool exp_skip = a.pad2 != 0 && (threadIdx.x & (a.pad2 == 1 ? 1 : 3)) != 0;
+  if (i < d.n && !exp_skip) sweep_point<kNormals>(d, T, i, lds_stack + threadIdx.x, sp, a.cert_rel);
   double M6[6] = {0, 0, 0, 0, 0, 0}, Ma[3] = {0, 0, 0}, pt[4] = {0, 0, 0, 0}, pp[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, aMa = 0.0;
   if (sp.matched) moments_of_point(T, sp, M6, Ma, aMa, pt, pp);
   const double live = sp.matched ? 1.0 : (sp.nonn ? NO_NN_MARK : 0.0);
@@ -1117,7 +1121,8 @@ void launch_sweep_fused(const PairDesc* descs, SweepArgs& a, uint32_t split_mask
   static const int refill = []() { const char* e = getenv("LH_WALK_REFILL"); int v = e ? atoi(e) : 16; return v < 1 ? 1 : (v > 64 ? 64 : v); }();
   a.span = sweep_walk_span();
   a.cert_rel = cert_margin();
-  a.pad2 = 0;
+  static const int exp_lanes = []() { const char* e = getenv("LH_EXP_LANES"); return e ? atoi(e) : 0; }();
+  a.pad2 = exp_lanes;
   a.refill = refill;
   SweepArgs f, sp;
   split_jobs(a, wmask ? split_mask : 0u, f, sp);

@@ -27,6 +27,8 @@ def morton_order(pts, bits=10):
 NP = int(os.environ.get("LH_PROBE_PAIRS", "32"))
 for p in range(NP):
     src, tgt, _ = synth.scan_pair(n_rings=64, n_az=1563, scale=2.0, noise=0.02, seed=10 + 2 * p)
+    if os.environ.get("LH_PROBE_TGT_STRIDE"):   # a sparser target (every k-th return): a smaller tree under the same 100 k queries
+        tgt = np.ascontiguousarray(tgt[::int(os.environ["LH_PROBE_TGT_STRIDE"])])
     if os.environ.get("LH_PROBE_SORT") == "1":
         src = src[morton_order(src)]
     elif os.environ.get("LH_PROBE_SORT") == "2":
