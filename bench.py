@@ -52,6 +52,36 @@ def gen_pairs_host(n_pairs, rank, rings, az, scale):
         return pool.map(_gen_pair, jobs, chunksize=4)
 
 
+def trajectory_pose(i, n):
+    """a smooth trajectory through the scene -- two laps of an ellipse (16 x 3.5 m, clear of the cylinders and
+    walls by > 1 m) in 512 steps of ~0.26 m, the sensor's yaw swinging +-0.5 rad independently of the heading (<= 0.7 deg per
+    step), a few centimetres / tenths of a degree of heave, roll and pitch: steps of the size of config 2's perturbations."""
+    t = i / float(n)
+    a = 4.0 * np.pi * t
+    return synth.pose_matrix(16.0 * np.cos(a), 3.5 * np.sin(a), 0.05 * np.sin(6.0 * np.pi * t), np.deg2rad(0.3) * np.sin(10.0 * np.pi * t),
+                             np.deg2rad(0.3) * np.cos(14.0 * np.pi * t), 0.5 * np.sin(4.0 * np.pi * t))
+
+
+def _gen_traj_scan(a):
+    i, n, rings, az, scale = a
+    return synth.scan(trajectory_pose(i, n), rings, az, (-25.0, 15.0), scale, 0.02, seed=100 + i)   # seed 100 + i: SURVEY 8d config 4
+
+
+def gen_trajectory_host(n_scans, rings, az, scale):
+    jobs = [(i, n_scans - 1, rings, az, scale) for i in range(n_scans)]
+    workers = max(1, min(16, (os.cpu_count() or 1) // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))))))
+    if workers <= 1:
+        return [_gen_traj_scan(j) for j in jobs]
+    import multiprocessing as mp
+    with mp.get_context("fork").Pool(workers) as pool:
+        return pool.map(_gen_traj_scan, jobs, chunksize=8)
+
+
+def host_pointf(cloud):
+    """a device cloud as the host array a ROS node holds: pcl::PointXYZINormal layout, 48 B per point"""
+    return cloud.download()
+
+
 def make_pairs(ctx, host):
     """device clouds of the pairs.  Normals are computed on the GPU with the K3 kernel (k=20), like the NormalComputation nodelet
     upstream of GICP."""
@@ -66,13 +96,17 @@ def make_pairs(ctx, host):
     return S, T, host
 
 
-# The reference's own float noise floor at this configuration (tests/perf/reference_noise_floor.py ->
-# profiles/r02_reference_noise_floor.json: the restatement built with vs. without FMA contraction in the functor's float T*p,
-# 16 bench pairs): |dt| 15 of 16 pairs <= 2.4e-4 m, max 2.5e-3 m; |dR| max 1.24e-4.  The benched mode is held to
-# max(1e-4, floor) against the CPU path: asserted below on the pairs the CPU leg samples.
-PARITY_TOL_T = max(1e-4, 2.5e-3)
+# Parity bars of the benched mode (cost_mode 1) against the CPU path on the step's own pairs, asserted on every run -- the same
+# quantile bars as tests/test_gpu_align.py::test_bench_pairs_device_loop_32_in_flight_vs_oracle, from the 64-pair distribution in
+# profiles/r03_fullsize_parity.json (mode 1 vs reference: median 7.5e-5 m, p90 1.6e-4 m, max 3.2e-4 m; the reference's own two
+# builds -- float T*p with / without FMA contraction, gicp.hpp:382 -- against each other: median 7.4e-5, p90 2.4e-4, max 3.3e-3):
+#   the median pair meets SURVEY 8d's 1e-4 m; nine in ten are within 2.5e-4 m; a pair beyond that passes only if the reference's
+#   two builds ALSO part by more than 2.5e-4 m on that very pair (computed here, reported by name), and never beyond 5e-3 m.
+PARITY_MEDIAN_T = 1e-4
+PARITY_P90_T = 2.5e-4
+PARITY_HARD_T = 5e-3
 PARITY_TOL_R = max(1e-4, 1.3e-4)
-PARITY_TYPICAL_T = max(1e-4, 2.4e-4)
+PARITY_PAIRS = 32
 
 
 class _Roctx:
@@ -169,6 +203,130 @@ def cpu_baseline(S, T, host, P):
                       % (best["pairs_timed"], len(S[0]), best["threads"], phys, t_total)}, poses
 
 
+def trajectory_leg(ctx, P, traj_host, args):
+    """BASELINE metric '...; ATE vs ref' / SURVEY 8d config 4: 513 consecutive scans along a smooth trajectory, the 512 pairs (i-1, i)
+    aligned as ONE batch (they are independent: PointCloudOdometry.cc:243-267), poses chained with PoseUpdate (:308-309);
+    ATE = RMSE of the chained positions against ground truth (all 513 poses) and against the CPU path's chain on a prefix.
+    Also the PCIe-inclusive rate of the same stream from HOST arrays (lh_gicp_align_batch_multi_views)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle as O
+    n = len(traj_host)
+    clouds = []
+    for pts in traj_host:
+        c = capi.Cloud(ctx, pts)
+        c.normals_knn(20)
+        c.drop_index()
+        clouds.append(c)
+    src, tgt = clouds[1:], clouds[:-1]
+    capi.align_batch(ctx, P, src[:64], tgt[:64], max_in_flight=64)   # warm-up of this shape
+    for c in clouds:
+        c.drop_index()
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    out = capi.align_batch(ctx, P, src, tgt, max_in_flight=args.in_flight)
+    ctx.synchronize()
+    dt = time.perf_counter() - t0
+    poses = [trajectory_pose(i, n - 1) for i in range(n)]
+    gt = np.stack([np.linalg.inv(poses[0]) @ p for p in poses])
+    chain = ldist.chain_poses(np.stack([o["T"] for o in out]))
+
+    def ate(a, b):
+        return float(np.sqrt(np.mean(np.sum((a[:, :3, 3] - b[:, :3, 3]) ** 2, axis=1))))
+    step_err = [float(np.abs(np.asarray(o["T"], np.float64).reshape(4, 4).T[:3, 3] - (np.linalg.inv(poses[i]) @ poses[i + 1])[:3, 3]).max()) for i, o in enumerate(out)]
+    res = {"scans": n, "pairs": n - 1, "points_per_scan": int(len(clouds[0])), "all_ok": bool(all(o["status"] == 0 for o in out)),
+           "pairs_per_s": round((n - 1) / dt, 2), "path_length_m": float(np.sum(np.linalg.norm(np.diff(gt[:, :3, 3], axis=0), axis=1))),
+           "ate_vs_ground_truth_m": ate(chain, gt), "max_single_step_translation_err_m": max(step_err),
+           "final_position_err_m": float(np.linalg.norm(chain[-1, :3, 3] - gt[-1, :3, 3]))}
+    # the CPU path's chain on a prefix (reference arithmetic, 4 OMP threads per pair, the pairs concurrently)
+    n_cpu = min(16, n - 1)
+    okw = dict(max_iterations=P.max_iterations, max_inner_iterations=P.max_inner_iterations, corr_dist=P.corr_dist,
+               transformation_epsilon=P.transformation_epsilon, rotation_epsilon=P.rotation_epsilon, gicp_epsilon=P.gicp_epsilon)
+    dl = [clouds[i].download() for i in range(n_cpu + 1)]
+
+    def inp(d):
+        return O.xyz4(np.stack([d["x"], d["y"], d["z"]], 1)), O.nrm4(np.stack([d["normal_x"], d["normal_y"], d["normal_z"]], 1))
+    ins = [inp(d) for d in dl]
+    with ThreadPoolExecutor(max(1, min(n_cpu, physical_cores() // 4))) as ex:
+        cpu = list(ex.map(lambda i: O.gicp_align(ins[i + 1][0], ins[i + 1][1], ins[i][0], ins[i][1], O.default_params(num_threads=4, **okw), want_trace=False), range(n_cpu)))
+    cchain = ldist.chain_poses(np.stack([r["T"] for r in cpu]))
+    res["cpu_chain_prefix_pairs"] = n_cpu
+    res["ate_vs_cpu_chain_prefix_m"] = ate(chain[: n_cpu + 1], cchain)
+    res["cpu_chain_prefix_ate_vs_ground_truth_m"] = ate(cchain, gt[: n_cpu + 1])
+    res["gpu_chain_prefix_ate_vs_ground_truth_m"] = ate(chain[: n_cpu + 1], gt[: n_cpu + 1])
+    # PCIe-inclusive: the same stream handed over as HOST PointXYZINormal arrays (what the ROS node holds): every scan uploaded once
+    # (scan i is the source of pair i and the target of pair i + 1), aligned, only the 96-byte results come back
+    n_pc = min(129, n)
+    hostf = [host_pointf(clouds[i]) for i in range(n_pc)]
+    capi.align_batch_multi_views([ctx], P, hostf[1:9], hostf[:8], max_in_flight=8)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    outv = capi.align_batch_multi_views([ctx], P, hostf[1:], hostf[:-1], max_in_flight=min(args.in_flight, n_pc - 1))
+    ctx.synchronize()
+    dtv = time.perf_counter() - t0
+    res["pcie_inclusive"] = {"pairs": n_pc - 1, "pairs_per_s": round((n_pc - 1) / dtv, 2), "bytes_uploaded_per_scan": int(hostf[0].nbytes),
+                             "same_results_as_resident": bool(all((np.asarray(a["T"]) == np.asarray(b["T"])).all() for a, b in zip(outv, out[: n_pc - 1]))),
+                             "what": "lh_gicp_align_batch_multi_views: host arrays (48 B / point) -> repack + upload of every scan once -> align -> results"}
+    for c in clouds:
+        c.close()
+    return res
+
+
+def production_leg(ctx):
+    """LOCUS's real operating point (lo_settings.yaml:84-85, Locus.cc:451-453, 780-810): ~3 000 points per scan after the adaptive
+    voxel grid, ONE pair at a time (lidar queue depth 1), the reference's own stopping rule -- through the drop-in mirror
+    locus_amd/host/PointCloudOdometry (host clouds in, aligned host cloud out, the previous query promoted to target on the GPU),
+    PCIe and every synchronisation included, beside the CPU path at LOCUS's 4 OMP threads on the same scans."""
+    import subprocess
+    import tempfile
+    from oracle import oracle as O
+    exe = os.path.join(ROOT, "locus_amd", "host", "odometry_stream")
+    if not os.path.exists(exe):
+        return {"skipped": "locus_amd/host/odometry_stream not built"}
+    n_scans = 40
+    scans = []
+    leaf = 0.35
+    for i in range(n_scans):   # VLP-16 pattern (SURVEY 8d config 1) along a short path, voxelised to ~3 000 points, k = 20 normals (the nodelet chain)
+        pose = synth.pose_matrix(0.12 * i, 0.03 * np.sin(0.5 * i), 0.0, 0.0, 0.0, 0.01 * i)
+        pts = synth.scan(pose, 16, 1800, (-15.0, 15.0), 1.0, 0.02, seed=900 + i)
+        raw = capi.Cloud(ctx, capi.make_pointxyzi(pts))
+        c = raw.voxel_grid(leaf)
+        for _ in range(6 if i == 0 else 0):   # the adaptive controller's job (Locus.cc:780-810): a leaf that leaves ~3 000 points
+            if 2800 <= len(c) <= 3200:
+                break
+            leaf *= (len(c) / 3000.0) ** 0.6
+            c = raw.voxel_grid(leaf)
+        c.normals_knn(20)
+        scans.append(host_pointf(c))
+    with tempfile.NamedTemporaryFile(suffix=".bin", delete=False) as f:
+        f.write(np.int32(n_scans).tobytes())
+        for a in scans:
+            f.write(np.int32(len(a)).tobytes())
+            f.write(a.tobytes())
+        path = f.name
+    res = {"points_per_scan_mean": float(np.mean([len(a) for a in scans])), "scans": n_scans, "voxel_leaf_m": round(float(leaf), 4)}
+    try:
+        for tag, env in (("gpu_promote", {}), ("gpu_two_uploads", {"LOCUS_HIP_NO_PROMOTE": "1"})):
+            o = subprocess.run([exe, path, "3"], capture_output=True, text=True, timeout=120, env=dict(os.environ, **env))
+            res[tag] = json.loads(o.stdout.strip().splitlines()[-1]) if o.returncode == 0 and o.stdout.strip() else {"error": (o.stderr or o.stdout)[-300:]}
+    finally:
+        os.unlink(path)
+    # the CPU path on the same scans: oracle.gicp_align at 4 OMP threads (LOCUS Husky default), tree build + covariances + 20-iteration loop
+    kw = dict(max_iterations=20, max_inner_iterations=20, corr_dist=1.0, transformation_epsilon=1e-3, rotation_epsilon=2e-3)
+    times = []
+    for i in range(1, n_scans):
+        a, b = scans[i], scans[i - 1]
+        s4, sn = O.xyz4(np.stack([a["x"], a["y"], a["z"]], 1)), O.nrm4(np.stack([a["normal_x"], a["normal_y"], a["normal_z"]], 1))
+        t4, tn = O.xyz4(np.stack([b["x"], b["y"], b["z"]], 1)), O.nrm4(np.stack([b["normal_x"], b["normal_y"], b["normal_z"]], 1))
+        t0 = time.perf_counter()
+        O.gicp_align(s4, sn, t4, tn, O.default_params(num_threads=4, **kw), want_trace=False)
+        if i > 3:
+            times.append(1e3 * (time.perf_counter() - t0))
+    res["cpu_4_threads_ms_per_update_median"] = float(np.median(times))
+    if isinstance(res.get("gpu_promote"), dict) and res["gpu_promote"].get("ms_per_update_median"):
+        res["speedup_vs_cpu_4_threads"] = round(res["cpu_4_threads_ms_per_update_median"] / res["gpu_promote"]["ms_per_update_median"], 2)
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -184,6 +342,10 @@ def main():
     ap.add_argument("--quick", action="store_true", help="timed region only: no roofline / mode-0 / natural-convergence / CPU legs (A/B runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single-latency", action="store_true", help="skip the one-pair-at-a-time lh_gicp_align latency leg")
+    ap.add_argument("--strong", action="store_true", help="strong scaling: --pairs is the TOTAL over all ranks (BASELINE configs[3]: 512 pairs over "
+                                                          "8 GPUs = 64 per GPU); default = weak scaling, --pairs per GPU")
+    ap.add_argument("--no-trajectory", action="store_true", help="skip the 513-scan trajectory leg (ATE of the chained poses)")
+    ap.add_argument("--trajectory-scans", type=int, default=513)
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the measured configuration) or gloo (functional check)")
     ap.add_argument("--same-gpu", action="store_true",
                     help="functional check of the N > 1 code path on a 1-GPU box: every rank uses cuda:0 (needs --dist-backend gloo); "
@@ -194,7 +356,15 @@ def main():
     import faulthandler
     faulthandler.dump_traceback_later(float(os.environ.get("LH_BENCH_WATCHDOG_S", "1500")), exit=True)
 
-    host_pairs = gen_pairs_host(args.pairs, int(os.environ.get("RANK", "0")), args.rings, args.azimuths, args.scale)   # (before any GPU runtime: worker processes)
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.strong:   # the same total work whatever the number of GPUs: this rank's contiguous block of the pairs
+        lo, hi = ldist.shard_range(args.pairs, int(os.environ.get("RANK", "0")), world_env)
+        pairs_here = hi - lo
+    else:
+        pairs_here = args.pairs
+    host_pairs = gen_pairs_host(pairs_here, int(os.environ.get("RANK", "0")), args.rings, args.azimuths, args.scale)   # (before any GPU runtime: worker processes)
+    want_traj = (not args.quick and not args.no_trajectory and world_env == 1 and int(os.environ.get("RANK", "0")) == 0)
+    traj_host = gen_trajectory_host(args.trajectory_scans, args.rings, args.azimuths, args.scale) if want_traj else None
 
     import torch
     import torch.distributed as dist
@@ -229,10 +399,10 @@ def main():
     _, A = capi.align_batch_out(ctx, P, S, T, max_in_flight=args.in_flight)
     gathered = [None]
 
-    def step(in_flight=None, exchange=True):
+    def step(in_flight=None, exchange=True, params=None):
         for t in T:
             t.drop_index()  # align() rebuilds the target index every scan, like pcl::Registration::initCompute
-        raw, _ = capi.align_batch_out(ctx, P, S, T, max_in_flight=in_flight or args.in_flight, aligned=A, raw=True)
+        raw, _ = capi.align_batch_out(ctx, params or P, S, T, max_in_flight=in_flight or args.in_flight, aligned=A, raw=True)
         if world > 1 and exchange:
             # the ONLY exchange of the pair-sharded path: one all_gather of the lh_gicp_result records (96 B per pair)
             # on device tensors over RCCL/xGMI; no data-path collective
@@ -266,7 +436,7 @@ def main():
         got = bytes(gathered[0].cpu().numpy().tobytes())[rank * len(mine):(rank + 1) * len(mine)]
         assert got == mine, "result all_gather corrupted the records"
     out = results(out)
-    total_pairs = args.pairs * args.steps * world
+    total_pairs = (args.pairs if args.strong else args.pairs * world) * args.steps
     value = total_pairs / elapsed
     ok = all(o["status"] == 0 for o in out)
     iters = [int(o["iterations"]) for o in out]
@@ -286,22 +456,31 @@ def main():
     if rank == 0:
         # ---- roofline leg: the same steps again with HIP-event timing of every launch on the library's stream ----
         # Profiling runs ONE scheduler group so kernels never overlap; to time launches of the same shape as the timed
-        # region's (four groups of in_flight/4 pairs each) the leg runs with in_flight/4 pairs per launch.
+        # region's (groups of 32 pairs each) the leg runs with in_flight / groups pairs per launch.
         groups = min(32, args.in_flight // 32) if args.in_flight >= 64 else (2 if args.in_flight >= 16 else 1)   # the scheduler's groups (lh_api.hip run_tasks_device)
         prof_in_flight = max(8, args.in_flight // groups)
-        ctx.profile(True)
-        ctx.profile_reset()
-        ctx.synchronize()
-        roctx.push("profile_leg")
-        for _ in range(max(1, min(args.steps, 2))):
-            step(prof_in_flight, exchange=False)  # rank 0 only: no collective may be called here
-        stats = ctx.profile_get()
-        ctx.synchronize()
-        roctx.pop()
-        ctx.profile(False)
-        dom = max(stats.items(), key=lambda kv: kv[1]["ms"])
-        name, st = dom
-        achieved = st["bytes"] / 1e9 / (st["ms"] / 1e3) if st["ms"] > 0 else 0.0
+
+        def roofline_leg(params, tag, reps):
+            ctx.profile(True)
+            ctx.profile_reset()
+            ctx.synchronize()
+            roctx.push(tag)
+            for _ in range(reps):
+                step(prof_in_flight, exchange=False, params=params)  # rank 0 only: no collective may be called here
+            stats = ctx.profile_get()
+            ctx.synchronize()
+            roctx.pop()
+            ctx.profile(False)
+            name, st = max(stats.items(), key=lambda kv: kv[1]["ms"])
+            achieved = st["bytes"] / 1e9 / (st["ms"] / 1e3) if st["ms"] > 0 else 0.0
+            avg_us = 1e3 * st["ms"] / max(1, st["launches"])
+            return name, st, stats, {
+                "bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "avg_launch_us": round(avg_us, 2), "launches": st["launches"],
+                "jobs_per_launch": prof_in_flight, "algorithmic_bytes_per_launch": round(st["bytes"] / max(1, st["launches"]), 1),
+                "kernels_ms": {k: round(v["ms"], 3) for k, v in sorted(stats.items(), key=lambda kv: -kv[1]["ms"])}}
+
+        name, st, stats, roofline = roofline_leg(None, "profile_leg", max(1, min(args.steps, 2)))
         traffic = None
         pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc_path):
@@ -312,27 +491,25 @@ def main():
                     traffic = traffic * prof_in_flight / ent["jobs_per_launch"]
             except Exception:
                 traffic = None
-        avg_us = 1e3 * st["ms"] / max(1, st["launches"])
         # hbm_frac_real: the kernel's MEASURED DRAM traffic (PMC, profiles/pmc_latest.json) / its launch time / peak -- how busy HBM
         # really is.  A fused kernel legitimately moves fewer bytes than the algorithmic model, so this sits below `frac`.
-        hbm_frac_real = round(traffic / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5) if traffic else None
-        roofline = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "hbm_frac_real": hbm_frac_real,
-                    "avg_launch_us": round(avg_us, 2), "launches": st["launches"],
-                    "jobs_per_launch": prof_in_flight,
-                    "algorithmic_bytes_per_launch": round(st["bytes"] / max(1, st["launches"]), 1),
-                    "kernels_ms": {k: round(v["ms"], 3) for k, v in sorted(stats.items(), key=lambda kv: -kv[1]["ms"])}}
+        roofline["traffic"] = traffic
+        roofline["hbm_frac_real"] = round(traffic / (roofline["avg_launch_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 5) if traffic else None
+        roofline["traffic_source"] = ("carried from profiles/pmc_latest.json (rocprofv3 --pmc passes of tools/pmc_traffic.sh on this kernel, a builder-side "
+                                      "run scaled to this leg's jobs per launch); NOT measured by this command") if traffic else None
+        roofline["measured_in"] = ("a separate leg of this command with HIP events around every launch and ONE scheduler group at a time (launches never "
+                                   "overlap); the timed region overlaps sixteen groups, where the same kernels take longer per launch")
         result = {
             "metric": "GICP scan-pairs/s (100k-pt clouds, 20 iters)", "value": round(value, 3), "unit": "scan-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 geometry / f64 cost",
+            "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "f32 geometry / f64 cost",
             "data": "synthetic",
             "config": {"workload": "configs[1]: 100k-pt Velodyne-style scan-to-scan GICP, 20 outer iterations (stopping thresholds "
                                    "-> 0; a pair whose iterate repeats bit for bit stops earlier, gicp.hpp:566, exactly as the reference "
                                    "does: see outer_iterations_min_mean_max), odometry params (corr_dist 1.0, inner 20), covariances from "
                                    "k=20 normals, index rebuilt and aligned output cloud written for every pair; %d independent pairs per "
-                                   "GPU per step, %d in flight" % (args.pairs, args.in_flight),
-                       "points_per_scan": n_pts, "pairs_per_gpu_per_step": args.pairs, "parallelism": "pairs sharded over %d GPU(s)" % world},
+                                   "GPU per step, %d in flight" % (pairs_here, min(args.in_flight, pairs_here)),
+                       "points_per_scan": n_pts, "pairs_per_gpu_per_step": pairs_here, "parallelism": "pairs sharded over %d GPU(s)" % world},
             "all_ok": bool(ok), "outer_iterations_min_mean_max": [min(iters), float(np.mean(iters)), max(iters)],
             "cost_mode": args.cost_mode, "mean_cost_evaluations_per_pair": passes, "max_translation_err_vs_truth_m": float(np.max(errs)),
             "roofline": roofline,
@@ -365,7 +542,7 @@ def main():
             out0 = step0()
             ctx.synchronize()
             dt0 = time.perf_counter() - t1
-            result["cost_mode0"] = {"value": round(args.pairs / dt0, 2), "unit": "scan-pairs/s",
+            result["cost_mode0"] = {"value": round(pairs_here / dt0, 2), "unit": "scan-pairs/s",
                                     "max_abs_pose_diff_vs_mode1": float(max(np.abs(np.asarray(a["T"]) - np.asarray(b["T"])).max()
                                                                             for a, b in zip(out0, out)))}
         if world == 1:
@@ -387,30 +564,79 @@ def main():
             dtn = time.perf_counter() - t1
             itn = [int(o["iterations"]) for o in outn]
             result["natural_convergence"] = {
-                "value": round(args.pairs / dtn, 2), "unit": "scan-pairs/s", "iterations_min_mean_max": [min(itn), float(np.mean(itn)), max(itn)],
+                "value": round(pairs_here / dtn, 2), "unit": "scan-pairs/s", "iterations_min_mean_max": [min(itn), float(np.mean(itn)), max(itn)],
                 "all_converged": bool(all(o["converged"] == 1 for o in outn)),
                 "max_abs_pose_diff_vs_20_forced_iterations": float(max(np.abs(np.asarray(a["T"]) - np.asarray(b["T"])).max() for a, b in zip(outn, out)))}
+            # ... and the roofline of ITS dominant kernel (nearly every sweep of this regime is an all-walk sweep + the index build and seed pass)
+            _, _, _, rn = roofline_leg(Pn, "profile_leg_natural", 1)
+            result["natural_convergence"]["roofline"] = rn
+            # BASELINE configs[3] gives each GPU 64 pairs: the same step with 64 pairs in flight (two scheduler streams) instead of 512
+            if args.in_flight > 64 and pairs_here >= 64:
+                step(64, exchange=False)
+                ctx.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(2):
+                    step(64, exchange=False)
+                ctx.synchronize()
+                result["in_flight_64"] = {"value": round(2 * pairs_here / (time.perf_counter() - t1), 2), "unit": "scan-pairs/s",
+                                          "what": "the timed step with max_in_flight = 64 (configs[3]'s per-GPU load: 512 pairs over 8 GPUs)"}
+        if world == 1 and traj_host is not None:
+            result["trajectory"] = trajectory_leg(ctx, P, traj_host, args)
+        if world == 1 and not args.no_cpu_baseline:
+            result["production_operating_point"] = production_leg(ctx)
         if world == 1 and not args.no_cpu_baseline:
             cb, poses = cpu_baseline(S, T, host, P)
-            # parity of the TIMED GPU work against the CPU path on every pair the CPU leg sampled: asserted against the stated
-            # tolerance max(1e-4, reference noise floor at this configuration) -- tests/test_gpu_align.py holds the same bar
+            result["cpu_baseline"] = cb
+            # parity of the TIMED GPU work against the CPU path: the pairs the CPU leg timed plus (untimed, run concurrently: 4 OMP
+            # threads each) enough more of the step's pairs to make PARITY_PAIRS, held to the quantile bars above
+            from concurrent.futures import ThreadPoolExecutor
+            from oracle import oracle as O
+            okw = dict(max_iterations=P.max_iterations, max_inner_iterations=P.max_inner_iterations, corr_dist=P.corr_dist,
+                       transformation_epsilon=P.transformation_epsilon, rotation_epsilon=P.rotation_epsilon, gicp_epsilon=P.gicp_epsilon)
+
+            def oracle_inputs(k):
+                a, b = S[k].download(), T[k].download()
+                return (O.xyz4(np.stack([a["x"], a["y"], a["z"]], 1)), O.nrm4(np.stack([a["normal_x"], a["normal_y"], a["normal_z"]], 1)),
+                        O.xyz4(np.stack([b["x"], b["y"], b["z"]], 1)), O.nrm4(np.stack([b["normal_x"], b["normal_y"], b["normal_z"]], 1)))
+
+            extra = [k for k in range(min(PARITY_PAIRS, len(S))) if k not in poses]
+            ins = {k: oracle_inputs(k) for k in extra}
+            with ThreadPoolExecutor(max(1, min(len(extra), physical_cores() // 4))) as ex:
+                for k, r in zip(extra, ex.map(lambda k: O.gicp_align(*ins[k], O.default_params(num_threads=4, **okw), want_trace=False), extra)):
+                    poses[k] = r["T"]
+            keys = sorted(poses)
             dts, drs = [], []
-            for k, To in sorted(poses.items()):
-                A_, B_ = np.asarray(out[k]["T"], np.float64).reshape(4, 4).T, np.asarray(To, np.float64).reshape(4, 4).T
+            for k in keys:
+                A_, B_ = np.asarray(out[k]["T"], np.float64).reshape(4, 4).T, np.asarray(poses[k], np.float64).reshape(4, 4).T
                 dts.append(float(np.abs(A_[:3, 3] - B_[:3, 3]).max()))
                 drs.append(float(np.abs(A_[:3, :3] - B_[:3, :3]).max()))
             cb["max_abs_pose_diff_vs_gpu"] = max(max(dts), max(drs))
-            result["cpu_baseline"] = cb
-            tol_t, tol_r = (1e-4, 1e-4) if args.cost_mode == 0 else (PARITY_TOL_T, PARITY_TOL_R)
+            outliers = []
+            if args.cost_mode == 1:
+                L = O.lib()
+                for k, d in zip(keys, dts):
+                    if d > PARITY_P90_T:   # the reference's own FMA / non-FMA distance on THIS pair
+                        L.lo_set_cost_variant(1)
+                        try:
+                            rf = O.gicp_align(*(ins[k] if k in ins else oracle_inputs(k)), O.default_params(num_threads=physical_cores(), **okw), want_trace=False)
+                        finally:
+                            L.lo_set_cost_variant(0)
+                        Af, Bf = np.asarray(rf["T"], np.float64).reshape(4, 4).T, np.asarray(poses[k], np.float64).reshape(4, 4).T
+                        outliers.append({"pair": int(k), "dt_m": d, "reference_fma_vs_nonfma_dt_m": float(np.abs(Af[:3, 3] - Bf[:3, 3]).max())})
+            q50, q90 = float(np.median(dts)), float(np.quantile(dts, 0.9))
+            if args.cost_mode == 0:   # reference arithmetic, only the summation order differs: the same quantile shape one decade lower (tests: median 0.0)
+                parity_ok = q50 <= 1e-6 and q90 <= 1e-4 and max(dts) <= PARITY_P90_T and max(drs) <= 1e-4
+            else:
+                parity_ok = (q50 <= PARITY_MEDIAN_T and q90 <= PARITY_P90_T and max(drs) <= PARITY_TOL_R and max(dts) <= PARITY_HARD_T and
+                             all(o["reference_fma_vs_nonfma_dt_m"] > PARITY_P90_T for o in outliers))
             result["parity"] = {
-                "against": "cpu_baseline poses (reference arithmetic), the %d pairs the CPU leg sampled" % len(dts),
-                "tolerance_translation_m": tol_t, "tolerance_rotation": tol_r, "typical_translation_m": PARITY_TYPICAL_T,
-                "tolerance_is": "1e-4 (SURVEY 8d)" if args.cost_mode == 0 else
-                                "max(1e-4, the reference's own FMA / non-FMA noise floor at this configuration, profiles/r02_reference_noise_floor.json)",
-                "max_dt_m": max(dts), "median_dt_m": float(np.median(dts)), "max_dR": max(drs),
-                "pairs_within_typical": int(sum(d <= PARITY_TYPICAL_T for d in dts)), "n_pairs": len(dts)}
-            parity_ok = max(dts) <= tol_t and max(drs) <= tol_r and (args.cost_mode == 0 or float(np.median(dts)) <= PARITY_TYPICAL_T)
-            result["parity"]["ok"] = bool(parity_ok)
+                "against": "CPU path (reference arithmetic, oracle) on %d of the step's own pairs: the ones the CPU leg timed + the rest of the first %d, "
+                           "4 OMP threads each" % (len(dts), PARITY_PAIRS),
+                "bars": {"median_dt_m": PARITY_MEDIAN_T, "p90_dt_m": PARITY_P90_T, "max_dR": PARITY_TOL_R, "hard_max_dt_m": PARITY_HARD_T,
+                         "beyond_p90_bar": "only pairs on which the reference's own FMA / non-FMA builds part by more than the bar (listed)"},
+                "median_dt_m": q50, "p90_dt_m": q90, "max_dt_m": max(dts), "max_dR": max(drs), "n_pairs": len(dts),
+                "pairs_within_1e-4": int(sum(d <= 1e-4 for d in dts)), "pairs_beyond_p90_bar": outliers,
+                "distribution_over_64_pairs": "profiles/r03_fullsize_parity.json", "ok": bool(parity_ok)}
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

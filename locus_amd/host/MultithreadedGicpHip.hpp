@@ -59,7 +59,11 @@ public:
     check(lh_gicp_set_target(g_, &v), "setInputTarget");
   }
   // odometry fast path: the previous query becomes the reference without leaving the GPU
-  void promoteSourceToTarget() { tgt_ = src_; check(lh_gicp_promote_source_to_target(g_), "promoteSourceToTarget"); }
+  // (reference_cloud: the host copy the caller holds of that same data -- what getInputTarget() would return)
+  void promoteSourceToTarget(const PointCloudF::Ptr& reference_cloud = PointCloudF::Ptr()) {
+    tgt_ = reference_cloud ? reference_cloud : src_;
+    check(lh_gicp_promote_source_to_target(g_), "promoteSourceToTarget");
+  }
 
   // pcl::Registration::align(output) / align(output, guess): column-major 4x4 like Eigen::Matrix4f
   void align(PointCloudF& output, const float* guess = nullptr) override {

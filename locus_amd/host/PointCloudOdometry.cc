@@ -1,6 +1,7 @@
 // PointCloudOdometry.cc -- control flow of point_cloud_odometry/src/PointCloudOdometry.cc:136-322 on the HIP path.
 #include "PointCloudOdometry.hpp"
 
+#include <cstdlib>
 #include <cstring>
 
 namespace locus_hip {
@@ -96,8 +97,16 @@ bool PointCloudOdometry::UpdateICP() {  // :249-322
       p.z = static_cast<float>(prior[8] * x + prior[9] * y + prior[10] * z + prior[11]);
     }
   }
+  // The reference of this update is the query of the last one (copyPointCloud(*query_, *reference_), :243).  When that query went
+  // to the registration object unchanged (no sensor prior was applied to it), it is already on the GPU as the previous SOURCE: it
+  // is promoted to target there (lh_gicp_promote_source_to_target: same data, same index build inside align, identical result)
+  // instead of being uploaded a second time.  LOCUS_HIP_NO_PROMOTE=1 restores the two uploads per scan (host_check compares both).
+  MultithreadedGicpHip* gicp = dynamic_cast<MultithreadedGicpHip*>(icp_.get());
+  static const bool no_promote = []() { const char* e = getenv("LOCUS_HIP_NO_PROMOTE"); return e && atoi(e) != 0; }();
+  if (gicp && device_source_is_last_query_ && device_promotion_ && !no_promote) gicp->promoteSourceToTarget(reference_);
+  else icp_->setInputTarget(reference_);
   icp_->setInputSource(query_trans_);
-  icp_->setInputTarget(reference_);
+  device_source_is_last_query_ = !have_prior;   // (with a prior the uploaded source is the MOVED query, not what the next update's reference is)
   icp_->align(icpAlignedPointsOdometry_);
   double T[16];
   for (int r = 0; r < 4; r++)

@@ -53,6 +53,8 @@ public:
   void EnableOdometryIntegration();
   void DisableSensorIntegration();
   void SetFlatGroundAssumptionValue(const bool& value);
+  // (not in the reference) false: upload the reference cloud every update instead of promoting the previous query on the GPU; results are identical
+  void EnableDevicePromotion(bool on) { device_promotion_ = on; }
 
   // diagnostic_msgs::DiagnosticStatus analogue: level 0 = OK, 2 = ERROR (PointCloudOdometry.cc:367-380)
   struct Diagnostics { int level; std::string message; };
@@ -76,6 +78,8 @@ private:
   double imu_delta_[9];
   double odometry_delta_[16];
   bool b_is_flat_ground_assumption_ = false;
+  bool device_promotion_ = true;
+  bool device_source_is_last_query_ = false;   // the registration object's device-resident source is *query_ as it was set (UpdateICP)
 };
 
 }  // namespace locus_hip

@@ -98,6 +98,41 @@ int main() {
     EXPECT_NEAR(pco.GetIncrementalEstimate().translation.z, 0.0, 1e-12);
   }
 
+  {  // a stream of scans: from the third scan on the reference cloud is the previous query, already on the GPU -- promoted there
+     // (lh_gicp_promote_source_to_target) instead of uploaded again.  Same data, same index build: the poses must be IDENTICAL to
+     // the wrapper that uploads both clouds every update, with and without a sensor prior in between.
+    auto pc_box = GenerateHollowCubic(ctx);
+    std::vector<PointCloudF> stream;
+    for (int k = 0; k < 6; k++) {
+      PointCloudF c = *pc_box;
+      for (auto& p : c.points) { p.x += 0.02f * k; p.y -= 0.015f * k; p.z += 0.004f * (k % 3); }
+      stream.push_back(c);
+    }
+    double poses[2][6][3];
+    for (int promote = 0; promote < 2; promote++) {
+      PointCloudOdometry pco(ctx);
+      PointCloudOdometry::Config cfg;
+      EXPECT(pco.Initialize(cfg));
+      pco.EnableDevicePromotion(promote != 0);
+      for (int k = 0; k < 6; k++) {
+        if (k == 4) {   // one update with an odometry prior in the middle: the moved query is NOT what the next reference is
+          pco.EnableOdometryIntegration();
+          double prior[16] = {1, 0, 0, 0.01, 0, 1, 0, -0.01, 0, 0, 1, 0, 0, 0, 0, 1};
+          pco.SetOdometryDelta(prior);
+        } else
+          pco.DisableSensorIntegration();
+        EXPECT(pco.SetLidar(stream[k]));
+        EXPECT(pco.UpdateEstimate() == (k > 0));
+        poses[promote][k][0] = pco.GetIntegratedEstimate().translation.x;
+        poses[promote][k][1] = pco.GetIntegratedEstimate().translation.y;
+        poses[promote][k][2] = pco.GetIntegratedEstimate().translation.z;
+      }
+    }
+    for (int k = 0; k < 6; k++)
+      for (int a = 0; a < 3; a++) EXPECT(poses[0][k][a] == poses[1][k][a]);
+    EXPECT(std::fabs(poses[1][5][0]) > 0.05);   // (and the stream did move)
+  }
+
   {  // a NON-identity odometry prior (PointCloudOdometry.cc:256-275): the query is moved by the prior in double arithmetic
      // (pcl::transformPointCloud with a Matrix4d), GICP only finds the remainder, and T * prior is the whole motion
     PointCloudOdometry pco(ctx);
