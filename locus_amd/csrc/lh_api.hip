@@ -476,8 +476,9 @@ static lh_status build_indices(lh_ctx* x, lh_cloud* const* clouds, int n_clouds,
     while ((1 << id_bits) < nb) id_bits++;
     { ProfScope p(x, "index_bbox_keys", 16.0 * total * 2, s); launch_index_keys(x->idx_descs_dev, nb, max_n, x->idx_bbox, x->k64a, x->v32a, s); }
     {
-      // LH_SORT=rocprim: the library's 64-bit sort (A/B); LH_SORT=check: both, compared element by element (tests)
-      static const int sort_cfg = []() { const char* e = getenv("LH_SORT"); return !e ? 0 : (strcmp(e, "rocprim") == 0 ? 1 : (strcmp(e, "check") == 0 ? 2 : 0)); }();
+      // LH_SORT=generic: the one-segment 64-bit sort over the whole concatenated array instead of the segmented one (A/B);
+      // LH_SORT=check: both, compared element by element (tests: two independent code paths must give the same stable order)
+      static const int sort_cfg = []() { const char* e = getenv("LH_SORT"); return !e ? 0 : (strcmp(e, "generic") == 0 ? 1 : (strcmp(e, "check") == 0 ? 2 : 0)); }();
       if (sort_cfg == 1) {
         ProfScope p(x, "index_radix_sort", 12.0 * total * 2 * 4, s);
         sort_pairs_u64(x->sort64_temp, x->sort64_temp_bytes, x->k64a, x->k64b, x->v32a, x->v32b, (int)total, 32 + id_bits, s);
@@ -503,7 +504,7 @@ static lh_status build_indices(lh_ctx* x, lh_cloud* const* clouds, int n_clouds,
           for (long i = 0; i < total; i++)
             if (kk[i] != kref[i] || vv[i] != vref[i]) bad++;
           if (bad) {
-            fprintf(stderr, "[locus_hip] LH_SORT=check: %ld of %ld sorted elements differ from the library sort\n", bad, total);
+            fprintf(stderr, "[locus_hip] LH_SORT=check: %ld of %ld sorted elements differ between the segmented and the one-segment sort\n", bad, total);
             return LH_EDEVICE;
           }
         }
@@ -2567,7 +2568,10 @@ static lh_status voxel_segments(lh_ctx* c, const float4* d_in, int n, float leaf
   }
   g.mul[0] = 1; g.mul[1] = divb[0]; g.mul[2] = divb[0] * divb[1];
   { ProfScope p(c, "voxel_keys", 24.0 * n); launch_voxel_keys(d_in, n, g, c->keys0, c->vals0, c->stream); }
-  { ProfScope p(c, "voxel_radix_sort", 64.0 * n); sort_pairs_u32(c->sort_temp, c->sort_temp_bytes, c->keys0, c->keys1, c->vals0, c->vals1, n, 32, c->stream); }
+  // only as many key bits as the grid has cells: a rejected point's key is all ones, so with 2^bits > cells it still sorts behind every voxel
+  int key_bits = 1;
+  while (key_bits < 32 && ((int64_t)1 << key_bits) <= (int64_t)divb[0] * divb[1] * divb[2]) key_bits++;
+  { ProfScope p(c, "voxel_radix_sort", 16.0 * n * ((key_bits + 9) / 10)); sort_pairs_u32(c->sort_temp, c->sort_temp_bytes, c->keys0, c->keys1, c->vals0, c->vals1, n, key_bits, c->stream); }
   { ProfScope p(c, "voxel_segments", 16.0 * n);
     launch_voxel_heads(c->keys1, n, vs->heads, c->stream);
     inclusive_scan_u32(vs->scan_tmp, scan_bytes, vs->heads, vs->rank, n, c->stream); }

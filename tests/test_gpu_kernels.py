@@ -398,9 +398,11 @@ def test_p2plane_information_kat_and_oracle(ctx, capi, oracle):
 
 
 def test_index_sort_matches_library_sort():
-    """K2's hand-written segmented radix sort (lh_radix.hip) against a stable library sort of the same (cloud id << 32 | Hilbert key)
-    array: LH_SORT=check runs both inside every index build and fails the call on the first differing element.  Ragged batches,
-    tiny clouds, runs of identical keys (ties must keep ascending point index), a 300 k-point cloud (147 tiles)."""
+    """K2's segmented radix sort (three 10-bit passes inside each cloud's segment, packed pairs) against the one-segment 64-bit sort
+    of the same (cloud id << 32 | key) array -- the sort the voxel grid and the local map use, itself held bit for bit to the
+    sequential restatements by test_voxel_grid_bit_exact / test_local_map_insert_refresh_and_scan_to_map: LH_SORT=check runs both
+    inside every index build and fails the call on the first differing element.  Ragged batches, tiny clouds, runs of identical
+    keys (ties must keep ascending point index), a 300 k-point cloud (147 tiles).  (No library sort is linked any more.)"""
     import os
     import subprocess
     import sys
