@@ -320,7 +320,6 @@ struct lh_cloud {
   bool has_index = false;
   float4* sorted = nullptr;    // [n + LEAF_CAP]
   NodeX* node_buf = nullptr;   // element 0 holds the TreeHeader, the nodes start at element 1
-  int32_t* pos = nullptr;      // original index -> sorted position
   int index_cap = 0;           // points the index buffers were allocated for
   NodeX* nodes() const { return node_buf ? node_buf + 1 : nullptr; }
   TreeHeader* hdr() const { return reinterpret_cast<TreeHeader*>(node_buf); }
@@ -338,7 +337,7 @@ static int round_up(int v, int m) { return (v + m - 1) / m * m; }
 static void cloud_free(lh_cloud* c) {
   if (!c) return;
   (void)lhFree(c->xyz); (void)lhFree(c->nrm); (void)lhFree(c->intensity);
-  (void)lhFree(c->sorted); (void)lhFree(c->node_buf); (void)lhFree(c->cov6); (void)lhFree(c->pos);
+  (void)lhFree(c->sorted); (void)lhFree(c->node_buf); (void)lhFree(c->cov6);
   delete c;
 }
 
@@ -399,6 +398,7 @@ static lh_status build_indices(lh_ctx* x, lh_cloud* const* clouds, int n_clouds,
       HIPCHK(hipMalloc(&x->idx_descs_dev, sizeof(IndexDesc) * MAX_INDEX_BATCH));
       HIPCHK(hipHostMalloc(&x->idx_descs_host, sizeof(IndexDesc) * MAX_INDEX_BATCH * lh_ctx::IDX_STAGE, hipHostMallocDefault));
       HIPCHK(hipMalloc(&x->idx_bbox, sizeof(uint32_t) * 8 * MAX_INDEX_BATCH));
+      launch_index_bbox_init(x->idx_bbox, s);   // (every build then leaves the slots reset for the next one)
       for (int k = 0; k < lh_ctx::IDX_STAGE; k++) HIPCHK(hipEventCreateWithFlags(&x->idx_copy_done[k], hipEventDisableTiming));
       HIPCHK(hipEventCreateWithFlags(&x->idx_build_done, hipEventDisableTiming));
     }
@@ -416,15 +416,14 @@ static lh_status build_indices(lh_ctx* x, lh_cloud* const* clouds, int n_clouds,
       if (c->n > c->index_cap) {
         (void)hipStreamSynchronize(x->stream);
         x->sync_side_streams();
-        (void)lhFree(c->sorted); (void)lhFree(c->pos); (void)lhFree(c->node_buf);
-        c->sorted = nullptr; c->pos = nullptr; c->node_buf = nullptr; c->index_cap = 0;
+        (void)lhFree(c->sorted); (void)lhFree(c->node_buf);
+        c->sorted = nullptr; c->node_buf = nullptr; c->index_cap = 0;
         HIPCHK(lhMalloc(&c->sorted, sizeof(float4) * ((size_t)c->n + LEAF_CAP)));
-        HIPCHK(lhMalloc(&c->pos, sizeof(int32_t) * (size_t)c->n));
         HIPCHK(lhMalloc(&c->node_buf, sizeof(NodeX) * ((size_t)c->n + 1)));  // worst case: every point its own leaf
         c->index_cap = c->n;
       }
       IndexDesc& d = stage_host[k];
-      d.xyz = c->xyz; d.sorted = c->sorted; d.nodes = c->nodes(); d.hdr = c->hdr(); d.pos = c->pos;
+      d.xyz = c->xyz; d.sorted = c->sorted; d.nodes = c->nodes(); d.hdr = c->hdr(); d.pos = nullptr;
       d.n = c->n; d.offset = (int)total;
       d.tile0 = tile0; d.pad = 0;
       tile0 += segsort_tiles(c->n);
@@ -448,8 +447,7 @@ static lh_status build_indices(lh_ctx* x, lh_cloud* const* clouds, int n_clouds,
       x->sort64_temp_bytes = sort64_temp_bytes(cap);
       HIPCHK(hipMalloc(&x->sort64_temp, x->sort64_temp_bytes ? x->sort64_temp_bytes : 16));
       HIPCHK(hipMalloc(&x->tree_tmp, TREE_SCRATCH_BYTES_PER_POINT * ((size_t)cap + 16) + 4096));
-      x->scan_tmp_bytes = scan_temp_bytes(cap);
-      HIPCHK(hipMalloc(&x->scan_tmp, x->scan_tmp_bytes ? x->scan_tmp_bytes : 16));
+      HIPCHK(hipMemsetAsync(x->tree_tmp, 0, TREE_SCRATCH_BYTES_PER_POINT * ((size_t)cap + 16) + 4096, s));   // (the per-tile leaf counts must start at zero; every build leaves them so)
       x->idx_cap = cap;
     }
     TreeScratch ts;
@@ -460,12 +458,15 @@ static lh_status build_indices(lh_ctx* x, lh_cloud* const* clouds, int n_clouds,
       ts.lbox = reinterpret_cast<float4*>(p); p += 32 * cap;
       ts.a1box = reinterpret_cast<float4*>(p); p += 32 * (cap / 32 + 16);
       ts.a2box = reinterpret_cast<float4*>(p); p += 32 * (cap / 1024 + 16);
+      ts.ibox = reinterpret_cast<float4*>(p); p += 32 * cap;
       ts.ichild = reinterpret_cast<int32_t*>(p); p += 8 * cap;
       ts.irange = reinterpret_cast<int32_t*>(p); p += 8 * cap;
       ts.iparent = reinterpret_cast<int32_t*>(p); p += 4 * cap;
       ts.flag = reinterpret_cast<uint32_t*>(p); p += 4 * cap;
       ts.lid = reinterpret_cast<uint32_t*>(p); p += 4 * cap;
       ts.lstart = reinterpret_cast<uint32_t*>(p); p += 4 * cap;
+      ts.tsum = reinterpret_cast<uint32_t*>(p); p += 4 * (cap / 4096 + 16);
+      ts.toff = reinterpret_cast<uint32_t*>(p); p += 4 * (cap / 4096 + 16);
       ts.keys = x->k64b;
       ts.total = (int)total;
     }
@@ -474,26 +475,27 @@ static lh_status build_indices(lh_ctx* x, lh_cloud* const* clouds, int n_clouds,
     HIPCHK(hipEventRecord(x->idx_copy_done[stage], s));
     int id_bits = 0;
     while ((1 << id_bits) < nb) id_bits++;
-    { ProfScope p(x, "index_bbox_keys", 16.0 * total * 2, s); launch_index_keys(x->idx_descs_dev, nb, max_n, x->idx_bbox, x->k64a, x->v32a, s); }
+    // LH_SORT=generic: the one-segment 64-bit sort over the whole concatenated array instead of the segmented one (A/B);
+    // LH_SORT=check: both, compared element by element (tests: two independent code paths must give the same stable order)
+    static const int sort_cfg = []() { const char* e = getenv("LH_SORT"); return !e ? 0 : (strcmp(e, "generic") == 0 ? 1 : (strcmp(e, "check") == 0 ? 2 : 0)); }();
+    { ProfScope p(x, "index_bbox_keys", 16.0 * total * 2, s);
+      launch_index_keys(x->idx_descs_dev, nb, max_n, x->idx_bbox, x->k32a, sort_cfg ? x->k64a : nullptr, sort_cfg ? x->v32a : nullptr, s); }
     {
-      // LH_SORT=generic: the one-segment 64-bit sort over the whole concatenated array instead of the segmented one (A/B);
-      // LH_SORT=check: both, compared element by element (tests: two independent code paths must give the same stable order)
-      static const int sort_cfg = []() { const char* e = getenv("LH_SORT"); return !e ? 0 : (strcmp(e, "generic") == 0 ? 1 : (strcmp(e, "check") == 0 ? 2 : 0)); }();
       if (sort_cfg == 1) {
         ProfScope p(x, "index_radix_sort", 12.0 * total * 2 * 4, s);
         sort_pairs_u64(x->sort64_temp, x->sort64_temp_bytes, x->k64a, x->k64b, x->v32a, x->v32b, (int)total, 32 + id_bits, s);
       } else {
         std::vector<uint64_t> kref;
         std::vector<uint32_t> vref;
-        if (sort_cfg == 2) {  // reference first (segsort clobbers v32a)
+        if (sort_cfg == 2) {  // reference first
           sort_pairs_u64(x->sort64_temp, x->sort64_temp_bytes, x->k64a, x->k64b, x->v32a, x->v32b, (int)total, 32 + id_bits, s);
           kref.resize(total); vref.resize(total);
           HIPCHK(hipMemcpyAsync(kref.data(), x->k64b, sizeof(uint64_t) * total, hipMemcpyDeviceToHost, s));
           HIPCHK(hipMemcpyAsync(vref.data(), x->v32b, sizeof(uint32_t) * total, hipMemcpyDeviceToHost, s));
           HIPCHK(hipStreamSynchronize(s));
         }
-        { ProfScope p(x, "index_radix_sort", 8.0 * total * 3 * 3, s);
-          segsort_pairs(x->idx_descs_dev, nb, max_n, x->k64a, x->k64b, x->v32a, x->v32b, x->k32a, x->k32b, x->rs_hist, s); }
+        { ProfScope p(x, "index_radix_sort", 8.0 * total * 3 * 2, s);
+          segsort_pairs(x->idx_descs_dev, nb, max_n, x->k32a, x->k32b, x->k64b, x->v32b, x->rs_hist, s); }
         if (sort_cfg == 2) {
           std::vector<uint64_t> kk(total);
           std::vector<uint32_t> vv(total);
@@ -510,13 +512,10 @@ static lh_status build_indices(lh_ctx* x, lh_cloud* const* clouds, int n_clouds,
         }
       }
     }
-    { ProfScope p(x, "index_leaves_scan", 8.0 * total * 3, s);
-      launch_index_leaves(ts, s);
-      inclusive_scan_u32(x->scan_tmp, x->scan_tmp_bytes, ts.flag, ts.lid, (int)total, s); }
-    { ProfScope p(x, "index_gather_leaves", 48.0 * total, s); launch_index_trees(x->idx_descs_dev, nb, max_n, ts, x->v32b, s, 0); }
-    { ProfScope p(x, "index_radix_tree", 8.0 * total, s); launch_index_trees(x->idx_descs_dev, nb, max_n, ts, x->v32b, s, 1); }
-    { ProfScope p(x, "index_box_tables", 24.0 * total, s); launch_index_trees(x->idx_descs_dev, nb, max_n, ts, x->v32b, s, 2); }
-    { ProfScope p(x, "index_nodes", 32.0 * total, s); launch_index_trees(x->idx_descs_dev, nb, max_n, ts, x->v32b, s, 3); }
+    { ProfScope p(x, "index_leaves", 8.0 * total * 3 + 48.0 * total, s); launch_index_leaves(x->idx_descs_dev, nb, ts, x->v32b, x->idx_bbox, s); }
+    { ProfScope p(x, "index_box_tables", 24.0 * total, s); launch_index_trees(x->idx_descs_dev, nb, max_n, ts, s, 0); }
+    { ProfScope p(x, "index_radix_tree", 8.0 * total, s); launch_index_trees(x->idx_descs_dev, nb, max_n, ts, s, 1); }
+    { ProfScope p(x, "index_nodes", 32.0 * total, s); launch_index_trees(x->idx_descs_dev, nb, max_n, ts, s, 2); }
     HIPCHK(hipEventRecord(x->idx_build_done, s));
     HIPCHK(hipGetLastError());
     for (int k = 0; k < nb; k++) clouds[o + k]->has_index = true;

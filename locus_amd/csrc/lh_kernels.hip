@@ -37,7 +37,20 @@ __global__ void __launch_bounds__(256) k_bbox_init_b(uint32_t* bbox, int n_cloud
 __global__ void __launch_bounds__(256) k_bbox_b(const IndexDesc* __restrict__ descs, uint32_t* bbox) {
   const IndexDesc d = descs[blockIdx.y];
   float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < d.n; i += gridDim.x * blockDim.x) {
+  const int stride = gridDim.x * blockDim.x;
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i + 3 * stride < d.n; i += 4 * stride) {   // four independent loads in flight
+    float4 p[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) p[k] = d.xyz[i + k * stride];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      lo[0] = fminf(lo[0], p[k].x); hi[0] = fmaxf(hi[0], p[k].x);
+      lo[1] = fminf(lo[1], p[k].y); hi[1] = fmaxf(hi[1], p[k].y);
+      lo[2] = fminf(lo[2], p[k].z); hi[2] = fmaxf(hi[2], p[k].z);
+    }
+  }
+  for (; i < d.n; i += stride) {
     float4 p = d.xyz[i];
     lo[0] = fminf(lo[0], p.x); hi[0] = fmaxf(hi[0], p.x);
     lo[1] = fminf(lo[1], p.y); hi[1] = fmaxf(hi[1], p.y);
@@ -63,8 +76,10 @@ __global__ void __launch_bounds__(256) k_bbox_b(const IndexDesc* __restrict__ de
   else if (threadIdx.x < 6)
     atomicMax(&bb[threadIdx.x], enc_ordered(fmaxf(fmaxf(sm[0][threadIdx.x], sm[1][threadIdx.x]), fmaxf(sm[2][threadIdx.x], sm[3][threadIdx.x]))));
 }
+// (key, index) leave as ONE 8-byte pair, the form the segmented sort keeps between its passes (lh_radix.hip); keys64 / vals32 (nullable)
+// are the same as separate arrays for the LH_SORT=check / generic debug paths
 __global__ void __launch_bounds__(256) k_key_b(const IndexDesc* __restrict__ descs, const uint32_t* __restrict__ bbox,
-                                               uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+                                               uint2* __restrict__ pairs, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
   const IndexDesc d = descs[blockIdx.y];
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t* bb = bbox + blockIdx.y * 8;
@@ -78,64 +93,143 @@ __global__ void __launch_bounds__(256) k_key_b(const IndexDesc* __restrict__ des
   // 30 bits (7.8 cm cells on an 80 m scene) are enough: 16 bits/axis (spatial_key48) leaves the visit counts unchanged
   uint32_t k = spatial_key30(p.x, p.y, p.z, dec_ordered(bb[0]), dec_ordered(bb[1]), dec_ordered(bb[2]), dec_ordered(bb[3]),
                              dec_ordered(bb[4]), dec_ordered(bb[5]));
-  keys[d.offset + i] = ((uint64_t)blockIdx.y << 32) | k;
-  vals[d.offset + i] = (uint32_t)(d.offset + i);
-}
-__global__ void __launch_bounds__(256) k_gather_b(const IndexDesc* __restrict__ descs, const uint32_t* __restrict__ vals) {
-  const IndexDesc d = descs[blockIdx.y];
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= d.n + LEAF_CAP) return;
-  float4 o;
-  if (i < d.n) {
-    uint32_t j = vals[d.offset + i] - (uint32_t)d.offset;
-    float4 p = d.xyz[j];
-    o = make_float4(p.x, p.y, p.z, __uint_as_float(j));
-    d.pos[j] = i;
-  } else {
-    o = make_float4(INFINITY, INFINITY, INFINITY, __uint_as_float(0x7fffffffu));  // padding behind the last leaf (scan_leaf loads 8)
+  pairs[d.offset + i] = make_uint2(k, (uint32_t)(d.offset + i));
+  if (keys) {
+    keys[d.offset + i] = ((uint64_t)blockIdx.y << 32) | k;
+    vals[d.offset + i] = (uint32_t)(d.offset + i);
   }
-  d.sorted[i] = o;
 }
-
 // --- leaves: the largest key-prefix cell around every sorted position with <= LEAF_CAP points --------------------------
-__global__ void __launch_bounds__(256) k_leafcell_b(TreeScratch t) {
-  int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= t.total) return;
-  t.flag[g] = leafcell_flag(t.keys, t.total, g);
+// One workgroup per tile of LEAF_TILE sorted positions.  k_leafcell_b: the leaf-start flags and the tile's number of leaves;
+// (one workgroup then turns the tile counts into offsets: k_tile_offsets); k_leaves_b: the same tile again -- the running leaf
+// number of every position (lid = inclusive scan of the flags), the sorted points (x, y, z, original index) gathered through the
+// sorted index, the inverse permutation, and for every flagged position the leaf's record.  (Round 2: flags, a library scan with
+// its own init kernel, gather, leaf records = five launches and two more round trips through the flags.)
+constexpr int LEAF_TILE = 4096, LEAF_PER_THREAD = LEAF_TILE / 256;
+__device__ __forceinline__ uint32_t block_exclusive_u32(uint32_t mine, uint32_t* wsum /*[4] shared*/, uint32_t* total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t inc = mine;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t u = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += u;
+  }
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  uint32_t b0 = inc - mine;
+  for (int w = 0; w < wave; w++) b0 += wsum[w];
+  if (total) *total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  __syncthreads();
+  return b0;
 }
-// after the inclusive scan lid[] of the flags: leaf L = lid[g] - 1 starts at the flagged position g
-__global__ void __launch_bounds__(256) k_leafrec_b(TreeScratch t) {
-  int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= t.total) return;
-  if (t.flag[g]) {
-    uint32_t L = t.lid[g] - 1u;
-    t.lkey[L] = t.keys[g];
-    t.lstart[L] = (uint32_t)g;
+__global__ void __launch_bounds__(256) k_leafcell_b(TreeScratch t) {   // one sorted position per thread
+  __shared__ uint64_t win[256 + 2 * LEAF_CAP];   // the workgroup's keys + LEAF_CAP on either side: every thread looks at keys[g - 8 .. g + 8]
+  __shared__ uint32_t wcnt[4];
+  const int64_t g0 = (int64_t)blockIdx.x * 256, g = g0 + threadIdx.x;
+  for (int k = threadIdx.x; k < 256 + 2 * LEAF_CAP; k += 256) {
+    const int64_t q = g0 - LEAF_CAP + k;
+    win[k] = (q >= 0 && q < t.total) ? t.keys[q] : 0ull;   // (positions outside the array are never compared: leafcell_flag checks the bounds)
   }
-  if (g == t.total - 1) {  // sentinel: leaf L's points are [lstart[L], lstart[L+1])
-    uint32_t Lt = t.lid[g];
-    t.lstart[Lt] = (uint32_t)t.total;
-    t.lkey[Lt] = ~0ull;
+  __syncthreads();
+  uint32_t f = 0;
+  if (g < t.total) {
+    f = leafcell_flag(win + LEAF_CAP - g0, t.total, g);     // same function, the window addressed like the whole array
+    t.flag[g] = f;
   }
+  const uint32_t c = (uint32_t)__popcll(__ballot(f != 0u));
+  if ((threadIdx.x & 63) == 0) wcnt[threadIdx.x >> 6] = c;
+  __syncthreads();
+  // leaves per tile of LEAF_TILE positions (16 workgroups each): integer adds, order-free.  tsum is zero when a build starts (k_tile_offsets
+  // of the previous build left it so)
+  if (threadIdx.x == 0) atomicAdd(&t.tsum[(blockIdx.x * 256) / LEAF_TILE], wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3]);
+}
+__global__ void __launch_bounds__(256) k_tile_offsets(uint32_t* __restrict__ tsum, uint32_t* __restrict__ toff, int tiles) {   // ONE workgroup: exclusive prefix; the counts are zeroed for the next build
+  __shared__ uint32_t wsum[4];
+  __shared__ uint32_t carry_s;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (int t0 = 0; t0 < tiles; t0 += 256) {
+    const int tt = t0 + threadIdx.x;
+    const uint32_t v = tt < tiles ? tsum[tt] : 0u;
+    uint32_t tot;
+    const uint32_t ex = block_exclusive_u32(v, wsum, &tot);
+    const uint32_t carry = carry_s;
+    if (tt < tiles) { toff[tt] = carry + ex; tsum[tt] = 0u; }
+    __syncthreads();
+    if (threadIdx.x == 0) carry_s = carry + tot;
+    __syncthreads();
+  }
+}
+__global__ void __launch_bounds__(256) k_leaves_b(const IndexDesc* __restrict__ descs, TreeScratch t, const uint32_t* __restrict__ vals, uint32_t* bbox_next) {
+  __shared__ uint32_t cnt[LEAF_PER_THREAD][4];   // leaves per (round, wave) of the tile, then their exclusive prefix in (round, wave) order
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  // (tile, round, thread) order: consecutive lanes hold consecutive sorted positions -> every load and store of a round is coalesced
+  uint32_t f[LEAF_PER_THREAD];
+  unsigned long long bal[LEAF_PER_THREAD];
+#pragma unroll
+  for (int r = 0; r < LEAF_PER_THREAD; r++) {
+    const int64_t g = (int64_t)blockIdx.x * LEAF_TILE + r * 256 + threadIdx.x;
+    f[r] = g < t.total ? t.flag[g] : 0u;
+    bal[r] = __ballot(f[r] != 0u);
+    if (lane == 0) cnt[r][wave] = (uint32_t)__popcll(bal[r]);
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {   // 64 (round, wave) counts -> exclusive prefix, one wave
+    const uint32_t v = (&cnt[0][0])[threadIdx.x];
+    uint32_t inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t u = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += u;
+    }
+    (&cnt[0][0])[threadIdx.x] = inc - v;
+  }
+  __syncthreads();
+  const uint32_t tile_base = t.toff[blockIdx.x];
+  int cur = -1;
+  const float4* xyz = nullptr; float4* sorted = nullptr; int d_off = 0, d_n = 0;
+#pragma unroll 4
+  for (int r = 0; r < LEAF_PER_THREAD; r++) {
+    const int64_t g = (int64_t)blockIdx.x * LEAF_TILE + r * 256 + threadIdx.x;
+    if (g >= t.total) continue;
+    const uint32_t lid = tile_base + cnt[r][wave] + (uint32_t)__popcll(bal[r] & below) + f[r];   // inclusive scan of the flags
+    t.lid[g] = lid;
+    const uint64_t key = t.keys[g];
+    const int cloud = (int)(key >> 32);
+    if (cloud != cur) {   // (a tile holds one cloud, two at a boundary)
+      const IndexDesc& d = descs[cloud];
+      xyz = d.xyz; sorted = d.sorted; d_off = d.offset; d_n = d.n; cur = cloud;
+    }
+    const uint32_t j = vals[g] - (uint32_t)d_off;            // original index of the point at sorted position g
+    const uint32_t i = (uint32_t)(g - d_off);                 // its position inside the cloud's own sorted array
+    const float4 p = xyz[j];
+    sorted[i] = make_float4(p.x, p.y, p.z, __uint_as_float(j));
+    if ((int)i == d_n - 1) {                                  // padding behind the last leaf (scan_leaf loads LEAF_CAP entries)
+#pragma unroll
+      for (int e = 1; e <= LEAF_CAP; e++) sorted[i + e] = make_float4(INFINITY, INFINITY, INFINITY, __uint_as_float(0x7fffffffu));
+    }
+    if (f[r]) {                                               // leaf L = lid - 1 starts here
+      t.lkey[lid - 1u] = key;
+      t.lstart[lid - 1u] = (uint32_t)g;
+    }
+    if (g == t.total - 1) {                                   // sentinel: leaf L's points are [lstart[L], lstart[L+1])
+      t.lstart[lid] = (uint32_t)t.total;
+      t.lkey[lid] = ~0ull;
+    }
+  }
+  // the bounding-box slots of this batch have been consumed (k_key_b): reset them for the NEXT build (builds are serialised on the
+  // shared scratch), which saves every build its own init launch
+  if (blockIdx.x == 0)
+    for (int k = threadIdx.x; k < MAX_INDEX_BATCH * 8; k += 256) bbox_next[k] = (k & 7) < 3 ? 0xffffffffu : 0u;
 }
 // --- Karras' binary radix tree over the leaf keys of the WHOLE batch (nodes that join two clouds are never used) -------
-__global__ void __launch_bounds__(256) k_radix_b(TreeScratch t) {
-  const int n_leaves = (int)t.lid[t.total - 1];
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_leaves - 1) return;
-  int left, right, lo, hi;
-  radix_node(t.lkey, n_leaves, i, left, right, lo, hi);
-  t.ichild[2 * i] = left;
-  t.ichild[2 * i + 1] = right;
-  t.irange[2 * i] = lo;
-  t.irange[2 * i + 1] = hi;
-  if (left >= 0) t.iparent[left] = i;    // (k_nodex_b climbs these to find a node's depth)
-  if (right >= 0) t.iparent[right] = i;
-}
-// --- boxes WITHOUT a bottom-up pass.  A node's box is the min/max over a contiguous range of leaves, so it can be read
-// off three tables: lbox (one box per leaf), a1box (per 32 consecutive leaves), a2box (per 1024).  Every thread works
-// alone on data written by earlier launches: no arrival counters, no agent-scope fences (a __threadfence() per tree level
-// costs ~3.5 us on this chip because the per-XCD L2s are not coherent: the climbing version took 3.5 ms per batch).
+// ... and, in the same thread, the box of the node: the min/max over its contiguous range of leaves, read off three tables --
+// lbox (one box per leaf), a1box (per 32 consecutive leaves), a2box (per 1024) -- written by earlier launches: no arrival counters,
+// no agent-scope fences (a __threadfence() per tree level costs ~3.5 us on this chip because the per-XCD L2s are not coherent:
+// the climbing version took 3.5 ms per batch).  ONE range box per binary node; the 4-ary nodes are assembled from them afterwards
+// (round 2 computed four range boxes per 4-ary node in k_nodex_b: twice the table reads, and the launch lasted as long as the
+// thread of a root, ~560 dependent table entries).
 struct Box6 { float lx, ly, lz, hx, hy, hz; };
 __device__ __forceinline__ Box6 box_empty() { return Box6{INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY}; }
 __device__ __forceinline__ void box_merge(Box6& b, const float4* __restrict__ tab, int idx) {  // table entry = 2 x float4
@@ -147,6 +241,7 @@ __device__ __forceinline__ void box_store(float4* tab, int idx, const Box6& b) {
   tab[2 * (size_t)idx] = make_float4(b.lx, b.ly, b.lz, 0.f);
   tab[2 * (size_t)idx + 1] = make_float4(b.hx, b.hy, b.hz, 0.f);
 }
+// one thread per leaf: its (<= LEAF_CAP) points in ONE round of loads (the sorted array is padded, the count masks)
 __global__ void __launch_bounds__(256) k_leafbox_b(const IndexDesc* __restrict__ descs, TreeScratch t) {
   const int n_leaves = (int)t.lid[t.total - 1];
   int L = blockIdx.x * blockDim.x + threadIdx.x;
@@ -154,12 +249,17 @@ __global__ void __launch_bounds__(256) k_leafbox_b(const IndexDesc* __restrict__
   const int cloud = (int)(t.lkey[L] >> 32);
   const IndexDesc d = descs[cloud];
   const uint32_t s0 = t.lstart[L], s1 = t.lstart[L + 1];
+  const float4* pp = d.sorted + (s0 - (uint32_t)d.offset);
+  float4 q[LEAF_CAP];
+#pragma unroll
+  for (int e = 0; e < LEAF_CAP; e++) q[e] = pp[e];
   Box6 b = box_empty();
-  for (uint32_t g = s0; g < s1; g++) {
-    float4 p = d.sorted[g - (uint32_t)d.offset];
-    b.lx = fminf(b.lx, p.x); b.ly = fminf(b.ly, p.y); b.lz = fminf(b.lz, p.z);
-    b.hx = fmaxf(b.hx, p.x); b.hy = fmaxf(b.hy, p.y); b.hz = fmaxf(b.hz, p.z);
-  }
+#pragma unroll
+  for (int e = 0; e < LEAF_CAP; e++)
+    if (s0 + (uint32_t)e < s1) {
+      b.lx = fminf(b.lx, q[e].x); b.ly = fminf(b.ly, q[e].y); b.lz = fminf(b.lz, q[e].z);
+      b.hx = fmaxf(b.hx, q[e].x); b.hy = fmaxf(b.hy, q[e].y); b.hz = fmaxf(b.hz, q[e].z);
+    }
   box_store(t.lbox, L, b);
   const int a_c = (int)t.lid[d.offset] - 1, b_c = (int)t.lid[d.offset + d.n - 1] - 1;
   if (a_c == b_c) {  // the whole cloud is one leaf: no internal node will write the header
@@ -167,25 +267,28 @@ __global__ void __launch_bounds__(256) k_leafbox_b(const IndexDesc* __restrict__
     d.hdr->n_leaves = 1;
   }
 }
-// chunk tables: dst[c] = union of src[32c .. 32c+31] (entries past n_src are skipped)
+// chunk tables: dst[c] = union of src[32c .. 32c+31] (entries past n_src are skipped).  32 lanes per chunk, one entry each, five
+// shuffle steps (a thread per chunk read its 64 table words one after the other).
 __global__ void __launch_bounds__(256) k_chunkbox_b(TreeScratch t, int level) {
   const int n_leaves = (int)t.lid[t.total - 1];
   const int n_src = level == 1 ? n_leaves : (n_leaves + 31) / 32;
   const float4* src = level == 1 ? t.lbox : t.a1box;
   float4* dst = level == 1 ? t.a1box : t.a2box;
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c * 32 >= n_src) return;
+  const int c = (blockIdx.x * blockDim.x + threadIdx.x) >> 5, e = c * 32 + (threadIdx.x & 31);
+  if (c * 32 >= n_src) return;   // (uniform per half wave)
   Box6 b = box_empty();
-  int e = min(n_src, c * 32 + 32);
-  for (int k = c * 32; k < e; k++) box_merge(b, src, k);
-  box_store(dst, c, b);
+  if (e < n_src) box_merge(b, src, e);
+#pragma unroll
+  for (int off = 16; off > 0; off >>= 1) {
+    b.lx = fminf(b.lx, __shfl_down(b.lx, off, 32)); b.ly = fminf(b.ly, __shfl_down(b.ly, off, 32)); b.lz = fminf(b.lz, __shfl_down(b.lz, off, 32));
+    b.hx = fmaxf(b.hx, __shfl_down(b.hx, off, 32)); b.hy = fmaxf(b.hy, __shfl_down(b.hy, off, 32)); b.hz = fmaxf(b.hz, __shfl_down(b.hz, off, 32));
+  }
+  if ((threadIdx.x & 31) == 0) box_store(dst, c, b);
 }
-// box of the leaves [a, e)
-// (The nodes near a root cover thousands of leaves: ~140 table entries per box, four boxes per node, in ONE thread -- the launch
-// lasts as long as that thread.  Entries are therefore fetched four at a time, independent loads in flight together, and
-// merged afterwards: min / max are exact and order-free, so the boxes do not change.)
+// box of the leaves [a, e): entries fetched four at a time, independent loads in flight together, merged afterwards (min / max are
+// exact and order-free, so the boxes do not depend on how they are gathered)
 __device__ __forceinline__ void box_merge_run(Box6& b, const float4* __restrict__ tab, int first, int last) {
-  constexpr int W = 4;
+  constexpr int W = 8;   // (one box per thread now: registers for eight entries in flight)
   int l = first;
   for (; l + W <= last; l += W) {
     float4 lo[W], hi[W];
@@ -219,6 +322,20 @@ __device__ __forceinline__ Box6 range_box(const TreeScratch& t, int a, int e) {
   box_merge_run(b, t.a2box, c0a >> 5, c1a >> 5);
   return b;
 }
+__global__ void __launch_bounds__(256) k_radix_b(TreeScratch t) {
+  const int n_leaves = (int)t.lid[t.total - 1];
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_leaves - 1) return;
+  int left, right, lo, hi;
+  radix_node(t.lkey, n_leaves, i, left, right, lo, hi);
+  t.ichild[2 * i] = left;
+  t.ichild[2 * i + 1] = right;
+  t.irange[2 * i] = lo;
+  t.irange[2 * i + 1] = hi;
+  if (left >= 0) t.iparent[left] = i;    // (k_nodex_b climbs these to find a node's depth)
+  if (right >= 0) t.iparent[right] = i;
+  if ((t.lkey[lo] >> 32) == (t.lkey[hi] >> 32)) box_store(t.ibox, i, range_box(t, lo, hi + 1));   // (a node that joins two clouds has no box)
+}
 // --- 4-ary nodes: every binary node of a cloud adopts its grandchildren (a leaf child stays a child) -------------------
 __global__ void __launch_bounds__(256) k_nodex_b(const IndexDesc* __restrict__ descs, TreeScratch t) {
   const int n_leaves = (int)t.lid[t.total - 1];
@@ -230,42 +347,38 @@ __global__ void __launch_bounds__(256) k_nodex_b(const IndexDesc* __restrict__ d
   const IndexDesc d = descs[cloud];
   const int a_c = (int)t.lid[d.offset] - 1, b_c = (int)t.lid[d.offset + d.n - 1] - 1;
   // A 4-ary node adopts its GRANDchildren, so the walk only ever reaches the binary nodes at even depth below the cloud's root:
-  // the other half would be built (four range boxes and a 64-byte store each) and never read.  The depth comes from climbing the
-  // parent links to the node that covers the whole cloud: ~15 dependent 12-byte reads, against ~100 table reads saved.
+  // the other half would be built (a 64-byte store each) and never read.  The depth comes from climbing the parent links to the
+  // node that covers the whole cloud: ~15 dependent 12-byte reads.
   {
     int depth = 0;
     for (int j = i; !(t.irange[2 * j] == a_c && t.irange[2 * j + 1] == b_c); j = t.iparent[j]) depth++;
     if (depth & 1) return;
   }
   const TreeHeader fr = *d.hdr;   // the quantisation frame, written by k_key_b (an earlier launch)
+  // the (<= 4) children and their boxes: a leaf's from the leaf table, an internal node's from the node table k_radix_b left
+  int cref[4] = {0, 0, 0, 0}, cnt = 0;
+#pragma unroll
+  for (int side = 0; side < 2; side++) {
+    const int c = t.ichild[2 * i + side];
+    if (c < 0) cref[cnt++] = c;
+    else { cref[cnt++] = t.ichild[2 * c]; cref[cnt++] = t.ichild[2 * c + 1]; }
+  }
   NodeX nd;
 #pragma unroll
   for (int k = 0; k < 4; k++) {
     nd.lo_xy[k] = 0xffffffffu; nd.hi_xy[k] = 0u; nd.z_lohi[k] = 0xffffffffu;
     nd.child[k] = NO_CHILD;
   }
-  int cnt = 0;
-  auto emit = [&](int ref) {
-    Box6 bx;
-    int32_t cref;
-    if (ref < 0) {
-      int L = ~ref;
-      bx = range_box(t, L, L + 1);
-      cref = leaf_ref(t.lstart[L] - (uint32_t)d.offset, (int)(t.lstart[L + 1] - t.lstart[L]));
-    } else {
-      bx = range_box(t, t.irange[2 * ref], t.irange[2 * ref + 1] + 1);
-      cref = ref - a_c;
-    }
-    quant_box(fr, bx.lx, bx.ly, bx.lz, bx.hx, bx.hy, bx.hz, nd.lo_xy[cnt], nd.hi_xy[cnt], nd.z_lohi[cnt]);
-    nd.child[cnt] = cref;
-    cnt++;
-  };
 #pragma unroll
-  for (int side = 0; side < 2; side++) {
-    int c = t.ichild[2 * i + side];
-    if (c < 0) emit(c);
-    else { emit(t.ichild[2 * c]); emit(t.ichild[2 * c + 1]); }
-  }
+  for (int k = 0; k < 4; k++)
+    if (k < cnt) {
+      const int ref = cref[k];
+      const float4* tab = ref < 0 ? t.lbox : t.ibox;
+      const int idx = ref < 0 ? ~ref : ref;
+      const float4 blo = tab[2 * (size_t)idx], bhi = tab[2 * (size_t)idx + 1];
+      quant_box(fr, blo.x, blo.y, blo.z, bhi.x, bhi.y, bhi.z, nd.lo_xy[k], nd.hi_xy[k], nd.z_lohi[k]);
+      nd.child[k] = ref < 0 ? leaf_ref(t.lstart[idx] - (uint32_t)d.offset, (int)(t.lstart[idx + 1] - t.lstart[idx])) : ref - a_c;
+    }
   d.nodes[i - a_c] = nd;
   if (lo == a_c && hi == b_c) {
     d.hdr->root = i - a_c;
@@ -273,26 +386,30 @@ __global__ void __launch_bounds__(256) k_nodex_b(const IndexDesc* __restrict__ d
   }
 }
 
-void launch_index_keys(const IndexDesc* descs, int n_clouds, int max_n, uint32_t* bbox, uint64_t* keys, uint32_t* vals, hipStream_t s) {
-  hipLaunchKernelGGL(k_bbox_init_b, dim3((n_clouds * 8 + 255) / 256), dim3(256), 0, s, bbox, n_clouds);
+void launch_index_bbox_init(uint32_t* bbox, hipStream_t s) {   // once, when the slots are allocated; afterwards every build resets them for the next
+  hipLaunchKernelGGL(k_bbox_init_b, dim3((MAX_INDEX_BATCH * 8 + 255) / 256), dim3(256), 0, s, bbox, MAX_INDEX_BATCH);
+}
+void launch_index_keys(const IndexDesc* descs, int n_clouds, int max_n, uint32_t* bbox, uint64_t* pairs, uint64_t* keys, uint32_t* vals, hipStream_t s) {
+  // (the bounding-box slots were reset by the previous build's k_leaves_b, or by the allocation)
   int blocks = (max_n + 255) / 256;
-  hipLaunchKernelGGL(k_bbox_b, dim3(blocks > 128 ? 128 : blocks, n_clouds), dim3(256), 0, s, descs, bbox);
-  hipLaunchKernelGGL(k_key_b, dim3(blocks, n_clouds), dim3(256), 0, s, descs, bbox, keys, vals);
+  hipLaunchKernelGGL(k_bbox_b, dim3(blocks > 48 ? 48 : blocks, n_clouds), dim3(256), 0, s, descs, bbox);   // (every workgroup ends in six atomics on its cloud's slots: few, fat workgroups)
+  hipLaunchKernelGGL(k_key_b, dim3(blocks, n_clouds), dim3(256), 0, s, descs, bbox, reinterpret_cast<uint2*>(pairs), keys, vals);
 }
-void launch_index_leaves(const TreeScratch& t, hipStream_t s) {
+void launch_index_leaves(const IndexDesc* descs, int n_clouds, const TreeScratch& t, const uint32_t* vals_sorted, uint32_t* bbox, hipStream_t s) {
+  const int tiles = (t.total + LEAF_TILE - 1) / LEAF_TILE;
   hipLaunchKernelGGL(k_leafcell_b, dim3((t.total + 255) / 256), dim3(256), 0, s, t);
+  hipLaunchKernelGGL(k_tile_offsets, dim3(1), dim3(256), 0, s, t.tsum, t.toff, tiles);
+  hipLaunchKernelGGL(k_leaves_b, dim3(tiles), dim3(256), 0, s, descs, t, vals_sorted, bbox);
+  (void)n_clouds;
 }
-void launch_index_trees(const IndexDesc* descs, int n_clouds, int max_n, const TreeScratch& t, const uint32_t* vals_sorted, hipStream_t s, int stage) {
+void launch_index_trees(const IndexDesc* descs, int n_clouds, int max_n, const TreeScratch& t, hipStream_t s, int stage) {
   int blocks = (t.total + 255) / 256;  // upper bound of the leaf count; the kernels read the real one from lid[total-1]
-  if (stage == 0) {        // sorted points + leaf records
-    hipLaunchKernelGGL(k_gather_b, dim3((max_n + LEAF_CAP + 255) / 256, n_clouds), dim3(256), 0, s, descs, vals_sorted);
-    hipLaunchKernelGGL(k_leafrec_b, dim3(blocks), dim3(256), 0, s, t);
-  } else if (stage == 1) { // hierarchy
-    hipLaunchKernelGGL(k_radix_b, dim3(blocks), dim3(256), 0, s, t);
-  } else if (stage == 2) { // box tables
+  if (stage == 0) {        // box tables: per leaf, per 32 leaves, per 1024 leaves
     hipLaunchKernelGGL(k_leafbox_b, dim3(blocks), dim3(256), 0, s, descs, t);
-    hipLaunchKernelGGL(k_chunkbox_b, dim3((blocks + 31) / 32), dim3(256), 0, s, t, 1);
-    hipLaunchKernelGGL(k_chunkbox_b, dim3((blocks + 1023) / 1024), dim3(256), 0, s, t, 2);
+    hipLaunchKernelGGL(k_chunkbox_b, dim3(blocks), dim3(256), 0, s, t, 1);                        // 32 lanes per chunk of 32 leaves: leaves <= points
+    hipLaunchKernelGGL(k_chunkbox_b, dim3((blocks + 31) / 32 + 1), dim3(256), 0, s, t, 2);
+  } else if (stage == 1) { // hierarchy + one box per binary node
+    hipLaunchKernelGGL(k_radix_b, dim3(blocks), dim3(256), 0, s, t);
   } else {                 // 4-ary nodes + headers
     hipLaunchKernelGGL(k_nodex_b, dim3(blocks), dim3(256), 0, s, descs, t);
   }

@@ -92,7 +92,7 @@ struct IndexDesc {
   float4* sorted;     // [n + LEAF_CAP]
   NodeX* nodes;       // [n] worst case (one internal node per leaf, one leaf per point)
   TreeHeader* hdr;
-  int32_t* pos;       // original index -> position in `sorted`
+  int32_t* pos;       // (unused: the inverse permutation was written by every build and read by nothing)
   int n, offset;      // offset = start of this cloud in the concatenated key/value arrays
   int tile0, pad;     // first tile of this cloud in the sort's histogram table (sum of segsort_tiles of the clouds before it)
 };
@@ -101,33 +101,39 @@ struct TreeScratch {
   const uint64_t* keys;   // sorted (cloud id << 32 | Hilbert key)      [total]
   uint32_t* flag;         // leaf-start flags                           [total]
   uint32_t* lid;          // inclusive scan of the flags                [total]
+  uint32_t* tsum;         // leaves per tile of 4096 sorted positions (zero between builds)   [total / 4096 + 2]
+  uint32_t* toff;         // ... and their exclusive prefix
   uint64_t* lkey;         // key of a leaf's first point (+ sentinel)   [leaves + 1]
   uint32_t* lstart;       // first sorted position of a leaf (+ sentinel)
   float4* lbox;           // leaf boxes, 2 x float4 (lo, hi) per leaf
   float4* a1box;          // boxes of 32 consecutive leaves
   float4* a2box;          // boxes of 1024 consecutive leaves
+  float4* ibox;           // box of every binary node (its leaf range), 2 x float4   [leaves]
   int32_t* ichild;        // binary children of internal node i [2]: >= 0 internal, < 0 leaf ~index
   int32_t* irange;        // covered leaf range [2]
   int32_t* iparent;       // binary parent of internal node i (undefined for a root)
   int total;
 };
-constexpr size_t TREE_SCRATCH_BYTES_PER_POINT = 4 + 4 + 8 + 4 + 32 + 2 + 8 + 8 + 4;  // flag lid lkey lstart lbox a1+a2 ichild irange iparent
+constexpr size_t TREE_SCRATCH_BYTES_PER_POINT = 4 + 4 + 8 + 4 + 32 + 2 + 32 + 8 + 8 + 4 + 1;  // flag lid lkey lstart lbox a1+a2 ibox ichild irange iparent tsum
 constexpr int MAX_INDEX_BATCH = 64;
 // the build's own sort (lh_radix.hip): segmented 3 x 10-bit LSD radix sort of the 30-bit keys, every cloud inside its segment
 int segsort_tiles(int n);
 size_t segsort_hist_elems(long total_points, int n_clouds);
-void segsort_pairs(const IndexDesc* descs, int n_clouds, int max_n, const uint64_t* keys_in, uint64_t* keys_out, const uint32_t* vals_in,
-                   uint32_t* vals_out, uint64_t* kv_a, uint64_t* kv_b, uint32_t* hist, hipStream_t s);
+// kv_a: the (key, index) pairs of all clouds, concatenated in cloud order (clobbered); kv_b: scratch of the same size
+void segsort_pairs(const IndexDesc* descs, int n_clouds, int max_n, uint64_t* kv_a, uint64_t* kv_b, uint64_t* keys_out, uint32_t* vals_out, uint32_t* hist,
+                   hipStream_t s);
 size_t sort64_temp_bytes(int n);
 void sort_pairs_u64(void* temp, size_t temp_bytes, const uint64_t* keys_in, uint64_t* keys_out, const uint32_t* vals_in,
                     uint32_t* vals_out, int n, int end_bit, hipStream_t s);
-void launch_index_keys(const IndexDesc* descs, int n_clouds, int max_n, uint32_t* bbox_enc /*[n_clouds][8]*/, uint64_t* keys,
+void launch_index_bbox_init(uint32_t* bbox_enc /*[MAX_INDEX_BATCH][8]*/, hipStream_t s);   // once per allocation; every build leaves the slots reset
+// pairs: (30-bit key, index) packed in 8 bytes, the segmented sort's input; keys / vals (nullable): the same as (cloud << 32 | key) + index arrays
+void launch_index_keys(const IndexDesc* descs, int n_clouds, int max_n, uint32_t* bbox_enc /*[n_clouds][8]*/, uint64_t* pairs, uint64_t* keys,
                        uint32_t* vals, hipStream_t s);
-// flags of the leaf starts (then the caller scans them into t.lid) ...
-void launch_index_leaves(const TreeScratch& t, hipStream_t s);
-// ... and everything after the scan: sorted points, leaf records, radix tree, boxes, 4-ary nodes, headers
-// stage 0: sorted points + leaf records, 1: radix hierarchy, 2: box tables, 3: 4-ary nodes + headers (separate so they can be timed)
-void launch_index_trees(const IndexDesc* descs, int n_clouds, int max_n, const TreeScratch& t, const uint32_t* vals_sorted, hipStream_t s, int stage);
+// leaf-start flags + leaves per tile -> tile offsets -> running leaf numbers (t.lid), sorted points, inverse permutation, leaf records
+void launch_index_leaves(const IndexDesc* descs, int n_clouds, const TreeScratch& t, const uint32_t* vals_sorted, uint32_t* bbox_enc, hipStream_t s);
+// ... and everything after: stage 0: box tables (per leaf, per 32, per 1024 leaves), 1: radix hierarchy + one box per binary node,
+// 2: 4-ary nodes + headers (separate so they can be timed)
+void launch_index_trees(const IndexDesc* descs, int n_clouds, int max_n, const TreeScratch& t, hipStream_t s, int stage);
 
 // ---- K4 / K5 ---------------------------------------------------------------------------------------
 void launch_sweep(const PairDesc* descs, SweepArgs& a, int max_n, hipStream_t s);

@@ -22,7 +22,7 @@ constexpr int RS_BITS = 10, RS_BINS = 1 << RS_BITS, RS_TILE = 4096, RS_PER_THREA
 
 // Elements in flight between the passes are (key, point index) PAIRS in one 8-byte word: an LSD pass scatters every element
 // to its own place (the low Hilbert digits of neighbouring points are unrelated), so what counts is the number of isolated
-// stores, and a pair costs one instead of two.  Pass 0 reads the build's u64 keys + u32 indices, pass 2 writes them again.
+// stores, and a pair costs one instead of two.  k_key_b writes the pairs, the last pass writes (cloud << 32 | key) and the index.
 template <bool kFirst>
 __device__ __forceinline__ uint32_t rs_key(const void* keys, size_t g) {
   if constexpr (kFirst) return (uint32_t)reinterpret_cast<const uint64_t*>(keys)[g];   // low word = the 30-bit key
@@ -402,26 +402,25 @@ void inclusive_scan_u32(void* temp, size_t, const uint32_t* in, uint32_t* out, i
 int segsort_tiles(int n) { return (n + RS_TILE - 1) / RS_TILE; }   // IndexDesc::tile0 = sum of the previous clouds' tiles
 size_t segsort_hist_elems(long total_points, int n_clouds) { return (size_t)(total_points / RS_TILE + n_clouds) * RS_BINS; }
 
-// keys_in: (cloud << 32 | 30-bit key) of all clouds, concatenated in cloud order (descs[c].offset / .n); vals_in: point indices.
-// kv_a / kv_b: two scratch arrays of (total points) 8-byte pairs.  On return keys_out / vals_out hold every cloud's segment
-// sorted by key, ties in ascending input position.
-void segsort_pairs(const IndexDesc* descs, int n_clouds, int max_n, const uint64_t* keys_in, uint64_t* keys_out, const uint32_t* vals_in,
-                   uint32_t* vals_out, uint64_t* kv_a, uint64_t* kv_b, uint32_t* hist, hipStream_t s) {
+// kv_a: (30-bit key, point index) pairs of all clouds, concatenated in cloud order (descs[c].offset / .n), written by k_key_b;
+// kv_b: scratch of the same size.  On return keys_out (cloud << 32 | key) / vals_out hold every cloud's segment sorted by key, ties
+// in ascending input position.  Every pass moves 8-byte pairs.
+void segsort_pairs(const IndexDesc* descs, int n_clouds, int max_n, uint64_t* kv_a, uint64_t* kv_b, uint64_t* keys_out, uint32_t* vals_out, uint32_t* hist,
+                   hipStream_t s) {
   const int tiles = (max_n + RS_TILE - 1) / RS_TILE;
   const dim3 grid(tiles, n_clouds), blk(256);
-  // pass 0: (u64 key, u32 index) in, pairs out
-  hipLaunchKernelGGL(k_rs_hist<true>, grid, blk, 0, s, descs, (const void*)keys_in, 0, hist);
+  hipLaunchKernelGGL(k_rs_hist<false>, grid, blk, 0, s, descs, (const void*)kv_a, 0, hist);
   hipLaunchKernelGGL(k_rs_scan, dim3(n_clouds), dim3(256), 0, s, descs, hist);
-  hipLaunchKernelGGL((k_rs_scatter<true, false>), grid, blk, 0, s, descs, (const void*)keys_in, vals_in, 0, (const uint32_t*)hist, (void*)kv_a, (uint32_t*)nullptr);
-  // pass 1: pairs -> pairs
-  hipLaunchKernelGGL(k_rs_hist<false>, grid, blk, 0, s, descs, (const void*)kv_a, RS_BITS, hist);
-  hipLaunchKernelGGL(k_rs_scan, dim3(n_clouds), dim3(256), 0, s, descs, hist);
-  hipLaunchKernelGGL((k_rs_scatter<false, false>), grid, blk, 0, s, descs, (const void*)kv_a, (const uint32_t*)nullptr, RS_BITS, (const uint32_t*)hist, (void*)kv_b,
+  hipLaunchKernelGGL((k_rs_scatter<false, false>), grid, blk, 0, s, descs, (const void*)kv_a, (const uint32_t*)nullptr, 0, (const uint32_t*)hist, (void*)kv_b,
                      (uint32_t*)nullptr);
-  // pass 2: pairs in, (cloud << 32 | key) and index out
-  hipLaunchKernelGGL(k_rs_hist<false>, grid, blk, 0, s, descs, (const void*)kv_b, 2 * RS_BITS, hist);
+  hipLaunchKernelGGL(k_rs_hist<false>, grid, blk, 0, s, descs, (const void*)kv_b, RS_BITS, hist);
   hipLaunchKernelGGL(k_rs_scan, dim3(n_clouds), dim3(256), 0, s, descs, hist);
-  hipLaunchKernelGGL((k_rs_scatter<false, true>), grid, blk, 0, s, descs, (const void*)kv_b, (const uint32_t*)nullptr, 2 * RS_BITS, (const uint32_t*)hist, (void*)keys_out,
+  hipLaunchKernelGGL((k_rs_scatter<false, false>), grid, blk, 0, s, descs, (const void*)kv_b, (const uint32_t*)nullptr, RS_BITS, (const uint32_t*)hist, (void*)kv_a,
+                     (uint32_t*)nullptr);
+  // last pass: pairs in, (cloud << 32 | key) and index out
+  hipLaunchKernelGGL(k_rs_hist<false>, grid, blk, 0, s, descs, (const void*)kv_a, 2 * RS_BITS, hist);
+  hipLaunchKernelGGL(k_rs_scan, dim3(n_clouds), dim3(256), 0, s, descs, hist);
+  hipLaunchKernelGGL((k_rs_scatter<false, true>), grid, blk, 0, s, descs, (const void*)kv_a, (const uint32_t*)nullptr, 2 * RS_BITS, (const uint32_t*)hist, (void*)keys_out,
                      vals_out);
 }
 
