@@ -945,7 +945,7 @@ static lh_status group_launch(lh_ctx* c, Group& g) {
       max_n = std::max(max_n, t->src->n);
     }
     ProfScope p(c, "cost_fdf", 0.0, st);
-    launch_cost(c->descs_dev, a, max_n, c->partials_host, st);
+    launch_cost(c->descs_dev, a, max_n, c->mom_partials_dev, c->mom_stride, c->partials_host, st);
   }
   HIPCHK(hipGetLastError());
   g.inflight = !g.costs.empty() || !g.sweeps.empty();
@@ -956,12 +956,9 @@ static lh_status group_collect(lh_ctx* c, Group& g) {
   if (g.inflight) HIPCHK(hipStreamSynchronize(g.stream));
   g.inflight = false;
   for (Task* t : g.costs) {
-    const double* part = c->partials_host + (size_t)t->slot * c->partials_per_slot;
-    int nb = cost_blocks(t->src->n);
+    const double* part = c->partials_host + (size_t)t->slot * c->partials_per_slot;   // the 14 sums, added in block order by k_cost_final
     double S[COST_NSUM];
-    for (int k = 0; k < COST_NSUM; k++) S[k] = 0.0;
-    for (int b = 0; b < nb; b++)  // fixed order => bitwise reproducible
-      for (int k = 0; k < COST_NSUM; k++) S[k] += part[(size_t)b * COST_NSUM + k];
+    for (int k = 0; k < COST_NSUM; k++) S[k] = part[k];
     if (c->reduce_fn && c->reduce_fn(S, COST_NSUM, c->reduce_user) != 0) return LH_EDEVICE;
     memcpy(t->res_sums, S, sizeof(S));
     if (c->prof) {  // algorithmic bytes with the measured K_t: B_fdf = 108 K_t, B_nn += 232 K_t
@@ -969,7 +966,15 @@ static lh_status group_collect(lh_ctx* c, Group& g) {
       if (t->sweep_bytes_pending) c->prof_entries[c->prof_entry("nn_sweep")].bytes += 232.0 * S[13];
     }
     t->sweep_bytes_pending = false;
-    t->resume();
+  }
+  if (!g.costs.empty()) {  // every pair's BFGS now takes its next step (up to its next evaluation request): independent, on the host pool
+    if (!c->pool) {
+      const char* e = getenv("LH_HOST_THREADS");
+      int nt = e ? atoi(e) : 8;
+      c->pool = new HostPool(std::max(0, nt - 1));
+    }
+    std::vector<Task*>& costs = g.costs;
+    c->pool->parallel_for((int)costs.size(), [&costs](int i) { costs[i]->resume(); });
   }
   for (Task* t : g.moms) {  // deliver the moments; the task then runs its whole BFGS solve on the host
     const double* part = c->partials_host + (size_t)t->slot * c->partials_per_slot;  // FINAL_CHUNKS x 74 chunk sums
@@ -1313,11 +1318,21 @@ static lh_status run_tasks_device(lh_ctx* c, std::vector<Task*>& tasks, int in_f
 
 // run a set of tasks to completion, at most `in_flight` concurrently
 static lh_status run_tasks_host(lh_ctx* c, std::vector<Task*>& tasks, int in_flight, bool rebuild_index, std::vector<Workspace>* slot_ws) {
-  const int G = (in_flight >= 16 && !c->prof) ? 2 : 1;  // profiling keeps one group so HIP-event times do not overlap
-  if (G == 2 && !c->stream2) HIPCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
-  Group groups[2];
+  // Groups: one per MAX_JOBS (32) pairs in flight like the device-driven loop, each on its own stream -- while the host thread delivers
+  // one group's sums and resumes its solves, the other groups' kernels keep the GPU busy.  With two groups (round 2) the reference-
+  // arithmetic mode, whose every cost evaluation is a launch + a synchronisation, left the GPU idle 40 % of the time (18 502 k_cost
+  // launches per 512-pair step).  Profiling keeps one group so HIP-event times do not overlap.
+  static const int host_groups_cfg = []() { const char* e = getenv("LH_HOST_GROUPS"); int v = e ? atoi(e) : 0; return v < 0 ? 0 : (v > lh_ctx::MAX_GROUPS ? lh_ctx::MAX_GROUPS : v); }();
+  int G = host_groups_cfg ? host_groups_cfg : (in_flight >= 64 ? std::min(16, in_flight / MAX_JOBS) : (in_flight >= 16 ? 2 : 1));
+  if (c->prof) G = 1;
+  G = std::max(1, std::min(G, in_flight));
+  hipStream_t* extra[lh_ctx::MAX_GROUPS - 1] = {&c->stream2, &c->stream3, &c->stream4};
+  for (int k = 0; k < lh_ctx::MAX_GROUPS - 4; k++) extra[3 + k] = &c->stream_more[k];
+  for (int gi = 1; gi < G; gi++)
+    if (!*extra[gi - 1]) HIPCHK(hipStreamCreateWithFlags(extra[gi - 1], hipStreamNonBlocking));
+  std::vector<Group> groups(G);
   groups[0].stream = c->stream;
-  groups[1].stream = c->stream2;
+  for (int gi = 1; gi < G; gi++) groups[gi].stream = *extra[gi - 1];
   {
     int per = (in_flight + G - 1) / G, s = 0;
     for (int gi = 0; gi < G; gi++)
@@ -2207,14 +2222,11 @@ lh_status lh_gicp_debug_cost(lh_gicp* g, const double x[6], double* f, double g6
   CostArgs a;
   a.njobs = 1; a.pad = 0; a.job[0].slot = 0; a.job[0].out_offset = 0;
   Task::T16_to_T12(T16, a.job[0].T);
-  { ProfScope p(c, "cost_fdf", 108.0 * g->src->n); launch_cost(c->descs_dev, a, g->src->n, c->partials_host, c->stream); }
+  { ProfScope p(c, "cost_fdf", 108.0 * g->src->n); launch_cost(c->descs_dev, a, g->src->n, c->mom_partials_dev, c->mom_stride, c->partials_host, c->stream); }
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(c->stream));
-  int nb = cost_blocks(g->src->n);
   double S[COST_NSUM];
-  for (int k = 0; k < COST_NSUM; k++) S[k] = 0.0;
-  for (int b = 0; b < nb; b++)
-    for (int k = 0; k < COST_NSUM; k++) S[k] += c->partials_host[(size_t)b * COST_NSUM + k];
+  for (int k = 0; k < COST_NSUM; k++) S[k] = c->partials_host[k];
   if (sums13) memcpy(sums13, S, sizeof(double) * 13);
   if (m) *m = (int)S[13];
   double ff = 0, gg[6] = {0, 0, 0, 0, 0, 0};

@@ -1265,7 +1265,7 @@ void launch_sweep(const PairDesc* descs, SweepArgs& a, int max_n, hipStream_t s)
 }
 
 // ===== K5: cost / gradient reduction =======================================================================
-__global__ void __launch_bounds__(256) k_cost(const PairDesc* __restrict__ descs, CostArgs a, double* __restrict__ out) {
+__global__ void __launch_bounds__(256) k_cost(const PairDesc* __restrict__ descs, CostArgs a, double* __restrict__ out, int out_stride) {
   const CostJob& job = a.job[blockIdx.y];
   const PairDesc d = descs[job.slot];
   int base = blockIdx.x * COST_CHUNK;
@@ -1315,12 +1315,35 @@ __global__ void __launch_bounds__(256) k_cost(const PairDesc* __restrict__ descs
   __syncthreads();
   if (threadIdx.x < COST_NSUM) {
     double v = ((sm[0][threadIdx.x] + sm[1][threadIdx.x]) + sm[2][threadIdx.x]) + sm[3][threadIdx.x];
-    out[job.out_offset + blockIdx.x * COST_NSUM + threadIdx.x] = v;
+    out[(size_t)job.slot * out_stride + blockIdx.x * COST_NSUM + threadIdx.x] = v;
   }
 }
+// The block sums of a job added in BLOCK ORDER, one after the other -- the order the host used while the partial sums still crossed
+// PCIe (22 KB per pair and evaluation, 90 k host additions per 32-pair launch: the reference-arithmetic mode was bound by exactly
+// that): the same 14 numbers, bit for bit, now 112 bytes per pair in pinned host memory.
+__global__ void __launch_bounds__(64) k_cost_final(const PairDesc* __restrict__ descs, CostArgs a, const double* __restrict__ part, int part_stride,
+                                                   double* __restrict__ out) {
+  const CostJob& job = a.job[blockIdx.x];
+  const int k = threadIdx.x;
+  if (k >= COST_NSUM) return;
+  const int nb = cost_blocks(descs[job.slot].n);
+  const double* p = part + (size_t)job.slot * part_stride + k;
+  double s = 0.0;
+  int b = 0;
+  for (; b + 8 <= nb; b += 8) {   // eight loads in flight, added in order
+    double v[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) v[e] = p[(size_t)(b + e) * COST_NSUM];
+#pragma unroll
+    for (int e = 0; e < 8; e++) s += v[e];
+  }
+  for (; b < nb; b++) s += p[(size_t)b * COST_NSUM];
+  out[job.out_offset + k] = s;
+}
 
-void launch_cost(const PairDesc* descs, const CostArgs& a, int max_n, double* out, hipStream_t s) {
-  hipLaunchKernelGGL(k_cost, dim3(cost_blocks(max_n), a.njobs), dim3(256), 0, s, descs, a, out);
+void launch_cost(const PairDesc* descs, const CostArgs& a, int max_n, double* partials_dev, int partials_stride, double* out, hipStream_t s) {
+  hipLaunchKernelGGL(k_cost, dim3(cost_blocks(max_n), a.njobs), dim3(256), 0, s, descs, a, partials_dev, partials_stride);
+  hipLaunchKernelGGL(k_cost_final, dim3(a.njobs), dim3(64), 0, s, descs, a, (const double*)partials_dev, partials_stride, out);
 }
 
 // ===== K5': second-order moments of the cost about T0 =====================================================

@@ -157,8 +157,10 @@ constexpr int FINAL_CHUNKS = 8;   // the final sum leaves FINAL_CHUNKS x 74 chun
 // cold-start helper: the nearest point of the leaf nearest to every 4th source point, written as the warm-start candidate of its group
 void launch_seed(const PairDesc* descs, SweepArgs& a, int max_n, hipStream_t s);
 constexpr int SEED_GROUP = 4;
-void launch_cost(const PairDesc* descs, const CostArgs& a, int max_n, double* out, hipStream_t s);
-inline int cost_blocks(int n) { return (n + COST_CHUNK - 1) / COST_CHUNK; }
+__host__ __device__ inline int cost_blocks(int n) { return (n + COST_CHUNK - 1) / COST_CHUNK; }
+// one pass of the cost functor: per-block sums in partials_dev[slot * partials_stride + block * COST_NSUM + k], then their sum in block
+// order in out[job.out_offset + k] (k < COST_NSUM; pinned host memory for the host-driven loop)
+void launch_cost(const PairDesc* descs, const CostArgs& a, int max_n, double* partials_dev, int partials_stride, double* out, hipStream_t s);
 // second-order moments of the cost about T0 = job.T (see lh_bfgs.hpp MomentModel): per-block partials on the device,
 // then one workgroup per job sums them in block order into out[job.out_offset + k], k < MOM_NSUM
 void launch_moments(const PairDesc* descs, const CostArgs& a, int max_n, double* partials_dev, int partials_stride, double* out,
