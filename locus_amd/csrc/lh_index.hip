@@ -1,0 +1,154 @@
+// lh_index.hip -- K2: the batched NN-index build (replaces tree_->setInputCloud of pcl::Registration::initCompute) and the k-NN
+// covariances of a cloud (gicp.hpp:85-154), host side (see lh_runtime.hpp; kernels in lh_kernels.hip / lh_radix.hip).
+#include "lh_runtime.hpp"
+
+// K2: Hilbert sort + cell-aligned radix tree with 4-ary nodes (replaces tree_->setInputCloud of pcl::Registration::initCompute).
+// All clouds of a batch are built by the same launches, one radix sort and one scan (see lh_kernels.hpp "K2 batched").
+lh_status build_indices(lh_ctx* x, lh_cloud* const* clouds, int n_clouds, hipStream_t s_in) {
+  if (n_clouds <= 0) return LH_OK;
+  hipStream_t s = s_in ? s_in : x->stream;
+  for (int o = 0; o < n_clouds; o += MAX_INDEX_BATCH) {
+    int nb = std::min(MAX_INDEX_BATCH, n_clouds - o);
+    long total = 0;
+    int max_n = 0, tile0 = 0;
+    if (!x->idx_descs_dev) {
+      HIPCHK(hipMalloc(&x->idx_descs_dev, sizeof(IndexDesc) * MAX_INDEX_BATCH));
+      HIPCHK(hipHostMalloc(&x->idx_descs_host, sizeof(IndexDesc) * MAX_INDEX_BATCH * lh_ctx::IDX_STAGE, hipHostMallocDefault));
+      HIPCHK(hipMalloc(&x->idx_bbox, sizeof(uint32_t) * 8 * MAX_INDEX_BATCH));
+      launch_index_bbox_init(x->idx_bbox, s);   // (every build then leaves the slots reset for the next one)
+      for (int k = 0; k < lh_ctx::IDX_STAGE; k++) HIPCHK(hipEventCreateWithFlags(&x->idx_copy_done[k], hipEventDisableTiming));
+      HIPCHK(hipEventCreateWithFlags(&x->idx_build_done, hipEventDisableTiming));
+    }
+    // The descriptors are staged in a ring: the upload of a build is queued behind the previous build on the GPU (shared scratch), so
+    // waiting for the PREVIOUS upload before refilling one staging buffer tied the scheduling thread to the GPU's index builds
+    // (1.6 ms per group of 32 with sixteen groups in flight: 25 of a 60-ms step).  Only the upload IDX_STAGE builds ago is waited for.
+    const int stage = x->idx_stage;
+    x->idx_stage = (x->idx_stage + 1) % lh_ctx::IDX_STAGE;
+    IndexDesc* const stage_host = x->idx_descs_host + (size_t)stage * MAX_INDEX_BATCH;
+    HIPCHK(hipEventSynchronize(x->idx_copy_done[stage]));   // (an event that was never recorded is complete)
+    for (int k = 0; k < nb; k++) {
+      lh_cloud* c = clouds[o + k];
+      if (!c || c->n <= 0 || c->ctx != x) return LH_EINVAL;
+      if (c->n > (1 << 27)) return LH_EINVAL;  // leaf references keep 27 bits of sorted position
+      if (c->n > c->index_cap) {
+        (void)hipStreamSynchronize(x->stream);
+        x->sync_side_streams();
+        (void)lhFree(c->sorted); (void)lhFree(c->node_buf);
+        c->sorted = nullptr; c->node_buf = nullptr; c->index_cap = 0;
+        HIPCHK(lhMalloc(&c->sorted, sizeof(float4) * ((size_t)c->n + LEAF_CAP)));
+        HIPCHK(lhMalloc(&c->node_buf, sizeof(NodeX) * ((size_t)c->n + 1)));  // worst case: every point its own leaf
+        c->index_cap = c->n;
+      }
+      IndexDesc& d = stage_host[k];
+      d.xyz = c->xyz; d.sorted = c->sorted; d.nodes = c->nodes(); d.hdr = c->hdr(); d.pos = nullptr;
+      d.n = c->n; d.offset = (int)total;
+      d.tile0 = tile0; d.pad = 0;
+      tile0 += segsort_tiles(c->n);
+      total += c->n;
+      max_n = std::max(max_n, c->n);
+    }
+    if (total > 0x7ffffff0L) return LH_EINVAL;
+    if ((int)total > x->idx_cap) {
+      (void)hipStreamSynchronize(x->stream);
+      x->sync_side_streams();
+      (void)lhFree(x->k64a); (void)lhFree(x->k64b); (void)lhFree(x->v32a); (void)lhFree(x->v32b); (void)lhFree(x->sort64_temp);
+      (void)lhFree(x->tree_tmp); (void)lhFree(x->scan_tmp); (void)lhFree(x->k32a); (void)lhFree(x->k32b); (void)lhFree(x->rs_hist);
+      int cap = round_up((int)std::min<long>(total + total / 4, 0x7fffff00L), 1024);
+      HIPCHK(hipMalloc(&x->k64a, sizeof(uint64_t) * (size_t)cap));
+      HIPCHK(hipMalloc(&x->k64b, sizeof(uint64_t) * (size_t)cap));
+      HIPCHK(hipMalloc(&x->v32a, sizeof(uint32_t) * (size_t)cap));
+      HIPCHK(hipMalloc(&x->v32b, sizeof(uint32_t) * (size_t)cap));
+      HIPCHK(hipMalloc(&x->k32a, sizeof(uint64_t) * (size_t)cap));
+      HIPCHK(hipMalloc(&x->k32b, sizeof(uint64_t) * (size_t)cap));
+      HIPCHK(hipMalloc(&x->rs_hist, sizeof(uint32_t) * segsort_hist_elems(cap, MAX_INDEX_BATCH)));
+      x->sort64_temp_bytes = sort64_temp_bytes(cap);
+      HIPCHK(hipMalloc(&x->sort64_temp, x->sort64_temp_bytes ? x->sort64_temp_bytes : 16));
+      HIPCHK(hipMalloc(&x->tree_tmp, TREE_SCRATCH_BYTES_PER_POINT * ((size_t)cap + 16) + 4096));
+      HIPCHK(hipMemsetAsync(x->tree_tmp, 0, TREE_SCRATCH_BYTES_PER_POINT * ((size_t)cap + 16) + 4096, s));   // (the per-tile leaf counts must start at zero; every build leaves them so)
+      x->idx_cap = cap;
+    }
+    TreeScratch ts;
+    {
+      size_t cap = (size_t)x->idx_cap + 16;
+      char* p = x->tree_tmp;
+      ts.lkey = reinterpret_cast<uint64_t*>(p); p += 8 * cap;       // 16-byte aligned arrays first (cap is a multiple of 16)
+      ts.lbox = reinterpret_cast<float4*>(p); p += 32 * cap;
+      ts.a1box = reinterpret_cast<float4*>(p); p += 32 * (cap / 32 + 16);
+      ts.a2box = reinterpret_cast<float4*>(p); p += 32 * (cap / 1024 + 16);
+      ts.ibox = reinterpret_cast<float4*>(p); p += 32 * cap;
+      ts.ichild = reinterpret_cast<int32_t*>(p); p += 8 * cap;
+      ts.irange = reinterpret_cast<int32_t*>(p); p += 8 * cap;
+      ts.iparent = reinterpret_cast<int32_t*>(p); p += 4 * cap;
+      ts.flag = reinterpret_cast<uint32_t*>(p); p += 4 * cap;
+      ts.lid = reinterpret_cast<uint32_t*>(p); p += 4 * cap;
+      ts.lstart = reinterpret_cast<uint32_t*>(p); p += 4 * cap;
+      ts.tsum = reinterpret_cast<uint32_t*>(p); p += 4 * (cap / 4096 + 16);
+      ts.toff = reinterpret_cast<uint32_t*>(p); p += 4 * (cap / 4096 + 16);
+      ts.keys = x->k64b;
+      ts.total = (int)total;
+    }
+    HIPCHK(hipStreamWaitEvent(s, x->idx_build_done, 0));  // the shared build scratch may still be in use on the other stream
+    HIPCHK(hipMemcpyAsync(x->idx_descs_dev, stage_host, sizeof(IndexDesc) * nb, hipMemcpyHostToDevice, s));
+    HIPCHK(hipEventRecord(x->idx_copy_done[stage], s));
+    int id_bits = 0;
+    while ((1 << id_bits) < nb) id_bits++;
+    // LH_SORT=generic: the one-segment 64-bit sort over the whole concatenated array instead of the segmented one (A/B);
+    // LH_SORT=check: both, compared element by element (tests: two independent code paths must give the same stable order)
+    static const int sort_cfg = []() { const char* e = getenv("LH_SORT"); return !e ? 0 : (strcmp(e, "generic") == 0 ? 1 : (strcmp(e, "check") == 0 ? 2 : 0)); }();
+    { ProfScope p(x, "index_bbox_keys", 16.0 * total * 2, s);
+      launch_index_keys(x->idx_descs_dev, nb, max_n, x->idx_bbox, x->k32a, sort_cfg ? x->k64a : nullptr, sort_cfg ? x->v32a : nullptr, s); }
+    {
+      if (sort_cfg == 1) {
+        ProfScope p(x, "index_radix_sort", 12.0 * total * 2 * 4, s);
+        sort_pairs_u64(x->sort64_temp, x->sort64_temp_bytes, x->k64a, x->k64b, x->v32a, x->v32b, (int)total, 32 + id_bits, s);
+      } else {
+        std::vector<uint64_t> kref;
+        std::vector<uint32_t> vref;
+        if (sort_cfg == 2) {  // reference first
+          sort_pairs_u64(x->sort64_temp, x->sort64_temp_bytes, x->k64a, x->k64b, x->v32a, x->v32b, (int)total, 32 + id_bits, s);
+          kref.resize(total); vref.resize(total);
+          HIPCHK(hipMemcpyAsync(kref.data(), x->k64b, sizeof(uint64_t) * total, hipMemcpyDeviceToHost, s));
+          HIPCHK(hipMemcpyAsync(vref.data(), x->v32b, sizeof(uint32_t) * total, hipMemcpyDeviceToHost, s));
+          HIPCHK(hipStreamSynchronize(s));
+        }
+        { ProfScope p(x, "index_radix_sort", 8.0 * total * 3 * 2, s);
+          segsort_pairs(x->idx_descs_dev, nb, max_n, x->k32a, x->k32b, x->k64b, x->v32b, x->rs_hist, s); }
+        if (sort_cfg == 2) {
+          std::vector<uint64_t> kk(total);
+          std::vector<uint32_t> vv(total);
+          HIPCHK(hipMemcpyAsync(kk.data(), x->k64b, sizeof(uint64_t) * total, hipMemcpyDeviceToHost, s));
+          HIPCHK(hipMemcpyAsync(vv.data(), x->v32b, sizeof(uint32_t) * total, hipMemcpyDeviceToHost, s));
+          HIPCHK(hipStreamSynchronize(s));
+          long bad = 0;
+          for (long i = 0; i < total; i++)
+            if (kk[i] != kref[i] || vv[i] != vref[i]) bad++;
+          if (bad) {
+            fprintf(stderr, "[locus_hip] LH_SORT=check: %ld of %ld sorted elements differ between the segmented and the one-segment sort\n", bad, total);
+            return LH_EDEVICE;
+          }
+        }
+      }
+    }
+    { ProfScope p(x, "index_leaves", 8.0 * total * 3 + 48.0 * total, s); launch_index_leaves(x->idx_descs_dev, nb, ts, x->v32b, x->idx_bbox, s); }
+    { ProfScope p(x, "index_box_tables", 24.0 * total, s); launch_index_trees(x->idx_descs_dev, nb, max_n, ts, s, 0); }
+    { ProfScope p(x, "index_radix_tree", 8.0 * total, s); launch_index_trees(x->idx_descs_dev, nb, max_n, ts, s, 1); }
+    { ProfScope p(x, "index_nodes", 32.0 * total, s); launch_index_trees(x->idx_descs_dev, nb, max_n, ts, s, 2); }
+    HIPCHK(hipEventRecord(x->idx_build_done, s));
+    HIPCHK(hipGetLastError());
+    for (int k = 0; k < nb; k++) clouds[o + k]->has_index = true;
+  }
+  return LH_OK;
+}
+
+lh_status cloud_ensure_cov(lh_cloud* c, int k, double eps) {
+  if (c->cov6 && c->cov_k == k && c->cov_eps == eps) return LH_OK;
+  if (k > c->n || k > 64 || k < 1) return LH_EINVAL;  // gicp.hpp:72-79
+  if (!c->has_index) { lh_status st = cloud_build_index(c); if (st) return st; }
+  if (!c->cov6) HIPCHK(lhMalloc(&c->cov6, sizeof(double) * 6 * (size_t)c->n_pad));
+  { ProfScope p(c->ctx, "knn_cov", (16.0 + 20 * 16.0 + 48.0) * c->n); launch_knn_cov(c->xyz, c->n, c->n_pad, c->view(), k, eps, c->cov6, c->ctx->stream); }
+  HIPCHK(hipGetLastError());
+  c->cov_k = k;
+  c->cov_eps = eps;
+  return LH_OK;
+}
+

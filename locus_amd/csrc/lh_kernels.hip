@@ -1615,6 +1615,26 @@ void launch_transform_copy(const float4* in_xyz, const float4* in_nrm, const flo
   hipLaunchKernelGGL(k_transform_copy, dim3((n + 255) / 256), dim3(256), 0, s, in_xyz, in_nrm, in_int, n, T, out_xyz, out_nrm, out_int);
 }
 
+// A host point array (pcl::PointXYZI / PointXYZINormal / any stride with float fields, lh_cloud_view) copied to the device AS IT IS and
+// taken apart here into the path's layout (xyz1 | normal + curvature | intensity): the host never touches the points (a scalar repack
+// loop + three staged copies cost ~0.45 ms per 100 k-point scan: the PCIe-inclusive rate was bound by the host, not by PCIe).
+__global__ void __launch_bounds__(256) k_unpack_view(const unsigned char* __restrict__ raw, int n, uint32_t stride, uint32_t off_xyz, uint32_t off_normal,
+                                                     uint32_t off_intensity, uint32_t off_curvature, float4* __restrict__ xyz, float4* __restrict__ nrm,
+                                                     float* __restrict__ inten) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const unsigned char* p = raw + (size_t)i * stride;
+  auto f = [&](uint32_t off) { float v; __builtin_memcpy(&v, p + off, 4); return v; };   // (fields are 4-byte aligned in every PCL point type; memcpy keeps odd strides legal)
+  xyz[i] = make_float4(f(off_xyz), f(off_xyz + 4), f(off_xyz + 8), 1.0f);
+  if (nrm) nrm[i] = make_float4(f(off_normal), f(off_normal + 4), f(off_normal + 8), off_curvature != 0xffffffffu ? f(off_curvature) : 0.0f);
+  if (inten) inten[i] = f(off_intensity);
+}
+void launch_unpack_view(const void* raw, int n, uint32_t stride, uint32_t off_xyz, uint32_t off_normal, uint32_t off_intensity, uint32_t off_curvature,
+                        float4* xyz, float4* nrm, float* inten, hipStream_t s) {
+  hipLaunchKernelGGL(k_unpack_view, dim3((n + 255) / 256), dim3(256), 0, s, (const unsigned char*)raw, n, stride, off_xyz, off_normal, off_intensity, off_curvature,
+                     xyz, nrm, inten);
+}
+
 __global__ void __launch_bounds__(256) k_fill_i32(int32_t* p, int n, int32_t v) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = v;

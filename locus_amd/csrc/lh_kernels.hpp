@@ -183,6 +183,9 @@ constexpr int MAX_XFORM_JOBS = 32;   // 32 x 104 B of launch arguments
 struct XformBatchArgs { int njobs, pad; XformJob job[MAX_XFORM_JOBS]; };
 void launch_transform_copy_batch(const XformBatchArgs& a, int max_n, hipStream_t s);
 void launch_fill_i32(int32_t* p, int n, int32_t v, hipStream_t s);
+// raw = a device copy of a host point array (n x stride bytes): its float fields into the path's arrays (nrm / inten nullable)
+void launch_unpack_view(const void* raw, int n, uint32_t stride, uint32_t off_xyz, uint32_t off_normal, uint32_t off_intensity, uint32_t off_curvature,
+                        float4* xyz, float4* nrm, float* inten, hipStream_t s);
 // ungated 1-NN of T*q against a tree; T12 may be null (identity)
 void launch_nn1(const float4* q, int nq, const float* T12, TreeView tree, int32_t* idx, float* d2, hipStream_t s);
 // instrumentation: per-query visit counts of a cold 1-NN search; stats[0..4] = sum nodes, sum leaves, sum over waves of
