@@ -733,6 +733,7 @@ lh_status lh_gicp_debug_sweep_fused(lh_gicp* g, const float T[16], int sweep_ind
   memcpy(ca.job[0].T, a.job[0].T, sizeof(a.job[0].T));
   launch_sweep_fused(c->descs_dev, a, sweep_is_split(&t, sweep_index) ? 1u : 0u, g->src->n, c->mom_partials_dev, c->mom_stride, nullptr, true, c->wmask_dev,
                      c->mask_stride, c->stream);
+  ca.pad = sweep_is_split(&t, sweep_index) ? 0 : 1;   // whose rows the final sum adds: the fused sweep's or k_late's + k_walk's
   launch_moments_final(c->descs_dev, ca, c->mom_partials_dev, c->mom_stride, c->partials_host, nullptr, c->wmask_dev, c->mask_stride, c->stream);
   HIPCHK(hipGetLastError());
   if (tgt_idx) HIPCHK(hipMemcpyAsync(tgt_idx, g->ws.prev_nn, sizeof(int32_t) * (size_t)g->src->n, hipMemcpyDeviceToHost, c->stream));

@@ -473,6 +473,7 @@ __global__ void __launch_bounds__(256) k_seed(const PairDesc* __restrict__ descs
       if (d.rec) { d.rec[2 * (size_t)(i + e)] = rt; d.rec[2 * (size_t)(i + e) + 1] = rn; }  // the record follows prev_nn
     }
 }
+
 void launch_seed(const PairDesc* descs, SweepArgs& a, int max_n, hipStream_t s) {
   static const int seed_group = []() { const char* e = getenv("LH_SEED_GROUP"); int v = e ? atoi(e) : SEED_GROUP; return v < 1 ? 1 : v; }();
   a.pad = seed_group;
@@ -527,7 +528,7 @@ struct SweepPoint {
 // operations, no square roots, and inverted as a symmetric 3x3 (six cofactors).  Its rounding differs from the reference's
 // order of operations (normalise, two 3x3x3 products) in the last bits of M, which is why only cost_mode 1 -- a bit-different
 // evaluation of the cost anyway -- uses it; k_sweep (cost_mode 0, the debug entry points) keeps the reference order.
-template <bool kRank1 = false>
+template <bool kRank1 = false, int kStride = 256>
 __device__ __forceinline__ void sweep_point(const PairDesc& d, const float* __restrict__ T, int i, uint64_t* stack, SweepPoint& o, float cm) {
   // first round of loads: everything whose address only depends on i goes out together (the certificate and, in the fused
   // kernel, the source normal as well: each was its own dependent memory round behind the candidate before, and the late
@@ -569,7 +570,7 @@ __device__ __forceinline__ void sweep_point(const PairDesc& d, const float* __re
   }
   o.searched = need_search;
   if (need_search) {
-    tree_search(tv, qx, qy, qz, col, stack, 256);
+    tree_search(tv, qx, qy, qz, col, stack, kStride);
     gst(d.cert + i, make_float4(qx, qy, qz, col.lb));
     if (d.stats) atomicAdd(&d.stats[0], 1ull);  // instrumentation only (lh_gicp_debug_sweep): contended atomics
   }
@@ -867,18 +868,28 @@ __device__ __forceinline__ void wg_row_sum(const double* lds_rows, int wave_stri
 // registers (239 VGPRs, 2 waves per SIMD) pays the reduction once per 4 points but was slower even on certificate-only
 // sweeps (142 vs 128 us): with so few waves the dependent src -> neighbour gathers are no longer hidden.
 // kNormals: every job's covariances come from stored normals (the production configuration) -> rank-one Mahalanobis path
+// FUSED_WG threads per workgroup.  256 (round 1-2): four waves share one LDS region and meet at a barrier before the reduction, so a
+// workgroup lives as long as its slowest wave (the walks of a wave end after 15-25 steps: the other three wait, parked, holding
+// their registers and LDS) and leaves one row per 256 points.  64 (default since round 3; -DLH_FUSED_WG=256 restores the other): every
+// wave is its own workgroup -- no barrier, its slot is free the moment its own walks are over -- and leaves one row per 64 points.
+// Measured: the three all-walk sweeps 590 / 386 / 340 -> 552 / 371 / 326 us per 32 pairs, +2.3 % scan-pairs/s.
+#ifndef LH_FUSED_WG
+#define LH_FUSED_WG 64
+#endif
+constexpr int FUSED_WG = LH_FUSED_WG;
+static_assert(FUSED_WG == 256 || FUSED_WG == 64, "LH_FUSED_WG");
 template <bool kNormals>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) k_sweep_fused(const PairDesc* __restrict__ descs, SweepArgs a, double* __restrict__ partials,
+__global__ void __launch_bounds__(FUSED_WG) __attribute__((amdgpu_waves_per_eu(6))) k_sweep_fused(const PairDesc* __restrict__ descs, SweepArgs a, double* __restrict__ partials,
                                                      int partials_stride, const OuterState* __restrict__ states) {
-  extern __shared__ __attribute__((aligned(16))) uint64_t lds_stack[];  // [entries][256], later reused as double[8][256]
+  extern __shared__ __attribute__((aligned(16))) uint64_t lds_stack[];  // [entries][FUSED_WG], later reused as the Gram staging rows
   int jb, blk;
   if (!xcd_job_map(a.njobs, a.bpj, jb, blk)) return;
   const SweepJob& job = a.job[jb];
   const PairDesc d = descs[job.slot];
-  if (blk * 256 >= d.n) return;  // whole workgroup out of range (uniform)
+  if (blk * FUSED_WG >= d.n) return;  // whole workgroup out of range (uniform)
   float T[12];
   if (!job_transform(job, states, T)) return;  // device-driven loop: this pair has already converged
-  int i = blk * 256 + threadIdx.x;
+  int i = blk * FUSED_WG + threadIdx.x;
   SweepPoint sp;
   sp.matched = false;
   sp.searched = false;
@@ -887,7 +898,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) k
   // does a sweep's time follow the number of LANES that walk (request-bound) or the number of WAVES that do (bound per wave step)?
   // Measured (round 3): a quarter of the lanes -> 25 / 13 / 14 % less time in the three all-walk sweeps: per wave step.
   const bool exp_skip = a.pad2 != 0 && (threadIdx.x & (a.pad2 == 1 ? 1 : 3)) != 0;
-  if (i < d.n && !exp_skip) sweep_point<kNormals>(d, T, i, lds_stack + threadIdx.x, sp, a.cert_rel);
+  if (i < d.n && !exp_skip) sweep_point<kNormals, FUSED_WG>(d, T, i, lds_stack + threadIdx.x, sp, a.cert_rel);
   double M6[6] = {0, 0, 0, 0, 0, 0}, Ma[3] = {0, 0, 0}, pt[4] = {0, 0, 0, 0}, pp[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, aMa = 0.0;
   if (sp.matched) moments_of_point(T, sp, M6, Ma, aMa, pt, pp);
   const double live = sp.matched ? 1.0 : (sp.nonn ? NO_NN_MARK : 0.0);
@@ -899,18 +910,23 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) k
     const double av[11] = {M6[0], M6[1], M6[2], M6[3], M6[4], M6[5], Ma[0], Ma[1], Ma[2], aMa, live};
     GramAcc acc;
     gram_zero(acc);
-    __syncthreads();  // every lane of the workgroup is done with its traversal stack
+    if constexpr (FUSED_WG > 64) __syncthreads();  // every lane of the workgroup is done with its traversal stack
+    else { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); }
     double* wl = reinterpret_cast<double*>(lds_stack) + wave * (32 * GRAM_RS);
     gram_accumulate(wl, av, sp.p, sp.matched, acc, sp.nonn);
-    gram_store(acc, wl, (double)walks);
-    wg_row_sum(reinterpret_cast<double*>(lds_stack), 32 * GRAM_RS, out);
+    if constexpr (FUSED_WG > 64) {
+      gram_store(acc, wl, (double)walks);
+      wg_row_sum(reinterpret_cast<double*>(lds_stack), 32 * GRAM_RS, out);
+    } else
+      gram_store(acc, out, (double)walks);   // the wave's row straight to its place
   }
   // every job has one more row per `span` source points (k_walk's, below); a job swept by this kernel leaves them zero, so that the
   // final sum adds the same rows in the same order whichever way the sweep was launched
   if (a.span > 0) {
-    const int bps = a.span >> 8;
-    if (blk % bps == 0 && threadIdx.x < MOM_ROW)
-      partials[(size_t)job.slot * partials_stride + ((size_t)((d.n + 255) / 256) + blk / bps) * MOM_ROW + threadIdx.x] = 0.0;
+    const int bps = a.span / FUSED_WG;
+    if (blk % bps == 0)
+      for (int k = threadIdx.x; k < MOM_ROW; k += FUSED_WG)
+        partials[(size_t)job.slot * partials_stride + ((size_t)((d.n + FUSED_WG - 1) / FUSED_WG) + blk / bps) * MOM_ROW + k] = 0.0;
   }
 }
 
@@ -1228,6 +1244,7 @@ int sweep_walk_span() {
   static const int span = []() { const char* e = getenv("LH_WALK_SPAN"); int v = e ? atoi(e) : 512; v = v >= 512 ? 512 : 256; return v; }();
   return span;
 }
+int sweep_fused_wg() { return FUSED_WG; }
 int sweep_split_from() {
   static const int from = []() { const char* e = getenv("LH_SPLIT_FROM"); int v = e ? atoi(e) : 3; return v < 0 ? 0 : v; }();
   return from;
@@ -1244,11 +1261,11 @@ void launch_sweep_fused(const PairDesc* descs, SweepArgs& a, uint32_t split_mask
   SweepArgs f, sp;
   split_jobs(a, wmask ? split_mask : 0u, f, sp);
   if (f.njobs > 0) {
-    size_t lds = stack_lds_bytes(f.max_depth, 256);
-    if (lds < 4 * 8 * 72 * sizeof(double)) lds = 4 * 8 * 72 * sizeof(double);
-    f.bpj = (max_n + 255) / 256;
-    if (normals_only) hipLaunchKernelGGL(k_sweep_fused<true>, dim3(xcd_grid(f.njobs, f.bpj)), dim3(256), lds, s, descs, f, partials_dev, partials_stride, states);
-    else hipLaunchKernelGGL(k_sweep_fused<false>, dim3(xcd_grid(f.njobs, f.bpj)), dim3(256), lds, s, descs, f, partials_dev, partials_stride, states);
+    size_t lds = stack_lds_bytes(f.max_depth, FUSED_WG);
+    if (lds < (FUSED_WG / 64) * 32 * GRAM_RS * sizeof(double)) lds = (FUSED_WG / 64) * 32 * GRAM_RS * sizeof(double);
+    f.bpj = (max_n + FUSED_WG - 1) / FUSED_WG;
+    if (normals_only) hipLaunchKernelGGL(k_sweep_fused<true>, dim3(xcd_grid(f.njobs, f.bpj)), dim3(FUSED_WG), lds, s, descs, f, partials_dev, partials_stride, states);
+    else hipLaunchKernelGGL(k_sweep_fused<false>, dim3(xcd_grid(f.njobs, f.bpj)), dim3(FUSED_WG), lds, s, descs, f, partials_dev, partials_stride, states);
   }
   if (sp.njobs > 0) {
     sp.bpj = (max_n + 255) / 256;
@@ -1463,6 +1480,7 @@ __global__ void __launch_bounds__(FINAL_SUB * MOM_ROW) k_moments_final(const Pai
   if (states && states[job.slot].done) return;  // device-driven loop: the pair's sweep did not run either
   const int c = blockIdx.x;
   int n = descs[job.slot].n;
+  if ((a.pad >> blockIdx.y) & 1) ppb = FUSED_WG;   // this job's rows were left by the fused sweep (a.pad: one bit per job)
   int nb = ((n + ppb - 1) / ppb) * rpb;
   if (extra_ppr > 0) nb += (n + extra_ppr - 1) / extra_ppr;   // the fused / split sweep's walk rows (one per extra_ppr source points)
   int v = threadIdx.x % MOM_ROW, sub = threadIdx.x / MOM_ROW;

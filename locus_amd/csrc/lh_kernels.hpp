@@ -75,7 +75,7 @@ struct CostJob {
 };
 struct CostArgs {
   int njobs;
-  int pad;
+  int pad;         // k_moments_final: bit j set = job j's rows come from the fused sweep (one row per sweep_fused_wg() points instead of 256)
   CostJob job[MAX_JOBS];
 };
 
@@ -146,7 +146,8 @@ void launch_sweep_fused(const PairDesc* descs, SweepArgs& a, uint32_t split_mask
                         const OuterState* states, bool normals_only, unsigned long long* wmask, int mask_stride, hipStream_t s);
 int sweep_walk_span();    // source points per walk row (LH_WALK_SPAN, default 512)
 int sweep_split_from();   // first outer iteration (0-based) swept in two launches (LH_SPLIT_FROM)
-inline int sweep_rows(int n) { return (n + 255) / 256 + (n + sweep_walk_span() - 1) / sweep_walk_span(); }   // partial rows of one job: one per 256-point workgroup + the walk rows
+int sweep_fused_wg();      // source points per partial row of the FUSED sweep (its workgroup size: 256, or 64 with one wave per workgroup)
+inline int sweep_rows(int n) { return (n + sweep_fused_wg() - 1) / sweep_fused_wg() + (n + sweep_walk_span() - 1) / sweep_walk_span(); }   // partial rows of one job at most: one per workgroup of the sweep + the walk rows
 void launch_moments_final(const PairDesc* descs, const CostArgs& a, double* partials_dev, int partials_stride, double* out, const OuterState* states,
                           unsigned long long* wmask, int mask_stride, hipStream_t s);
 // the BFGS solve + convergence test of one outer iteration, on the device (cost_mode 1): reads the FINAL_CHUNKS x MOM_ROW chunk

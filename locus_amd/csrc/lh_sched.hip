@@ -221,6 +221,7 @@ static lh_status group_launch(lh_ctx* c, Group& g) {
         t->sweeps_done++;
       }
       launch_sweep_fused(c->descs_dev, a, split_mask, max_n, c->mom_partials_dev, c->mom_stride, nullptr, normals_only, c->wmask_dev, c->mask_stride, st);
+      ca.pad = (int)(~split_mask & (a.njobs >= 32 ? 0xffffffffu : ((1u << a.njobs) - 1u)));   // the jobs whose rows the fused sweep left
       launch_moments_final(c->descs_dev, ca, c->mom_partials_dev, c->mom_stride, c->partials_host, nullptr, c->wmask_dev, c->mask_stride, st);
     } else {
       {
@@ -451,6 +452,7 @@ static lh_status dev_enqueue(lh_ctx* c, DevGroup& g, int rounds) {
       {
         ProfScope p(c, "nn_sweep", bytes, st);
         launch_sweep_fused(c->descs_dev, a, split_mask, max_n, c->mom_partials_dev, c->mom_stride, c->states_dev, normals_only, c->wmask_dev, c->mask_stride, st);
+        ca.pad = (int)(~split_mask & (a.njobs >= 32 ? 0xffffffffu : ((1u << a.njobs) - 1u)));   // the jobs whose rows the fused sweep left
         launch_moments_final(c->descs_dev, ca, c->mom_partials_dev, c->mom_stride, c->chunks_dev, c->states_dev, c->wmask_dev, c->mask_stride, st);
       }
       {
