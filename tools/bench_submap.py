@@ -30,17 +30,26 @@ def mat_to_T16(M):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=5)
-    ap.add_argument("--scans", type=int, default=24)
+    ap.add_argument("--scans", type=int, default=40)
+    ap.add_argument("--map-points", type=int, default=2_000_000)
     args = ap.parse_args()
     ctx = capi.Context(0)
+    # SURVEY 8d config 3 (the same construction as tests/test_gpu_configs.py::_submap_2M): the union of 40 scans along a 20 m path,
+    # voxelised at 0.05 m, padded to EXACTLY 2 000 000 points with a seeded sample of the raw union
     parts = []
     for i in range(args.scans):
-        pose = synth.pose_matrix(tx=-8.0 + 16.0 * i / max(1, args.scans - 1), ty=1.5 * np.sin(i / 4.0), yaw=0.05 * np.cos(i / 3.0))
+        pose = synth.pose_matrix(tx=-10.0 + 20.0 * i / max(1, args.scans - 1), ty=1.5 * np.sin(i / 4.0), yaw=0.05 * np.cos(i / 3.0))
         pts = synth.scan(pose, 64, 1563, (-25.0, 15.0), 2.0, 0.01, seed=200 + i)
         parts.append((pts.astype(np.float64) @ pose[:3, :3].T + pose[:3, 3]).astype(np.float32))
     allpts = np.concatenate(parts)
     vox, cnt = ctx.voxel_grid(capi.make_pointxyzi(allpts), 0.05, 2, -100.0, 100.0)
-    mpts = vox[:cnt, :3].copy()
+    vox = vox[:cnt, :3].copy()
+    rng = np.random.default_rng(2_000_000)
+    if vox.shape[0] >= args.map_points:
+        mpts = vox[np.sort(rng.choice(vox.shape[0], args.map_points, replace=False))]
+    else:
+        mpts = np.concatenate([vox, allpts[rng.choice(allpts.shape[0], args.map_points - vox.shape[0], replace=False)]])
+    mpts = np.ascontiguousarray(mpts, np.float32)
     cmap = capi.Cloud(ctx, mpts)
     cmap.normals_knn(20)
     true_pose = synth.pose_matrix(tx=0.7, ty=0.2, yaw=0.03)

@@ -16,7 +16,7 @@ rname = sys.argv[3] if len(sys.argv) > 3 else "profile_leg"
 lo = hi = None
 for r in csv.DictReader(open(mtrace)):
     fn = r.get("Function", "")
-    if rname in fn or rname in r.get("Message", ""):
+    if fn == rname or r.get("Message", "") == rname:   # (exact: "profile_leg" must not pick "profile_leg_natural")
         lo, hi = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
 if lo is None:
     sys.exit("range %s not found in %s" % (rname, mtrace))
