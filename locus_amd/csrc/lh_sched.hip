@@ -477,7 +477,11 @@ static lh_status run_tasks_device(lh_ctx* c, std::vector<Task*>& tasks, int in_f
   static const int groups_cfg = []() { const char* e = getenv("LH_DEVICE_GROUPS"); int v = e ? atoi(e) : 0; return v < 0 ? 0 : (v > lh_ctx::MAX_GROUPS ? lh_ctx::MAX_GROUPS : v); }();
   // one group per MAX_JOBS (32) pairs in flight -- a group's launch covers all its pairs -- up to 32 groups = streams: with 256 in
   // flight, eight groups of 32 ran 14 % more pairs/s than four of 64 (each chain is half latency: solve, start-up, lone searches)
-  int G = groups_cfg ? groups_cfg : (in_flight >= 64 ? std::min(lh_ctx::MAX_GROUPS, in_flight / MAX_JOBS) : (in_flight >= 16 ? 2 : 1));
+  // With few pairs in flight the chains are the bound, not the GPU: three groups of 21-22 run 64 pairs 5 % faster than two of 32 (7 320 ->
+  // 7 690 pairs/s), six of 21 run 128 pairs 2 % faster than four of 32; from 256 in flight on, full launches of 32 win (512: 16 groups
+  // 8 917, 21 groups 8 509, 32 groups 7 554).
+  int G = groups_cfg ? groups_cfg
+                     : (in_flight > 128 ? std::min(lh_ctx::MAX_GROUPS, in_flight / MAX_JOBS) : (in_flight >= 64 ? (in_flight + 10) / 21 : (in_flight >= 16 ? 2 : 1)));
   if (c->prof) G = 1;
   G = std::max(1, std::min(G, in_flight));
   hipStream_t* extra[lh_ctx::MAX_GROUPS - 1] = {&c->stream2, &c->stream3, &c->stream4};
