@@ -5,9 +5,9 @@
 //
 // NN index ("K2", replaces the FLANN kd-tree built by tree_->setInputCloud in pcl::Registration::initCompute):
 //   * target points are sorted by a 30-bit Morton (Z-order) index (10 bits per axis of a cubic grid over the cloud's box): a key
-//     PREFIX is then an axis-aligned box whose extent can be read off the prefix length -- what the bottom-up search's
-//     termination test needs (tree_search, NodeUp).  (Round 1-2 sorted along a Hilbert curve, which mattered for the first
-//     layout's equal-count runs; the cell-aligned leaves below are the same sets of grid cells under either curve.)
+//     PREFIX is then an axis-aligned box whose extent can be read off the prefix length -- what the start grid of the GICP
+//     sweeps needs (grid_start below).  (Round 1-2 sorted along a Hilbert curve, which mattered for the first layout's
+//     equal-count runs; the cell-aligned leaves below are the same sets of grid cells under either curve.)
 //   * LEAVES are cells of that grid hierarchy: the largest key-prefix cell around a point that holds <= LEAF_CAP points
 //     (runs of > LEAF_CAP identical keys are cut into chunks).  A key prefix is an aligned box, so leaves are DISJOINT in
 //     space; equal-count runs of the curve (the previous layout) overlap their neighbours at every level and cost 2-3x
@@ -87,30 +87,33 @@ struct TreeHeader {
   float inv;          // 1 / step
   float scl;          // step = largest extent / QUANT_STEPS (>= 1e-30)
   float scl2;         // step^2
-  int32_t pad[8];
+  int32_t grid_on;    // the start grid behind this header is filled (clouds of >= GRID_MIN_POINTS points)
+  float key_sc;       // cells of the 10-bit KEY grid per metre (spatial_key30's scale: same float, so a query is binned like the points were)
+  float key_inv;      // 1 / key_sc
+  int32_t pad[5];
 };
-static_assert(sizeof(TreeHeader) == 64, "TreeHeader occupies one NodeX slot in front of the nodes");
-// The way UP from a node (the bottom-up search of the GICP sweeps, tree_search<..., kUp>): its 4-ary parent and its CELL -- the
-// key-prefix box every point of the subtree lies in and NO other point of the cloud does (leaves are disjoint cells).  Stored
-// rounded INWARDS on the 16-bit grid of the node boxes: a query strictly inside it at d_out steps from the nearest face is at
-// least d_out steps from every point outside the subtree, so once d_out^2 exceeds the best distance found in the subtree the
-// search is over without ever having seen the levels above.  A face on the grid's own boundary is stored as 0 / 65535 and
-// counts as infinitely far: no point of the cloud lies beyond it.  A node that only separates identical keys has no cell of its
-// own: lo > hi, the test never holds.
-struct alignas(16) NodeUp {
-  uint32_t in_lo_xy;   // lox | loy << 16
-  uint32_t in_hi_xy;   // hix | hiy << 16
-  uint32_t in_z;       // loz | hiz << 16
-  int32_t parent;      // cloud-local 4-ary node index; -1: this node is the root
-};
-static_assert(sizeof(NodeUp) == 16, "one 16-B load per level climbed");
+static_assert(sizeof(TreeHeader) == 64, "TreeHeader occupies one NodeX slot in front of the grid and the nodes");
+// The START GRID of the GICP sweeps (grid_start): three direct tables -- the 32^3, 16^3 and 8^3 coarsenings of the key grid -- whose
+// entry for a cell is the child reference of the radix-tree node (or leaf) that holds EXACTLY the cloud's points inside that cell:
+// keys that share a prefix are one subtree of a binary radix tree, and a Morton prefix of 3 l bits is the level-l cell.  A warm 1-NN
+// query starts its walk there instead of at the root (the five or six levels above are the same for every query of a cell) and
+// owes the rest of the cloud only the neighbour cells its candidate's distance ball reaches: their subtrees go on the traversal
+// stack with the cell's box distance as key, and everything else is bounded by the distance to the faces it does not cross.
+// Layout: [TreeHeader][GRID_ENTRIES x int32][nodes ...] in one buffer, so the tables need no pointer of their own.
+constexpr int GRID_LEVELS = 3;                       // levels 5, 4, 3: cells of 32, 64, 128 key cells (2.5 / 5 / 10 m on an 80-m scene)
+constexpr int GRID_OFF5 = 0, GRID_OFF4 = 32768, GRID_OFF3 = 32768 + 4096;
+constexpr int GRID_ENTRIES = 32768 + 4096 + 512;     // 37 376 entries = 146 KB
+constexpr int GRID_NODEX = GRID_ENTRIES * 4 / 64;    // the same in NodeX slots (2 336)
+static_assert(GRID_NODEX * 64 == GRID_ENTRIES * 4, "the grid fills whole node slots");
+constexpr int32_t GRID_EMPTY = (int32_t)0x80000000;  // no point of the cloud lies in the cell (never a valid reference)
+constexpr int GRID_MIN_POINTS = 8192;                // smaller clouds: the tree is shallow, the tables would cost more than they save
+constexpr float GRID_SLACK = 4e-3f;                  // key cells (0.3 mm on an 80-m scene): ten times the float rounding of a key coordinate
 struct TreeView {
   const float4* pts;        // sorted points (+ LEAF_CAP padding entries of +inf / id INT_MAX)
   const NodeX* nodes;       // internal nodes, cloud-local indices
-  const TreeHeader* hdr;    // written by the build kernels (device memory)
+  const TreeHeader* hdr;    // written by the build kernels (device memory); the start grid lies right behind it
   int n_points;
-  const NodeUp* up = nullptr;      // per internal node (same index as `nodes`); only the bottom-up searches read it
-  const int32_t* lpar = nullptr;   // [first sorted position of a leaf] -> the 4-ary node that holds the leaf as a child (-1: the leaf is the root)
+  LH_HD const int32_t* grid() const { return reinterpret_cast<const int32_t*>(hdr + 1); }
 };
 LH_HD int32_t leaf_ref(uint32_t first_pos, int count) { return ~(int32_t)((first_pos << 4) | (uint32_t)(count - 1)); }
 
@@ -141,6 +144,11 @@ LH_HD float boxd2(float qx, float qy, float qz, float lx, float ly, float lz, fl
   return (dx * dx + dy * dy) + dz * dz;
 }
 
+// cells of the 10-bit key grid per metre: ONE isotropic cell size (cubes), the largest extent spans the 1024 cells
+LH_HD float key_scale(float lx, float ly, float lz, float hx, float hy, float hz) {
+  float ext = fmaxf(fmaxf(hx - lx, hy - ly), fmaxf(hz - lz, 1e-30f));
+  return 1023.999f / ext;
+}
 // The cloud's quantisation frame from its bounding box (written once per index build; shared with the host-side check).
 LH_HD void quant_frame(const float lo[3], const float hi[3], TreeHeader* h) {
   float ext = 0.0f;
@@ -154,6 +162,9 @@ LH_HD void quant_frame(const float lo[3], const float hi[3], TreeHeader* h) {
   h->inv = 1.0f / h->scl;
   h->scl2 = h->scl * h->scl;
   for (int a = 0; a < 3; a++) h->org[a] = ok ? lo[a] : 0.0f;
+  h->key_sc = ok ? key_scale(lo[0], lo[1], lo[2], hi[0], hi[1], hi[2]) : 1.0f;
+  h->key_inv = 1.0f / h->key_sc;
+  h->grid_on = 0;   // the build switches it on once the tables are filled (k_key_b)
 }
 // Outward rounding: org + quant_lo(v) * scl <= v <= org + quant_hi(v) * scl for every v inside the cloud's box, with
 // a whole grid step of slack on each side; the float error of (v - org) * inv (< 0.02 step at 65532 steps), the integer
@@ -243,34 +254,9 @@ LH_HD uint32_t expand10(uint32_t v) {  // 10 bits -> every third bit
 }
 LH_HD uint32_t morton30(uint32_t ix, uint32_t iy, uint32_t iz) { return (expand10(ix) << 2) | (expand10(iy) << 1) | expand10(iz); }
 
-// 30-bit 3-D Hilbert index of 10-bit cell coordinates (Skilling's axes-to-transpose transform, then bit interleave).
-// A contiguous run of a Hilbert curve is a compact connected region, so the implicit tree's equal-count splits of the
-// sorted array give tight boxes at every level; a Z-order (Morton) run can straddle the curve's long jumps.
-LH_HD uint32_t hilbert30(uint32_t x0, uint32_t x1, uint32_t x2) {
-  uint32_t X[3] = {x0 & 0x3ffu, x1 & 0x3ffu, x2 & 0x3ffu};
-  const uint32_t M = 1u << 9;
-  for (uint32_t Q = M; Q > 1; Q >>= 1) {
-    uint32_t P = Q - 1;
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
-      if (X[i] & Q) X[0] ^= P;
-      else { uint32_t t = (X[0] ^ X[i]) & P; X[0] ^= t; X[i] ^= t; }
-    }
-  }
-  X[1] ^= X[0];
-  X[2] ^= X[1];
-  uint32_t t = 0;
-  for (uint32_t Q = M; Q > 1; Q >>= 1)
-    if (X[2] & Q) t ^= Q - 1;
-  X[0] ^= t; X[1] ^= t; X[2] ^= t;
-  return morton30(X[0], X[1], X[2]);
-}
-
 // sort key of a point given the cloud's bounding box (shared by the build kernel and the host-side traversal check)
 LH_HD uint32_t spatial_key30(float px, float py, float pz, float lx, float ly, float lz, float hx, float hy, float hz) {
-  // one isotropic cell size so cells are cubes
-  float ext = fmaxf(fmaxf(hx - lx, hy - ly), fmaxf(hz - lz, 1e-30f));
-  float sc = 1023.999f / ext;
+  float sc = key_scale(lx, ly, lz, hx, hy, hz);
   int ix = (int)((px - lx) * sc), iy = (int)((py - ly) * sc), iz = (int)((pz - lz) * sc);
   ix = ix < 0 ? 0 : (ix > 1023 ? 1023 : ix);
   iy = iy < 0 ? 0 : (iy > 1023 ? 1023 : iy);
@@ -299,35 +285,6 @@ LH_HD void morton_cell(uint32_t key30, int common, uint32_t c0[3], uint32_t c1[3
     c1[a] = c0[a] + ((1u << free_bits) - 1u);
   }
 }
-// NodeUp of a node whose keys share `common` leading bits (common >= 30 with > 1 leaf below: identical keys, no cell of its own).
-// Cell a of the 10-bit key grid starts at (a / 1023.999) of the cloud's largest extent = a * (65532 / 1023.999) steps of the
-// 16-bit grid (spatial_key30 / quant_frame: both measure from the same origin).  The key of a point is the truncation of a
-// FLOAT product, so the true boundary can sit a few 1e-7 relative (< 0.02 step) off that value: the faces are moved inwards by
-// a whole step beyond the rounding.  Faces on the grid's boundary (cell 0 / 1023) are marked 0 / 65535: nothing lies beyond.
-LH_HD NodeUp node_up(uint32_t key30, int common, bool has_cell, int32_t parent) {
-  NodeUp u;
-  u.parent = parent;
-  if (!has_cell) {
-    u.in_lo_xy = 0xffffffffu; u.in_hi_xy = 0u; u.in_z = 0x0000ffffu;   // lo = 65535 > hi = 0 on every axis
-    return u;
-  }
-  uint32_t c0[3], c1[3], lo[3], hi[3];
-  morton_cell(key30, common > 30 ? 30 : common, c0, c1);
-  const double steps_per_cell = 65532.0 / 1023.999;
-#pragma unroll
-  for (int a = 0; a < 3; a++) {
-    double l = ceil((double)c0[a] * steps_per_cell) + 1.0, h = floor((double)(c1[a] + 1u) * steps_per_cell) - 1.0;
-    l = l < 1.0 ? 1.0 : (l > 65534.0 ? 65534.0 : l);     // 0 and 65535 are reserved for the grid's own boundary
-    h = h < 1.0 ? 1.0 : (h > 65534.0 ? 65534.0 : h);
-    lo[a] = c0[a] == 0u ? 0u : (uint32_t)l;
-    hi[a] = c1[a] == 1023u ? 65535u : (uint32_t)h;
-  }
-  u.in_lo_xy = lo[0] | (lo[1] << 16);
-  u.in_hi_xy = hi[0] | (hi[1] << 16);
-  u.in_z = lo[2] | (hi[2] << 16);
-  return u;
-}
-
 LH_HD void cswap(uint64_t& a, uint64_t& b) {
   uint64_t lo = a < b ? a : b, hi = a < b ? b : a;
   a = lo; b = hi;
@@ -363,19 +320,101 @@ LH_HD void scan_leaf(const TreeView& t, int32_t ref, float qx, float qy, float q
   const uint32_t u = (uint32_t)~ref;
   const int cnt = (int)(u & 15u) + 1;
   const float4* p = t.pts + (u >> 4);
+  if constexpr (Collector::kGreedy && !Collector::kXyz) {
+    // 1-NN collectors (re-offering a point is harmless): ALL LEAF_CAP entries, unconditionally.  The ones past the leaf's own are the
+    // next leaf's points (or the +inf padding): real points at their real distances, so neither the neighbour nor a certificate
+    // bound can suffer -- and without a branch per entry the eight loads go out together.  (With `if (e < cnt)` around each offer
+    // the compiler sank every load into its branch: a leaf scan was a chain of up to eight dependent memory round trips.)
+    float4 v[LEAF_CAP];
 #pragma unroll
-  for (int e = 0; e < LEAF_CAP; e++) {
-    float4 v = gload16<float4>(p + e);  // the array is padded by LEAF_CAP entries, so the load is always in bounds
-    if (e < cnt) {
-      if constexpr (Collector::kXyz) col.offer_xyz(d2f(qx, qy, qz, v.x, v.y, v.z), v.x, v.y, v.z);
-      else col.offer(d2f(qx, qy, qz, v.x, v.y, v.z), (int)f2u(v.w));
-    }
+    for (int e = 0; e < LEAF_CAP; e++) v[e] = gload16<float4>(p + e);
+#pragma unroll
+    for (int e = 0; e < LEAF_CAP; e++) col.offer(d2f(qx, qy, qz, v[e].x, v[e].y, v[e].z), (int)f2u(v[e].w));
+    (void)cnt;
+    return;
   }
+  // the other collectors (k-NN lists, radius sums) must not see a point twice: only the leaf's own entries are offered, but every
+  // distance is formed unconditionally so that the loads cannot sink into the branches (the array is padded: always in bounds)
+  float4 v[LEAF_CAP];
+  float dd[LEAF_CAP];
+#pragma unroll
+  for (int e = 0; e < LEAF_CAP; e++) v[e] = gload16<float4>(p + e);
+#pragma unroll
+  for (int e = 0; e < LEAF_CAP; e++) dd[e] = d2f(qx, qy, qz, v[e].x, v[e].y, v[e].z);
+#pragma unroll
+  for (int e = 0; e < LEAF_CAP; e++)
+    if (e < cnt) {
+      if constexpr (Collector::kXyz) col.offer_xyz(dd[e], v[e].x, v[e].y, v[e].z);
+      else col.offer(dd[e], (int)f2u(v[e].w));
+    }
+}
+
+// ---- start grid (see TreeHeader) --------------------------------------------------------------------------------------------
+LH_HD int grid_index(int level, int cx, int cy, int cz) {
+  const int off = level == 5 ? GRID_OFF5 : (level == 4 ? GRID_OFF4 : GRID_OFF3);
+  return off + (((cx << level) | cy) << level | cz);
+}
+constexpr int32_t GRID_USE_ROOT = NO_CHILD - 1;   // grid_start: the candidate is too far for the coarsest table, walk from the root
+// Where a WARM 1-NN walk starts.  `col` holds a real candidate at squared distance bd (finite).  The table level is the finest one
+// whose cells are wider than the ball's diameter, so along every axis the ball crosses AT MOST one face of the query's cell; the
+// (up to 7) neighbour cells behind crossed faces are pushed with a lower bound of their box distance as key (the walk's own pop
+// prunes them against the bound of the moment and tells the collector), every other point of the cloud lies behind a face that
+// is not crossed or two cells away, and the collector is told those bounds too (skip), so its certificate stays a bound on
+// EVERY other point.  Returns the reference of the query's own cell (GRID_EMPTY: nothing there, start with a pop).
+// Exactness: a point binned below coarse cell c (key coordinate < c << sh, a truncated FLOAT product) is, in real numbers, at
+// least (g - (c << sh) - 4e-4) key cells below a query whose float key coordinate is g; the faces are moved by GRID_SLACK = 4e-3
+// cells, the bounds are formed with the operation order of d2f ((x^2 + y^2) + z^2, monotone rounding), so bound <= float distance
+// of every point behind the face, exactly like the node boxes (boxd2_q).  A query outside the grid belongs to the nearest boundary
+// cell: the face it lies beyond counts as crossed (bound 0) and has no cells behind it.
+template <class Collector, class Push>
+LH_HD int32_t grid_start(const float* org, float key_sc, float key_inv, const int32_t* __restrict__ grid, float qx, float qy, float qz,
+                         Collector& col, Push&& push) {
+  const float bd = col.bound();
+  const float ru = sqrtf(bd) * key_sc * 1.000001f + 2.0f * GRID_SLACK;   // the ball's radius in key cells, rounded up
+  if (!(ru < 63.5f)) return GRID_USE_ROOT;
+  const int sh = 5 + (ru >= 15.5f ? 1 : 0) + (ru >= 31.5f ? 1 : 0);      // key-cell bits inside one table cell: wider than the ball
+  const int level = 10 - sh, G = 1 << level;
+  const float cell = (float)(1 << sh);
+  const float q[3] = {qx, qy, qz};
+  int home = level == 5 ? GRID_OFF5 : (level == 4 ? GRID_OFF4 : GRID_OFF3);
+  int cm = 0, dstep[3];
+  float sq[3];   // squared metres to the crossed face (a lower bound), per axis
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    const float g = (q[a] - org[a]) * key_sc;                     // the key coordinate spatial_key30 truncates
+    const int ci = (int)fminf(fmaxf(g, 0.0f), 1023.0f) >> sh;
+    const float f_lo = g - (float)(ci << sh), f_hi = cell - f_lo; // key cells to the two faces (negative: the query lies beyond)
+    const float l_lo = fmaxf((f_lo - GRID_SLACK) * key_inv, 0.0f), l_hi = fmaxf((f_hi - GRID_SLACK) * key_inv, 0.0f);
+    const float s_lo = l_lo * l_lo, s_hi = l_hi * l_hi;
+    const bool x_lo = s_lo <= bd, x_hi = !x_lo && s_hi <= bd;     // crossed faces (never both: the cell is wider than the ball)
+    col.skip(x_lo ? s_hi : (x_hi ? s_lo : fminf(s_lo, s_hi)));    // everything behind the nearest face that is NOT crossed
+    int dir = x_lo ? -1 : (x_hi ? 1 : 0);
+    if (ci + dir < 0 || ci + dir >= G) dir = 0;                   // beyond the grid's own boundary: no cells, no points, nothing to bound
+    if (dir) {
+      const float l_far = ((x_lo ? f_lo : f_hi) + (cell - GRID_SLACK)) * key_inv;   // two cells away behind the crossed face
+      col.skip(l_far * l_far);
+      cm |= 1 << a;
+    }
+    sq[a] = x_lo ? s_lo : s_hi;
+    const int stride_bits = (2 - a) * level;
+    dstep[a] = dir * (1 << stride_bits);
+    home += ci << stride_bits;
+  }
+  // the neighbour cells behind crossed faces: the non-empty subsets of the crossed axes (usually one, at most seven)
+  for (int m = cm; m; m = (m - 1) & cm) {
+    const float lb = (((m & 1) ? sq[0] : 0.0f) + ((m & 2) ? sq[1] : 0.0f)) + ((m & 4) ? sq[2] : 0.0f);
+    if (lb <= bd) {
+      const int32_t ref = gld(grid + home + ((m & 1) ? dstep[0] : 0) + ((m & 2) ? dstep[1] : 0) + ((m & 4) ? dstep[2] : 0));
+      if (ref != GRID_EMPTY) push(f2u(lb) & ~3u, ref);
+    } else
+      col.skip(lb);
+  }
+  return gld(grid + home);
 }
 
 // Nearest-child descent to ONE leaf and a scan of it: a good candidate, not the neighbour (nothing is stacked, nothing pruned).  What a
 // cold search starts with anyway (tree_search's kGreedy phase); on its own it is a seed: any target point is a valid warm-start candidate.
-template <class Collector>
+template <class Collector, bool kGrid = false>
 LH_HD void tree_descend(const TreeView& t, float qx, float qy, float qz, Collector& col) {
   const float INF = inf_f();
   TreeHeader h;
@@ -385,6 +424,15 @@ LH_HD void tree_descend(const TreeView& t, float qx, float qy, float qz, Collect
   const GridQuery gq = grid_query(h, qx, qy, qz);
   const float scl2 = h.scl2;
   int32_t r = h.root;
+  if constexpr (kGrid) {   // a seed only has to be A point near the query: the subtree of the query's own level-5 cell, if it holds anything
+    if (gld(&t.hdr->grid_on)) {
+      const float ksc = gld(&t.hdr->key_sc);
+      const int cx = (int)fminf(fmaxf((qx - h.org[0]) * ksc, 0.0f), 1023.0f) >> 5, cy = (int)fminf(fmaxf((qy - h.org[1]) * ksc, 0.0f), 1023.0f) >> 5,
+                cz = (int)fminf(fmaxf((qz - h.org[2]) * ksc, 0.0f), 1023.0f) >> 5;
+      const int32_t g = gld(t.grid() + grid_index(5, cx, cy, cz));
+      if (g != GRID_EMPTY) r = g;
+    }
+  }
   while (r >= 0) {
     const NodeX& nd = t.nodes[r];
     const uint4 a = gload16<uint4>(nd.lo_xy);
@@ -405,7 +453,8 @@ LH_HD void tree_descend(const TreeView& t, float qx, float qy, float qz, Collect
   scan_leaf(t, r, qx, qy, qz, col);
 }
 
-template <class Collector>
+// kGrid (the GICP sweeps' warm 1-NN walks): start at the query's cell of the start grid instead of at the root (grid_start)
+template <class Collector, bool kGrid = false>
 LH_HD void tree_search(const TreeView& t, float qx, float qy, float qz, Collector& col, uint64_t* stack, int stride) {
   const uint32_t NONE = 0xffffffffu;
   const float INF = inf_f();
@@ -475,6 +524,12 @@ LH_HD void tree_search(const TreeView& t, float qx, float qy, float qz, Collecto
     }
   };
   int32_t ref = root;
+  if constexpr (kGrid) {
+    if (col.bound() < INF && gld(&t.hdr->grid_on)) {
+      const int32_t g = grid_start(h.org, gld(&t.hdr->key_sc), gld(&t.hdr->key_inv), t.grid(), qx, qy, qz, col, push);
+      if (g != GRID_USE_ROOT) ref = (g == GRID_EMPTY) ? pop() : g;
+    }
+  }
   for (;;) {
     while (ref >= 0 && ref != DONE) {
       col.count_node(0);
@@ -599,7 +654,7 @@ LH_HD int32_t node_visit(const NodeX& nd, const GridQuery& gq, float scl2, Colle
 }
 
 // ---- index build, per-element steps shared by the build kernels and the host-side check ---------------------------------
-// sorted keys: (cloud id << 32) | 30-bit Hilbert key, so a batch of clouds is one sorted array and no cell spans two clouds
+// sorted keys: (cloud id << 32) | 30-bit Morton key, so a batch of clouds is one sorted array and no cell spans two clouds
 constexpr int KEY_PREFIX_MIN = 34;  // 64 - 30: shortest prefix that still pins the cloud id (and the two unused bits)
 
 // does sorted position g start a leaf?  Leaf = the largest prefix cell around g with <= LEAF_CAP points.
@@ -635,7 +690,7 @@ LH_HD int radix_delta(const uint64_t* __restrict__ lkey, int n_leaves, int i, in
   return x ? clz64(x) : 64 + clz32((uint32_t)i ^ (uint32_t)j);
 }
 // children are returned as binary-tree references: >= 0 internal node, < 0 leaf ~index; [lo, hi] = leaf range covered
-LH_HD void radix_node(const uint64_t* __restrict__ lkey, int n_leaves, int i, int& left, int& right, int& lo, int& hi) {
+LH_HD void radix_node(const uint64_t* __restrict__ lkey, int n_leaves, int i, int& left, int& right, int& lo, int& hi, int* delta_out = nullptr) {
   int d = (radix_delta(lkey, n_leaves, i, i + 1) - radix_delta(lkey, n_leaves, i, i - 1)) >= 0 ? 1 : -1;
   int dmin = radix_delta(lkey, n_leaves, i, i - d);
   int lmax = 2;
@@ -645,6 +700,7 @@ LH_HD void radix_node(const uint64_t* __restrict__ lkey, int n_leaves, int i, in
     if (radix_delta(lkey, n_leaves, i, i + (l + t) * d) > dmin) l += t;
   int j = i + l * d;
   int dnode = radix_delta(lkey, n_leaves, i, j);
+  if (delta_out) *delta_out = dnode;   // leading bits of the 64-bit key shared by the whole range (>= 64: identical keys)
   int s = 0;
   for (int t = (l + 1) >> 1;; t = (t + 1) >> 1) {
     if (radix_delta(lkey, n_leaves, i, i + (s + t) * d) > dnode) s += t;
@@ -655,6 +711,40 @@ LH_HD void radix_node(const uint64_t* __restrict__ lkey, int n_leaves, int i, in
   hi = i < j ? j : i;
   left = (lo == gamma) ? ~gamma : gamma;
   right = (hi == gamma + 1) ? ~(gamma + 1) : gamma + 1;
+}
+
+// leading bits of the 30-bit key shared by a node's range, from radix_node's delta (the 64-bit key = cloud id << 32 | key30):
+// -1 for a node that joins two clouds, 30 for identical keys
+LH_HD int key_common(int delta) { return delta < 34 ? -1 : (delta > 64 ? 30 : delta - 34); }
+// how many of the start grid's levels (3, 4, 5 = 9, 12, 15 prefix bits) a node with `com` common bits lies inside a cell of
+LH_HD int grid_depth(int com) { return (com >= 9 ? 1 : 0) + (com >= 12 ? 1 : 0) + (com >= 15 ? 1 : 0); }
+// Start-grid entries contributed by ONE child of binary node i (com_i common key bits); called for both children of every node of
+// a cloud.  An internal child whose keys share >= 3 l bits while i's do not IS the level-l cell of its keys: the keys of a radix-tree
+// node are all keys with its prefix, so the child holds exactly the cloud's points inside that cell.  A LEAF child is the cell of
+// the (com_i + 1)-bit prefix, which may span several table cells (a few points in a large empty region): every one of them gets the
+// leaf.  key30_c = any key of the child, ref_c = the child reference the walk uses (cloud-local node index / leaf reference).
+LH_HD void grid_fill_child(int32_t* grid, int com_i, bool child_is_leaf, int com_c, uint32_t key30_c, int32_t ref_c) {
+#pragma unroll
+  for (int l = 5; l >= 3; l--) {
+    const int bits = 3 * l, sh = 10 - l;
+    if (com_i >= bits) continue;                      // i lies inside a level-l cell already: an ancestor's child made that entry
+    if (!child_is_leaf && com_c < bits) continue;     // the child still spans several level-l cells: its descendants make the entries
+    uint32_t c0[3], c1[3];
+    morton_cell(key30_c, child_is_leaf ? (com_i + 1 < bits ? com_i + 1 : bits) : bits, c0, c1);
+    for (uint32_t x = c0[0] >> sh; x <= c1[0] >> sh; x++)
+      for (uint32_t y = c0[1] >> sh; y <= c1[1] >> sh; y++)
+        for (uint32_t z = c0[2] >> sh; z <= c1[2] >> sh; z++) grid[grid_index(l, (int)x, (int)y, (int)z)] = ref_c;
+  }
+}
+// ... and by the cloud's root, for the levels at which the WHOLE cloud lies inside one cell
+LH_HD void grid_fill_root(int32_t* grid, int com_root, uint32_t key30, int32_t ref_root) {
+#pragma unroll
+  for (int l = 5; l >= 3; l--) {
+    if (com_root < 3 * l) continue;
+    uint32_t c0[3], c1[3];
+    morton_cell(key30, 3 * l, c0, c1);
+    grid[grid_index(l, (int)(c0[0] >> (10 - l)), (int)(c0[1] >> (10 - l)), (int)(c0[2] >> (10 - l)))] = ref_root;
+  }
 }
 
 struct Nn1Collector {

@@ -36,7 +36,7 @@ lh_status build_indices(lh_ctx* x, lh_cloud* const* clouds, int n_clouds, hipStr
         (void)lhFree(c->sorted); (void)lhFree(c->node_buf);
         c->sorted = nullptr; c->node_buf = nullptr; c->index_cap = 0;
         HIPCHK(lhMalloc(&c->sorted, sizeof(float4) * ((size_t)c->n + LEAF_CAP)));
-        HIPCHK(lhMalloc(&c->node_buf, sizeof(NodeX) * ((size_t)c->n + 1)));  // worst case: every point its own leaf
+        HIPCHK(lhMalloc(&c->node_buf, sizeof(NodeX) * ((size_t)c->n + 1 + GRID_NODEX)));  // header + start grid + worst case: every point its own leaf
         c->index_cap = c->n;
       }
       IndexDesc& d = stage_host[k];
@@ -79,6 +79,7 @@ lh_status build_indices(lh_ctx* x, lh_cloud* const* clouds, int n_clouds, hipStr
       ts.ichild = reinterpret_cast<int32_t*>(p); p += 8 * cap;
       ts.irange = reinterpret_cast<int32_t*>(p); p += 8 * cap;
       ts.iparent = reinterpret_cast<int32_t*>(p); p += 4 * cap;
+      ts.icom = reinterpret_cast<int32_t*>(p); p += 4 * cap;
       ts.flag = reinterpret_cast<uint32_t*>(p); p += 4 * cap;
       ts.lid = reinterpret_cast<uint32_t*>(p); p += 4 * cap;
       ts.lstart = reinterpret_cast<uint32_t*>(p); p += 4 * cap;

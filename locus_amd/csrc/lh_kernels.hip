@@ -83,10 +83,16 @@ __global__ void __launch_bounds__(256) k_key_b(const IndexDesc* __restrict__ des
   const IndexDesc d = descs[blockIdx.y];
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t* bb = bbox + blockIdx.y * 8;
+  const bool grid_on = d.n >= GRID_MIN_POINTS;
   if (i == 0) {  // the grid the node boxes are quantised on (also for empty clouds: block 0 always runs)
     const float lo[3] = {dec_ordered(bb[0]), dec_ordered(bb[1]), dec_ordered(bb[2])};
     const float hi[3] = {dec_ordered(bb[3]), dec_ordered(bb[4]), dec_ordered(bb[5])};
     quant_frame(lo, hi, d.hdr);
+    d.hdr->grid_on = grid_on ? 1 : 0;   // (its tables are filled by k_nodex_b, the last launch of this build)
+  }
+  if (grid_on) {   // the start grid behind the header: every cell empty until k_nodex_b says otherwise
+    int32_t* grid = reinterpret_cast<int32_t*>(d.hdr + 1);
+    for (int k = i; k < GRID_ENTRIES; k += gridDim.x * 256) grid[k] = GRID_EMPTY;
   }
   if (i >= d.n) return;
   float4 p = d.xyz[i];
@@ -326,8 +332,9 @@ __global__ void __launch_bounds__(256) k_radix_b(TreeScratch t) {
   const int n_leaves = (int)t.lid[t.total - 1];
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_leaves - 1) return;
-  int left, right, lo, hi;
-  radix_node(t.lkey, n_leaves, i, left, right, lo, hi);
+  int left, right, lo, hi, delta;
+  radix_node(t.lkey, n_leaves, i, left, right, lo, hi, &delta);
+  t.icom[i] = key_common(delta);
   t.ichild[2 * i] = left;
   t.ichild[2 * i + 1] = right;
   t.irange[2 * i] = lo;
@@ -346,12 +353,34 @@ __global__ void __launch_bounds__(256) k_nodex_b(const IndexDesc* __restrict__ d
   if (cloud != (int)(t.lkey[hi] >> 32)) return;  // joins two clouds: not part of any cloud's tree
   const IndexDesc d = descs[cloud];
   const int a_c = (int)t.lid[d.offset] - 1, b_c = (int)t.lid[d.offset + d.n - 1] - 1;
-  // A 4-ary node adopts its GRANDchildren, so the walk only ever reaches the binary nodes at even depth below the cloud's root:
-  // the other half would be built (a 64-byte store each) and never read.  The depth comes from climbing the parent links to the
-  // node that covers the whole cloud: ~15 dependent 12-byte reads.
+  const bool is_root = lo == a_c && hi == b_c;
+  const int com_i = t.icom[i];
+  const bool grid_on = d.n >= GRID_MIN_POINTS;
+  const int lc = t.ichild[2 * i], rc = t.ichild[2 * i + 1];
+  const int com_l = lc >= 0 ? t.icom[lc] : 30, com_r = rc >= 0 ? t.icom[rc] : 30;
+  auto child_ref = [&](int c) -> int32_t {   // the reference the walk uses: cloud-local node index / leaf reference
+    return c < 0 ? leaf_ref(t.lstart[~c] - (uint32_t)d.offset, (int)(t.lstart[~c + 1] - t.lstart[~c])) : c - a_c;
+  };
+  if (grid_on) {   // the start grid's entries (grid_fill_child, lh_device.hpp): every binary node offers its two children
+    int32_t* grid = reinterpret_cast<int32_t*>(d.hdr + 1);
+    if (com_i < 15) {
+      grid_fill_child(grid, com_i, lc < 0, com_l, (uint32_t)t.lkey[lc < 0 ? ~lc : t.irange[2 * lc]] & 0x3fffffffu, child_ref(lc));
+      grid_fill_child(grid, com_i, rc < 0, com_r, (uint32_t)t.lkey[rc < 0 ? ~rc : t.irange[2 * rc]] & 0x3fffffffu, child_ref(rc));
+    }
+    if (is_root) grid_fill_root(grid, com_i, (uint32_t)t.lkey[lo] & 0x3fffffffu, i - a_c);
+  }
+  // A 4-ary node adopts its GRANDchildren, so the walk only ever reaches the binary nodes at even depth below the cloud's root -- or
+  // below a CELL ROOT of the start grid (a node that lies inside a table cell while its parent does not: walks start there too, so
+  // it is a 4-ary node whatever its depth, and its parent keeps it as a child instead of adopting its children).  The other nodes
+  // would be built (a 64-byte store each) and never read.  The distance to the nearest such ancestor comes from climbing the
+  // parent links: ~8 dependent reads.
   {
-    int depth = 0;
-    for (int j = i; !(t.irange[2 * j] == a_c && t.irange[2 * j + 1] == b_c); j = t.iparent[j]) depth++;
+    int depth = 0, j = i, cj = com_i;
+    while (!(t.irange[2 * j] == a_c && t.irange[2 * j + 1] == b_c)) {
+      const int pj = t.iparent[j], cp = t.icom[pj];
+      if (grid_on && grid_depth(cj) > grid_depth(cp)) break;   // j is a cell root
+      j = pj; cj = cp; depth++;
+    }
     if (depth & 1) return;
   }
   const TreeHeader fr = *d.hdr;   // the quantisation frame, written by k_key_b (an earlier launch)
@@ -359,8 +388,9 @@ __global__ void __launch_bounds__(256) k_nodex_b(const IndexDesc* __restrict__ d
   int cref[4] = {0, 0, 0, 0}, cnt = 0;
 #pragma unroll
   for (int side = 0; side < 2; side++) {
-    const int c = t.ichild[2 * i + side];
-    if (c < 0) cref[cnt++] = c;
+    const int c = side ? rc : lc;
+    const bool cell_root = c >= 0 && grid_on && grid_depth(side ? com_r : com_l) > grid_depth(com_i);
+    if (c < 0 || cell_root) cref[cnt++] = c;
     else { cref[cnt++] = t.ichild[2 * c]; cref[cnt++] = t.ichild[2 * c + 1]; }
   }
   NodeX nd;
@@ -377,10 +407,10 @@ __global__ void __launch_bounds__(256) k_nodex_b(const IndexDesc* __restrict__ d
       const int idx = ref < 0 ? ~ref : ref;
       const float4 blo = tab[2 * (size_t)idx], bhi = tab[2 * (size_t)idx + 1];
       quant_box(fr, blo.x, blo.y, blo.z, bhi.x, bhi.y, bhi.z, nd.lo_xy[k], nd.hi_xy[k], nd.z_lohi[k]);
-      nd.child[k] = ref < 0 ? leaf_ref(t.lstart[idx] - (uint32_t)d.offset, (int)(t.lstart[idx + 1] - t.lstart[idx])) : ref - a_c;
+      nd.child[k] = child_ref(ref);
     }
   d.nodes[i - a_c] = nd;
-  if (lo == a_c && hi == b_c) {
+  if (is_root) {
     d.hdr->root = i - a_c;
     d.hdr->n_leaves = b_c - a_c + 1;
   }
@@ -459,7 +489,7 @@ __global__ void __launch_bounds__(256) k_seed(const PairDesc* __restrict__ descs
   xform_pt(job.T, p.x, p.y, p.z, qx, qy, qz);
   TreeView tv{d.tgt_sorted, d.tgt_nodes, d.tgt_hdr, d.m};
   Nn1Collector col{INFINITY, 0x7fffffff};
-  tree_descend(tv, qx, qy, qz, col);   // the nearest point of the nearest leaf: no stack, no backtracking, a third of an exact cold search
+  tree_descend<Nn1Collector, true>(tv, qx, qy, qz, col);   // the nearest point of the nearest leaf (below the query's own grid cell): no stack, no backtracking, a third of an exact cold search
   int j = (col.bi == 0x7fffffff) ? -1 : col.bi;
   float4 rt = make_float4(0.f, 0.f, 0.f, 0.f), rn = rt;
   if (j >= 0 && d.rec) {
@@ -570,7 +600,7 @@ __device__ __forceinline__ void sweep_point(const PairDesc& d, const float* __re
   }
   o.searched = need_search;
   if (need_search) {
-    tree_search(tv, qx, qy, qz, col, stack, kStride);
+    tree_search<Nn1CertCollector, true>(tv, qx, qy, qz, col, stack, kStride);
     gst(d.cert + i, make_float4(qx, qy, qz, col.lb));
     if (d.stats) atomicAdd(&d.stats[0], 1ull);  // instrumentation only (lh_gicp_debug_sweep): contended atomics
   }
@@ -1132,6 +1162,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) k
     h.org[0] = gld(&tv.hdr->org[0]); h.org[1] = gld(&tv.hdr->org[1]); h.org[2] = gld(&tv.hdr->org[2]);
     h.inv = gld(&tv.hdr->inv); h.scl2 = gld(&tv.hdr->scl2);
     const int32_t root = h.root;
+    const bool grid_on = gld(&tv.hdr->grid_on) != 0;
+    const float key_sc = gld(&tv.hdr->key_sc), key_inv = gld(&tv.hdr->key_inv);
     const int32_t DONE = NO_CHILD;
     WalkStack<WALK_STACK> stk(lds_stack + lane, 64);
     Nn1CertCollector col{INFINITY, 0x7fffffff, INFINITY};
@@ -1169,6 +1201,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) k
             gq = grid_query(h, qx, qy, qz);
             stk.sp = 0;
             ref = root;
+            if (grid_on && col.bd < INFINITY) {   // start at the query's own cell of the start grid (grid_start, lh_device.hpp), like tree_search<.., true>
+              const int32_t g = grid_start(h.org, key_sc, key_inv, tv.grid(), qx, qy, qz, col, [&](uint32_t key, int32_t r) { stk.push(key, r); });
+              if (g != GRID_USE_ROOT) ref = (g == GRID_EMPTY) ? stk.pop(col) : g;
+            }
           }
         }
         head = min(total, head + nidle);

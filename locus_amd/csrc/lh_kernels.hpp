@@ -91,7 +91,7 @@ struct IndexDesc {
   const float4* xyz;
   float4* sorted;     // [n + LEAF_CAP]
   NodeX* nodes;       // [n] worst case (one internal node per leaf, one leaf per point)
-  TreeHeader* hdr;
+  TreeHeader* hdr;    // the start grid (GRID_ENTRIES x int32) lies between the header and the nodes
   int32_t* pos;       // (unused: the inverse permutation was written by every build and read by nothing)
   int n, offset;      // offset = start of this cloud in the concatenated key/value arrays
   int tile0, pad;     // first tile of this cloud in the sort's histogram table (sum of segsort_tiles of the clouds before it)
@@ -112,9 +112,10 @@ struct TreeScratch {
   int32_t* ichild;        // binary children of internal node i [2]: >= 0 internal, < 0 leaf ~index
   int32_t* irange;        // covered leaf range [2]
   int32_t* iparent;       // binary parent of internal node i (undefined for a root)
+  int32_t* icom;          // leading bits of the 30-bit key shared by node i's range (key_common)
   int total;
 };
-constexpr size_t TREE_SCRATCH_BYTES_PER_POINT = 4 + 4 + 8 + 4 + 32 + 2 + 32 + 8 + 8 + 4 + 1;  // flag lid lkey lstart lbox a1+a2 ibox ichild irange iparent tsum
+constexpr size_t TREE_SCRATCH_BYTES_PER_POINT = 4 + 4 + 8 + 4 + 32 + 2 + 32 + 8 + 8 + 4 + 4 + 1;  // flag lid lkey lstart lbox a1+a2 ibox ichild irange iparent icom tsum
 constexpr int MAX_INDEX_BATCH = 64;
 // the build's own sort (lh_radix.hip): segmented 3 x 10-bit LSD radix sort of the 30-bit keys, every cloud inside its segment
 int segsort_tiles(int n);

@@ -254,9 +254,9 @@ struct lh_cloud {
   // NN index
   bool has_index = false;
   float4* sorted = nullptr;    // [n + LEAF_CAP]
-  NodeX* node_buf = nullptr;   // element 0 holds the TreeHeader, the nodes start at element 1
+  NodeX* node_buf = nullptr;   // element 0 holds the TreeHeader, the start grid follows (GRID_NODEX slots), then the nodes
   int index_cap = 0;           // points the index buffers were allocated for
-  NodeX* nodes() const { return node_buf ? node_buf + 1 : nullptr; }
+  NodeX* nodes() const { return node_buf ? node_buf + 1 + GRID_NODEX : nullptr; }
   TreeHeader* hdr() const { return reinterpret_cast<TreeHeader*>(node_buf); }
   // k-NN covariances (6 planes of n_pad doubles), valid for (cov_k, cov_eps)
   double* cov6 = nullptr;

@@ -15,10 +15,16 @@ using namespace lh;
 
 struct HostTree {
   std::vector<float4> sorted;
-  std::vector<NodeX> nodes;
-  TreeHeader hdr;
+  std::vector<NodeX> buf;          // the device layout: [TreeHeader][start grid: GRID_NODEX slots][nodes]
+  NodeX* nodes = nullptr;
+  TreeHeader& hdr() { return *reinterpret_cast<TreeHeader*>(buf.data()); }
+  const TreeHeader& hdr() const { return *reinterpret_cast<const TreeHeader*>(buf.data()); }
+  int32_t* grid() { return reinterpret_cast<int32_t*>(buf.data() + 1); }
   int n = 0, n_leaves = 0, depth = 0;
-  TreeView view() const { return TreeView{sorted.data(), nodes.data(), &hdr, n}; }
+  std::vector<uint64_t> lkey;      // leaf keys (+ one sentinel), leaf start positions (+ n), binary radix nodes: children / leaf ranges
+  std::vector<uint32_t> lstart;
+  std::vector<int> ich, irg;
+  TreeView view() const { return TreeView{sorted.data(), nodes, &hdr(), n}; }
 };
 
 // serial restatement of the build kernels (k_key_b / k_leafcell_b / scan / k_leafrec_b / k_radix_b / k_boxes_b / k_nodex_b)
@@ -33,7 +39,10 @@ static HostTree build(const std::vector<float4>& pts, uint64_t cloud_id = 3) {
     lo[1] = fminf(lo[1], p.y); hi[1] = fmaxf(hi[1], p.y);
     lo[2] = fminf(lo[2], p.z); hi[2] = fmaxf(hi[2], p.z);
   }
-  quant_frame(lo, hi, &t.hdr);  // k_key_b
+  t.buf.assign((size_t)1 + GRID_NODEX + std::max(n, 1), NodeX{});
+  t.nodes = t.buf.data() + 1 + GRID_NODEX;
+  quant_frame(lo, hi, &t.hdr());  // k_key_b
+  for (int k = 0; k < GRID_ENTRIES; k++) t.grid()[k] = GRID_EMPTY;
   std::vector<std::pair<uint64_t, uint32_t>> kv(n);
   for (int i = 0; i < n; i++)
     kv[i] = {(cloud_id << 32) | spatial_key30(pts[i].x, pts[i].y, pts[i].z, lo[0], lo[1], lo[2], hi[0], hi[1], hi[2]), (uint32_t)i};
@@ -69,13 +78,17 @@ static HostTree build(const std::vector<float4>& pts, uint64_t cloud_id = 3) {
   for (int l = 0; l < L; l++)
     if ((int)(lstart[l + 1] - lstart[l]) > LEAF_CAP || lstart[l + 1] <= lstart[l]) { printf("bad leaf size\n"); exit(2); }
   if (L == 1) {
-    t.hdr.root = leaf_ref(0u, n);
-    t.hdr.n_leaves = 1;
-    t.nodes.resize(1);
+    t.hdr().root = leaf_ref(0u, n);
+    t.hdr().n_leaves = 1;
     return t;
   }
   std::vector<int> ich(2 * (L - 1)), irg(2 * (L - 1));
-  for (int i = 0; i < L - 1; i++) radix_node(lkey.data(), L, i, ich[2 * i], ich[2 * i + 1], irg[2 * i], irg[2 * i + 1]);
+  std::vector<int> icom(L - 1);
+  for (int i = 0; i < L - 1; i++) {
+    int delta;
+    radix_node(lkey.data(), L, i, ich[2 * i], ich[2 * i + 1], irg[2 * i], irg[2 * i + 1], &delta);
+    icom[i] = key_common(delta);
+  }
   // boxes by recursion from the root (the kernels climb from the leaves with arrival counters; same result)
   std::vector<B6> ibox(L - 1);
   std::vector<int> idepth(L - 1, 0);
@@ -90,21 +103,20 @@ static HostTree build(const std::vector<float4>& pts, uint64_t cloud_id = 3) {
   };
   boxof(0, 0);
   if (irg[0] != 0 || irg[1] != L - 1) { printf("root range wrong\n"); exit(2); }
-  t.nodes.resize(L);
   for (int i = 0; i < L - 1; i++) {
     NodeX nd;
     for (int k = 0; k < 4; k++) { nd.lo_xy[k] = 0xffffffffu; nd.hi_xy[k] = 0u; nd.z_lohi[k] = 0xffffffffu; nd.child[k] = NO_CHILD; }
     int cnt = 0;
     auto emit = [&](int ref) {
       B6 b = ref < 0 ? leaf_box(~ref) : ibox[ref];
-      quant_box(t.hdr, b.v[0], b.v[1], b.v[2], b.v[3], b.v[4], b.v[5], nd.lo_xy[cnt], nd.hi_xy[cnt], nd.z_lohi[cnt]);
+      quant_box(t.hdr(), b.v[0], b.v[1], b.v[2], b.v[3], b.v[4], b.v[5], nd.lo_xy[cnt], nd.hi_xy[cnt], nd.z_lohi[cnt]);
       // the decoded box must enclose the float box with at least half a step to spare (double arithmetic = ground truth)
       const uint32_t qlo[3] = {nd.lo_xy[cnt] & 0xffffu, nd.lo_xy[cnt] >> 16, nd.z_lohi[cnt] & 0xffffu};
       const uint32_t qhi[3] = {nd.hi_xy[cnt] & 0xffffu, nd.hi_xy[cnt] >> 16, 65535u - (nd.z_lohi[cnt] >> 16)};
       for (int a = 0; a < 3; a++) {
-        double dlo = (double)t.hdr.org[a] + (double)qlo[a] * (double)t.hdr.scl;
-        double dhi = (double)t.hdr.org[a] + (double)qhi[a] * (double)t.hdr.scl;
-        double half = 0.5 * (double)t.hdr.scl;
+        double dlo = (double)t.hdr().org[a] + (double)qlo[a] * (double)t.hdr().scl;
+        double dhi = (double)t.hdr().org[a] + (double)qhi[a] * (double)t.hdr().scl;
+        double half = 0.5 * (double)t.hdr().scl;
         bool lo_ok = qlo[a] == 0 ? dlo <= (double)b.v[a] : dlo + half <= (double)b.v[a];
         if (!lo_ok || dhi - half < (double)b.v[3 + a]) { printf("quantised box does not enclose: axis %d\n", a); exit(2); }
       }
@@ -118,8 +130,20 @@ static HostTree build(const std::vector<float4>& pts, uint64_t cloud_id = 3) {
     }
     t.nodes[i] = nd;
   }
-  t.hdr.root = 0;  // Karras: node 0 covers every leaf
-  t.hdr.n_leaves = L;
+  t.hdr().root = 0;  // Karras: node 0 covers every leaf
+  t.hdr().n_leaves = L;
+  // the start grid (k_nodex_b): every binary node offers its two children, the root itself where the whole cloud is one cell.  (The host
+  // builds a 4-ary node for EVERY binary node with plain grandchild adoption, so every cell root has one; the device builds only the
+  // reachable ones -- its rule is exercised by the GPU tests against the exhaustive search.)
+  auto ref_of = [&](int c) -> int32_t { return c < 0 ? leaf_ref(lstart[~c], (int)(lstart[~c + 1] - lstart[~c])) : c; };
+  for (int i = 0; i < L - 1; i++)
+    for (int side = 0; side < 2; side++) {
+      const int c = ich[2 * i + side];
+      grid_fill_child(t.grid(), icom[i], c < 0, c < 0 ? 30 : icom[c], (uint32_t)lkey[c < 0 ? ~c : irg[2 * c]] & 0x3fffffffu, ref_of(c));
+    }
+  grid_fill_root(t.grid(), icom[0], (uint32_t)lkey[0] & 0x3fffffffu, 0);
+  t.hdr().grid_on = 1;
+  t.lkey = lkey; t.lstart = lstart; t.ich = ich; t.irg = irg;
   return t;
 }
 
@@ -146,12 +170,12 @@ static int run_case(int n, int nq, int k, unsigned seed, int dup) {
   // the quantised box bound must never exceed the float distance to any point of the leaf it bounds (what pruning relies on)
   if (t.n_leaves > 1) {
     for (int i = 0; i < std::min(nq, 64); i++) {
-      GridQuery gq = grid_query(t.hdr, qs[i].x, qs[i].y, qs[i].z);
+      GridQuery gq = grid_query(t.hdr(), qs[i].x, qs[i].y, qs[i].z);
       for (int nd = 0; nd < t.n_leaves - 1; nd++)
         for (int c = 0; c < 4; c++) {
           int32_t ref = t.nodes[nd].child[c];
           if (ref == NO_CHILD || ref >= 0) continue;
-          float bnd = boxd2_q(gq, t.nodes[nd].lo_xy[c], t.nodes[nd].hi_xy[c], t.nodes[nd].z_lohi[c], t.hdr.scl2);
+          float bnd = boxd2_q(gq, t.nodes[nd].lo_xy[c], t.nodes[nd].hi_xy[c], t.nodes[nd].z_lohi[c], t.hdr().scl2);
           uint32_t u = (uint32_t)~ref;
           for (uint32_t e = 0; e <= (u & 15u); e++) {
             float4 p = t.sorted[(u >> 4) + e];
@@ -207,6 +231,21 @@ static int run_case(int n, int nq, int k, unsigned seed, int dup) {
         if (n > 1 && cb.lb > bd[ord[1]]) bad++;        // ... and never above the true runner-up
       }
     }
+    if (t.n_leaves > 1) {  // the sweeps' warm walks from the start grid (tree_search<.., true>): candidates near (the ball stays inside a few cells),
+                           // far (coarser tables) and absurd (falls back to the root); neighbour AND certificate bound against brute force
+      const int cands[4] = {ord[std::min(n - 1, 2)], ord[std::min(n - 1, 40)], w, ord[0]};
+      for (int cidx = 0; cidx < 4; cidx++) {
+        const int cw = cands[cidx];
+        Nn1CertCollector cg{bd[cw], cw, inf_f()};
+        tree_search<Nn1CertCollector, true>(tv, q.x, q.y, q.z, cg, stk.data(), 1);
+        if (cg.bi != ord[0] || cg.bd != bd[ord[0]]) bad++;
+        if (n > 1 && !(cg.lb >= bd[ord[0]])) bad++;
+        if (n > 1 && cg.lb > bd[ord[1]]) bad++;
+      }
+      Nn1Collector cs{inf_f(), 0x7fffffff};   // the seed descent from the query's own cell
+      tree_descend<Nn1Collector, true>(tv, q.x, q.y, q.z, cs);
+      if (cs.bi < 0 || cs.bi >= n || cs.bd != bd[cs.bi]) bad++;
+    }
     KnnCollector ck{kd.data(), ki.data(), kk, 1, 0};
     tree_search(tv, q.x, q.y, q.z, ck, stk.data(), 1);
     if (ck.cnt != kk) bad++;
@@ -239,6 +278,7 @@ static int run_case(int n, int nq, int k, unsigned seed, int dup) {
   return bad;
 }
 
+#ifndef TRAVERSAL_CHECK_NO_MAIN
 int main() {
   int bad = 0;
   bad += run_case(1, 16, 1, 1, false);
@@ -254,3 +294,4 @@ int main() {
   printf(bad ? "TRAVERSAL_CHECK_FAILED\n" : "TRAVERSAL_CHECK_OK\n");
   return bad ? 1 : 0;
 }
+#endif
