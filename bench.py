@@ -450,7 +450,20 @@ def main():
 
     result = None
     if rank == 0 and args.quick:
-        print(json.dumps({"value": round(value, 2), "ms_per_step": round(1e3 * elapsed / args.steps, 3), "solver": args.solver,
+        nat = None
+        if world == 1:   # the natural-convergence rate of the full line (same definition), two timed steps
+            Pq = capi.default_params(max_iterations=20, max_inner_iterations=20, corr_dist=1.0, transformation_epsilon=1e-3,
+                                     rotation_epsilon=2e-3, cost_mode=args.cost_mode)
+            for rep in range(3):
+                if rep == 1:
+                    ctx.synchronize()
+                    tq = time.perf_counter()
+                for t in T:
+                    t.drop_index()
+                capi.align_batch(ctx, Pq, S, T, max_in_flight=args.in_flight)
+            ctx.synchronize()
+            nat = round(2 * pairs_here / (time.perf_counter() - tq), 1)
+        print(json.dumps({"value": round(value, 2), "natural": nat, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "solver": args.solver,
                           "iters": [min(iters), float(np.mean(iters)), max(iters)], "env": {k: v for k, v in os.environ.items() if k.startswith("LH_")}}))
         return
     if rank == 0:
