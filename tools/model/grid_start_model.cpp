@@ -40,7 +40,21 @@ static void walk_from(const TreeView& tv, int32_t ref, float qx, float qy, float
 // that did useful work in them.
 struct LaneState { Nn1CertCollector col; std::vector<uint64_t> mem; WalkStack<LDS_STACK> ws; GridQuery gq; float q[3]; int32_t ref;
                    LaneState() : col{inf_f(), 0x7fffffff, inf_f()}, mem(LDS_STACK), ws(mem.data(), 1), gq{0, 0, 0, 0.f}, ref(NO_CHILD) {} };
-static void wave_lockstep(const TreeView& tv, const TreeHeader& h, std::vector<LaneState>& L, long& node_iters, long& leaf_iters, long& busy) {
+static int g_policy = 0;
+static long g_hist[65];      // iterations by number of busy lanes
+static long g_cut_iters[5], g_cut_lanes[5];   // iterations executed / lanes handed off if a wave stops once <= {0,2,4,8,16} lanes are busy
+static void wave_lockstep(const TreeView& tv, const TreeHeader& h, std::vector<LaneState>& L, long& node_iters, long& leaf_iters, long& busy, bool hist = false) {
+  const int cuts[5] = {0, 2, 4, 8, 16};
+  bool cut_done[5] = {false, false, false, false, false};
+  auto note = [&](int act) {
+    if (!hist) return;
+    g_hist[act]++;
+    for (int k = 0; k < 5; k++) {
+      if (!cut_done[k] && act <= cuts[k]) { cut_done[k] = true; g_cut_lanes[k] += act; }
+      if (!cut_done[k]) g_cut_iters[k]++;
+    }
+  };
+  if (g_policy == 0) {
   for (;;) {
     bool any = false;
     for (auto& l : L) any |= l.ref != NO_CHILD;
@@ -49,20 +63,43 @@ static void wave_lockstep(const TreeView& tv, const TreeHeader& h, std::vector<L
       int act = 0;
       for (auto& l : L) if (l.ref >= 0 && l.ref != NO_CHILD) act++;
       if (!act) break;
-      node_iters++; busy += act;
+      node_iters++; busy += act; note(act);
       for (auto& l : L) if (l.ref >= 0 && l.ref != NO_CHILD) l.ref = node_visit(tv.nodes[l.ref], l.gq, h.scl2, l.col, l.ws);
     }
     int act = 0;
     for (auto& l : L) if (l.ref < 0) act++;
     if (act) {
-      leaf_iters++; busy += act;
+      leaf_iters++; busy += act; note(act);
       for (auto& l : L) if (l.ref < 0) { scan_leaf(tv, l.ref, l.q[0], l.q[1], l.q[2], l.col); l.ref = l.ws.pop(l.col); }
+    }
+  }
+  } else {
+    bool last_leaf = true;
+    for (;;) {
+      int nn = 0, nl = 0;
+      for (auto& l : L) { if (l.ref >= 0 && l.ref != NO_CHILD) nn++; else if (l.ref < 0) nl++; }
+      if (!nn && !nl) break;
+      bool do_node;
+      if (g_policy == 1) do_node = nn * 1.0 >= nl * 1.0;           // majority vote
+      else if (g_policy >= 10) do_node = nl == 0 || (nn > 0 && nn * 4 >= nl * (g_policy - 10));   // weighted vote: policy 10 + 4 w
+      else if (g_policy == 3) do_node = nl == 0 || (nn > 0 && nn >= 3 * nl);   // leaves first unless nodes dominate 3:1
+      else do_node = nn > 0 && (last_leaf || nl == 0);           // if-if: alternate
+      if (do_node) {
+        node_iters++; busy += nn; note(nn);
+        for (auto& l : L) if (l.ref >= 0 && l.ref != NO_CHILD) l.ref = node_visit(tv.nodes[l.ref], l.gq, h.scl2, l.col, l.ws);
+        last_leaf = false;
+      } else {
+        leaf_iters++; busy += nl; note(nl);
+        for (auto& l : L) if (l.ref < 0) { scan_leaf(tv, l.ref, l.q[0], l.q[1], l.q[2], l.col); l.ref = l.ws.pop(l.col); }
+        last_leaf = true;
+      }
     }
   }
 }
 
 int main(int argc, char** argv) {
   std::string dir = argc > 1 ? argv[1] : "/tmp/wm";
+  g_policy = argc > 2 ? atoi(argv[2]) : 0;
   auto tg = read_f32(dir + "/tgt.f32"), sr = read_f32(dir + "/src.f32"), po = read_f32(dir + "/poses.f32");
   int m = (int)tg.size() / 3, n = (int)sr.size() / 3, np = (int)po.size() / 12;
   std::vector<float4> tp(m);
@@ -138,7 +175,7 @@ int main(int argc, char** argv) {
         }
         if (ln == 63 || i == n - 1) {
           wave_lockstep(tv, h, LA, a_node, a_leaf, a_busy);
-          wave_lockstep(tv, h, LB, g_node, g_leaf, g_busy);
+          wave_lockstep(tv, h, LB, g_node, g_leaf, g_busy, true);
           if (s == 0) {
             int dmax = 0; for (int k = 0; k < 64; k++) dmax = std::max(dmax, desc_nodes[k]);
             c_desc += dmax + 1;
@@ -193,6 +230,19 @@ int main(int argc, char** argv) {
     printf("         lockstep wave: root %.1f node + %.1f leaf iterations (%.1f lanes busy) | grid %.1f + %.1f (%.1f lanes busy)\n",
            (double)a_node / waves, (double)a_leaf / waves, (double)a_busy / (a_node + a_leaf), (double)g_node / waves, (double)g_leaf / waves,
            (double)g_busy / (g_node + g_leaf));
+    {
+      long tot = 0; for (int k = 0; k <= 64; k++) tot += g_hist[k];
+      printf("         grid walk, iterations by busy lanes: <=2 %.1f %%, <=4 %.1f %%, <=8 %.1f %%, <=16 %.1f %%, <=32 %.1f %% of %.1f per wave;", 
+             100.0 * (g_hist[1] + g_hist[2]) / tot, 100.0 * (g_hist[1] + g_hist[2] + g_hist[3] + g_hist[4]) / tot,
+             [&]{ long a = 0; for (int k = 1; k <= 8; k++) a += g_hist[k]; return 100.0 * a / tot; }(),
+             [&]{ long a = 0; for (int k = 1; k <= 16; k++) a += g_hist[k]; return 100.0 * a / tot; }(),
+             [&]{ long a = 0; for (int k = 1; k <= 32; k++) a += g_hist[k]; return 100.0 * a / tot; }(), (double)tot / waves);
+      printf(" stop at <= 2 / 4 / 8 / 16 busy lanes: %.1f / %.1f / %.1f / %.1f iterations, %.2f / %.2f / %.2f / %.2f lanes handed off per wave\n",
+             (double)g_cut_iters[1] / waves, (double)g_cut_iters[2] / waves, (double)g_cut_iters[3] / waves, (double)g_cut_iters[4] / waves,
+             (double)g_cut_lanes[1] / waves, (double)g_cut_lanes[2] / waves, (double)g_cut_lanes[3] / waves, (double)g_cut_lanes[4] / waves);
+      for (int k = 0; k <= 64; k++) g_hist[k] = 0;
+      for (int k = 0; k < 5; k++) g_cut_iters[k] = g_cut_lanes[k] = 0;
+    }
     if (s == 0)
       printf("         no seed pass (own descent from the level-5 cell, then the grid walk): %.1f descent + %.1f node + %.1f leaf iterations (%.1f lanes busy in the walk), mismatches %ld\n",
              (double)c_desc / waves, (double)c_node / waves, (double)c_leaf / waves, (double)c_busy / (c_node + c_leaf), c_mism);
