@@ -34,6 +34,21 @@ from locus_amd import dist as ldist  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
 
+def _pool_map(fn, jobs, workers, chunk):
+    """pool.map over forked workers; a pool that does not deliver (a worker forked while another thread held a lock) is abandoned
+    after a generous wait and the jobs run here instead"""
+    import multiprocessing as mp
+    pool = mp.get_context("fork").Pool(workers)
+    try:
+        res = pool.map_async(fn, jobs, chunksize=chunk).get(timeout=60.0 + 1.0 * len(jobs))
+        pool.close()
+        return res
+    except mp.TimeoutError:
+        print("[bench] worker pool stalled: generating %d scans in this process" % len(jobs), file=sys.stderr, flush=True)
+        pool.terminate()
+        return [fn(j) for j in jobs]
+
+
 def _gen_pair(a):
     seed, rings, az, scale = a
     return synth.scan_pair(n_rings=rings, n_az=az, scale=scale, noise=0.02, seed=seed)
@@ -47,9 +62,7 @@ def gen_pairs_host(n_pairs, rank, rings, az, scale):
     workers = max(1, min(16, (os.cpu_count() or 1) // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))), n_pairs // 8))
     if workers <= 1:
         return [_gen_pair(j) for j in jobs]
-    import multiprocessing as mp
-    with mp.get_context("fork").Pool(workers) as pool:
-        return pool.map(_gen_pair, jobs, chunksize=4)
+    return _pool_map(_gen_pair, jobs, workers, 4)
 
 
 def trajectory_pose(i, n):
@@ -72,9 +85,7 @@ def gen_trajectory_host(n_scans, rings, az, scale):
     workers = max(1, min(16, (os.cpu_count() or 1) // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))))))
     if workers <= 1:
         return [_gen_traj_scan(j) for j in jobs]
-    import multiprocessing as mp
-    with mp.get_context("fork").Pool(workers) as pool:
-        return pool.map(_gen_traj_scan, jobs, chunksize=8)
+    return _pool_map(_gen_traj_scan, jobs, workers, 8)
 
 
 def host_pointf(cloud):
@@ -107,6 +118,44 @@ PARITY_P90_T = 2.5e-4
 PARITY_HARD_T = 5e-3
 PARITY_TOL_R = max(1e-4, 1.3e-4)
 PARITY_PAIRS = 32
+
+
+_T0 = time.perf_counter()
+_BEAT = [time.perf_counter(), "start"]   # last sign of life, and the leg it came from
+_PARTIAL = [None]                        # the result line as far as it has been measured (rank 0)
+_STALL_LIMIT_S = float(os.environ.get("BENCH_STALL_LIMIT_S", "420"))
+
+
+def _beat():
+    _BEAT[0] = time.perf_counter()
+
+
+def _leg(name):
+    """progress marker on stderr (which leg a slow or hung run was in; stdout stays ONE JSON line)"""
+    _BEAT[0], _BEAT[1] = time.perf_counter(), name
+    print("[bench %7.1f s] %s" % (time.perf_counter() - _T0, name), file=sys.stderr, flush=True)
+
+
+def _start_watchdog():
+    """A leg that makes no progress for _STALL_LIMIT_S (no step finished, no leg started) ends the run instead of hanging it: if the
+    BASELINE metric, its roofline and the CPU baseline have been measured by then -- every leg after those is an extra -- the line goes out
+    with what has been measured and the name of the leg that stalled; otherwise the run fails loudly."""
+    import threading
+
+    def watch():
+        while True:
+            time.sleep(5.0)
+            if time.perf_counter() - _BEAT[0] > _STALL_LIMIT_S:
+                print("[bench] no progress for %.0f s in leg %r" % (_STALL_LIMIT_S, _BEAT[1]), file=sys.stderr, flush=True)
+                r = _PARTIAL[0]
+                if r is not None and "roofline" in r and ("cpu_baseline" in r or r.get("cpu_baseline_skipped")):
+                    r["incomplete"] = "leg %r made no progress for %.0f s and was abandoned; the fields it would have added are missing" % (_BEAT[1], _STALL_LIMIT_S)
+                    print(json.dumps(r))
+                    sys.stdout.flush()
+                    os._exit(0)
+                os._exit(3)
+
+    threading.Thread(target=watch, daemon=True).start()
 
 
 class _Roctx:
@@ -351,6 +400,7 @@ def main():
                     help="functional check of the N > 1 code path on a 1-GPU box: every rank uses cuda:0 (needs --dist-backend gloo); "
                          "the printed rate is meaningless")
     args = ap.parse_args()
+    _start_watchdog()
 
     # safety net: a rank that stops making progress dumps every thread's Python stack and exits instead of hanging the box
     import faulthandler
@@ -403,6 +453,7 @@ def main():
         for t in T:
             t.drop_index()  # align() rebuilds the target index every scan, like pcl::Registration::initCompute
         raw, _ = capi.align_batch_out(ctx, params or P, S, T, max_in_flight=in_flight or args.in_flight, aligned=A, raw=True)
+        _beat()
         if world > 1 and exchange:
             # the ONLY exchange of the pair-sharded path: one all_gather of the lh_gicp_result records (96 B per pair)
             # on device tensors over RCCL/xGMI; no data-path collective
@@ -467,6 +518,7 @@ def main():
                           "iters": [min(iters), float(np.mean(iters)), max(iters)], "env": {k: v for k, v in os.environ.items() if k.startswith("LH_")}}))
         return
     if rank == 0:
+        _leg("timed region done; roofline leg")
         # ---- roofline leg: the same steps again with HIP-event timing of every launch on the library's stream ----
         # Profiling runs ONE scheduler group so kernels never overlap; to time launches of the same shape as the timed
         # region's (groups of 32 pairs each) the leg runs with in_flight / groups pairs per launch.
@@ -484,7 +536,9 @@ def main():
             ctx.synchronize()
             roctx.pop()
             ctx.profile(False)
-            name, st = max(stats.items(), key=lambda kv: kv[1]["ms"])
+            # the dominant kernel: most time among the kernels that fill the GPU (bfgs_solve is one wave per pair running beside the other
+            # groups' sweeps: its launches are long but occupy 32 of the chip's 24 576 wave slots; it moves no data and has no byte model)
+            name, st = max(((k, v) for k, v in stats.items() if v["bytes"] > 0), key=lambda kv: kv[1]["ms"])
             achieved = st["bytes"] / 1e9 / (st["ms"] / 1e3) if st["ms"] > 0 else 0.0
             avg_us = 1e3 * st["ms"] / max(1, st["launches"])
             return name, st, stats, {
@@ -527,76 +581,7 @@ def main():
             "cost_mode": args.cost_mode, "mean_cost_evaluations_per_pair": passes, "max_translation_err_vs_truth_m": float(np.max(errs)),
             "roofline": roofline,
         }
-        if not args.no_single_latency:
-            g = capi.Gicp(ctx, P)
-            g.set_source(S[0])
-            g.set_target(T[0])
-            T[0].drop_index()
-            g.align(want_trace=False)
-            t1 = time.perf_counter()
-            for _ in range(5):
-                T[0].drop_index()
-                g.align(want_trace=False)
-            result["single_pair_latency_ms"] = round(1e3 * (time.perf_counter() - t1) / 5, 3)
-        if world == 1 and args.cost_mode == 1:
-            # the same workload in the reference-arithmetic mode (one device pass per BFGS evaluation, float T*p): the strict
-            # parity mode (<= 1e-4 m vs the CPU path); reported next to the headline, never as `value`
-            P0 = capi.default_params(max_iterations=20, max_inner_iterations=20, corr_dist=1.0, transformation_epsilon=1e-12,
-                                     rotation_epsilon=1e-12, cost_mode=0)
-
-            def step0():
-                for t in T:
-                    t.drop_index()
-                return capi.align_batch(ctx, P0, S, T, max_in_flight=args.in_flight)
-
-            step0()
-            ctx.synchronize()
-            t1 = time.perf_counter()
-            out0 = step0()
-            ctx.synchronize()
-            dt0 = time.perf_counter() - t1
-            result["cost_mode0"] = {"value": round(pairs_here / dt0, 2), "unit": "scan-pairs/s",
-                                    "max_abs_pose_diff_vs_mode1": float(max(np.abs(np.asarray(a["T"]) - np.asarray(b["T"])).max()
-                                                                            for a, b in zip(out0, out)))}
-        if world == 1:
-            # SURVEY 8d "natural convergence" run: the same pairs with the production stopping rule (tf_eps 1e-3, rot_eps 2e-3,
-            # gicp.h:119, parameters.yaml) instead of 20 forced iterations: iterations to converge, rate, distance to the forced result
-            Pn = capi.default_params(max_iterations=20, max_inner_iterations=20, corr_dist=1.0, transformation_epsilon=1e-3,
-                                     rotation_epsilon=2e-3, cost_mode=args.cost_mode)
-
-            def stepn():
-                for t in T:
-                    t.drop_index()
-                return capi.align_batch(ctx, Pn, S, T, max_in_flight=args.in_flight)
-
-            stepn()
-            ctx.synchronize()
-            t1 = time.perf_counter()
-            outn = stepn()
-            ctx.synchronize()
-            dtn = time.perf_counter() - t1
-            itn = [int(o["iterations"]) for o in outn]
-            result["natural_convergence"] = {
-                "value": round(pairs_here / dtn, 2), "unit": "scan-pairs/s", "iterations_min_mean_max": [min(itn), float(np.mean(itn)), max(itn)],
-                "all_converged": bool(all(o["converged"] == 1 for o in outn)),
-                "max_abs_pose_diff_vs_20_forced_iterations": float(max(np.abs(np.asarray(a["T"]) - np.asarray(b["T"])).max() for a, b in zip(outn, out)))}
-            # ... and the roofline of ITS dominant kernel (nearly every sweep of this regime is an all-walk sweep + the index build and seed pass)
-            _, _, _, rn = roofline_leg(Pn, "profile_leg_natural", 1)
-            result["natural_convergence"]["roofline"] = rn
-            # BASELINE configs[3] gives each GPU 64 pairs: the same step with 64 pairs in flight (two scheduler streams) instead of 512
-            if args.in_flight > 64 and pairs_here >= 64:
-                step(64, exchange=False)
-                ctx.synchronize()
-                t1 = time.perf_counter()
-                for _ in range(2):
-                    step(64, exchange=False)
-                ctx.synchronize()
-                result["in_flight_64"] = {"value": round(2 * pairs_here / (time.perf_counter() - t1), 2), "unit": "scan-pairs/s",
-                                          "what": "the timed step with max_in_flight = 64 (configs[3]'s per-GPU load: 512 pairs over 8 GPUs)"}
-        if world == 1 and traj_host is not None:
-            result["trajectory"] = trajectory_leg(ctx, P, traj_host, args)
-        if world == 1 and not args.no_cpu_baseline:
-            result["production_operating_point"] = production_leg(ctx)
+        _leg("CPU baseline + parity")
         if world == 1 and not args.no_cpu_baseline:
             cb, poses = cpu_baseline(S, T, host, P)
             result["cpu_baseline"] = cb
@@ -650,6 +635,84 @@ def main():
                 "median_dt_m": q50, "p90_dt_m": q90, "max_dt_m": max(dts), "max_dR": max(drs), "n_pairs": len(dts),
                 "pairs_within_1e-4": int(sum(d <= 1e-4 for d in dts)), "pairs_beyond_p90_bar": outliers,
                 "distribution_over_64_pairs": "profiles/r03_fullsize_parity.json", "ok": bool(parity_ok)}
+        if args.no_cpu_baseline or world != 1:
+            result["cpu_baseline_skipped"] = True
+        _PARTIAL[0] = result
+        _leg("single-pair latency")
+        if not args.no_single_latency:
+            g = capi.Gicp(ctx, P)
+            g.set_source(S[0])
+            g.set_target(T[0])
+            T[0].drop_index()
+            g.align(want_trace=False)
+            t1 = time.perf_counter()
+            for _ in range(5):
+                T[0].drop_index()
+                g.align(want_trace=False)
+            result["single_pair_latency_ms"] = round(1e3 * (time.perf_counter() - t1) / 5, 3)
+        _leg("cost_mode 0")
+        if world == 1 and args.cost_mode == 1:
+            # the same workload in the reference-arithmetic mode (one device pass per BFGS evaluation, float T*p): the strict
+            # parity mode (<= 1e-4 m vs the CPU path); reported next to the headline, never as `value`
+            P0 = capi.default_params(max_iterations=20, max_inner_iterations=20, corr_dist=1.0, transformation_epsilon=1e-12,
+                                     rotation_epsilon=1e-12, cost_mode=0)
+
+            def step0():
+                for t in T:
+                    t.drop_index()
+                return capi.align_batch(ctx, P0, S, T, max_in_flight=args.in_flight)
+
+            step0()
+            ctx.synchronize()
+            t1 = time.perf_counter()
+            out0 = step0()
+            ctx.synchronize()
+            dt0 = time.perf_counter() - t1
+            result["cost_mode0"] = {"value": round(pairs_here / dt0, 2), "unit": "scan-pairs/s",
+                                    "max_abs_pose_diff_vs_mode1": float(max(np.abs(np.asarray(a["T"]) - np.asarray(b["T"])).max()
+                                                                            for a, b in zip(out0, out)))}
+        _leg("natural convergence")
+        if world == 1:
+            # SURVEY 8d "natural convergence" run: the same pairs with the production stopping rule (tf_eps 1e-3, rot_eps 2e-3,
+            # gicp.h:119, parameters.yaml) instead of 20 forced iterations: iterations to converge, rate, distance to the forced result
+            Pn = capi.default_params(max_iterations=20, max_inner_iterations=20, corr_dist=1.0, transformation_epsilon=1e-3,
+                                     rotation_epsilon=2e-3, cost_mode=args.cost_mode)
+
+            def stepn():
+                for t in T:
+                    t.drop_index()
+                return capi.align_batch(ctx, Pn, S, T, max_in_flight=args.in_flight)
+
+            stepn()
+            ctx.synchronize()
+            t1 = time.perf_counter()
+            outn = stepn()
+            ctx.synchronize()
+            dtn = time.perf_counter() - t1
+            itn = [int(o["iterations"]) for o in outn]
+            result["natural_convergence"] = {
+                "value": round(pairs_here / dtn, 2), "unit": "scan-pairs/s", "iterations_min_mean_max": [min(itn), float(np.mean(itn)), max(itn)],
+                "all_converged": bool(all(o["converged"] == 1 for o in outn)),
+                "max_abs_pose_diff_vs_20_forced_iterations": float(max(np.abs(np.asarray(a["T"]) - np.asarray(b["T"])).max() for a, b in zip(outn, out)))}
+            # ... and the roofline of ITS dominant kernel (nearly every sweep of this regime is an all-walk sweep + the index build and seed pass)
+            _, _, _, rn = roofline_leg(Pn, "profile_leg_natural", 1)
+            result["natural_convergence"]["roofline"] = rn
+            # BASELINE configs[3] gives each GPU 64 pairs: the same step with 64 pairs in flight (two scheduler streams) instead of 512
+            if args.in_flight > 64 and pairs_here >= 64:
+                step(64, exchange=False)
+                ctx.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(2):
+                    step(64, exchange=False)
+                ctx.synchronize()
+                result["in_flight_64"] = {"value": round(2 * pairs_here / (time.perf_counter() - t1), 2), "unit": "scan-pairs/s",
+                                          "what": "the timed step with max_in_flight = 64 (configs[3]'s per-GPU load: 512 pairs over 8 GPUs)"}
+        _leg("trajectory")
+        if world == 1 and traj_host is not None:
+            result["trajectory"] = trajectory_leg(ctx, P, traj_host, args)
+        _leg("production operating point")
+        if world == 1 and not args.no_cpu_baseline:
+            result["production_operating_point"] = production_leg(ctx)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
