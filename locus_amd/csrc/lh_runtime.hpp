@@ -61,7 +61,10 @@ struct HostPool {
   std::condition_variable cv_work, cv_done;
   std::function<void(int)> fn;
   int n_items = 0, pending = 0;
-  std::atomic<int> next{0};
+  // (generation << 32) | next index: an index is claimed by a compare-exchange on the WHOLE word, so a worker that is still leaving the
+  // previous parallel_for can never take (or skip) an index of the next one -- with a bare counter it could read the new n_items before
+  // the counter was reset, run an index that would be handed out again later, and resume the same coroutine twice
+  std::atomic<uint64_t> ticket{0};
   uint64_t generation = 0;
   bool stop = false;
   explicit HostPool(int n_workers) {
@@ -72,11 +75,14 @@ struct HostPool {
     cv_work.notify_all();
     for (auto& t : workers) t.join();
   }
-  void drain() {
+  void drain(uint64_t gen, int n) {
     for (;;) {
-      int i = next.fetch_add(1);
-      if (i >= n_items) break;
-      fn(i);
+      uint64_t t = ticket.load();
+      if ((t >> 32) != (gen & 0xffffffffull)) return;   // a later parallel_for has begun: nothing of ours is left
+      const uint32_t idx = (uint32_t)t;
+      if ((int)idx >= n) return;
+      if (!ticket.compare_exchange_weak(t, t + 1)) continue;
+      fn((int)idx);   // (fn is not reassigned before every claimed index of this generation has finished: pending > 0 until then)
       std::lock_guard<std::mutex> l(m);
       if (--pending == 0) cv_done.notify_all();
     }
@@ -84,28 +90,31 @@ struct HostPool {
   void loop() {
     uint64_t seen = 0;
     for (;;) {
+      int n;
       {
         std::unique_lock<std::mutex> l(m);
         cv_work.wait(l, [&] { return stop || generation != seen; });
         if (stop) return;
         seen = generation;
+        n = n_items;
       }
-      drain();
+      drain(seen, n);
     }
   }
   void parallel_for(int n, std::function<void(int)> f) {
     if (n <= 0) return;
     if (workers.empty() || n == 1) { for (int i = 0; i < n; i++) f(i); return; }
+    uint64_t gen;
     {
       std::lock_guard<std::mutex> l(m);
       fn = std::move(f);
       n_items = n;
       pending = n;
-      next.store(0);
-      generation++;
+      gen = ++generation;
+      ticket.store((gen & 0xffffffffull) << 32);
     }
     cv_work.notify_all();
-    drain();
+    drain(gen, n);
     std::unique_lock<std::mutex> l(m);
     cv_done.wait(l, [&] { return pending == 0; });
   }
