@@ -482,6 +482,15 @@ LH_HD void tree_search(const TreeView& t, float qx, float qy, float qz, Collecto
   if constexpr (Collector::kGreedy) {
     if (!(col.bound() < INF)) {  // cold start: nearest-child descent to one leaf, nothing stacked, nothing pruned
       int32_t r = root;
+      if constexpr (kGrid) {      // ... from the query's own level-5 cell of the start grid, if that holds anything (any point is a valid candidate)
+        if (gld(&t.hdr->grid_on)) {
+          const float ksc = gld(&t.hdr->key_sc);
+          const int cx = (int)fminf(fmaxf((qx - h.org[0]) * ksc, 0.0f), 1023.0f) >> 5, cy = (int)fminf(fmaxf((qy - h.org[1]) * ksc, 0.0f), 1023.0f) >> 5,
+                    cz = (int)fminf(fmaxf((qz - h.org[2]) * ksc, 0.0f), 1023.0f) >> 5;
+          const int32_t g = gld(t.grid() + grid_index(5, cx, cy, cz));
+          if (g != GRID_EMPTY) r = g;
+        }
+      }
       while (r >= 0) {
         int4 ch;
         float d0, d1, d2, d3;

@@ -1706,7 +1706,7 @@ __global__ void __launch_bounds__(256) k_nn1(const float4* __restrict__ q, int n
   float x = p.x, y = p.y, z = p.z;
   if (has_T) xform_pt(T.v, p.x, p.y, p.z, x, y, z);
   Nn1Collector col{INFINITY, 0x7fffffff};
-  tree_search(tv, x, y, z, col, lds_stack + threadIdx.x, 256);
+  tree_search<Nn1Collector, true>(tv, x, y, z, col, lds_stack + threadIdx.x, 256);   // (a descent below the query's own grid cell for a bound, then the walk from there)
   idx[i] = nn_index(col.bi, col.bd);   // a non-finite query has no neighbour (pcl::KdTreeFLANN: isValid(query))
   d2[i] = col.bd;
 }

@@ -242,6 +242,9 @@ static int run_case(int n, int nq, int k, unsigned seed, int dup) {
         if (n > 1 && !(cg.lb >= bd[ord[0]])) bad++;
         if (n > 1 && cg.lb > bd[ord[1]]) bad++;
       }
+      Nn1CertCollector cc{inf_f(), 0x7fffffff, inf_f()};   // cold: a descent below the query's own cell for a bound, then the grid walk (lh_nn1)
+      tree_search<Nn1CertCollector, true>(tv, q.x, q.y, q.z, cc, stk.data(), 1);
+      if (cc.bi != ord[0] || cc.bd != bd[ord[0]] || (n > 1 && (!(cc.lb >= bd[ord[0]]) || cc.lb > bd[ord[1]]))) bad++;
       Nn1Collector cs{inf_f(), 0x7fffffff};   // the seed descent from the query's own cell
       tree_descend<Nn1Collector, true>(tv, q.x, q.y, q.z, cs);
       if (cs.bi < 0 || cs.bi >= n || cs.bd != bd[cs.bi]) bad++;
