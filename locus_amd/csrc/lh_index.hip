@@ -2,7 +2,7 @@
 // covariances of a cloud (gicp.hpp:85-154), host side (see lh_runtime.hpp; kernels in lh_kernels.hip / lh_radix.hip).
 #include "lh_runtime.hpp"
 
-// K2: Hilbert sort + cell-aligned radix tree with 4-ary nodes (replaces tree_->setInputCloud of pcl::Registration::initCompute).
+// K2: Morton sort + cell-aligned radix tree with 4-ary nodes (replaces tree_->setInputCloud of pcl::Registration::initCompute).
 // All clouds of a batch are built by the same launches, one radix sort and one scan (see lh_kernels.hpp "K2 batched").
 lh_status build_indices(lh_ctx* x, lh_cloud* const* clouds, int n_clouds, hipStream_t s_in) {
   if (n_clouds <= 0) return LH_OK;

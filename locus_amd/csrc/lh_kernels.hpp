@@ -24,7 +24,7 @@ struct PairDesc {
   const float4* tgt_xyz;    // target xyz1 in ORIGINAL order                             [m]
   const float4* tgt_nrm;    // target normals or null
   const double* tgt_cov6;   // target covariances planes (stride m_pad) or null
-  const float4* tgt_sorted; // Hilbert-sorted target (x,y,z,id)
+  const float4* tgt_sorted; // Morton-sorted target (x,y,z,id)
   const NodeX* tgt_nodes;
   const TreeHeader* tgt_hdr;
   int32_t* prev_nn;         // warm-start NN index per source point                      [n]
@@ -86,7 +86,7 @@ void sort_pairs_u32(void* temp, size_t temp_bytes, const uint32_t* keys_in, uint
                     uint32_t* vals_out, int n, int end_bit, hipStream_t s);
 
 // ---- K2 batched: the indexes of several clouds are built by the same launches (grid.y = cloud) and ONE radix sort of
-// the concatenated 64-bit keys (cloud id << 32 | 30-bit Hilbert index); the per-pair build was launch-bound.
+// the concatenated 64-bit keys (cloud id << 32 | 30-bit Morton key); the per-pair build was launch-bound.
 struct IndexDesc {
   const float4* xyz;
   float4* sorted;     // [n + LEAF_CAP]
@@ -98,7 +98,7 @@ struct IndexDesc {
 };
 // build scratch shared by the clouds of a batch (capacity = total points of the batch + 1)
 struct TreeScratch {
-  const uint64_t* keys;   // sorted (cloud id << 32 | Hilbert key)      [total]
+  const uint64_t* keys;   // sorted (cloud id << 32 | Morton key)       [total]
   uint32_t* flag;         // leaf-start flags                           [total]
   uint32_t* lid;          // inclusive scan of the flags                [total]
   uint32_t* tsum;         // leaves per tile of 4096 sorted positions (zero between builds)   [total / 4096 + 2]

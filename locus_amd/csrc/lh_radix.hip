@@ -2,7 +2,7 @@
 // least-significant-digit radix sort of the batched index build (K2), the one-segment sort of the voxel grid and the local map (K1,
 // SURVEY 8f-1), and the inclusive scan behind every stream compaction.  No library sort or scan is linked.
 //
-// The build sorts (cloud id << 32 | 30-bit Hilbert key) -> point index for all targets admitted together.  The cloud id only
+// The build sorts (cloud id << 32 | 30-bit Morton key) -> point index for all targets admitted together.  The cloud id only
 // says which segment of the concatenated array an element belongs to, and the segments are already in id order, so the
 // library sort's 37-bit passes over one long array are replaced by three 10-bit passes over 30-bit keys INSIDE each segment
 // (grid.y = cloud): 32-bit keys in flight instead of 64-bit ones, three passes instead of five, nothing shared between clouds.
@@ -21,7 +21,7 @@ namespace lh {
 constexpr int RS_BITS = 10, RS_BINS = 1 << RS_BITS, RS_TILE = 4096, RS_PER_THREAD = RS_TILE / 256;
 
 // Elements in flight between the passes are (key, point index) PAIRS in one 8-byte word: an LSD pass scatters every element
-// to its own place (the low Hilbert digits of neighbouring points are unrelated), so what counts is the number of isolated
+// to its own place (the low key digits of neighbouring points are unrelated), so what counts is the number of isolated
 // stores, and a pair costs one instead of two.  k_key_b writes the pairs, the last pass writes (cloud << 32 | key) and the index.
 template <bool kFirst>
 __device__ __forceinline__ uint32_t rs_key(const void* keys, size_t g) {

@@ -254,6 +254,51 @@ def test_sweep_queries_outside_the_target_box_stay_bit_exact(ctx, capi, oracle):
         assert (idx == io).all(), (shift, int((idx != io).sum()))
 
 
+def test_start_grid_edge_cases_stay_bit_exact(ctx, capi, oracle):
+    # clouds of >= 8 192 points carry the start grid (a warm walk begins at the query's own cell and owes the rest of the cloud only the
+    # neighbour cells its candidate's ball reaches).  Edge cases of that construction, every sweep against the exhaustive search: far
+    # outliers stretch the key grid until the whole scene sits in a handful of cells and the outliers' leaves span thousands of empty
+    # ones; queries inside, just outside and far outside the grid; candidates from nearby (finest table) to metres away (coarser tables,
+    # then the walk from the root); both sweep flavours (reference-arithmetic kernel, cost_mode 1 kernels incl. k_late + k_walk).
+    base = synth.scan(rings=24, azimuths=600, scale=2.0, seed=41)[:, :3].astype(np.float32)
+    assert base.shape[0] >= 8192
+    rng = np.random.default_rng(42)
+    targets = {"plain": base,
+               "outliers": np.concatenate([base, np.array([[4000.0, 0.0, 0.0], [0.0, -3000.0, 10.0], [-50.0, 60.0, 900.0]], np.float32)])}
+    src = (base[rng.choice(base.shape[0], 9000, replace=False)] + rng.normal(0, 0.02, (9000, 3))).astype(np.float32)
+    ns = np.tile(np.array([0.0, 0.0, 1.0, 0.0], np.float32), (src.shape[0], 1))
+    for name, tgt in targets.items():
+        ttree = oracle.Tree(oracle.xyz4(tgt))
+        nt = oracle.normals_knn(oracle.xyz4(tgt), 20, threads=4, tree=ttree)
+        g = capi.Gicp(ctx, capi.default_params(corr_dist=1.0e7))
+        g.set_source(capi.make_pointf(src, ns))
+        g.set_target(capi.make_pointf(tgt, nt))
+        # consecutive sweeps: each one's candidates are the previous one's neighbours, so the shifts between them set the ball radii
+        shifts = [(0.0, 0.0, 0.0), (0.05, -0.03, 0.01), (0.6, 0.4, -0.1), (3.0, -2.0, 0.5), (11.0, 7.0, 1.0), (60.0, -45.0, 6.0),
+                  (-900.0, 1400.0, 60.0), (0.0, 0.0, 0.0), (0.01, 0.0, 0.0)]
+        for k, sh in enumerate(shifts):
+            T16 = oracle.apply_state(np.array([sh[0], sh[1], sh[2], 0.004 * k, -0.003 * k, 0.01 * k]))
+            idx, _ = g.debug_sweep(T16, src.shape[0])
+            q = oracle.transform(oracle.xyz4(src), T16)
+            io, do = ttree.nn1(q, threads=4)
+            assert (idx == io).all(), (name, "sweep", k, int((idx != io).sum()))
+        g2 = capi.Gicp(ctx, capi.default_params(corr_dist=1.0e7))
+        g2.set_source(capi.make_pointf(src, ns))
+        g2.set_target(capi.make_pointf(tgt, nt))
+        for k, sh in enumerate(shifts):
+            T16 = oracle.apply_state(np.array([sh[0], sh[1], sh[2], 0.004 * k, -0.003 * k, 0.01 * k]))
+            idx, walks, sums = g2.debug_sweep_fused(T16, src.shape[0], k)
+            q = oracle.transform(oracle.xyz4(src), T16)
+            io, do = ttree.nn1(q, threads=4)
+            assert (idx == io).all(), (name, "fused", k, int((idx != io).sum()))
+            assert sums[73] == float(src.shape[0]), (name, k, sums[73])
+        # the cold 1-NN lookups (lh_nn1: a descent below the query's own cell for a bound, then the grid walk)
+        qs = np.concatenate([src, src + np.array([40.0, -30.0, 5.0], np.float32), (rng.normal(size=(2000, 3)) * [3000, 3000, 500]).astype(np.float32)])
+        idx, d2 = capi.Cloud(ctx, tgt).nn1(capi.Cloud(ctx, qs))
+        io, do = ttree.nn1(oracle.xyz4(qs), threads=4)
+        assert (idx == io).all() and (d2 == do).all(), name
+
+
 def test_voxel_grid_bit_exact(ctx, capi, oracle):
     pts = synth.scan(rings=32, azimuths=900, scale=2.0, seed=8)
     rng = np.random.default_rng(9)
