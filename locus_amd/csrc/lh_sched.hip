@@ -470,7 +470,7 @@ static lh_status dev_enqueue(lh_ctx* c, DevGroup& g, int rounds) {
 }
 
 static lh_status run_tasks_device(lh_ctx* c, std::vector<Task*>& tasks, int in_flight, bool rebuild_index, std::vector<Workspace>* slot_ws) {
-  static const int rounds_cfg = []() { const char* e = getenv("LH_DEVICE_ROUNDS"); int v = e ? atoi(e) : 4; return v < 1 ? 1 : v; }();
+  static const int rounds_cfg = []() { const char* e = getenv("LH_DEVICE_ROUNDS"); int v = e ? atoi(e) : 6; return v < 1 ? 1 : v; }();   // (4 / 5 / 6 / 7 / 10 / 20 rounds: 9 800 / 9 940 / 10 010 / 9 990 / 9 990 / 9 890 pairs/s forced-20, natural convergence 19 650 / 19 700 / 19 670 / 19 670 / 19 330 / 18 530)
   // Groups: a pair's solve (one wave, tens of sequential cost evaluations) takes about as long as its sweep, so with more groups
   // in flight there is always somebody's sweep to run beside the other groups' solves.  Profiling keeps one group so that the
   // HIP-event times of the launches do not overlap.
