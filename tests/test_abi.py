@@ -128,6 +128,18 @@ def test_traversal_device_functions_on_host():
     assert "TRAVERSAL_CHECK_OK" in out.stdout
 
 
+def test_host_pool_runs_every_index_exactly_once():
+    """HostPool (lh_runtime.hpp) resumes the alignment coroutines of a scheduler group on a few host threads: over 100 000 back-to-back
+    parallel_for calls of changing size every index must run exactly once (a worker still leaving the previous call must never take
+    an index of the next one)"""
+    exe = "/tmp/lh_hostpool_check"
+    src = os.path.join(ROOT, "tests", "host_emu", "hostpool_check.cpp")
+    subprocess.check_call(["hipcc", "-O2", "-std=c++17", "--offload-arch=gfx950", "-pthread", src, "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "HOSTPOOL_CHECK_OK" in out.stdout
+
+
 def test_ndt_host_algebra_matches_oracle(oracle):
     """lh_ndt_host.hpp (pose <-> matrix, the 6x6 SVD solve of the Newton step) against the oracle's restatement of the same
     pclomp pieces; the `oracle` fixture makes sure oracle/liblocus_oracle.so is built"""
