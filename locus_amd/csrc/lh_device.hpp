@@ -150,7 +150,7 @@ LH_HD float key_scale(float lx, float ly, float lz, float hx, float hy, float hz
   return 1023.999f / ext;
 }
 // The cloud's quantisation frame from its bounding box (written once per index build; shared with the host-side check).
-LH_HD void quant_frame(const float lo[3], const float hi[3], TreeHeader* h) {
+LH_HD bool quant_frame(const float lo[3], const float hi[3], TreeHeader* h) {   // false: empty or non-finite bounding box
   float ext = 0.0f;
   bool ok = true;
   for (int a = 0; a < 3; a++) {
@@ -165,6 +165,7 @@ LH_HD void quant_frame(const float lo[3], const float hi[3], TreeHeader* h) {
   h->key_sc = ok ? key_scale(lo[0], lo[1], lo[2], hi[0], hi[1], hi[2]) : 1.0f;
   h->key_inv = 1.0f / h->key_sc;
   h->grid_on = 0;   // the build switches it on once the tables are filled (k_key_b)
+  return ok;
 }
 // Outward rounding: org + quant_lo(v) * scl <= v <= org + quant_hi(v) * scl for every v inside the cloud's box, with
 // a whole grid step of slack on each side; the float error of (v - org) * inv (< 0.02 step at 65532 steps), the integer

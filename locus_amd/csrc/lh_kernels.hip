@@ -87,8 +87,9 @@ __global__ void __launch_bounds__(256) k_key_b(const IndexDesc* __restrict__ des
   if (i == 0) {  // the grid the node boxes are quantised on (also for empty clouds: block 0 always runs)
     const float lo[3] = {dec_ordered(bb[0]), dec_ordered(bb[1]), dec_ordered(bb[2])};
     const float hi[3] = {dec_ordered(bb[3]), dec_ordered(bb[4]), dec_ordered(bb[5])};
-    quant_frame(lo, hi, d.hdr);
-    d.hdr->grid_on = grid_on ? 1 : 0;   // (its tables are filled by k_nodex_b, the last launch of this build)
+    const bool ok = quant_frame(lo, hi, d.hdr);
+    d.hdr->grid_on = (grid_on && ok) ? 1 : 0;   // (its tables are filled by k_nodex_b, the last launch of this build; a cloud with a
+                                                // non-finite point has no usable key grid: its walks start at the root)
   }
   if (grid_on) {   // the start grid behind the header: every cell empty until k_nodex_b says otherwise
     int32_t* grid = reinterpret_cast<int32_t*>(d.hdr + 1);
