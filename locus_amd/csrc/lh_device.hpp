@@ -697,19 +697,19 @@ LH_HD uint32_t leafcell_flag(const uint64_t* __restrict__ keys, int64_t total, i
     L[k - 1] = (g - k >= 0) ? clz64(K ^ keys[g - k]) : 0;
     R[k - 1] = (g + k < total) ? clz64(K ^ keys[g + k]) : 0;
   }
-  auto fits = [&](int p) {  // the cell of prefix length p around g holds <= LEAF_CAP points
-    int c = 1;
-#pragma unroll
-    for (int k = 0; k < LEAF_CAP; k++) c += (L[k] >= p ? 1 : 0) + (R[k] >= p ? 1 : 0);
-    return c <= LEAF_CAP;
-  };
+  // The cell of prefix length p around g holds 1 + #{k: L[k] >= p} + #{k: R[k] >= p} points.  L and R are non-increasing in k (sorted
+  // keys: the common prefix with a farther element is the minimum over the adjacent ones), so "more than LEAF_CAP points" means: for
+  // some split a + b = LEAF_CAP the a-th left AND the b-th right neighbour still share p bits, i.e. p <= max_a min(L[a-1], R[b-1]) =: P.
+  // The smallest prefix that fits is P + 1 (round 2 found it by bisection over p: five passes over the sixteen values).
   const int c_prev = L[0];
-  if (!fits(64)) return (c_prev < 64 || (g % LEAF_CAP) == 0) ? 1u : 0u;  // > LEAF_CAP identical keys: fixed-size chunks
-  int lo = KEY_PREFIX_MIN, hi = 64;  // smallest p in [lo, hi] that fits (fits is monotone in p, fits(64) holds)
-  while (lo < hi) {
-    int mid = (lo + hi) >> 1;
-    if (fits(mid)) hi = mid; else lo = mid + 1;
+  int P = R[LEAF_CAP - 1] < L[LEAF_CAP - 1] ? L[LEAF_CAP - 1] : R[LEAF_CAP - 1];   // a = 0 (all on the right) or a = LEAF_CAP (all on the left)
+#pragma unroll
+  for (int a = 1; a < LEAF_CAP; a++) {
+    const int m = L[a - 1] < R[LEAF_CAP - 1 - a] ? L[a - 1] : R[LEAF_CAP - 1 - a];
+    P = P < m ? m : P;
   }
+  if (P >= 64) return (c_prev < 64 || (g % LEAF_CAP) == 0) ? 1u : 0u;  // > LEAF_CAP identical keys: fixed-size chunks
+  const int lo = P + 1 < KEY_PREFIX_MIN ? KEY_PREFIX_MIN : P + 1;
   return c_prev < lo ? 1u : 0u;
 }
 

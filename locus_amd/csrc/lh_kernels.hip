@@ -296,18 +296,21 @@ __global__ void __launch_bounds__(256) k_chunkbox_b(TreeScratch t, int level) {
 // exact and order-free, so the boxes do not depend on how they are gathered)
 __device__ __forceinline__ void box_merge_run(Box6& b, const float4* __restrict__ tab, int first, int last) {
   constexpr int W = 8;   // (one box per thread now: registers for eight entries in flight)
-  int l = first;
-  for (; l + W <= last; l += W) {
+  // every batch issues its W loads together; a short batch repeats its last entry (min / max do not mind) -- a one-by-one tail was a
+  // chain of dependent loads, and most nodes of a tree have ranges of two to seven leaves: ALL of their entries went through it
+  for (int l = first; l < last; l += W) {
     float4 lo[W], hi[W];
 #pragma unroll
-    for (int k = 0; k < W; k++) { lo[k] = tab[2 * (l + k)]; hi[k] = tab[2 * (l + k) + 1]; }
+    for (int k = 0; k < W; k++) {
+      const int idx = l + k < last ? l + k : last - 1;
+      lo[k] = tab[2 * (size_t)idx]; hi[k] = tab[2 * (size_t)idx + 1];
+    }
 #pragma unroll
     for (int k = 0; k < W; k++) {
       b.lx = fminf(b.lx, lo[k].x); b.ly = fminf(b.ly, lo[k].y); b.lz = fminf(b.lz, lo[k].z);
       b.hx = fmaxf(b.hx, hi[k].x); b.hy = fmaxf(b.hy, hi[k].y); b.hz = fmaxf(b.hz, hi[k].z);
     }
   }
-  for (; l < last; l++) box_merge(b, tab, l);
 }
 __device__ __forceinline__ Box6 range_box(const TreeScratch& t, int a, int e) {
   Box6 b = box_empty();
