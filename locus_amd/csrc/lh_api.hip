@@ -727,6 +727,7 @@ lh_status lh_gicp_debug_sweep_fused(lh_gicp* g, const float T[16], int sweep_ind
   if (sweep_index == 0) {
     SweepArgs sa = a;
     launch_seed(c->descs_dev, sa, g->src->n, c->stream);
+    a.job[0].pad = 1;   // the cold sweep: seeds in prev_nn, certificates / records not read
   }
   CostArgs ca;
   ca.njobs = 1; ca.pad = 0; ca.job[0].slot = 0; ca.job[0].out_offset = 0;

@@ -494,18 +494,10 @@ __global__ void __launch_bounds__(256) k_seed(const PairDesc* __restrict__ descs
   TreeView tv{d.tgt_sorted, d.tgt_nodes, d.tgt_hdr, d.m};
   Nn1Collector col{INFINITY, 0x7fffffff};
   tree_descend<Nn1Collector, true>(tv, qx, qy, qz, col);   // the nearest point of the nearest leaf (below the query's own grid cell): no stack, no backtracking, a third of an exact cold search
-  int j = (col.bi == 0x7fffffff) ? -1 : col.bi;
-  float4 rt = make_float4(0.f, 0.f, 0.f, 0.f), rn = rt;
-  if (j >= 0 && d.rec) {
-    rt = d.tgt_xyz[j];
-    if (d.tgt_nrm) rn = d.tgt_nrm[j];
-  }
+  const int j = (col.bi == 0x7fffffff) ? -1 : col.bi;
+  // only the candidate: the sweep that follows is launched `cold` (SweepJob::pad) and reads neither certificate nor record
   for (int e = 0; e < group; e++)
-    if (i + e < d.n) {
-      d.prev_nn[i + e] = j;
-      d.cert[i + e] = make_float4(0.f, 0.f, 0.f, 0.f);  // lower bound 0 => the certificate can never skip the search
-      if (d.rec) { d.rec[2 * (size_t)(i + e)] = rt; d.rec[2 * (size_t)(i + e) + 1] = rn; }  // the record follows prev_nn
-    }
+    if (i + e < d.n) d.prev_nn[i + e] = j;
 }
 
 void launch_seed(const PairDesc* descs, SweepArgs& a, int max_n, hipStream_t s) {
@@ -562,22 +554,30 @@ struct SweepPoint {
 // operations, no square roots, and inverted as a symmetric 3x3 (six cofactors).  Its rounding differs from the reference's
 // order of operations (normalise, two 3x3x3 products) in the last bits of M, which is why only cost_mode 1 -- a bit-different
 // evaluation of the cost anyway -- uses it; k_sweep (cost_mode 0, the debug entry points) keeps the reference order.
+// `cold` (wave-uniform: the pair's FIRST sweep, after the seed pass): prev_nn holds a seed -- any target point, a bound and nothing more --
+// while the certificate and the neighbour record of this workspace slot are a former pair's: neither is read, every point searches,
+// and the record is (re)written whatever the search finds.  (The seed pass used to write a zero certificate and the record for every
+// point: 52 B per source point of stores, 110 us per 32 pairs, for one sweep's use.)
 template <bool kRank1 = false, int kStride = 256>
-__device__ __forceinline__ void sweep_point(const PairDesc& d, const float* __restrict__ T, int i, uint64_t* stack, SweepPoint& o, float cm) {
+__device__ __forceinline__ void sweep_point(const PairDesc& d, const float* __restrict__ T, int i, uint64_t* stack, SweepPoint& o, float cm, bool cold = false) {
   // first round of loads: everything whose address only depends on i goes out together (the certificate and, in the fused
   // kernel, the source normal as well: each was its own dependent memory round behind the candidate before, and the late
   // sweeps are bound by exactly that chain -- a workgroup lives for two memory latencies instead of three)
   o.p = gld(d.src + i);
   int w = gld(d.prev_nn + i);
-  const float4 cq = gld(d.cert + i);   // only meaningful when w >= 0; the buffer always holds n entries
+  float4 cq = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (!cold) cq = gld(d.cert + i);   // only meaningful when w >= 0; the buffer always holds n entries
   float4 nn = make_float4(0.f, 0.f, 0.f, 0.f);
   float4 t = make_float4(0.f, 0.f, 0.f, 0.f), tn = make_float4(0.f, 0.f, 0.f, 0.f);
   if constexpr (kRank1) {
     nn = gld(d.src_nrm + i);
     // ... and so does the candidate itself: rec[i] holds the position and normal of target point prev_nn[i] (kept in step with
     // prev_nn by every writer), so the gather through w -- a second, dependent memory round -- is gone from every sweep
-    t = gld(d.rec + 2 * (size_t)i);
-    tn = gld(d.rec + 2 * (size_t)i + 1);
+    if (!cold) {
+      t = gld(d.rec + 2 * (size_t)i);
+      tn = gld(d.rec + 2 * (size_t)i + 1);
+    } else if (w >= 0)
+      t = gld(d.tgt_xyz + w);   // the seed: its position only (it is a bound, not yet a neighbour)
   }
   float qx, qy, qz;
   xform_pt(T, o.p.x, o.p.y, o.p.z, qx, qy, qz);  // gicp.hpp:469
@@ -600,7 +600,7 @@ __device__ __forceinline__ void sweep_point(const PairDesc& d, const float* __re
     // (float arithmetic: sqrtf is correctly rounded to ~1e-7 relative, two orders below the 1e-5 margins)
     float e = sqrtf(d2f(qx, qy, qz, cq.x, cq.y, cq.z));
     float dw = sqrtf(col.bd), lo = sqrtf(cq.w);
-    if (dw * (1.0f + cm) + e * (1.0f + cm) + 1e-12f < lo * (1.0f - cm)) need_search = false;
+    if (!cold && dw * (1.0f + cm) + e * (1.0f + cm) + 1e-12f < lo * (1.0f - cm)) need_search = false;
   }
   o.searched = need_search;
   if (need_search) {
@@ -616,7 +616,7 @@ __device__ __forceinline__ void sweep_point(const PairDesc& d, const float* __re
     t = gld(d.tgt_xyz + j);
     if (d.tgt_nrm) tn = gld(d.tgt_nrm + j);
     if constexpr (kRank1) nn = gld(d.src_nrm + i);   // re-read after a walk, so that the normal is not live across it
-    if (j != w && d.rec) {                           // the record follows prev_nn
+    if ((j != w || cold) && d.rec) {                 // the record follows prev_nn
       gst(d.rec + 2 * (size_t)i, t);
       gst(d.rec + 2 * (size_t)i + 1, tn);
     }
@@ -706,7 +706,7 @@ __global__ void __launch_bounds__(256) k_sweep(const PairDesc* __restrict__ desc
   int i = blk * 256 + threadIdx.x;
   if (i >= d.n) return;
   SweepPoint sp;
-  sweep_point(d, job.T, i, lds_stack + threadIdx.x, sp, a.cert_rel);
+  sweep_point(d, job.T, i, lds_stack + threadIdx.x, sp, a.cert_rel, job.pad != 0);
   float4 c = make_float4(0.f, 0.f, 0.f, __int_as_float(sp.nonn ? -2 : -1));   // -1: gated out; -2: no neighbour at all (the failure path)
   if (sp.matched) {
     d.maha6[(size_t)0 * d.n_pad + i] = sp.M[0];
@@ -932,7 +932,7 @@ __global__ void __launch_bounds__(FUSED_WG) __attribute__((amdgpu_waves_per_eu(6
   // does a sweep's time follow the number of LANES that walk (request-bound) or the number of WAVES that do (bound per wave step)?
   // Measured (round 3): a quarter of the lanes -> 25 / 13 / 14 % less time in the three all-walk sweeps: per wave step.
   const bool exp_skip = a.pad2 != 0 && (threadIdx.x & (a.pad2 == 1 ? 1 : 3)) != 0;
-  if (i < d.n && !exp_skip) sweep_point<kNormals, FUSED_WG>(d, T, i, lds_stack + threadIdx.x, sp, a.cert_rel);
+  if (i < d.n && !exp_skip) sweep_point<kNormals, FUSED_WG>(d, T, i, lds_stack + threadIdx.x, sp, a.cert_rel, job.pad != 0);
   double M6[6] = {0, 0, 0, 0, 0, 0}, Ma[3] = {0, 0, 0}, pt[4] = {0, 0, 0, 0}, pp[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, aMa = 0.0;
   if (sp.matched) moments_of_point(T, sp, M6, Ma, aMa, pt, pp);
   const double live = sp.matched ? 1.0 : (sp.nonn ? NO_NN_MARK : 0.0);

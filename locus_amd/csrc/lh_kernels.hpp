@@ -48,7 +48,7 @@ struct PairDesc {
 
 struct SweepJob {  // dynamic per-launch part
   int slot;
-  int pad;
+  int pad;         // 1: the pair's first sweep, right after the seed pass (`cold`: certificate and neighbour record are not read)
   float T[12];     // transformation_ (row-major 3x4 float)
 };
 struct SweepArgs {

@@ -146,7 +146,7 @@ struct Group {
 // parameters and k, so that both loop flavours, any batching and any number of GPUs add the same partial rows in the same order.
 bool sweep_is_split(const Task* t, int k) {
   return t->P.cost_mode == 1 && !t->P.recompute_source_cov && !t->P.recompute_target_cov && t->guess_is_identity && t->src->nrm &&
-         t->tgt->nrm && t->ws->rec && k >= sweep_split_from();
+         t->tgt->nrm && t->ws->rec && k >= std::max(1, sweep_split_from());   // (never the cold sweep: k_late reads certificates and records)
 }
 
 static lh_status group_launch(lh_ctx* c, Group& g) {
@@ -187,6 +187,7 @@ static lh_status group_launch(lh_ctx* c, Group& g) {
         Task* t = g.sweeps[o + j];
         if (t->first_sweep) {
           sa.job[sa.njobs++] = a.job[j];
+          a.job[j].pad = 1;   // ... and the sweep that follows is the pair's cold one: it reads the seeds, not the slot's old certificates / records
           smax = std::max(smax, t->src->n);
           t->first_sweep = false;
         }
@@ -439,6 +440,7 @@ static lh_status dev_enqueue(lh_ctx* c, DevGroup& g, int rounds) {
         if (t->enq_iters < t->P.max_iterations) bytes += 20.0 * t->src->n;  // SURVEY 8d B_nn = 20 N + 232 K_t; the K_t terms are added at retirement
         if (t->first_sweep) {  // cold pair: seed pre-pass so its first sweep starts warm
           seed.job[seed.njobs++] = a.job[j];
+          a.job[j].pad = 1;      // (the fused sweep's `cold` flag, lh_kernels.hip sweep_point)
           smax = std::max(smax, t->src->n);
           t->first_sweep = false;
         }
