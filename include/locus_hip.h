@@ -181,7 +181,7 @@ lh_status lh_knn_cloud(lh_cloud* target, const lh_cloud* q, int k, int32_t* idx,
    src[p] -> tgt[p].  The NN index of every target is (re)built inside the call, like align() does.
    max_in_flight: pairs that share the GPU at any time (one HIP stream per group of 21-32 pairs; about 100 bytes of device
    workspace per source point and slot).  Throughput keeps growing with it until the streams cover each other's latencies: on
-   100 k-point pairs 64 in flight ran 7 690 pairs/s, 512 in flight 8 900 (DESIGN.md sections 5, 7).  Every pair's own outcome
+   100 k-point pairs 64 in flight ran 8 540 pairs/s, 512 in flight 10 200 (DESIGN.md sections 5, 7).  Every pair's own outcome
    (LH_OK, LH_ETOO_FEW_CORR, LH_ESOLVER, LH_ENO_NN) is in out[i].status; the return value reports usage / device errors. */
 lh_status lh_gicp_align_batch(lh_ctx* ctx, const lh_gicp_params* p, int n_pairs, lh_cloud* const* src,
                               lh_cloud* const* tgt, const float* guesses /* n_pairs*16 or NULL */,
