@@ -753,17 +753,24 @@ LH_HD int grid_depth(int com) { return (com >= 9 ? 1 : 0) + (com >= 12 ? 1 : 0) 
 // node are all keys with its prefix, so the child holds exactly the cloud's points inside that cell.  A LEAF child is the cell of
 // the (com_i + 1)-bit prefix, which may span several table cells (a few points in a large empty region): every one of them gets the
 // leaf.  key30_c = any key of the child, ref_c = the child reference the walk uses (cloud-local node index / leaf reference).
+LH_HD bool grid_child_cells(int l, int com_i, bool child_is_leaf, int com_c, uint32_t key30_c, uint32_t lo3[3], uint32_t hi3[3]) {
+  const int bits = 3 * l, sh = 10 - l;
+  if (com_i >= bits) return false;                      // i lies inside a level-l cell already: an ancestor's child made that entry
+  if (!child_is_leaf && com_c < bits) return false;     // the child still spans several level-l cells: its descendants make the entries
+  uint32_t c0[3], c1[3];
+  morton_cell(key30_c, child_is_leaf ? (com_i + 1 < bits ? com_i + 1 : bits) : bits, c0, c1);
+#pragma unroll
+  for (int a = 0; a < 3; a++) { lo3[a] = c0[a] >> sh; hi3[a] = c1[a] >> sh; }
+  return true;
+}
 LH_HD void grid_fill_child(int32_t* grid, int com_i, bool child_is_leaf, int com_c, uint32_t key30_c, int32_t ref_c) {
 #pragma unroll
   for (int l = 5; l >= 3; l--) {
-    const int bits = 3 * l, sh = 10 - l;
-    if (com_i >= bits) continue;                      // i lies inside a level-l cell already: an ancestor's child made that entry
-    if (!child_is_leaf && com_c < bits) continue;     // the child still spans several level-l cells: its descendants make the entries
-    uint32_t c0[3], c1[3];
-    morton_cell(key30_c, child_is_leaf ? (com_i + 1 < bits ? com_i + 1 : bits) : bits, c0, c1);
-    for (uint32_t x = c0[0] >> sh; x <= c1[0] >> sh; x++)
-      for (uint32_t y = c0[1] >> sh; y <= c1[1] >> sh; y++)
-        for (uint32_t z = c0[2] >> sh; z <= c1[2] >> sh; z++) grid[grid_index(l, (int)x, (int)y, (int)z)] = ref_c;
+    uint32_t lo3[3], hi3[3];
+    if (!grid_child_cells(l, com_i, child_is_leaf, com_c, key30_c, lo3, hi3)) continue;
+    for (uint32_t x = lo3[0]; x <= hi3[0]; x++)
+      for (uint32_t y = lo3[1]; y <= hi3[1]; y++)
+        for (uint32_t z = lo3[2]; z <= hi3[2]; z++) grid[grid_index(l, (int)x, (int)y, (int)z)] = ref_c;
   }
 }
 // ... and by the cloud's root, for the levels at which the WHOLE cloud lies inside one cell

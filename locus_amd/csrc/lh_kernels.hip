@@ -351,28 +351,70 @@ __global__ void __launch_bounds__(256) k_radix_b(TreeScratch t) {
 __global__ void __launch_bounds__(256) k_nodex_b(const IndexDesc* __restrict__ descs, TreeScratch t) {
   const int n_leaves = (int)t.lid[t.total - 1];
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_leaves - 1) return;
-  const int lo = t.irange[2 * i], hi = t.irange[2 * i + 1];
-  const int cloud = (int)(t.lkey[lo] >> 32);
-  if (cloud != (int)(t.lkey[hi] >> 32)) return;  // joins two clouds: not part of any cloud's tree
-  const IndexDesc d = descs[cloud];
-  const int a_c = (int)t.lid[d.offset] - 1, b_c = (int)t.lid[d.offset + d.n - 1] - 1;
-  const bool is_root = lo == a_c && hi == b_c;
-  const int com_i = t.icom[i];
-  const bool grid_on = d.n >= GRID_MIN_POINTS;
-  const int lc = t.ichild[2 * i], rc = t.ichild[2 * i + 1];
-  const int com_l = lc >= 0 ? t.icom[lc] : 30, com_r = rc >= 0 ? t.icom[rc] : 30;
+  // (no early return before the start grid's entries are made: a long run of table cells is written by the whole wave)
+  bool valid = i < n_leaves - 1;
+  int lo = 0, hi = 0, cloud = 0;
+  if (valid) {
+    lo = t.irange[2 * i]; hi = t.irange[2 * i + 1];
+    cloud = (int)(t.lkey[lo] >> 32);
+    valid = cloud == (int)(t.lkey[hi] >> 32);   // a node that joins two clouds is not part of any cloud's tree
+  }
+  IndexDesc d = descs[0];
+  int a_c = 0, b_c = 0, com_i = 0, lc = -1, rc = -1, com_l = 30, com_r = 30;
+  bool is_root = false, grid_on = false;
+  if (valid) {
+    d = descs[cloud];
+    a_c = (int)t.lid[d.offset] - 1; b_c = (int)t.lid[d.offset + d.n - 1] - 1;
+    is_root = lo == a_c && hi == b_c;
+    com_i = t.icom[i];
+    grid_on = d.n >= GRID_MIN_POINTS;
+    lc = t.ichild[2 * i]; rc = t.ichild[2 * i + 1];
+    com_l = lc >= 0 ? t.icom[lc] : 30; com_r = rc >= 0 ? t.icom[rc] : 30;
+  }
   auto child_ref = [&](int c) -> int32_t {   // the reference the walk uses: cloud-local node index / leaf reference
     return c < 0 ? leaf_ref(t.lstart[~c] - (uint32_t)d.offset, (int)(t.lstart[~c + 1] - t.lstart[~c])) : c - a_c;
   };
-  if (grid_on) {   // the start grid's entries (grid_fill_child, lh_device.hpp): every binary node offers its two children
+  {   // the start grid's entries (grid_child_cells, lh_device.hpp): every binary node offers its two children.  A child's cells are
+      // written by its own thread when they are few (nearly always: one); a leaf in a large empty region -- an outlier that stretched
+      // the key grid can own thousands of cells -- is entered by the whole wave (one thread doing it made a 100 k-point build with three
+      // 4-km outliers take 0.52 instead of 0.16 ms)
     int32_t* grid = reinterpret_cast<int32_t*>(d.hdr + 1);
-    if (com_i < 15) {
-      grid_fill_child(grid, com_i, lc < 0, com_l, (uint32_t)t.lkey[lc < 0 ? ~lc : t.irange[2 * lc]] & 0x3fffffffu, child_ref(lc));
-      grid_fill_child(grid, com_i, rc < 0, com_r, (uint32_t)t.lkey[rc < 0 ? ~rc : t.irange[2 * rc]] & 0x3fffffffu, child_ref(rc));
+    const bool offer = valid && grid_on && com_i < 15;
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int side = 0; side < 2; side++) {
+      const int c = side ? rc : lc;
+      uint32_t key = 0; int32_t ref = 0;
+      if (offer) { key = (uint32_t)t.lkey[c < 0 ? ~c : t.irange[2 * c]] & 0x3fffffffu; ref = child_ref(c); }
+#pragma unroll
+      for (int l = 5; l >= 3; l--) {
+        uint32_t lo3[3] = {0, 0, 0}, hi3[3] = {0, 0, 0};
+        const bool app = offer && grid_child_cells(l, com_i, c < 0, side ? com_r : com_l, key, lo3, hi3);
+        const uint32_t nx = hi3[0] - lo3[0] + 1, ny = hi3[1] - lo3[1] + 1, nz = hi3[2] - lo3[2] + 1, cnt = nx * ny * nz;
+        if (app && cnt <= 8)
+          for (uint32_t x = lo3[0]; x <= hi3[0]; x++)
+            for (uint32_t y = lo3[1]; y <= hi3[1]; y++)
+              for (uint32_t z = lo3[2]; z <= hi3[2]; z++) grid[grid_index(l, (int)x, (int)y, (int)z)] = ref;
+        unsigned long long big = __ballot(app && cnt > 8);
+        while (big) {   // (wave-uniform loop)
+          const int src = __ffsll((long long)big) - 1;
+          big &= big - 1;
+          const uint32_t bx = (uint32_t)__shfl((int)lo3[0], src, 64), by = (uint32_t)__shfl((int)lo3[1], src, 64), bz = (uint32_t)__shfl((int)lo3[2], src, 64);
+          const uint32_t by_n = (uint32_t)__shfl((int)ny, src, 64), bz_n = (uint32_t)__shfl((int)nz, src, 64), bcnt = (uint32_t)__shfl((int)cnt, src, 64);
+          const int32_t bref = __shfl(ref, src, 64);
+          const unsigned long long gp = (unsigned long long)(uintptr_t)grid;
+          int32_t* bgrid = reinterpret_cast<int32_t*>((uintptr_t)(((unsigned long long)(uint32_t)__shfl((int)(gp >> 32), src, 64) << 32) |
+                                                                  (uint32_t)__shfl((int)(uint32_t)gp, src, 64)));
+          for (uint32_t k = (uint32_t)lane; k < bcnt; k += 64u) {
+            const uint32_t z = k % bz_n, y = (k / bz_n) % by_n, x = k / (bz_n * by_n);
+            bgrid[grid_index(l, (int)(bx + x), (int)(by + y), (int)(bz + z))] = bref;
+          }
+        }
+      }
     }
-    if (is_root) grid_fill_root(grid, com_i, (uint32_t)t.lkey[lo] & 0x3fffffffu, i - a_c);
+    if (valid && grid_on && is_root) grid_fill_root(grid, com_i, (uint32_t)t.lkey[lo] & 0x3fffffffu, i - a_c);
   }
+  if (!valid) return;
   // A 4-ary node adopts its GRANDchildren, so the walk only ever reaches the binary nodes at even depth below the cloud's root -- or
   // below a CELL ROOT of the start grid (a node that lies inside a table cell while its parent does not: walks start there too, so
   // it is a 4-ary node whatever its depth, and its parent keeps it as a child instead of adopting its children).  The other nodes
