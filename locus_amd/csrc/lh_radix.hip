@@ -23,13 +23,8 @@ constexpr int RS_BITS = 10, RS_BINS = 1 << RS_BITS, RS_TILE = 4096, RS_PER_THREA
 // Elements in flight between the passes are (key, point index) PAIRS in one 8-byte word: an LSD pass scatters every element
 // to its own place (the low key digits of neighbouring points are unrelated), so what counts is the number of isolated
 // stores, and a pair costs one instead of two.  k_key_b writes the pairs, the last pass writes (cloud << 32 | key) and the index.
-template <bool kFirst>
-__device__ __forceinline__ uint32_t rs_key(const void* keys, size_t g) {
-  if constexpr (kFirst) return (uint32_t)reinterpret_cast<const uint64_t*>(keys)[g];   // low word = the 30-bit key
-  else return reinterpret_cast<const uint2*>(keys)[g].x;
-}
+__device__ __forceinline__ uint32_t rs_key(const void* keys, size_t g) { return reinterpret_cast<const uint2*>(keys)[g].x; }
 
-template <bool kFirst>
 __global__ void __launch_bounds__(256) k_rs_hist(const IndexDesc* __restrict__ descs, const void* __restrict__ keys, int shift,
                                                  uint32_t* __restrict__ hist) {
   __shared__ uint32_t h[RS_BINS];
@@ -41,7 +36,7 @@ __global__ void __launch_bounds__(256) k_rs_hist(const IndexDesc* __restrict__ d
 #pragma unroll
   for (int r = 0; r < RS_PER_THREAD; r++) {
     int i = tile * RS_TILE + r * 256 + threadIdx.x;
-    if (i < n) atomicAdd(&h[(rs_key<kFirst>(keys, (size_t)off + i) >> shift) & (RS_BINS - 1)], 1u);
+    if (i < n) atomicAdd(&h[(rs_key(keys, (size_t)off + i) >> shift) & (RS_BINS - 1)], 1u);
   }
   __syncthreads();
   uint32_t* out = hist + ((size_t)descs[cloud].tile0 + tile) * RS_BINS;
@@ -102,8 +97,8 @@ __global__ void __launch_bounds__(256) k_rs_scan(const IndexDesc* __restrict__ d
   }
 }
 
-template <bool kFirst, bool kLast>
-__global__ void __launch_bounds__(256) k_rs_scatter(const IndexDesc* __restrict__ descs, const void* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+template <bool kLast>
+__global__ void __launch_bounds__(256) k_rs_scatter(const IndexDesc* __restrict__ descs, const void* __restrict__ keys_in,
                                                     int shift, const uint32_t* __restrict__ offs, void* __restrict__ keys_out,
                                                     uint32_t* __restrict__ vals_out) {
   __shared__ uint32_t cnt[4][RS_BINS];   // per-wave running digit counters, then the waves' base positions
@@ -122,8 +117,8 @@ __global__ void __launch_bounds__(256) k_rs_scatter(const IndexDesc* __restrict_
     const bool live = i < n;
     key[r] = 0xffffffffu; val[r] = 0;
     if (live) {
-      if constexpr (kFirst) { key[r] = rs_key<true>(keys_in, (size_t)off + i); val[r] = vals_in[(size_t)off + i]; }
-      else { const uint2 kv = reinterpret_cast<const uint2*>(keys_in)[(size_t)off + i]; key[r] = kv.x; val[r] = kv.y; }
+      const uint2 kv = reinterpret_cast<const uint2*>(keys_in)[(size_t)off + i];
+      key[r] = kv.x; val[r] = kv.y;
     }
     const uint32_t dig = live ? ((key[r] >> shift) & (RS_BINS - 1)) : RS_BINS;   // bit 10 set: idle lanes match only each other
     unsigned long long m = ~0ull;
@@ -409,18 +404,18 @@ void segsort_pairs(const IndexDesc* descs, int n_clouds, int max_n, uint64_t* kv
                    hipStream_t s) {
   const int tiles = (max_n + RS_TILE - 1) / RS_TILE;
   const dim3 grid(tiles, n_clouds), blk(256);
-  hipLaunchKernelGGL(k_rs_hist<false>, grid, blk, 0, s, descs, (const void*)kv_a, 0, hist);
+  hipLaunchKernelGGL(k_rs_hist, grid, blk, 0, s, descs, (const void*)kv_a, 0, hist);
   hipLaunchKernelGGL(k_rs_scan, dim3(n_clouds), dim3(256), 0, s, descs, hist);
-  hipLaunchKernelGGL((k_rs_scatter<false, false>), grid, blk, 0, s, descs, (const void*)kv_a, (const uint32_t*)nullptr, 0, (const uint32_t*)hist, (void*)kv_b,
+  hipLaunchKernelGGL((k_rs_scatter<false>), grid, blk, 0, s, descs, (const void*)kv_a, 0, (const uint32_t*)hist, (void*)kv_b,
                      (uint32_t*)nullptr);
-  hipLaunchKernelGGL(k_rs_hist<false>, grid, blk, 0, s, descs, (const void*)kv_b, RS_BITS, hist);
+  hipLaunchKernelGGL(k_rs_hist, grid, blk, 0, s, descs, (const void*)kv_b, RS_BITS, hist);
   hipLaunchKernelGGL(k_rs_scan, dim3(n_clouds), dim3(256), 0, s, descs, hist);
-  hipLaunchKernelGGL((k_rs_scatter<false, false>), grid, blk, 0, s, descs, (const void*)kv_b, (const uint32_t*)nullptr, RS_BITS, (const uint32_t*)hist, (void*)kv_a,
+  hipLaunchKernelGGL((k_rs_scatter<false>), grid, blk, 0, s, descs, (const void*)kv_b, RS_BITS, (const uint32_t*)hist, (void*)kv_a,
                      (uint32_t*)nullptr);
   // last pass: pairs in, (cloud << 32 | key) and index out
-  hipLaunchKernelGGL(k_rs_hist<false>, grid, blk, 0, s, descs, (const void*)kv_a, 2 * RS_BITS, hist);
+  hipLaunchKernelGGL(k_rs_hist, grid, blk, 0, s, descs, (const void*)kv_a, 2 * RS_BITS, hist);
   hipLaunchKernelGGL(k_rs_scan, dim3(n_clouds), dim3(256), 0, s, descs, hist);
-  hipLaunchKernelGGL((k_rs_scatter<false, true>), grid, blk, 0, s, descs, (const void*)kv_a, (const uint32_t*)nullptr, 2 * RS_BITS, (const uint32_t*)hist, (void*)keys_out,
+  hipLaunchKernelGGL((k_rs_scatter<true>), grid, blk, 0, s, descs, (const void*)kv_a, 2 * RS_BITS, (const uint32_t*)hist, (void*)keys_out,
                      vals_out);
 }
 

@@ -14,7 +14,7 @@ clouds = []
 for pts in traj:
     c = capi.Cloud(ctx, pts); c.normals_knn(20); c.drop_index(); clouds.append(c)
 S, T, _ = bench.make_pairs(ctx, pairs)
-for name, (src, tgt) in (("independent", (S, T)), ("trajectory", (clouds[1:], clouds[:-1])), ("trajectory-copies", None)):
+for name, src, tgt in (("independent", S, T), ("trajectory", clouds[1:], clouds[:-1]), ("trajectory-copies", None, None)):
     if tgt is None:   # the same trajectory with every target an own copy of the scan (no cloud is source and target)
         tgt = []
         for pts in traj[:-1]:
