@@ -401,6 +401,7 @@ LH_HD int32_t grid_start(const float* org, float key_sc, float key_inv, const in
     dstep[a] = dir * (1 << stride_bits);
     home += ci << stride_bits;
   }
+  const int32_t href = gld(grid + home);   // (issued before the neighbour loop: its latency runs beside that loop's own table reads)
   // the neighbour cells behind crossed faces: the non-empty subsets of the crossed axes (usually one, at most seven)
   for (int m = cm; m; m = (m - 1) & cm) {
     const float lb = (((m & 1) ? sq[0] : 0.0f) + ((m & 2) ? sq[1] : 0.0f)) + ((m & 4) ? sq[2] : 0.0f);
@@ -410,7 +411,7 @@ LH_HD int32_t grid_start(const float* org, float key_sc, float key_inv, const in
     } else
       col.skip(lb);
   }
-  return gld(grid + home);
+  return href;
 }
 
 // Nearest-child descent to ONE leaf and a scan of it: a good candidate, not the neighbour (nothing is stacked, nothing pruned).  What a
