@@ -132,6 +132,15 @@ LH_HD float u2f(uint32_t u) {
 #endif
 }
 LH_HD float inf_f() { return u2f(0x7f800000u); }
+// square root for BOUNDS that carry a relative margin of >= 1e-6 anyway (certificate tests, the start grid's ball radius): the raw
+// v_sqrt_f32 (1 ulp) on the device -- sqrtf is the correctly rounded one, fifteen instructions of refinement each
+LH_HD float sqrt_bound(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_sqrtf(x);
+#else
+  return sqrtf(x);
+#endif
+}
 
 LH_HD float d2f(float qx, float qy, float qz, float px, float py, float pz) {
   float dx = qx - px, dy = qy - py, dz = qz - pz;
@@ -371,7 +380,7 @@ template <class Collector, class Push>
 LH_HD int32_t grid_start(const float* org, float key_sc, float key_inv, const int32_t* __restrict__ grid, float qx, float qy, float qz,
                          Collector& col, Push&& push) {
   const float bd = col.bound();
-  const float ru = sqrtf(bd) * key_sc * 1.000001f + 2.0f * GRID_SLACK;   // the ball's radius in key cells, rounded up
+  const float ru = sqrt_bound(bd) * key_sc * 1.000001f + 2.0f * GRID_SLACK;   // the ball's radius in key cells, rounded up
   if (!(ru < 63.5f)) return GRID_USE_ROOT;
   const int sh = 5 + (ru >= 15.5f ? 1 : 0) + (ru >= 31.5f ? 1 : 0);      // key-cell bits inside one table cell: wider than the ball
   const int level = 10 - sh, G = 1 << level;

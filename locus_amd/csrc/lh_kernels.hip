@@ -639,9 +639,9 @@ __device__ __forceinline__ void sweep_point(const PairDesc& d, const float* __re
     // certificate from the last full search at query position cq: every other target point was at squared distance
     // >= cq.w from cq, so it is at distance >= sqrt(cq.w) - |q - cq| from q.  If the candidate is strictly closer
     // (1e-5 relative margin >> float rounding of the d2 evaluations), the traversal cannot change the result.
-    // (float arithmetic: sqrtf is correctly rounded to ~1e-7 relative, two orders below the 1e-5 margins)
-    float e = sqrtf(d2f(qx, qy, qz, cq.x, cq.y, cq.z));
-    float dw = sqrtf(col.bd), lo = sqrtf(cq.w);
+    // (float arithmetic: the raw hardware square root is good to 1 ulp ~ 1e-7 relative, two orders below the 1e-5 margins)
+    float e = sqrt_bound(d2f(qx, qy, qz, cq.x, cq.y, cq.z));
+    float dw = sqrt_bound(col.bd), lo = sqrt_bound(cq.w);
     if (!cold && dw * (1.0f + cm) + e * (1.0f + cm) + 1e-12f < lo * (1.0f - cm)) need_search = false;
   }
   o.searched = need_search;
@@ -1114,8 +1114,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))
     float bd = 0.f;
     if (w >= 0) {  // the certificate test of sweep_point: the neighbour of the last search is provably still the nearest
       bd = d2f(qx, qy, qz, t.x, t.y, t.z);
-      float e = sqrtf(d2f(qx, qy, qz, cq.x, cq.y, cq.z));
-      float dw = sqrtf(bd), lo = sqrtf(cq.w);
+      float e = sqrt_bound(d2f(qx, qy, qz, cq.x, cq.y, cq.z));
+      float dw = sqrt_bound(bd), lo = sqrt_bound(cq.w);
       ok = dw * (1.0f + a.cert_rel) + e * (1.0f + a.cert_rel) + 1e-12f < lo * (1.0f - a.cert_rel);
     }
     walker = !ok;
