@@ -140,6 +140,37 @@ def test_host_pool_runs_every_index_exactly_once():
     assert "HOSTPOOL_CHECK_OK" in out.stdout
 
 
+def test_start_grid_walks_on_a_scan_pair_host_model(tmp_path):
+    """tools/model/grid_start_model.cpp drives the product's own start-grid functions (grid_fill_child / grid_start / node_visit /
+    scan_leaf, lh_device.hpp) on the host over a lidar-like scan pair at four poses from the cold guess to the true motion: every
+    neighbour must equal the walk from the root, and every certificate bound must be a bound (never below the winner, never above the
+    exhaustive runner-up on the sampled queries).  The GPU runs the same functions; this is their CPU check on scan geometry (surfaces,
+    queries outside the target's box, stale candidates)."""
+    import numpy as np
+    from scipy.spatial.transform import Rotation as R
+    from locus_amd import synth
+    src, tgt, delta = synth.scan_pair(n_rings=24, n_az=500, scale=2.0, noise=0.02, seed=77)
+    src.astype(np.float32).tofile(tmp_path / "src.f32")
+    tgt.astype(np.float32).tofile(tmp_path / "tgt.f32")
+    D = np.asarray(delta, np.float64)
+    poses = []
+    for f in (0.0, 0.7, 0.95, 1.0):
+        T = np.eye(4)
+        T[:3, 3] = f * D[:3, 3]
+        T[:3, :3] = R.from_rotvec(R.from_matrix(D[:3, :3]).as_rotvec() * f).as_matrix()
+        poses.append(T[:3, :4])
+    np.stack(poses).astype(np.float32).tofile(tmp_path / "poses.f32")
+    exe = "/tmp/lh_grid_start_model"
+    src_cpp = os.path.join(ROOT, "tools", "model", "grid_start_model.cpp")
+    subprocess.check_call(["hipcc", "-O2", "-std=c++17", "-ffp-contract=off", "--offload-arch=gfx950", "-x", "hip", src_cpp, "-o", exe])
+    out = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    sweeps = [l for l in out.stdout.splitlines() if l.startswith("sweep ")]
+    assert len(sweeps) == 4, out.stdout
+    for l in sweeps:
+        assert "mismatches 0, bad certificate bounds 0" in l, l
+
+
 def test_ndt_host_algebra_matches_oracle(oracle):
     """lh_ndt_host.hpp (pose <-> matrix, the 6x6 SVD solve of the Newton step) against the oracle's restatement of the same
     pclomp pieces; the `oracle` fixture makes sure oracle/liblocus_oracle.so is built"""
