@@ -519,8 +519,10 @@ static inline size_t stack_lds_bytes(int /*depth*/, int threads) { return (size_
 
 // K2': seeds for a cold sweep.  One thread per group of SEED_GROUP consecutive source points descends the tree to the leaf nearest to
 // the group's first point and hands that leaf's nearest point to the whole group as warm-start candidate (any target point is a
-// valid candidate, so exactness is untouched; consecutive lidar returns are spatial neighbours, so the bound is tight).  An exact
-// search per seed (with groups of 8) was 220 us per 32 pairs; the descent with groups of 4 is 120 us and the first sweep 1 % slower.
+// valid candidate, so exactness is untouched; consecutive lidar returns are spatial neighbours, so the bound is tight).  The descent
+// starts at the query's own cell of the start grid (lh_device.hpp) and ONLY the candidates are written: the sweep that follows is
+// launched cold (SweepJob::pad) and reads neither certificates nor neighbour records.  Per 32 pairs: an exact search per seed (groups
+// of 8) 220 us; the descent from the root with groups of 4, certificates and records written, 120 us; now 39-48 us.
 __global__ void __launch_bounds__(256) k_seed(const PairDesc* __restrict__ descs, SweepArgs a) {
   int jb, blk;
   if (!xcd_job_map(a.njobs, a.bpj, jb, blk)) return;
