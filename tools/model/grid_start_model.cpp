@@ -6,6 +6,7 @@
 //   (/tmp/wm: tgt.f32, src.f32 = a scan pair as float triples, poses.f32 = 3x4 row-major transforms, one per modelled sweep)
 #define TRAVERSAL_CHECK_NO_MAIN
 #include "../../tests/host_emu/traversal_check.cpp"
+#include <cstring>
 #include <string>
 
 static std::vector<float> read_f32(const std::string& path) {
@@ -43,7 +44,28 @@ struct LaneState { Nn1CertCollector col; std::vector<uint64_t> mem; WalkStack<LD
 static int g_policy = 0;
 static long g_hist[65];      // iterations by number of busy lanes
 static long g_cut_iters[5], g_cut_lanes[5];   // iterations executed / lanes handed off if a wave stops once <= {0,2,4,8,16} lanes are busy
+static int g_group = 64;   // lanes that share one instruction stream in the model (64 = a wave with one query per lane; 16 = a wave of sixteen
+                           // 4-lane query groups would execute max-over-16 iterations: what a cooperative search would pay)
+static void wave_lockstep_all(const TreeView& tv, const TreeHeader& h, std::vector<LaneState>& L, long& node_iters, long& leaf_iters, long& busy, bool hist);
 static void wave_lockstep(const TreeView& tv, const TreeHeader& h, std::vector<LaneState>& L, long& node_iters, long& leaf_iters, long& busy, bool hist = false) {
+  if (g_group >= (int)L.size()) { wave_lockstep_all(tv, h, L, node_iters, leaf_iters, busy, hist); return; }
+  for (size_t b = 0; b < L.size(); b += g_group) {
+    std::vector<LaneState> sub(g_group);
+    for (int k = 0; k < g_group; k++) {   // (a copy whose stack lives in its own memory)
+      const LaneState& o = L[b + k];
+      LaneState& n = sub[k];
+      n.col = o.col; n.gq = o.gq; n.ref = o.ref;
+      n.q[0] = o.q[0]; n.q[1] = o.q[1]; n.q[2] = o.q[2];
+      n.mem = o.mem;
+      n.ws = WalkStack<LDS_STACK>(n.mem.data(), 1);
+      n.ws.sp = o.ws.sp;
+      memcpy(n.ws.spill, o.ws.spill, sizeof(n.ws.spill));
+    }
+    wave_lockstep_all(tv, h, sub, node_iters, leaf_iters, busy, hist);
+    for (int k = 0; k < g_group; k++) L[b + k].col = sub[k].col;
+  }
+}
+static void wave_lockstep_all(const TreeView& tv, const TreeHeader& h, std::vector<LaneState>& L, long& node_iters, long& leaf_iters, long& busy, bool hist) {
   const int cuts[5] = {0, 2, 4, 8, 16};
   bool cut_done[5] = {false, false, false, false, false};
   auto note = [&](int act) {
@@ -100,6 +122,7 @@ static void wave_lockstep(const TreeView& tv, const TreeHeader& h, std::vector<L
 int main(int argc, char** argv) {
   std::string dir = argc > 1 ? argv[1] : "/tmp/wm";
   g_policy = argc > 2 ? atoi(argv[2]) : 0;
+  g_group = argc > 3 ? atoi(argv[3]) : 64;
   auto tg = read_f32(dir + "/tgt.f32"), sr = read_f32(dir + "/src.f32"), po = read_f32(dir + "/poses.f32");
   int m = (int)tg.size() / 3, n = (int)sr.size() / 3, np = (int)po.size() / 12;
   std::vector<float4> tp(m);
