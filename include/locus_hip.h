@@ -259,6 +259,13 @@ lh_status lh_cloud_voxel_grid_pointf(const lh_cloud* in, float leaf, lh_cloud** 
    out = float[count][4] (nx, ny, nz, curvature) */
 lh_status lh_normals_knn(lh_ctx* ctx, const lh_cloud_view* in, int k, float* out_normals4);
 lh_status lh_normals_knn_cloud(lh_cloud* c, int k); /* in place: fills the cloud's normals on the device */
+/* the same for a queue of scans (every LOCUS scan passes the normal filter before UpdateEstimate): ONE batched index build for the
+   clouds that have no index yet and ONE k-NN launch for all of them; the index stays with each cloud for the alignment that follows.
+   Results are identical to n_clouds calls of lh_normals_knn_cloud. */
+lh_status lh_normals_knn_batch(lh_cloud* const* clouds, int n_clouds, int k);
+/* computeCovariances' k-NN branch (gicp.hpp:85-154) for a queue of clouds: what lh_gicp_* computes on demand when
+   recompute_source_cov / recompute_target_cov is set, in one launch; the covariances stay with the clouds (valid for this k, epsilon) */
+lh_status lh_cov_knn_batch(lh_cloud* const* clouds, int n_clouds, int k, double gicp_epsilon);
 /* radius mode of the same nodelet (normal_search_method = radius, normal_computation.cc:71-74; default radius 0.3): every
    neighbour with d2 < radius^2 enters the covariance; fewer than 3 neighbours -> NaN normal and curvature.  The nodelet then
    drops those points (pcl::removeNaNNormalsFromPointCloud, normal_computation.cc:52-56): lh_cloud_remove_nan_normals is

@@ -109,7 +109,7 @@ EXPORTS = [
     "lh_gicp_align_batch", "lh_gicp_align_batch_out", "lh_device_count", "lh_gicp_align_batch_multi", "lh_gicp_align_batch_multi_views", "lh_cov_knn", "lh_gicp_debug_sweep", "lh_gicp_debug_sweep_fused", "lh_gicp_debug_stats", "lh_debug_traversal_stats", "lh_gicp_debug_cost", "lh_p2plane_information",
     "lh_icp_covariance", "lh_voxel_grid", "lh_cloud_voxel_grid", "lh_cloud_voxel_grid_pointf", "lh_cloud_nearest_neighbors", "lh_cloud_crop_box", "lh_default_ndt_params", "lh_ndt_create", "lh_ndt_destroy", "lh_ndt_set_params",
     "lh_ndt_set_source", "lh_ndt_set_target", "lh_ndt_set_source_cloud", "lh_ndt_set_target_cloud", "lh_ndt_align", "lh_ndt_debug_cells",
-    "lh_ndt_debug_derivatives", "lh_map_create", "lh_map_destroy", "lh_map_insert", "lh_map_refresh", "lh_map_cloud", "lh_map_size", "lh_normals_knn", "lh_normals_knn_cloud",
+    "lh_ndt_debug_derivatives", "lh_map_create", "lh_map_destroy", "lh_map_insert", "lh_map_refresh", "lh_map_cloud", "lh_map_size", "lh_normals_knn", "lh_normals_knn_cloud", "lh_normals_knn_batch", "lh_cov_knn_batch",
     "lh_normals_radius", "lh_normals_radius_cloud", "lh_cloud_remove_nan_normals", "lh_profile_enable",
     "lh_profile_reset", "lh_profile_get",
 ]
@@ -181,6 +181,8 @@ def lib():
         L.lh_cloud_nearest_neighbors.argtypes = [vp, vp, C.POINTER(vp)]
         L.lh_normals_knn.argtypes = [vp, C.POINTER(CloudView), i32, vp]
         L.lh_normals_knn_cloud.argtypes = [vp, i32]
+        L.lh_normals_knn_batch.argtypes = [C.POINTER(vp), i32, i32]
+        L.lh_cov_knn_batch.argtypes = [C.POINTER(vp), i32, i32, dbl]
         L.lh_cloud_slice.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(vp)]
         L.lh_cloud_concat.argtypes = [C.POINTER(vp), i32, C.POINTER(vp)]
         L.lh_default_ndt_params.argtypes = [C.POINTER(NdtParams)]
@@ -276,6 +278,17 @@ def view_of(points, with_normals=None):
     assert a.ndim == 2 and a.shape[1] in (3, 4)
     v = CloudView(_ptr(a), a.shape[0], a.shape[1] * 4, 0, UINT32_MAX, UINT32_MAX, UINT32_MAX)
     return v, a
+
+
+def normals_knn_batch(clouds, k=20):
+    """lh_normals_knn_batch: the normal filter for a queue of device clouds, one index build + one k-NN launch"""
+    arr = (C.c_void_p * len(clouds))(*[c.h for c in clouds])
+    _check(lib().lh_normals_knn_batch(arr, len(clouds), k), "lh_normals_knn_batch")
+
+
+def cov_knn_batch(clouds, k=20, eps=1e-3):
+    arr = (C.c_void_p * len(clouds))(*[c.h for c in clouds])
+    _check(lib().lh_cov_knn_batch(arr, len(clouds), k, eps), "lh_cov_knn_batch")
 
 
 def default_params(**kw):
@@ -495,6 +508,10 @@ class Cloud:
 
     def normals_radius(self, radius=0.3):
         _check(lib().lh_normals_radius_cloud(self.h, radius), "lh_normals_radius_cloud")
+
+    def cov_knn_planes(self, k=20, eps=1e-3):
+        """the covariances the cloud already holds on the device (after cov_knn_batch / an alignment in recompute mode), as lh_cov_knn returns them"""
+        return self.cov_knn(k, eps)
 
     def remove_nan_normals(self):
         """pcl::removeNaNNormalsFromPointCloud (normal_computation.cc:52-56): new cloud without the NaN-normal points"""

@@ -120,6 +120,7 @@ void lh_destroy(lh_ctx* c) {
   (void)lhFree(c->k64a); (void)lhFree(c->k64b); (void)lhFree(c->v32a); (void)lhFree(c->v32b); (void)lhFree(c->sort64_temp);
   (void)lhFree(c->tree_tmp); (void)lhFree(c->scan_tmp); (void)lhFree(c->k32a); (void)lhFree(c->k32b); (void)lhFree(c->rs_hist);
   (void)lhFree(c->idx_bbox); (void)lhFree(c->idx_descs_dev);
+  (void)lhFree(c->knn_descs_dev); (void)lhFree(c->knn_redo_cnt); (void)lhFree(c->knn_redo);
   if (c->idx_descs_host) (void)hipHostFree(c->idx_descs_host);
   for (hipEvent_t e : c->idx_copy_done)
     if (e) (void)hipEventDestroy(e);
@@ -471,7 +472,13 @@ lh_status lh_knn_cloud(lh_cloud* target, const lh_cloud* q, int k, int32_t* idx,
   size_t cnt = (size_t)q->n * k;
   HIPCHK(lhMalloc(&d_idx, sizeof(int32_t) * cnt));
   HIPCHK(lhMalloc(&d_d2, sizeof(float) * cnt));
-  { ProfScope p(c, "knn", (16.0 + 8.0 * k) * q->n); launch_knn(q->xyz, q->n, target->view(), k, d_idx, d_d2, c->stream); }
+  if (q == target && k <= KNN_BLOCK_MAX_K) {   // a cloud against itself: the block search (one wave per 64 Morton-consecutive queries)
+    lh_status st = knn_block_batch(c, &target, 1, k, KNN_MODE_RAW, 0.0, d_idx, d_d2);
+    if (st) { (void)lhFree(d_idx); (void)lhFree(d_d2); return st; }
+  } else {
+    ProfScope p(c, "knn", (16.0 + 8.0 * k) * q->n);
+    launch_knn(q->xyz, q->n, target->view(), k, d_idx, d_d2, c->stream);
+  }
   HIPCHK(hipGetLastError());
   if (idx) HIPCHK(hipMemcpyAsync(idx, d_idx, sizeof(int32_t) * cnt, hipMemcpyDeviceToHost, c->stream));
   if (d2) HIPCHK(hipMemcpyAsync(d2, d_d2, sizeof(float) * cnt, hipMemcpyDeviceToHost, c->stream));

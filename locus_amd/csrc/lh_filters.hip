@@ -215,14 +215,23 @@ lh_status lh_icp_covariance(const double Ap[36], double upper_bound, double cov[
 
 // ---- K3 filter flavour ---------------------------------------------------------------------------------------
 lh_status lh_normals_knn_cloud(lh_cloud* c, int k) {
-  if (!c || k < 3 || k > 64) return LH_EINVAL;
-  lh_ctx* x = c->ctx;
+  if (!c) return LH_EINVAL;
+  return lh_normals_knn_batch(&c, 1, k);
+}
+// the NormalComputation nodelet (normal_computation.cc:26-59) for a queue of scans: one index build and one k-NN launch for all of them
+lh_status lh_normals_knn_batch(lh_cloud* const* clouds, int n_clouds, int k) {
+  if (!clouds || n_clouds <= 0 || !clouds[0] || k < 3 || k > 64) return LH_EINVAL;
+  lh_ctx* x = clouds[0]->ctx;
   HIPCHK(hipSetDevice(x->device));
-  if (!c->has_index) { lh_status st = cloud_build_index(c); if (st) return st; }
-  if (!c->nrm) HIPCHK(lhMalloc(&c->nrm, sizeof(float4) * (size_t)c->n_pad));
-  { ProfScope p(x, "knn_normals", (16.0 + 16.0 * k + 16.0) * c->n); launch_knn_normals(c->xyz, c->n, c->view(), k, c->nrm, x->stream); }
-  HIPCHK(hipGetLastError());
-  return LH_OK;
+  return knn_block_batch(x, clouds, n_clouds, k, KNN_MODE_NORMALS, 0.0);
+}
+// computeCovariances' k-NN branch (gicp.hpp:85-154) for a queue of clouds: fills the covariances lh_gicp_* uses when
+// recompute_*_cov is set (they stay with the cloud, like lh_cov_knn's)
+lh_status lh_cov_knn_batch(lh_cloud* const* clouds, int n_clouds, int k, double gicp_epsilon) {
+  if (!clouds || n_clouds <= 0 || !clouds[0] || k < 1 || k > 64) return LH_EINVAL;
+  lh_ctx* x = clouds[0]->ctx;
+  HIPCHK(hipSetDevice(x->device));
+  return knn_block_batch(x, clouds, n_clouds, k, KNN_MODE_COV, gicp_epsilon);
 }
 // radius mode (normal_computation.cc:71-74): NaN normals where fewer than 3 neighbours lie within `radius`
 lh_status lh_normals_radius_cloud(lh_cloud* c, float radius) {

@@ -141,15 +141,83 @@ lh_status build_indices(lh_ctx* x, lh_cloud* const* clouds, int n_clouds, hipStr
   return LH_OK;
 }
 
+// K3 over a batch of clouds (normal_computation.cc:26-59 for every scan of a stream; gicp.hpp:85-154 in the recompute mode): the
+// clouds without an index are built together (one batched build), then ONE launch of the block search serves up to MAX_INDEX_BATCH
+// clouds -- a scan's tree is built once and stays with the cloud for the alignment that follows.
+lh_status knn_block_batch(lh_ctx* x, lh_cloud* const* clouds, int n_clouds, int k, int mode, double eps, int32_t* idx_dev, float* d2_dev) {
+  if (!x || !clouds || n_clouds <= 0 || k < 1 || k > 64) return LH_EINVAL;
+  if (mode == KNN_MODE_RAW && n_clouds != 1) return LH_EINVAL;
+  std::vector<lh_cloud*> need;
+  for (int i = 0; i < n_clouds; i++) {
+    lh_cloud* c = clouds[i];
+    if (!c || c->ctx != x || c->n <= 0) return LH_EINVAL;
+    if (mode == KNN_MODE_COV && k > c->n) return LH_EINVAL;   // gicp.hpp:72-79
+    if (!c->has_index) need.push_back(c);
+  }
+  if (!need.empty()) {
+    lh_status st = build_indices(x, need.data(), (int)need.size());
+    if (st) return st;
+  }
+  for (int i = 0; i < n_clouds; i++) {
+    lh_cloud* c = clouds[i];
+    if (mode == KNN_MODE_NORMALS && !c->nrm) HIPCHK(lhMalloc(&c->nrm, sizeof(float4) * (size_t)c->n_pad));
+    if (mode == KNN_MODE_COV && !c->cov6) HIPCHK(lhMalloc(&c->cov6, sizeof(double) * 6 * (size_t)c->n_pad));
+  }
+  const double model_bytes = mode == KNN_MODE_COV ? 16.0 + 16.0 * k + 48.0 : (mode == KNN_MODE_NORMALS ? 16.0 + 16.0 * k + 16.0 : 16.0 + 8.0 * k);
+  const char* tag = mode == KNN_MODE_COV ? "knn_cov" : (mode == KNN_MODE_NORMALS ? "knn_normals" : "knn");
+  if (k > KNN_BLOCK_MAX_K) {   // beyond the register lists of the block search: one query per lane, one cloud per launch
+    for (int i = 0; i < n_clouds; i++) {
+      lh_cloud* c = clouds[i];
+      ProfScope p(x, tag, model_bytes * c->n);
+      if (mode == KNN_MODE_NORMALS) launch_knn_normals(c->xyz, c->n, c->view(), k, c->nrm, x->stream);
+      else if (mode == KNN_MODE_COV) launch_knn_cov(c->xyz, c->n, c->n_pad, c->view(), k, eps, c->cov6, x->stream);
+      else launch_knn(c->xyz, c->n, c->view(), k, idx_dev, d2_dev, x->stream);
+    }
+    HIPCHK(hipGetLastError());
+    return LH_OK;
+  }
+  if (!x->knn_descs_dev) {
+    HIPCHK(lhMalloc(&x->knn_descs_dev, sizeof(KnnCloudDesc) * MAX_INDEX_BATCH));
+    HIPCHK(lhMalloc(&x->knn_redo_cnt, 256));
+  }
+  for (int o = 0; o < n_clouds; o += MAX_INDEX_BATCH) {
+    const int nb = std::min(MAX_INDEX_BATCH, n_clouds - o);
+    KnnCloudDesc hd[MAX_INDEX_BATCH];
+    long pts = 0;
+    int max_n = 0;
+    for (int i = 0; i < nb; i++) {
+      lh_cloud* c = clouds[o + i];
+      KnnCloudDesc& d = hd[i];
+      d.pts = c->sorted; d.nodes = c->nodes(); d.hdr = c->hdr(); d.xyz = c->xyz;
+      d.nrm = c->nrm; d.cov6 = c->cov6; d.idx = idx_dev; d.d2 = d2_dev;
+      d.n = c->n; d.n_pad = c->n_pad;
+      pts += c->n;
+      max_n = std::max(max_n, c->n);
+    }
+    if (pts > x->knn_redo_cap) {
+      (void)hipStreamSynchronize(x->stream);
+      (void)lhFree(x->knn_redo);
+      x->knn_redo = nullptr; x->knn_redo_cap = 0;
+      const long cap = pts + pts / 4 + 1024;
+      HIPCHK(lhMalloc(&x->knn_redo, sizeof(uint2) * (size_t)cap));
+      x->knn_redo_cap = cap;
+    }
+    // (pageable source: the copy is staged before the call returns, and it is queued behind the previous launch that reads the table)
+    HIPCHK(hipMemcpyAsync(x->knn_descs_dev, hd, sizeof(KnnCloudDesc) * nb, hipMemcpyHostToDevice, x->stream));
+    {
+      ProfScope p(x, tag, model_bytes * pts);
+      launch_knn_block(x->knn_descs_dev, nb, max_n, k, mode, eps, x->knn_redo_cnt, x->knn_redo, x->stream);
+    }
+    HIPCHK(hipGetLastError());
+  }
+  if (mode == KNN_MODE_COV)
+    for (int i = 0; i < n_clouds; i++) { clouds[i]->cov_k = k; clouds[i]->cov_eps = eps; }
+  return LH_OK;
+}
+
 lh_status cloud_ensure_cov(lh_cloud* c, int k, double eps) {
   if (c->cov6 && c->cov_k == k && c->cov_eps == eps) return LH_OK;
   if (k > c->n || k > 64 || k < 1) return LH_EINVAL;  // gicp.hpp:72-79
-  if (!c->has_index) { lh_status st = cloud_build_index(c); if (st) return st; }
-  if (!c->cov6) HIPCHK(lhMalloc(&c->cov6, sizeof(double) * 6 * (size_t)c->n_pad));
-  { ProfScope p(c->ctx, "knn_cov", (16.0 + 20 * 16.0 + 48.0) * c->n); launch_knn_cov(c->xyz, c->n, c->n_pad, c->view(), k, eps, c->cov6, c->ctx->stream); }
-  HIPCHK(hipGetLastError());
-  c->cov_k = k;
-  c->cov_eps = eps;
-  return LH_OK;
+  return knn_block_batch(c->ctx, &c, 1, k, KNN_MODE_COV, eps);
 }
 

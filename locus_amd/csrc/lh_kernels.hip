@@ -13,6 +13,7 @@
 #include <cstdlib>
 
 #include "lh_kernels.hpp"
+#include "lh_launch.hpp"
 #include "lh_ndt.hpp"
 
 namespace lh {
@@ -492,30 +493,6 @@ void launch_index_trees(const IndexDesc* descs, int n_clouds, int max_n, const T
 }
 
 // ===== K4: NN + Mahalanobis sweep ==========================================================================
-// XCD-aware workgroup -> (job, block) map.  The dispatcher places workgroup b on XCD b % 8 (observed, used for speed
-// only): all workgroups of one job are given ids congruent mod 8, so a job's tree (2 MB for 100 k points) is walked
-// from ONE XCD's 4-MB L2 instead of being pulled into all eight.
-// Only complete groups of 8 jobs are pinned; the remaining (njobs % 8) jobs -- e.g. a single lh_gicp_align -- use the
-// plain map and spread over all XCDs.
-__device__ __forceinline__ bool xcd_job_map(int njobs, int bpj, int& job, int& blk) {
-  int L = blockIdx.x;
-  int pinned = njobs & ~7;
-  int npin = pinned * bpj;
-  if (L < npin) {
-    int xcd = L & 7, s = L >> 3;
-    int jl = s / bpj;
-    blk = s - jl * bpj;
-    job = jl * 8 + xcd;
-    return true;
-  }
-  L -= npin;
-  int jl = L / bpj;
-  blk = L - jl * bpj;
-  job = pinned + jl;
-  return job < njobs;
-}
-static inline int xcd_grid(int njobs, int bpj) { return njobs * bpj; }
-static inline size_t stack_lds_bytes(int /*depth*/, int threads) { return (size_t)LDS_STACK * threads * sizeof(uint64_t); }
 
 // K2': seeds for a cold sweep.  One thread per group of SEED_GROUP consecutive source points descends the tree to the leaf nearest to
 // the group's first point and hands that leaf's nearest point to the whole group as warm-start candidate (any target point is a
@@ -1828,236 +1805,7 @@ void launch_sum_f32(const float* v, const int32_t* idx, int n, double* partials,
   hipLaunchKernelGGL(k_sum_f32, dim3(sum_blocks(n)), dim3(256), 0, s, v, idx, n, partials);
 }
 
-// ===== K3: k-NN, covariances, normals ======================================================================
-constexpr int KNN_BLOCK = 128;
-
-template <int KCAP>
-__device__ __forceinline__ int knn_search_regs(const TreeView& tv, float x, float y, float z, int k, float* kd, int* ki, uint64_t* stack) {
-  KnnRegCollector<KCAP> col;
-  col.init(k);
-  tree_search(tv, x, y, z, col, stack, KNN_BLOCK);
-  return col.dump(kd, ki, KNN_BLOCK);
-}
-// k best of one query into kd/ki ([k][KNN_BLOCK] LDS, already offset by threadIdx.x); returns the number found.
-// KCAP = register-list capacity chosen by the host (smallest of 8 / 20 / 32 that holds k; 0 = LDS insertion list for k > 32),
-// a template parameter of the kernels so that each instantiation only pays for its own registers.
-template <int KCAP>
-__device__ __forceinline__ int knn_search(const TreeView& tv, float x, float y, float z, int k, float* kd, int* ki, uint64_t* stack) {
-  if constexpr (KCAP > 0) {
-    return knn_search_regs<KCAP>(tv, x, y, z, k, kd, ki, stack);
-  } else {
-    KnnCollector col{kd, ki, k, KNN_BLOCK, 0};
-    tree_search(tv, x, y, z, col, stack, KNN_BLOCK);
-    return col.cnt;
-  }
-}
-#define LH_KNN_DISPATCH(KERNEL, k, ...)                                              \
-  do {                                                                              \
-    if ((k) <= 8) hipLaunchKernelGGL(KERNEL<8>, __VA_ARGS__);                       \
-    else if ((k) <= 20) hipLaunchKernelGGL(KERNEL<20>, __VA_ARGS__);                \
-    else if ((k) <= 32) hipLaunchKernelGGL(KERNEL<32>, __VA_ARGS__);                \
-    else hipLaunchKernelGGL(KERNEL<0>, __VA_ARGS__);                                \
-  } while (0)
-
-template <int KCAP>
-__global__ void __launch_bounds__(KNN_BLOCK) k_knn(const float4* __restrict__ q, int nq, TreeView tv, int k, int32_t* __restrict__ idx,
-                                                   float* __restrict__ d2) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* kd = reinterpret_cast<float*>(smem);
-  int* ki = reinterpret_cast<int*>(smem + sizeof(float) * (size_t)k * KNN_BLOCK);
-  int i = blockIdx.x * KNN_BLOCK + threadIdx.x;
-  if (i >= nq) return;
-  float4 p = q[i];
-  uint64_t* lds_stack = reinterpret_cast<uint64_t*>(smem + (size_t)8 * k * KNN_BLOCK);
-  struct { int cnt; } col;
-  col.cnt = knn_search<KCAP>(tv, p.x, p.y, p.z, k, kd + threadIdx.x, ki + threadIdx.x, lds_stack + threadIdx.x);
-  for (int e = 0; e < k; e++) {
-    bool ok = e < col.cnt;
-    idx[(size_t)i * k + e] = ok ? ki[e * KNN_BLOCK + threadIdx.x] : -1;
-    d2[(size_t)i * k + e] = ok ? kd[e * KNN_BLOCK + threadIdx.x] : INFINITY;
-  }
-}
-void launch_knn(const float4* q, int nq, TreeView tree, int k, int32_t* idx, float* d2, hipStream_t s) {
-  size_t sh = (size_t)k * KNN_BLOCK * 8 + stack_lds_bytes(0, KNN_BLOCK);
-  LH_KNN_DISPATCH(k_knn, k, dim3((nq + KNN_BLOCK - 1) / KNN_BLOCK), dim3(KNN_BLOCK), sh, s, q, nq, tree, k, idx, d2);
-}
-
-// computeCovariances k-NN branch (gicp.hpp:85-154)
-template <int KCAP>
-__global__ void __launch_bounds__(KNN_BLOCK) k_knn_cov(const float4* __restrict__ xyz, int n, int n_pad, TreeView tv, int k, double eps,
-                                                       double* __restrict__ cov6) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* kd = reinterpret_cast<float*>(smem);
-  int* ki = reinterpret_cast<int*>(smem + sizeof(float) * (size_t)k * KNN_BLOCK);
-  int i = blockIdx.x * KNN_BLOCK + threadIdx.x;
-  if (i >= n) return;
-  float4 p = xyz[i];
-  uint64_t* lds_stack = reinterpret_cast<uint64_t*>(smem + (size_t)8 * k * KNN_BLOCK);
-  struct { int cnt; } col;
-  col.cnt = knn_search<KCAP>(tv, p.x, p.y, p.z, k, kd + threadIdx.x, ki + threadIdx.x, lds_stack + threadIdx.x);
-  double mean[3] = {0, 0, 0}, c00 = 0, c10 = 0, c11 = 0, c20 = 0, c21 = 0, c22 = 0;
-  for (int e = 0; e < k; e++) {  // neighbours in ascending (d2, id) order, like the search returns them
-    float4 t = xyz[ki[e * KNN_BLOCK + threadIdx.x]];
-    double x = t.x, y = t.y, z = t.z;
-    mean[0] += x; mean[1] += y; mean[2] += z;
-    c00 += x * x;
-    c10 += y * x; c11 += y * y;
-    c20 += z * x; c21 += z * y; c22 += z * z;
-  }
-  double kk = (double)k;
-  mean[0] /= kk; mean[1] /= kk; mean[2] /= kk;
-  double cov[9];
-  cov[0] = c00 / kk - mean[0] * mean[0];
-  cov[3] = c10 / kk - mean[1] * mean[0];
-  cov[4] = c11 / kk - mean[1] * mean[1];
-  cov[6] = c20 / kk - mean[2] * mean[0];
-  cov[7] = c21 / kk - mean[2] * mean[1];
-  cov[8] = c22 / kk - mean[2] * mean[2];
-  cov[1] = cov[3]; cov[2] = cov[6]; cov[5] = cov[7];
-  double u[3];
-  smallest_sv_vector3(cov, u);
-  double s = 1.0 - eps;
-  cov6[(size_t)0 * n_pad + i] = 1.0 - s * u[0] * u[0];
-  cov6[(size_t)1 * n_pad + i] = 0.0 - s * u[0] * u[1];
-  cov6[(size_t)2 * n_pad + i] = 0.0 - s * u[0] * u[2];
-  cov6[(size_t)3 * n_pad + i] = 1.0 - s * u[1] * u[1];
-  cov6[(size_t)4 * n_pad + i] = 0.0 - s * u[1] * u[2];
-  cov6[(size_t)5 * n_pad + i] = 1.0 - s * u[2] * u[2];
-}
-void launch_knn_cov(const float4* xyz, int n, int n_pad, TreeView tree, int k, double eps, double* cov6, hipStream_t s) {
-  size_t sh = (size_t)k * KNN_BLOCK * 8 + stack_lds_bytes(0, KNN_BLOCK);
-  LH_KNN_DISPATCH(k_knn_cov, k, dim3((n + KNN_BLOCK - 1) / KNN_BLOCK), dim3(KNN_BLOCK), sh, s, xyz, n, n_pad, tree, k, eps, cov6);
-}
-
-// pcl::eigen33 smallest eigenpair, float closed form (PCL 1.10 common/eigen.hpp restated)
-__device__ void roots2f(float b, float c, float* r) {
-  r[0] = 0.0f;
-  float d = b * b - 4.0f * c;
-  if (d < 0.0f) d = 0.0f;
-  float sd = sqrtf(d);
-  r[2] = 0.5f * (b + sd);
-  r[1] = 0.5f * (b - sd);
-}
-__device__ void roots3f(float m00, float m01, float m02, float m11, float m12, float m22, float* r) {
-  float c0 = m00 * m11 * m22 + 2.0f * m01 * m02 * m12 - m00 * m12 * m12 - m11 * m02 * m02 - m22 * m01 * m01;
-  float c1 = m00 * m11 - m01 * m01 + m00 * m22 - m02 * m02 + m11 * m22 - m12 * m12;
-  float c2 = m00 + m11 + m22;
-  if (fabsf(c0) < 1.1920929e-07f) {
-    roots2f(c2, c1, r);
-    return;
-  }
-  const float s_inv3 = 1.0f / 3.0f, s_sqrt3 = sqrtf(3.0f);
-  float c2_over_3 = c2 * s_inv3;
-  float a_over_3 = (c1 - c2 * c2_over_3) * s_inv3;
-  if (a_over_3 > 0.0f) a_over_3 = 0.0f;
-  float half_b = 0.5f * (c0 + c2_over_3 * (2.0f * c2_over_3 * c2_over_3 - c1));
-  float q = half_b * half_b + a_over_3 * a_over_3 * a_over_3;
-  if (q > 0.0f) q = 0.0f;
-  float rho = sqrtf(-a_over_3);
-  float theta = atan2f(sqrtf(-q), half_b) * s_inv3;
-  float ct = cosf(theta), st = sinf(theta);
-  r[0] = c2_over_3 + 2.0f * rho * ct;
-  r[1] = c2_over_3 - rho * (ct + s_sqrt3 * st);
-  r[2] = c2_over_3 - rho * (ct - s_sqrt3 * st);
-  float t;
-  if (r[0] >= r[1]) { t = r[0]; r[0] = r[1]; r[1] = t; }
-  if (r[1] >= r[2]) {
-    t = r[1]; r[1] = r[2]; r[2] = t;
-    if (r[0] >= r[1]) { t = r[0]; r[0] = r[1]; r[1] = t; }
-  }
-  if (r[0] <= 0.0f) roots2f(c2, c1, r);
-}
-
-// solvePlaneParameters + flipNormalTowardsViewpoint on the nine raw moment sums of `cnt` neighbours (PCL 1.10)
-__device__ float4 normal_from_moments(float a0, float a1, float a2, float a3, float a4, float a5, float a6, float a7, float a8, int cnt,
-                                      float4 p) {
-  float c = (float)cnt;
-  a0 /= c; a1 /= c; a2 /= c; a3 /= c; a4 /= c; a5 /= c; a6 /= c; a7 /= c; a8 /= c;
-  float m00 = a0 - a6 * a6, m01 = a1 - a6 * a7, m02 = a2 - a6 * a8, m11 = a3 - a7 * a7, m12 = a4 - a7 * a8, m22 = a5 - a8 * a8;
-  // pcl::eigen33(mat, eigenvalue, eigenvector)
-  float scale = fmaxf(fmaxf(fmaxf(fabsf(m00), fabsf(m01)), fmaxf(fabsf(m02), fabsf(m11))), fmaxf(fabsf(m12), fabsf(m22)));
-  if (scale <= 1.17549435e-38f) scale = 1.0f;
-  float s00 = m00 / scale, s01 = m01 / scale, s02 = m02 / scale, s11 = m11 / scale, s12 = m12 / scale, s22 = m22 / scale;
-  float r[3];
-  roots3f(s00, s01, s02, s11, s12, s22, r);
-  float ev = r[0] * scale;
-  s00 -= r[0]; s11 -= r[0]; s22 -= r[0];
-  // rows: r0 = (s00,s01,s02) r1 = (s01,s11,s12) r2 = (s02,s12,s22)
-  float v1x = s01 * s12 - s02 * s11, v1y = s02 * s01 - s00 * s12, v1z = s00 * s11 - s01 * s01;  // r0 x r1
-  float v2x = s01 * s22 - s02 * s12, v2y = s02 * s02 - s00 * s22, v2z = s00 * s12 - s01 * s02;  // r0 x r2
-  float v3x = s11 * s22 - s12 * s12, v3y = s12 * s02 - s01 * s22, v3z = s01 * s12 - s11 * s02;  // r1 x r2
-  float l1 = (v1x * v1x + v1y * v1y) + v1z * v1z;
-  float l2 = (v2x * v2x + v2y * v2y) + v2z * v2z;
-  float l3 = (v3x * v3x + v3y * v3y) + v3z * v3z;
-  float nx, ny, nz, l;
-  if (l1 >= l2 && l1 >= l3) { nx = v1x; ny = v1y; nz = v1z; l = l1; }
-  else if (l2 >= l1 && l2 >= l3) { nx = v2x; ny = v2y; nz = v2z; l = l2; }
-  else { nx = v3x; ny = v3y; nz = v3z; l = l3; }
-  float sl = sqrtf(l);
-  nx /= sl; ny /= sl; nz /= sl;
-  float eig_sum = m00 + m11 + m22;
-  float curv = (eig_sum != 0.0f) ? fabsf(ev / eig_sum) : 0.0f;
-  float vx = 0.0f - p.x, vy = 0.0f - p.y, vz = 0.0f - p.z;  // flipNormalTowardsViewpoint, vp = 0
-  float cos_theta = (vx * nx + vy * ny) + vz * nz;
-  if (cos_theta < 0) { nx = -nx; ny = -ny; nz = -nz; }
-  return make_float4(nx, ny, nz, curv);
-}
-
-template <int KCAP>
-__global__ void __launch_bounds__(KNN_BLOCK) k_knn_normals(const float4* __restrict__ xyz, int n, TreeView tv, int k,
-                                                           float4* __restrict__ out) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* kd = reinterpret_cast<float*>(smem);
-  int* ki = reinterpret_cast<int*>(smem + sizeof(float) * (size_t)k * KNN_BLOCK);
-  int i = blockIdx.x * KNN_BLOCK + threadIdx.x;
-  if (i >= n) return;
-  float4 p = xyz[i];
-  uint64_t* lds_stack = reinterpret_cast<uint64_t*>(smem + (size_t)8 * k * KNN_BLOCK);
-  struct { int cnt; } col;
-  col.cnt = knn_search<KCAP>(tv, p.x, p.y, p.z, k, kd + threadIdx.x, ki + threadIdx.x, lds_stack + threadIdx.x);
-  const float qnan = __uint_as_float(0x7fc00000u);
-  if (col.cnt < 3) {
-    out[i] = make_float4(qnan, qnan, qnan, qnan);
-    return;
-  }
-  float a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, a6 = 0, a7 = 0, a8 = 0;
-  for (int e = 0; e < col.cnt; e++) {  // computeMeanAndCovarianceMatrix, float accumulators (PCL 1.10)
-    float4 t = xyz[ki[e * KNN_BLOCK + threadIdx.x]];
-    a0 += t.x * t.x; a1 += t.x * t.y; a2 += t.x * t.z;
-    a3 += t.y * t.y; a4 += t.y * t.z; a5 += t.z * t.z;
-    a6 += t.x; a7 += t.y; a8 += t.z;
-  }
-  out[i] = normal_from_moments(a0, a1, a2, a3, a4, a5, a6, a7, a8, col.cnt, p);
-}
-void launch_knn_normals(const float4* xyz, int n, TreeView tree, int k, float4* out_nrm, hipStream_t s) {
-  size_t sh = (size_t)k * KNN_BLOCK * 8 + stack_lds_bytes(0, KNN_BLOCK);
-  LH_KNN_DISPATCH(k_knn_normals, k, dim3((n + KNN_BLOCK - 1) / KNN_BLOCK), dim3(KNN_BLOCK), sh, s, xyz, n, tree, k, out_nrm);
-}
-
-// radius mode of the normal filter (normal_computation.cc:71-74): moments of all points with d2 < r2, < 3 neighbours -> NaN
-__global__ void __launch_bounds__(KNN_BLOCK) k_radius_normals(const float4* __restrict__ xyz, int n, TreeView tv, float r2,
-                                                              float4* __restrict__ out) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  int i = blockIdx.x * KNN_BLOCK + threadIdx.x;
-  if (i >= n) return;
-  float4 p = xyz[i];
-  uint64_t* lds_stack = reinterpret_cast<uint64_t*>(smem);
-  RadiusMomentCollector col;
-  col.r2 = r2; col.cnt = 0;
-#pragma unroll
-  for (int e = 0; e < 9; e++) col.a[e] = 0.0f;
-  tree_search(tv, p.x, p.y, p.z, col, lds_stack + threadIdx.x, KNN_BLOCK);
-  const float qnan = __uint_as_float(0x7fc00000u);
-  if (col.cnt < 3) {
-    out[i] = make_float4(qnan, qnan, qnan, qnan);
-    return;
-  }
-  out[i] = normal_from_moments(col.a[0], col.a[1], col.a[2], col.a[3], col.a[4], col.a[5], col.a[6], col.a[7], col.a[8], col.cnt, p);
-}
-void launch_radius_normals(const float4* xyz, int n, TreeView tree, float radius, float4* out_nrm, hipStream_t s) {
-  size_t sh = stack_lds_bytes(0, KNN_BLOCK);
-  hipLaunchKernelGGL(k_radius_normals, dim3((n + KNN_BLOCK - 1) / KNN_BLOCK), dim3(KNN_BLOCK), sh, s, xyz, n, tree, radius * radius, out_nrm);
-}
+// (K3 -- k-NN lists, covariances, normals -- lives in lh_knn.hip)
 
 // removeNaNNormalsFromPointCloud (normal_computation.cc:52-56): order-preserving compaction of points with finite normals
 __global__ void __launch_bounds__(256) k_finite_normal_flags(const float4* __restrict__ nrm, int n, uint32_t* __restrict__ flags) {

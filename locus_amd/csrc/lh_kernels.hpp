@@ -205,6 +205,25 @@ void launch_knn_cov(const float4* xyz, int n, int n_pad, TreeView tree, int k, d
 // NormalEstimationOMP k-NN restated (normal_computation.cc:26-59): out = (nx,ny,nz,curvature)
 void launch_knn_normals(const float4* xyz, int n, TreeView tree, int k, float4* out_nrm, hipStream_t s);
 void launch_radius_normals(const float4* xyz, int n, TreeView tree, float radius, float4* out_nrm, hipStream_t s);
+// The block k-NN search (lh_knn_block.hpp): every point of a cloud against its OWN cloud, one wave per 64 consecutive points of the
+// Morton-sorted array, any number of clouds per launch.  One descriptor per cloud (device memory); the consumer is chosen by `mode`.
+struct KnnCloudDesc {
+  const float4* pts;        // Morton-sorted points (x, y, z, original index) + LEAF_CAP pads
+  const NodeX* nodes;
+  const TreeHeader* hdr;
+  const float4* xyz;        // the cloud in its original order (the neighbours' coordinates are accumulated from here)
+  float4* nrm;              // KNN_MODE_NORMALS: (nx, ny, nz, curvature) per point                [n]
+  double* cov6;             // KNN_MODE_COV: 6 planes of n_pad doubles (gicp.hpp:85-154)
+  int32_t* idx;             // KNN_MODE_RAW: the k neighbour indices / squared distances per point [n * k]
+  float* d2;
+  int n, n_pad;
+};
+enum { KNN_MODE_NORMALS = 0, KNN_MODE_COV = 1, KNN_MODE_RAW = 2 };
+constexpr int KNN_BLOCK_MAX_K = 32;   // larger k: the one-query-per-lane kernels above
+// redo_cnt: one uint32 (reset by the launch), redo: room for every point of the batch -- the queries the block search hands to the
+// one-query-per-lane search (ties at the k-th distance, pathological blocks); both launches are queued on `s`
+void launch_knn_block(const KnnCloudDesc* descs_dev, int n_clouds, int max_n, int k, int mode, double eps, uint32_t* redo_cnt, uint2* redo,
+                      hipStream_t s);
 void launch_finite_normal_flags(const float4* nrm, int n, uint32_t* flags, hipStream_t s);
 void launch_compact(const uint32_t* incl, int n, const float4* xyz, const float4* nrm, const float* inten, float4* oxyz, float4* onrm,
                     float* ointen, hipStream_t s);

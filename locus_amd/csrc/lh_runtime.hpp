@@ -171,6 +171,11 @@ struct lh_ctx {
   hipEvent_t idx_copy_done[IDX_STAGE] = {};
   hipEvent_t idx_build_done = nullptr;
   int idx_stage = 0;
+  // K3, the block k-NN search over a batch of clouds (lh_index.hip knn_block_batch): the launch's descriptor table and its redo list
+  KnnCloudDesc* knn_descs_dev = nullptr;   // [MAX_INDEX_BATCH]
+  uint32_t* knn_redo_cnt = nullptr;
+  uint2* knn_redo = nullptr;
+  long knn_redo_cap = 0;                    // points the redo list has room for
   // pair slots
   PairDesc* descs_dev = nullptr;   // [n_slots]
   PairDesc* descs_host = nullptr;  // pinned staging
@@ -307,6 +312,10 @@ lh_status ctx_ensure_slots(lh_ctx* c, int n_slots, int max_n);
 lh_status build_indices(lh_ctx* x, lh_cloud* const* clouds, int n_clouds, hipStream_t s_in = nullptr);
 static inline lh_status cloud_build_index(lh_cloud* c) { return build_indices(c->ctx, &c, 1); }
 lh_status cloud_ensure_cov(lh_cloud* c, int k, double eps);
+// K3 for a batch of clouds: ONE index build for those that have none and ONE block k-NN launch per MAX_INDEX_BATCH clouds.
+// mode = KNN_MODE_NORMALS (fills lh_cloud::nrm), KNN_MODE_COV (lh_cloud::cov6) or KNN_MODE_RAW (one cloud: idx_dev / d2_dev, n * k each)
+lh_status knn_block_batch(lh_ctx* x, lh_cloud* const* clouds, int n_clouds, int k, int mode, double eps, int32_t* idx_dev = nullptr,
+                          float* d2_dev = nullptr);
 
 // one alignment = one coroutine
 enum Req { REQ_NONE = 0, REQ_SWEEP, REQ_COST, REQ_DONE };

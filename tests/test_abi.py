@@ -128,6 +128,28 @@ def test_traversal_device_functions_on_host():
     assert "TRAVERSAL_CHECK_OK" in out.stdout
 
 
+def test_block_knn_search_on_host():
+    """The block k-NN search of K3 (lh_knn_block.hpp: one wave per 64 Morton-consecutive queries, sorted-key lists, window + one shared
+    tree walk, second pass, redo list) stepped lane by lane on the host with the product's own per-lane functions and networks: every
+    query's k-NN list (indices and float distances) against an exhaustive search -- tiny clouds, k < K, duplicates, runs of 50
+    identical points, a lattice (ties everywhere: the redo path), 20 000 points"""
+    exe = "/tmp/lh_knn_block_model"
+    src = os.path.join(ROOT, "tools", "model", "knn_block_model.cpp")
+    subprocess.check_call(["hipcc", "-O2", "-std=c++17", "-ffp-contract=off", "--offload-arch=gfx950", src, "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "KNN_BLOCK_MODEL_OK" in out.stdout
+
+
+def test_knn_networks_are_the_generators_output():
+    """lh_knn_net.hpp is generated (tools/gen_knn_net.py checks every network before writing it): the committed header is what the
+    generator writes today"""
+    hdr = os.path.join(ROOT, "locus_amd", "csrc", "lh_knn_net.hpp")
+    before = open(hdr).read()
+    subprocess.check_call(["python", os.path.join(ROOT, "tools", "gen_knn_net.py")], stdout=subprocess.DEVNULL)
+    assert open(hdr).read() == before
+
+
 def test_host_pool_runs_every_index_exactly_once():
     """HostPool (lh_runtime.hpp) resumes the alignment coroutines of a scheduler group on a few host threads: over 100 000 back-to-back
     parallel_for calls of changing size every index must run exactly once (a worker still leaving the previous call must never take

@@ -79,6 +79,67 @@ def test_knn_bit_exact(ctx, capi, oracle, k):
     assert (idx == io).all() and (d2 == do).all()
 
 
+@pytest.mark.parametrize("k", [3, 8, 10, 20, 25, 32, 40])
+def test_block_knn_bit_exact_every_list_size(ctx, capi, oracle, k):
+    """a cloud against itself goes through the block search (lh_knn_block.hpp) for k <= 32 -- lists of 8 / 20 / 32 keys, k below the
+    list size (phantom keys), duplicates (ties at the k-th distance: the redo list) -- and through the one-query-per-lane kernel above"""
+    pts = _cloud_pts(30 + k, 6000)
+    tgt = capi.Cloud(ctx, pts)
+    idx, d2 = tgt.knn(tgt, k)
+    io, do = oracle.Tree(oracle.xyz4(pts)).knn(oracle.xyz4(pts), k, threads=4)
+    assert (idx == io).all() and (d2 == do).all()
+
+
+@pytest.mark.parametrize("n", [1, 2, 7, 8, 9, 19, 20, 21, 63, 64, 65, 127, 129, 1000])
+def test_block_knn_small_and_ragged_clouds(ctx, capi, oracle, n):
+    pts = _cloud_pts(5, 1000, dup=False)[:n]
+    tgt = capi.Cloud(ctx, pts)
+    k = 20
+    idx, d2 = tgt.knn(tgt, k)
+    io, do = oracle.Tree(oracle.xyz4(pts)).knn(oracle.xyz4(pts), k)
+    m = min(n, k)
+    assert (idx[:, :m] == io[:, :m]).all() and (d2[:, :m] == do[:, :m]).all()
+    assert (idx[:, m:] == -1).all() and np.isinf(d2[:, m:]).all()
+
+
+def test_block_knn_ties_everywhere(ctx, capi, oracle):
+    """a lattice, runs of identical points and a lidar sweep with every 5th point repeated: the k-th distance is shared by several
+    points, the block search hands those queries to the redo list, and the lowest index still wins"""
+    rng = np.random.default_rng(3)
+    g = np.stack(np.meshgrid(np.arange(12), np.arange(12), np.arange(12), indexing="ij"), -1).reshape(-1, 3).astype(np.float32) * np.float32(0.1)
+    base = (rng.normal(size=(100, 3)) * [5, 3, 1]).astype(np.float32)
+    scan = synth.scan(rings=16, azimuths=300, scale=1.0, seed=8)
+    clouds = {"lattice": g, "dup50": np.repeat(base, 50, axis=0), "scan_dup": np.concatenate([scan, scan[::5]])}
+    for name, pts in clouds.items():
+        tgt = capi.Cloud(ctx, pts)
+        idx, d2 = tgt.knn(tgt, 20)
+        io, do = oracle.Tree(oracle.xyz4(pts)).knn(oracle.xyz4(pts), 20, threads=4)
+        assert (idx == io).all() and (d2 == do).all(), name
+
+
+def test_normals_and_covariances_batch_equals_one_by_one(ctx, capi, oracle):
+    """lh_normals_knn_batch / lh_cov_knn_batch: ragged clouds (one without an index, one with), one launch -- bit-identical to the
+    per-cloud calls, and the normals against the oracle"""
+    sizes = [(16, 300, 1), (16, 431, 2), (8, 50, 3), (32, 500, 4), (4, 5, 5), (16, 300, 6), (16, 257, 7), (16, 300, 8), (24, 300, 9)]
+    pts = [synth.scan(rings=r, azimuths=a, scale=1.0, seed=s) for r, a, s in sizes]
+    A = [capi.Cloud(ctx, p) for p in pts]
+    B = [capi.Cloud(ctx, p) for p in pts]
+    A[3].build_index()
+    capi.normals_knn_batch(A, 20)
+    capi.cov_knn_batch(A, 20, 1e-3)
+    for a, b, p in zip(A, B, pts):
+        b.normals_knn(20)
+        da, db = a.download(), b.download()
+        for f in ("normal_x", "normal_y", "normal_z", "curvature"):
+            assert (da[f].view(np.uint32) == db[f].view(np.uint32)).all(), (len(p), f)
+        assert (a.cov_knn(20, 1e-3) == b.cov_knn(20, 1e-3)).all()
+    p = pts[3]
+    ref = oracle.normals_knn(oracle.xyz4(p), 20, threads=4)
+    d = A[3].download()
+    out = np.stack([d["normal_x"], d["normal_y"], d["normal_z"]], 1)
+    assert np.quantile(np.abs((out * ref[:, :3]).sum(1)), 0.01) > 1 - 1e-4
+
+
 def test_knn_more_neighbours_than_points(ctx, capi, oracle):
     pts = _cloud_pts(4, 8, dup=False)[:5]
     tgt = capi.Cloud(ctx, pts)
