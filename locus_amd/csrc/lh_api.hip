@@ -120,7 +120,7 @@ void lh_destroy(lh_ctx* c) {
   (void)lhFree(c->k64a); (void)lhFree(c->k64b); (void)lhFree(c->v32a); (void)lhFree(c->v32b); (void)lhFree(c->sort64_temp);
   (void)lhFree(c->tree_tmp); (void)lhFree(c->scan_tmp); (void)lhFree(c->k32a); (void)lhFree(c->k32b); (void)lhFree(c->rs_hist);
   (void)lhFree(c->idx_bbox); (void)lhFree(c->idx_descs_dev);
-  (void)lhFree(c->knn_descs_dev); (void)lhFree(c->knn_redo_cnt); (void)lhFree(c->knn_redo);
+  (void)lhFree(c->knn_descs_dev); (void)lhFree(c->knn_redo_cnt); (void)lhFree(c->knn_redo); (void)lhFree(c->knn_soa);
   if (c->idx_descs_host) (void)hipHostFree(c->idx_descs_host);
   for (hipEvent_t e : c->idx_copy_done)
     if (e) (void)hipEventDestroy(e);

@@ -196,11 +196,20 @@ lh_status knn_block_batch(lh_ctx* x, lh_cloud* const* clouds, int n_clouds, int 
     }
     if (pts > x->knn_redo_cap) {
       (void)hipStreamSynchronize(x->stream);
-      (void)lhFree(x->knn_redo);
-      x->knn_redo = nullptr; x->knn_redo_cap = 0;
+      (void)lhFree(x->knn_redo); (void)lhFree(x->knn_soa);
+      x->knn_redo = nullptr; x->knn_soa = nullptr; x->knn_redo_cap = 0;
       const long cap = pts + pts / 4 + 1024;
       HIPCHK(lhMalloc(&x->knn_redo, sizeof(uint2) * (size_t)cap));
+      HIPCHK(lhMalloc(&x->knn_soa, sizeof(float) * 3 * ((size_t)cap + (size_t)16 * MAX_INDEX_BATCH)));
       x->knn_redo_cap = cap;
+    }
+    {
+      size_t off = 0;   // every array starts on a 64-byte boundary
+      for (int i = 0; i < nb; i++) {
+        const size_t len = ((size_t)hd[i].n + LEAF_CAP + 15) & ~(size_t)15;
+        hd[i].sx = x->knn_soa + off; hd[i].sy = hd[i].sx + len; hd[i].sz = hd[i].sy + len;
+        off += 3 * len;
+      }
     }
     // (pageable source: the copy is staged before the call returns, and it is queued behind the previous launch that reads the table)
     HIPCHK(hipMemcpyAsync(x->knn_descs_dev, hd, sizeof(KnnCloudDesc) * nb, hipMemcpyHostToDevice, x->stream));

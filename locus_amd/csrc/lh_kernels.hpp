@@ -212,6 +212,8 @@ struct KnnCloudDesc {
   const NodeX* nodes;
   const TreeHeader* hdr;
   const float4* xyz;        // the cloud in its original order (the neighbours' coordinates are accumulated from here)
+  float *sx, *sy, *sz;      // the sorted points' coordinates as three arrays [n + LEAF_CAP] (filled by the launch itself: a chunk of 8 candidates
+                            // is then three scalar loads whose register PAIRS feed packed-f32 instructions, two candidates each)
   float4* nrm;              // KNN_MODE_NORMALS: (nx, ny, nz, curvature) per point                [n]
   double* cov6;             // KNN_MODE_COV: 6 planes of n_pad doubles (gicp.hpp:85-154)
   int32_t* idx;             // KNN_MODE_RAW: the k neighbour indices / squared distances per point [n * k]

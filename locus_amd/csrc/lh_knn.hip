@@ -246,27 +246,55 @@ void launch_radius_normals(const float4* xyz, int n, TreeView tree, float radius
 // ===== the block search (lh_knn_block.hpp) ===================================================================================
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x16 __attribute__((ext_vector_type(16), aligned(16)));   // four consecutive sorted points (16-byte aligned only)
-// the 8 points of a chunk as two scalar 64-byte loads issued together (separate 16-byte loads were scheduled one after the other, each
-// with its own wait)
-struct Chunk8 { f32x16 lo, hi; };
-__device__ __forceinline__ Chunk8 load_chunk(const float4* p) {
-  Chunk8 c;
-  c.lo = *reinterpret_cast<const f32x16 __attribute__((address_space(4)))*>(reinterpret_cast<uintptr_t>(p));
-  c.hi = *reinterpret_cast<const f32x16 __attribute__((address_space(4)))*>(reinterpret_cast<uintptr_t>(p + 4));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x8 __attribute__((ext_vector_type(8), aligned(4)));   // eight consecutive coordinates (4-byte aligned: a chunk starts anywhere)
+// The 8 candidates of a chunk for the lane's query: three scalar loads (x, y, z of sorted positions first .. first + 7, from the launch's
+// own coordinate arrays), then the squared distances TWO CANDIDATES PER INSTRUCTION: the register pair (x_e, x_e+1) is one operand of a
+// packed-f32 subtract / multiply / add -- 4 vector instructions per candidate instead of 8, each component rounded exactly like d2f's
+// (dx*dx + dy*dy) + dz*dz (packed f32 arithmetic is IEEE, and the unit is compiled without contraction).
+struct ChunkSoa { f32x8 x, y, z; };
+__device__ __forceinline__ ChunkSoa load_chunk(const float* sx, const float* sy, const float* sz, int first) {
+  ChunkSoa c;
+  c.x = *reinterpret_cast<const f32x8 __attribute__((address_space(4)))*>(reinterpret_cast<uintptr_t>(sx + first));
+  c.y = *reinterpret_cast<const f32x8 __attribute__((address_space(4)))*>(reinterpret_cast<uintptr_t>(sy + first));
+  c.z = *reinterpret_cast<const f32x8 __attribute__((address_space(4)))*>(reinterpret_cast<uintptr_t>(sz + first));
   return c;
 }
-#define LH_CHUNK_X(c, e) ((e) < 4 ? (c).lo[4 * (e)] : (c).hi[4 * ((e)-4)])
-#define LH_CHUNK_Y(c, e) ((e) < 4 ? (c).lo[4 * (e) + 1] : (c).hi[4 * ((e)-4) + 1])
-#define LH_CHUNK_Z(c, e) ((e) < 4 ? (c).lo[4 * (e) + 2] : (c).hi[4 * ((e)-4) + 2])
-// a load through the CONSTANT address space: with a wave-uniform address it is an s_load (the data are in SGPRs, every lane's vector
-// instruction takes them as a scalar operand: no LDS staging, no broadcast).  The tree and the sorted points were written by earlier
-// launches and are read-only here.
+__device__ __forceinline__ void chunk_keys(const ChunkSoa& c, int cnt, f32x2 qx2, f32x2 qy2, f32x2 qz2, uint32_t* B) {
+#pragma unroll
+  for (int e = 0; e < 8; e += 2) {
+    const f32x2 x = {c.x[e], c.x[e + 1]}, y = {c.y[e], c.y[e + 1]}, z = {c.z[e], c.z[e + 1]};
+    const f32x2 dx = qx2 - x, dy = qy2 - y, dz = qz2 - z;
+    const f32x2 dd = (dx * dx + dy * dy) + dz * dz;
+    B[e] = __float_as_uint(dd.x);
+    B[e + 1] = __float_as_uint(dd.y);
+  }
+  if (cnt < 8) {   // a short chunk: the entries past its count are the NEXT leaf's points -- their keys become +INF (one v_max with a scalar mask each)
+#pragma unroll
+    for (int e = 1; e < 8; e++) B[e] = max(B[e], e < cnt ? 0u : KNN_KEY_INF);
+  }
+}
+// the launch's first step: the sorted points' coordinates as three arrays (pads included: +INF)
+__global__ void __launch_bounds__(256) k_knn_soa(const KnnCloudDesc* __restrict__ descs, int n_clouds, int bpc) {
+  int cl, blk;
+  if (!xcd_job_map(n_clouds, bpc, cl, blk)) return;
+  const KnnCloudDesc d = descs[cl];
+  const int i = blk * 256 + threadIdx.x;
+  if (i >= d.n + LEAF_CAP) return;
+  const float4 p = d.pts[i];
+  d.sx[i] = p.x; d.sy[i] = p.y; d.sz[i] = p.z;
+}
+// a load through the CONSTANT address space: with a wave-uniform address it is an s_load (the data arrive in SGPRs and every lane's
+// vector instruction takes them as a scalar operand: no LDS staging, no broadcast).  The tree and the sorted points were written by
+// earlier launches and are read-only here.
 template <class V>
 __device__ __forceinline__ V sload(const void* p) {
   return *reinterpret_cast<const V __attribute__((address_space(4)))*>(reinterpret_cast<uintptr_t>(p));
 }
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// wave-wide votes straight from a comparison (HIP's __any / __ballot take an int: the compiler then materialises 0 / 1 and compares again)
+__device__ __forceinline__ bool any_lane(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+__device__ __forceinline__ int count_lanes(bool p) { return __builtin_popcountll(__builtin_amdgcn_ballot_w64(p)); }
 
 // what a finished query does with its neighbours: entries 0 .. cnt-1 in ascending (d2, index) order, id_at(j) / d2_at(j) with a
 // compile-time j (the block search keeps them in registers, the redo kernel in LDS)
@@ -331,22 +359,37 @@ __device__ __forceinline__ void knn_consume(const KnnCloudDesc& d, int qid, floa
   }
 }
 
+// A 64-entry table of wave-uniform words kept in ONE vector register: entry i lives in lane i (v_writelane / v_readlane).  The walk's
+// stack (four such registers: child reference + its packed box) and the list of remembered chunks live here -- no LDS, no exec-mask
+// juggling for a one-lane store, and a popped entry arrives in SCALAR registers, where the per-lane box test wants it.
+// (v_writelane through inline assembly: this compiler has no builtin for it.  gfx9 allows a vector instruction ONE scalar-register
+// operand, so the lane select goes through M0, as the compiler's own lowering of the intrinsic does.)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"   // (M0 on the clobber list: nothing else in this kernel uses it)
+__device__ __forceinline__ uint32_t lane_put(uint32_t tab, uint32_t v, int i) {
+  const uint32_t sv = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);   // (wave-uniform by construction; this pins them to scalar registers)
+  const int si = __builtin_amdgcn_readfirstlane(i);
+  asm("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(tab) : "s"(sv), "s"(si) : "m0");
+  return tab;
+}
+#pragma clang diagnostic pop
+__device__ __forceinline__ uint32_t lane_get(uint32_t tab, int i) { return (uint32_t)__builtin_amdgcn_readlane((int)tab, i); }
+
 template <int K, int MODE>
-__global__ void __launch_bounds__(KNN_BLOCK_Q) k_knn_block(const KnnCloudDesc* __restrict__ descs, int n_clouds, int bpc, int k, double eps,
-                                                           uint32_t* __restrict__ redo_cnt, uint2* __restrict__ redo) {
+__device__ __forceinline__ void knn_block_body(const KnnCloudDesc* __restrict__ descs, int n_clouds, int bpc, int k, double eps,
+                                               uint32_t* __restrict__ redo_cnt, uint2* __restrict__ redo) {
   int cl, blk;
   if (!xcd_job_map(n_clouds, bpc, cl, blk)) return;
   const KnnCloudDesc d = descs[cl];
   const int b0 = blk * KNN_BLOCK_Q;
   if (b0 >= d.n) return;
-  __shared__ uint4 stack[KNN_STACK_CAP];
-  __shared__ uint32_t acc[KNN_ACC_CAP];
-  __shared__ uint32_t table[K * KNN_BLOCK_Q];
+  __shared__ uint32_t table[(K + 1) * KNN_BLOCK_Q];   // rows 0 .. K-1: a lane's candidates within its k-th distance; row K: where the others go
   const int lane = threadIdx.x;
   const int n = d.n;
   const int my_pos = min(b0 + lane, n - 1);   // (the lanes past the cloud's end repeat its last point: they want nothing the others do not)
   const float4 qp = gload16<float4>(d.pts + my_pos);
   const float qx = qp.x, qy = qp.y, qz = qp.z;
+  const f32x2 qx2 = {qx, qx}, qy2 = {qy, qy}, qz2 = {qz, qz};
   TreeHeader h;
   h.root = gld(&d.hdr->root);
   h.org[0] = gld(&d.hdr->org[0]); h.org[1] = gld(&d.hdr->org[1]); h.org[2] = gld(&d.hdr->org[2]);
@@ -357,9 +400,11 @@ __global__ void __launch_bounds__(KNN_BLOCK_Q) k_knn_block(const KnnCloudDesc* _
   knn_list_init<K>(L, k);
   uint32_t tau = L[K - 1];   // the lane's bound: its k-th smallest key so far (lh_knn_block.hpp: phantom keys make that L[K - 1] for every k <= K)
   const int w0 = max(0, b0 - KNN_WIN_SIDE), w1 = min(n, b0 + KNN_BLOCK_Q + KNN_WIN_SIDE);
-  int n_acc = 0, sp = 0, fail = 0, wi = 0;   // wave-uniform
+  uint32_t st_ref = 0, st_lo = 0, st_hi = 0, st_z = 0;   // the walk's stack (lane tables)
+  uint32_t acc0 = 0, acc1 = 0, acc2 = 0;                  // the remembered chunks (3 x 64)
+  int n_acc = 0, sp = 0, fail = 0, wi = 0;               // wave-uniform
   if (h.root >= 0) {   // the root's entry: a box at distance zero from everything
-    if (lane == 0) stack[0] = make_uint4((uint32_t)h.root, 0u, 0xffffffffu, 0u);
+    st_ref = lane_put(st_ref, (uint32_t)h.root, 0); st_lo = lane_put(st_lo, 0u, 0); st_hi = lane_put(st_hi, 0xffffffffu, 0); st_z = lane_put(st_z, 0u, 0);
     sp = 1;
   }
   // ---- pass 1: the window's chunks (the block's own first, then outwards), then the wave's walk; ONE place where a chunk is merged ----
@@ -377,61 +422,63 @@ __global__ void __launch_bounds__(KNN_BLOCK_Q) k_knn_block(const KnnCloudDesc* _
     } else {
       bool have = false;
       while (sp > 0 && !fail) {
-        --sp;
-        const uint4 e = stack[sp];
-        const int32_t ref = uni((int)e.x);
-        const float bd = boxd2_q(gq, e.y, e.z, e.w, scl2);
-        if (!__any(__float_as_uint(bd) <= tau)) continue;   // the bounds have tightened since the entry was pushed
+        sp = uni(sp - 1);
+        const int32_t ref = (int32_t)lane_get(st_ref, sp);
+        const uint32_t e_lo = lane_get(st_lo, sp), e_hi = lane_get(st_hi, sp), e_z = lane_get(st_z, sp);
+        const float bd = boxd2_q(gq, e_lo, e_hi, e_z, scl2);
+        if (!any_lane(__float_as_uint(bd) <= tau)) continue;   // the bounds have tightened since the entry was pushed
         if (ref < 0) {
           const uint32_t u = (uint32_t)~ref;
           if (knn_clip_chunk((int)(u >> 4), (int)(u & 15u) + 1, w0, w1, first, cnt)) { have = true; break; }
           continue;
         }
-        // an internal node: a child is stacked if ANY lane's ball reaches its box; the most wanted child goes on top
+        // an internal node: a child is stacked if ANY lane's ball reaches its box; the child most lanes want goes on top
         const u32x16 nd = sload<u32x16>(d.nodes + ref);
-        uint32_t key[4];
+        uint32_t want[4];
 #pragma unroll
         for (int c = 0; c < 4; c++) {
           const float bc = boxd2_q(gq, nd[c], nd[4 + c], nd[8 + c], scl2);
           const bool w = (int32_t)nd[12 + c] != NO_CHILD && __float_as_uint(bc) <= tau;
-          key[c] = ((uint32_t)__popcll(__ballot(w)) << 2) | (uint32_t)c;
+          want[c] = (uint32_t)count_lanes(w);
         }
-        uint32_t x, y;
-        x = min(key[0], key[1]); y = max(key[0], key[1]); key[0] = x; key[1] = y;
-        x = min(key[2], key[3]); y = max(key[2], key[3]); key[2] = x; key[3] = y;
-        x = min(key[0], key[2]); y = max(key[0], key[2]); key[0] = x; key[2] = y;
-        x = min(key[1], key[3]); y = max(key[1], key[3]); key[1] = x; key[3] = y;
-        x = min(key[1], key[2]); y = max(key[1], key[2]); key[1] = x; key[2] = y;
+        int top = 0;
+        uint32_t best = want[0];
 #pragma unroll
-        for (int o = 0; o < 4; o++) {
-          if (key[o] < 4u) continue;   // wanted by no lane (or no such child)
-          const int c = (int)(key[o] & 3u);
-          if (sp >= KNN_STACK_CAP) { fail |= KNN_FAIL_STACK; break; }
-          if (lane == 0) stack[sp] = make_uint4(nd[12 + c], nd[c], nd[4 + c], nd[8 + c]);
+        for (int c = 1; c < 4; c++)
+          if (want[c] > best) { best = want[c]; top = c; }
+        if (sp + 4 > KNN_BLOCK_Q) { fail |= KNN_FAIL_STACK; break; }
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+          if (want[c] != 0u && c != top) {
+            st_ref = lane_put(st_ref, nd[12 + c], sp); st_lo = lane_put(st_lo, nd[c], sp); st_hi = lane_put(st_hi, nd[4 + c], sp); st_z = lane_put(st_z, nd[8 + c], sp);
+            sp++;
+          }
+        if (best != 0u) {
+          const uint32_t t_ref = top == 0 ? nd[12] : (top == 1 ? nd[13] : (top == 2 ? nd[14] : nd[15]));
+          const uint32_t t_lo = top == 0 ? nd[0] : (top == 1 ? nd[1] : (top == 2 ? nd[2] : nd[3]));
+          const uint32_t t_hi = top == 0 ? nd[4] : (top == 1 ? nd[5] : (top == 2 ? nd[6] : nd[7]));
+          const uint32_t t_z = top == 0 ? nd[8] : (top == 1 ? nd[9] : (top == 2 ? nd[10] : nd[11]));
+          st_ref = lane_put(st_ref, t_ref, sp); st_lo = lane_put(st_lo, t_lo, sp); st_hi = lane_put(st_hi, t_hi, sp); st_z = lane_put(st_z, t_z, sp);
           sp++;
         }
       }
       if (!have) break;
     }
     // merge the chunk [first, first + cnt): 8 keys per lane from a uniform (scalar) read of the sorted points
+    first = uni(first);
+    cnt = uni(cnt);
     uint32_t B[8];
-    {
-      const Chunk8 c = load_chunk(d.pts + first);
-#pragma unroll
-      for (int e = 0; e < 8; e++) {
-        const float x = e < cnt ? LH_CHUNK_X(c, e) : INFINITY;
-        B[e] = __float_as_uint(d2f(qx, qy, qz, x, LH_CHUNK_Y(c, e), LH_CHUNK_Z(c, e)));
-      }
-    }
+    chunk_keys(load_chunk(d.sx, d.sy, d.sz, first), cnt, qx2, qy2, qz2, B);
     const uint32_t m = knn_min8(B);
-    if (__any(m <= tau)) {   // pass 2 must see this chunk again
-      if (n_acc < KNN_ACC_CAP) {
-        if (lane == 0) acc[n_acc] = knn_chunk_ref((uint32_t)first, cnt);
-        n_acc++;
-      } else
-        fail |= KNN_FAIL_CHUNKS;
+    if (any_lane(m <= tau)) {   // pass 2 must see this chunk again
+      const uint32_t r = knn_chunk_ref((uint32_t)first, cnt);
+      if (n_acc < 64) acc0 = lane_put(acc0, r, n_acc);
+      else if (n_acc < 128) acc1 = lane_put(acc1, r, n_acc - 64);
+      else if (n_acc < KNN_ACC_CAP) acc2 = lane_put(acc2, r, n_acc - 128);
+      else fail |= KNN_FAIL_CHUNKS;
+      n_acc = uni(min(n_acc + 1, KNN_ACC_CAP));
     }
-    if (__any(m < tau)) {
+    if (any_lane(m < tau)) {
       knn_sort8(B);
       KnnNet<K>::merge(L, B);
       tau = L[K - 1];
@@ -443,22 +490,45 @@ __global__ void __launch_bounds__(KNN_BLOCK_Q) k_knn_block(const KnnCloudDesc* _
   const uint32_t tau_fin = min(tau, 0x7f7fffffu);   // (never a masked entry; with fewer than k points in the cloud: every real one)
   int cnt = 0;
   for (int a = 0; a < n_acc; a++) {
-    const uint32_t r = (uint32_t)uni((int)acc[a]);
+    const uint32_t r = a < 64 ? lane_get(acc0, a) : (a < 128 ? lane_get(acc1, a - 64) : lane_get(acc2, a - 128));
     const int first = (int)(r >> 4), c8 = (int)(r & 15u) + 1;
-    const Chunk8 c = load_chunk(d.pts + first);
+    uint32_t B[8];
+    chunk_keys(load_chunk(d.sx, d.sy, d.sz, first), c8, qx2, qy2, qz2, B);
 #pragma unroll
     for (int e = 0; e < 8; e++) {
-      const float x = e < c8 ? LH_CHUNK_X(c, e) : INFINITY;
-      const uint32_t key = __float_as_uint(d2f(qx, qy, qz, x, LH_CHUNK_Y(c, e), LH_CHUNK_Z(c, e)));
-      if (key <= tau_fin) {
-        table[min(cnt, K - 1) * KNN_BLOCK_Q + lane] = (uint32_t)(first + e);
-        cnt++;
+      const bool in = B[e] <= tau_fin;
+      table[(in ? min(cnt, K) : K) * KNN_BLOCK_Q + lane] = (uint32_t)(first + e);   // (row K: not a neighbour, or one too many)
+      cnt += in ? 1 : 0;
+    }
+  }
+  const bool ties = !lane_fail && (cnt > min(k, K) || (n >= k && cnt != k));   // more than k candidates within the k-th distance
+  const bool live = b0 + lane < n;
+  const int qid = (int)__float_as_uint(qp.w);
+  uint64_t keys[K];
+  if (any_lane(ties)) {
+    // Ties at the k-th distance (two points at bit-identical float distances: about one query per 100 k-point lidar scan; everywhere in
+    // lattices and clouds with repeated points): the wave settles them itself -- the lanes concerned run a (d2, index) insertion list
+    // over the remembered chunks, which hold every candidate within their k-th distance.  The other lanes idle through it.
+    KnnRegCollector<K> col;
+    col.init(k);
+    for (int a = 0; a < n_acc; a++) {
+      const uint32_t r = a < 64 ? lane_get(acc0, a) : (a < 128 ? lane_get(acc1, a - 64) : lane_get(acc2, a - 128));
+      const int first = (int)(r >> 4), c8 = (int)(r & 15u) + 1;
+#pragma unroll 1
+      for (int e = 0; e < c8; e++) {
+        const f32x4 c = sload<f32x4>(d.pts + first + e);
+        col.offer(ties ? d2f(qx, qy, qz, c.x, c.y, c.z) : INFINITY, ties ? (int)__float_as_uint(c.w) : 0x7fffffff);
+      }
+    }
+    if (ties) {
+      cnt = 0;
+#pragma unroll
+      for (int j = 0; j < K; j++) {
+        keys[j] = col.id[j] != 0x7fffffff ? ((uint64_t)__float_as_uint(col.d[j]) << 32) | (uint64_t)(uint32_t)col.id[j] : ~0ull;
+        cnt += col.id[j] != 0x7fffffff ? 1 : 0;
       }
     }
   }
-  if (cnt > min(k, K) || (n >= k && cnt != k)) lane_fail |= KNN_FAIL_TIES;   // ties at the k-th distance (or anything unexpected): the other search decides
-  const bool live = b0 + lane < n;
-  const int qid = (int)__float_as_uint(qp.w);
   if (lane_fail) {
     if (live) {
       const uint32_t slot = atomicAdd(redo_cnt, 1u);
@@ -468,18 +538,33 @@ __global__ void __launch_bounds__(KNN_BLOCK_Q) k_knn_block(const KnnCloudDesc* _
   }
   if (!live) return;
   // ---- the k (d2, index) pairs in ascending order: what nearestKSearch returns ----
-  uint64_t keys[K];
+  if (!ties) {
 #pragma unroll
-  for (int j = 0; j < K; j++) {
-    const bool ok = j < cnt;
-    const uint32_t pos = ok ? table[j * KNN_BLOCK_Q + lane] : (uint32_t)my_pos;
-    const float4 p = gload16<float4>(d.pts + pos);
-    keys[j] = ok ? ((uint64_t)__float_as_uint(d2f(qx, qy, qz, p.x, p.y, p.z)) << 32) | (uint64_t)__float_as_uint(p.w) : ~0ull;
+    for (int j = 0; j < K; j++) {
+      const bool ok = j < cnt;
+      const uint32_t pos = ok ? table[j * KNN_BLOCK_Q + lane] : (uint32_t)my_pos;
+      const float4 p = gload16<float4>(d.pts + pos);
+      keys[j] = ok ? ((uint64_t)__float_as_uint(d2f(qx, qy, qz, p.x, p.y, p.z)) << 32) | (uint64_t)__float_as_uint(p.w) : ~0ull;
+    }
+    KnnNet<K>::sort_pairs(keys);
   }
-  KnnNet<K>::sort_pairs(keys);
   knn_consume<MODE, K>(d, qid, qx, qy, qz, cnt, k, eps, [&](int j) { return (uint32_t)keys[j]; },
                        [&](int j) { return __uint_as_float((uint32_t)(keys[j] >> 32)); });
 }
+
+// The kernels: one per list size, because the waves per SIMD the register allocation aims at differ (the rarely taken tie path's insertion
+// list is what gets squeezed).  Measured, 32 x 100 k points: 20 keys -- 4 waves 53.8 us per cloud, 5 waves 50.3, 6 waves 48.4; 32 keys --
+// 112 / 81 / 112 (six waves spill there).
+#define LH_KNN_BLOCK_KERNEL(NAME, KK, WAVES)                                                                                                  \
+  template <int MODE>                                                                                                                         \
+  __global__ void __launch_bounds__(KNN_BLOCK_Q) __attribute__((amdgpu_waves_per_eu(WAVES, 8)))                                               \
+  NAME(const KnnCloudDesc* __restrict__ descs, int n_clouds, int bpc, int k, double eps, uint32_t* __restrict__ redo_cnt, uint2* __restrict__ redo) { \
+    knn_block_body<KK, MODE>(descs, n_clouds, bpc, k, eps, redo_cnt, redo);                                                                  \
+  }
+LH_KNN_BLOCK_KERNEL(k_knn_block8, 8, 6)
+LH_KNN_BLOCK_KERNEL(k_knn_block20, 20, 6)
+LH_KNN_BLOCK_KERNEL(k_knn_block32, 32, 5)
+#undef LH_KNN_BLOCK_KERNEL
 
 // the redo list's engine: one query per lane, the register-list search of k_knn_*, the same consumer
 template <int K, int MODE>
@@ -503,7 +588,10 @@ __global__ void __launch_bounds__(KNN_BLOCK) k_knn_redo(const KnnCloudDesc* __re
 
 template <int K, int MODE>
 static void launch_knn_block_t(const KnnCloudDesc* descs, int n_clouds, int bpc, int k, double eps, uint32_t* redo_cnt, uint2* redo, hipStream_t s) {
-  hipLaunchKernelGGL((k_knn_block<K, MODE>), dim3(xcd_grid(n_clouds, bpc)), dim3(KNN_BLOCK_Q), 0, s, descs, n_clouds, bpc, k, eps, redo_cnt, redo);
+  const dim3 grid(xcd_grid(n_clouds, bpc)), wg(KNN_BLOCK_Q);
+  if constexpr (K == 8) hipLaunchKernelGGL(k_knn_block8<MODE>, grid, wg, 0, s, descs, n_clouds, bpc, k, eps, redo_cnt, redo);
+  else if constexpr (K == 20) hipLaunchKernelGGL(k_knn_block20<MODE>, grid, wg, 0, s, descs, n_clouds, bpc, k, eps, redo_cnt, redo);
+  else hipLaunchKernelGGL(k_knn_block32<MODE>, grid, wg, 0, s, descs, n_clouds, bpc, k, eps, redo_cnt, redo);
   const size_t sh = (size_t)K * KNN_BLOCK * 8 + stack_lds_bytes(0, KNN_BLOCK);
   hipLaunchKernelGGL((k_knn_redo<K, MODE>), dim3(128), dim3(KNN_BLOCK), sh, s, descs, redo_cnt, redo, k, eps);
 }
@@ -517,6 +605,10 @@ void launch_knn_block(const KnnCloudDesc* descs_dev, int n_clouds, int max_n, in
                       hipStream_t s) {
   const int bpc = (max_n + KNN_BLOCK_Q - 1) / KNN_BLOCK_Q;
   (void)hipMemsetAsync(redo_cnt, 0, sizeof(uint32_t), s);
+  {
+    const int bps = (max_n + LEAF_CAP + 255) / 256;
+    hipLaunchKernelGGL(k_knn_soa, dim3(xcd_grid(n_clouds, bps)), dim3(256), 0, s, descs_dev, n_clouds, bps);
+  }
   if (mode == KNN_MODE_NORMALS) launch_knn_block_m<KNN_MODE_NORMALS>(descs_dev, n_clouds, bpc, k, eps, redo_cnt, redo, s);
   else if (mode == KNN_MODE_COV) launch_knn_block_m<KNN_MODE_COV>(descs_dev, n_clouds, bpc, k, eps, redo_cnt, redo, s);
   else launch_knn_block_m<KNN_MODE_RAW>(descs_dev, n_clouds, bpc, k, eps, redo_cnt, redo, s);

@@ -10,15 +10,18 @@
 //     no (distance, index) pairs, no insertion chains, no divergence.
 //   * pass 1: the block's own stretch of the sorted array (the window: the 64 points and 32 on either side) gives every lane a first
 //     bound; then the wave walks the cloud's tree ONCE for all its lanes (a uniform stack of (child, box) entries): a child is visited if
-//     ANY lane's ball (its current k-th distance) reaches the child's box, leaves are clipped against the window (no point is offered
-//     twice) and merged.  Every chunk in which some lane found a key <= its bound is remembered (<= 192 chunks).
+//     ANY lane's ball (its current k-th distance) reaches the child's box (the child most lanes want is visited first), leaves are
+//     clipped against the window (no point is offered twice) and merged.  Every chunk in which some lane found a key <= its bound is
+//     remembered (<= 192 chunks).  The stack and the chunk list are wave-uniform: they live in the lanes of a few vector registers.
 //   * pass 2: with tau = the lane's exact k-th smallest distance, the remembered chunks are read once more and every candidate with
 //     d <= tau leaves its sorted position in the lane's column of an LDS table -- exactly k entries unless the cloud holds ties at tau.
 //   * the k (d, original index) pairs are then formed from the table, sorted as 64-bit keys (ascending distance, lowest index first:
 //     the order nearestKSearch returns and the moments are accumulated in) and handed to the consumer (normal / covariance / raw list).
-// A lane that cannot be finished this way -- more than K candidates at d <= tau (ties), a full chunk table or stack, an infinite bound
-// with k points available -- is put on a redo list and served by the one-query-per-lane search (tree_search + KnnRegCollector), so
-// every result is the exact (d2, index)-lexicographic k-NN set whatever the data look like.
+// Ties at the k-th distance (more than k candidates within tau: about one query per 100 k-point lidar scan, everywhere in lattices) are
+// settled by the wave itself: the lanes concerned run a (d2, index) insertion list over the remembered chunks.  A block that cannot be
+// finished at all -- a full chunk list or stack, an infinite bound with k points available -- goes to a redo list served by the
+// one-query-per-lane search (tree_search + KnnRegCollector).  Every result is the exact (d2, index)-lexicographic k-NN set whatever
+// the data look like.
 // Exactness of the pruning is the tree's usual argument: boxd2_q is a lower bound of the float distance of every point in the box, a
 // lane's bound only ever shrinks, and a subtree is dropped only when its bound EXCEEDS every lane's current k-th distance.
 #pragma once
@@ -30,7 +33,7 @@ namespace lh {
 constexpr int KNN_BLOCK_Q = 64;      // queries per wave
 constexpr int KNN_WIN_SIDE = 32;     // sorted positions on either side of the block that belong to the window
 constexpr int KNN_ACC_CAP = 192;     // remembered chunks per block
-constexpr int KNN_STACK_CAP = 128;   // uniform traversal stack entries (structural bound of a root walk: 3 per 4-ary level + 1 < 100)
+constexpr int KNN_STACK_CAP = 64;    // the walk's stack: one lane of four vector registers per entry (observed depth <= 27 on lidar scans; a deeper walk goes to the redo list)
 constexpr uint32_t KNN_KEY_INF = 0x7f800000u;
 
 // reasons a lane goes to the redo list (instrumentation only)

@@ -176,6 +176,7 @@ struct lh_ctx {
   uint32_t* knn_redo_cnt = nullptr;
   uint2* knn_redo = nullptr;
   long knn_redo_cap = 0;                    // points the redo list has room for
+  float* knn_soa = nullptr;                 // the batch's sorted coordinates as separate x / y / z arrays (3 x (points + LEAF_CAP per cloud))
   // pair slots
   PairDesc* descs_dev = nullptr;   // [n_slots]
   PairDesc* descs_host = nullptr;  // pinned staging

@@ -77,16 +77,14 @@ static void run_block(const HostTree& t, const std::vector<float4>& pts, int b0,
   auto visit_node = [&](int32_t ref) {
     st.nodes++;
     const NodeX& nd = t.nodes[ref];
-    int w[4], ord[4] = {0, 1, 2, 3};
+    int w[4], top = 0;
     for (int c = 0; c < 4; c++) w[c] = nd.child[c] == NO_CHILD ? 0 : wanted(nd.lo_xy[c], nd.hi_xy[c], nd.z_lohi[c]);
-    if (!getenv("KNN_MODEL_NOORDER")) std::stable_sort(ord, ord + 4, [&](int a, int b) { return w[a] < w[b]; });   // least wanted first: most wanted on top
-    else std::reverse(ord, ord + 4);                                                                                 // (A/B: plain child order, child 0 on top)
-    for (int o = 0; o < 4; o++) {
-      int c = ord[o];
-      if (!w[c]) continue;
-      if (sp >= KNN_STACK_CAP) { fail |= KNN_FAIL_STACK; continue; }
-      stack[sp++] = Ent{nd.child[c], nd.lo_xy[c], nd.hi_xy[c], nd.z_lohi[c]};
-    }
+    for (int c = 1; c < 4; c++)
+      if (w[c] > w[top]) top = c;
+    if (sp + 4 > KNN_STACK_CAP) { fail |= KNN_FAIL_STACK; return; }
+    for (int c = 0; c < 4; c++)   // the child most lanes want goes on top, the others in child order
+      if (w[c] && c != top) stack[sp++] = Ent{nd.child[c], nd.lo_xy[c], nd.hi_xy[c], nd.z_lohi[c]};
+    if (w[top]) stack[sp++] = Ent{nd.child[top], nd.lo_xy[top], nd.hi_xy[top], nd.z_lohi[top]};
     st.max_sp = std::max<long>(st.max_sp, sp);
   };
   auto visit_leaf = [&](int32_t ref) {
@@ -131,10 +129,27 @@ static void run_block(const HostTree& t, const std::vector<float4>& pts, int b0,
       if (cnt > std::min(k, K) || (n >= k && cnt != k)) lane_fail |= KNN_FAIL_TIES;
     }
     const int qid = (int)f2u(t.sorted[ln[l].pos].w);
+    if (lane_fail == KNN_FAIL_TIES) {   // the wave settles ties itself: a (d2, index) insertion list over the remembered chunks
+      st.fail_ties++;
+      KnnRegCollector<K> col;
+      col.init(std::min(k, K));
+      for (int a = 0; a < n_acc; a++) {
+        int first = (int)(acc[a] >> 4), c = (int)(acc[a] & 15u) + 1;
+        for (int e = 0; e < c; e++) {
+          float4 p = t.sorted[first + e];
+          col.offer(d2f(ln[l].qx, ln[l].qy, ln[l].qz, p.x, p.y, p.z), (int)f2u(p.w));
+        }
+      }
+      for (int j = 0; j < k; j++) {
+        bool ok = j < K && col.id[j] != 0x7fffffff;
+        out_idx[(size_t)qid * k + j] = ok ? col.id[j] : -1;
+        out_d2[(size_t)qid * k + j] = ok ? col.d[j] : INFINITY;
+      }
+      continue;
+    }
     if (lane_fail) {
       st.redo++;
       redo[qid] = 1;
-      if (lane_fail & KNN_FAIL_TIES) st.fail_ties++;
       if (lane_fail & KNN_FAIL_CHUNKS) st.fail_chunks++;
       if (lane_fail & KNN_FAIL_STACK) st.fail_stack++;
       if (lane_fail & KNN_FAIL_INF) st.fail_inf++;
@@ -196,9 +211,9 @@ static long run_cloud(const std::vector<float4>& pts, int k, int win_side, bool 
   }
   double B = (double)std::max<long>(1, st.blocks);
   printf("%s n=%d k=%d K=%d win=%d: %s  blocks=%ld  per block: window chunks %.1f (merged %.1f)  nodes %.1f  pops %.1f (pruned %.1f)  leaf chunks %.1f (merged %.1f)  "
-         "remembered %.1f (max %ld)  max stack %ld | redo %ld of %ld (ties %ld chunks %ld stack %ld inf %ld)\n",
+         "remembered %.1f (max %ld)  max stack %ld | ties settled in the wave %ld, redo %ld of %ld (chunks %ld stack %ld inf %ld)\n",
          tag, n, k, K, win_side, st.bad ? "FAIL" : "ok", st.blocks, st.win_chunks / B, st.win_merged / B, st.nodes / B, st.pops / B, st.pop_pruned / B,
-         st.leaves_proc / B, st.leaves_merged / B, st.acc / B, st.max_acc, st.max_sp, st.redo, st.queries, st.fail_ties, st.fail_chunks, st.fail_stack, st.fail_inf);
+         st.leaves_proc / B, st.leaves_merged / B, st.acc / B, st.max_acc, st.max_sp, st.fail_ties, st.redo, st.queries, st.fail_chunks, st.fail_stack, st.fail_inf);
   // what a wave executes, in vector instructions (model: chunk = 64 distance + 12 bound/min ops; merge = 38 + merge network; node = 4 x 11 + 8; pop test 12;
   // pass-2 chunk = 64 + 8 x 5)
   const double merge_ops = K == 20 ? 96 : (K == 8 ? 32 : 152);

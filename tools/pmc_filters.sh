@@ -5,13 +5,14 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/pmc_filters
 mkdir -p $O
-rm -rf /tmp/pf_*
+rm -rf /tmp/pf_* $O/pass*.csv
 timeout 280 rocprofv3 --kernel-trace --stats -d /tmp/pf_stats -o run --output-format csv -- python $R/tools/probe_k3_k1.py > /tmp/pf_stats.log 2>&1
 cp $(find /tmp/pf_stats -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv
 i=0
+PASSES=${PMC_PASSES:-4}
 for set in "SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES SQ_WAVE_CYCLES" "SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_ANY" \
            "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_HIT_sum TCC_MISS_sum"; do
-  i=$((i+1))
+  i=$((i+1)); [ $i -gt $PASSES ] && break
   timeout 280 rocprofv3 --kernel-trace --pmc $set -d /tmp/pf_$i -o run --output-format csv -- python $R/tools/probe_k3_k1.py > /tmp/pf_$i.log 2>&1
   cp $(find /tmp/pf_$i -name "*counter_collection.csv" | head -1) $O/pass$i.csv
 done
@@ -38,6 +39,7 @@ for kn in sorted(a):
                   e["SQ_INSTS_LDS"] / waves, e["SQ_INSTS_VMEM_RD"] / waves, e["SQ_INSTS_VMEM_WR"] / waves, 100.0 * d["SQ_ACTIVE_INST_VALU"] * 4 / max(d["SQ_BUSY_CYCLES"], 1.0)))
 open(O + "/counters.txt", "w").write("\n".join(txt) + "\n")
 print("\n".join(txt))
+if not os.path.exists(O + "/pass4.csv"): raise SystemExit
 rd, wr = load(O + "/pass3.csv"), load(O + "/pass4.csv")
 def rbytes(d):
     other = d["TCC_EA0_RDREQ_sum"] - d["TCC_EA0_RDREQ_32B_sum"] - d["TCC_EA0_RDREQ_64B_sum"] - d["TCC_EA0_RDREQ_128B_sum"]
