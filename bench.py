@@ -96,14 +96,12 @@ def host_pointf(cloud):
 def make_pairs(ctx, host):
     """device clouds of the pairs.  Normals are computed on the GPU with the K3 kernel (k=20), like the NormalComputation nodelet
     upstream of GICP."""
-    S, T = [], []
-    for src, tgt, _ in host:
-        cs, ct = capi.Cloud(ctx, src), capi.Cloud(ctx, tgt)
-        cs.normals_knn(20)
-        ct.normals_knn(20)
-        ct.drop_index()
-        S.append(cs)
-        T.append(ct)
+    S = [capi.Cloud(ctx, src) for src, _, _ in host]
+    T = [capi.Cloud(ctx, tgt) for _, tgt, _ in host]
+    for o in range(0, len(S), 32):
+        capi.normals_knn_batch(S[o:o + 32] + T[o:o + 32], 20)
+    for c in S + T:
+        c.drop_index()
     return S, T, host
 
 
@@ -260,12 +258,11 @@ def trajectory_leg(ctx, P, traj_host, args):
     from concurrent.futures import ThreadPoolExecutor
     from oracle import oracle as O
     n = len(traj_host)
-    clouds = []
-    for pts in traj_host:
-        c = capi.Cloud(ctx, pts)
-        c.normals_knn(20)
+    clouds = [capi.Cloud(ctx, pts) for pts in traj_host]
+    for o in range(0, n, 64):
+        capi.normals_knn_batch(clouds[o:o + 64], 20)
+    for c in clouds:
         c.drop_index()
-        clouds.append(c)
     src, tgt = clouds[1:], clouds[:-1]
     capi.align_batch(ctx, P, src, tgt, max_in_flight=args.in_flight)   # untimed pass: every cloud's index buffers exist afterwards (a streaming caller keeps them)
     for c in clouds:
@@ -317,6 +314,111 @@ def trajectory_leg(ctx, P, traj_host, args):
                              "what": "lh_gicp_align_batch_multi_views: host arrays (48 B / point) -> repack + upload of every scan once -> align -> results"}
     for c in clouds:
         c.close()
+    return res
+
+
+def stream_leg(ctx, P, traj_host, args):
+    """The whole per-scan path of a LOCUS stream, raw scans in HBM to poses: every scan passes the normal filter (NormalComputation,
+    normal_computation.cc:26-59, k = 20) before UpdateEstimate sees it.  Timed: ONE batched index build + ONE block k-NN launch per 64 scans
+    (lh_normals_knn_batch), then lh_gicp_align_stream over the queue (pair i = scan i+1 -> scan i), which keeps the indices the filter
+    built -- a scan's tree is built once and serves both uses.  The headline `value` has the normals precomputed (configs[1]); this is the
+    rate with them inside."""
+    n = len(traj_host)
+    raw = [capi.Cloud(ctx, pts) for pts in traj_host]   # xyz only: no normals, no index
+
+    def run(params):
+        for c in raw:
+            c.drop_index()            # a new scan arrives without an index
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        for o in range(0, n, 64):
+            capi.normals_knn_batch(raw[o:o + 64], 20)
+        ctx.synchronize()
+        t1 = time.perf_counter()
+        out = capi.align_stream(ctx, params, raw, max_in_flight=args.in_flight)
+        ctx.synchronize()
+        t2 = time.perf_counter()
+        return out, t1 - t0, t2 - t1
+
+    # the stopping rule LOCUS runs with (parameters.yaml:12: tf_eps 1e-3; gicp.h:119 rotation_epsilon 2e-3) next to the headline's 20 forced iterations
+    Pn = capi.default_params(max_iterations=P.max_iterations, max_inner_iterations=P.max_inner_iterations, corr_dist=P.corr_dist,
+                             transformation_epsilon=1e-3, rotation_epsilon=2e-3, cost_mode=P.cost_mode, solver=P.solver)
+    run(P)
+    _beat()
+    out, t_nrm, t_align = run(P)
+    _beat()
+    run(Pn)
+    outn, tn_nrm, tn_align = run(Pn)
+    _beat()
+    # the filter stage's kernels, HIP events around every launch (a separate pass: the events serialise the scheduler's streams)
+    for c in raw:
+        c.drop_index()
+    ctx.profile(True)
+    ctx.profile_reset()
+    for o in range(0, n, 64):
+        capi.normals_knn_batch(raw[o:o + 64], 20)
+    stats = ctx.profile_get()
+    ctx.profile(False)
+    npts = len(raw[0])
+    knn = stats.get("knn_normals", {"ms": 0.0, "launches": 1, "bytes": 0.0})
+    idx_ms = sum(v["ms"] for k, v in stats.items() if k.startswith("index_"))
+    k3_us = 1e3 * knn["ms"] / n
+    k3_bytes = (16.0 + 16.0 * 20 + 16.0) * npts   # SURVEY 8d: N (16 + 20 x 16 gather + 16 write)
+    pmc = {}
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r04_k3_k1_traffic.json")))
+    except Exception:
+        pass
+    blk = next((v for k, v in pmc.items() if "k_knn_block20" in k), None)
+    res = {"scans": n, "pairs": n - 1, "points_per_scan": npts, "all_ok": bool(all(o["status"] == 0 for o in out)),
+           "scans_per_s": round((n - 1) / (t_nrm + t_align), 1), "normals_stage_ms": round(1e3 * t_nrm, 3), "align_stage_ms": round(1e3 * t_align, 3),
+           "production_stopping": {"scans_per_s": round((n - 1) / (tn_nrm + tn_align), 1), "normals_stage_ms": round(1e3 * tn_nrm, 3),
+                                   "align_stage_ms": round(1e3 * tn_align, 3), "all_converged": bool(all(o["converged"] == 1 for o in outn)),
+                                   "iterations_mean": float(np.mean([o["iterations"] for o in outn])),
+                                   "what": "the same stream under the stopping rule LOCUS runs with (tf_eps 1e-3, rotation_epsilon 2e-3) instead of 20 forced iterations"},
+           "us_per_scan": {"index_build": round(1e3 * idx_ms / n, 2), "knn_normals_k20": round(k3_us, 2), "normals_stage_wall": round(1e6 * t_nrm / n, 2),
+                           "gicp_align_wall": round(1e6 * t_align / (n - 1), 2)},
+           "roofline_k3": {"kernel": "k_knn_soa + k_knn_block20 + k_knn_redo (lh_normals_knn_batch, 64 scans per launch)",
+                           "bound": "vector-instruction issue (the k-NN selection: 16.6 k VALU instructions per 64 queries, profiles/r04_k3_k1_counters.txt), not HBM",
+                           "algorithmic_bytes_per_scan": k3_bytes, "achieved": round(k3_bytes / (k3_us * 1e-6) / 1e9, 2) if k3_us > 0 else None,
+                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(k3_bytes / (k3_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5) if k3_us > 0 else None,
+                           "traffic_per_scan": ((blk["read_bytes_last_launch"] + blk["write_bytes_last_launch"]) / 32.0) if blk else None,
+                           "traffic_source": "carried from profiles/r04_k3_k1_traffic.json (rocprofv3 --pmc, sized TCC_EA0 requests, 32 scans per launch); not measured by this command"},
+           "what": "raw scans resident in HBM -> lh_normals_knn_batch (index build + k = 20 normals, 64 scans per launch) -> lh_gicp_align_stream (indices kept)"}
+    for c in raw:
+        c.close()
+    return res, out
+
+
+def filter_k1_leg(ctx):
+    """K1 (CustomVoxelGrid, custom_voxel_grid.cc:76-87) on BASELINE configs[4]'s input: a 1 M-point merged multi-lidar cloud, leaf 0.1 -- the
+    filter's kernels under HIP events, against SURVEY 8d's byte model N_in (32 + 16) + N_out 32."""
+    big = np.concatenate(synth.multi_lidar_parts(np.eye(4), synth.husky_extrinsics(), rings=128, azimuths=2604, seed=300))
+    c = capi.Cloud(ctx, big)
+    v = c.voxel_grid(0.1)
+    ctx.synchronize()
+    ctx.profile(True)
+    ctx.profile_reset()
+    reps = 5
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        v2 = c.voxel_grid(0.1)
+        v2.close()
+    ctx.synchronize()
+    wall = (time.perf_counter() - t0) / reps
+    st = ctx.profile_get()
+    ctx.profile(False)
+    n_in, n_out = len(big), len(v)
+    kern_ms = sum(x["ms"] for x in st.values()) / reps
+    model = n_in * 48.0 + n_out * 32.0
+    res = {"points_in": n_in, "points_out": n_out, "leaf_m": 0.1, "wall_ms": round(1e3 * wall, 3), "kernels_ms": round(kern_ms, 3),
+           "kernels_ms_by_stage": {k: round(x["ms"] / reps, 4) for k, x in sorted(st.items(), key=lambda kv: -kv[1]["ms"])},
+           "roofline_k1": {"bound": "hbm", "algorithmic_bytes": model, "achieved": round(model / (kern_ms * 1e-3) / 1e9, 2) if kern_ms > 0 else None, "peak": HBM_PEAK_GBS,
+                           "unit": "GB/s", "frac": round(model / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if kern_ms > 0 else None,
+                           "note": "about thirty short launches (bbox, keys, 8-bit-digit radix passes, head flags, scan, centroids): launch- and latency-bound at this "
+                                   "size, not bandwidth-bound; per-kernel counters in profiles/r04_k3_k1_counters.txt, traffic in profiles/r04_k3_k1_traffic.json"}}
+    v.close()
+    c.close()
     return res
 
 
@@ -710,6 +812,12 @@ def main():
         _leg("trajectory")
         if world == 1 and traj_host is not None:
             result["trajectory"] = trajectory_leg(ctx, P, traj_host, args)
+            _PARTIAL[0] = result
+            _leg("stream with normals")
+            sw, sw_out = stream_leg(ctx, P, traj_host, args)
+            result["stream_with_normals"] = sw
+            _leg("voxel filter")
+            result["filter_k1"] = filter_k1_leg(ctx)
         _leg("production operating point")
         if world == 1 and not args.no_cpu_baseline:
             result["production_operating_point"] = production_leg(ctx)

@@ -192,6 +192,13 @@ lh_status lh_gicp_align_batch(lh_ctx* ctx, const lh_gicp_params* p, int n_pairs,
    existing cloud of src[i]'s size on this context, overwritten.  aligned == NULL: lh_gicp_align_batch. */
 lh_status lh_gicp_align_batch_out(lh_ctx* ctx, const lh_gicp_params* p, int n_pairs, lh_cloud* const* src, lh_cloud* const* tgt,
                                   const float* guesses, lh_gicp_result* out, lh_cloud** aligned /* n_pairs, nullable */, int max_in_flight);
+/* The odometry stream (PointCloudOdometry.cc:237-322 over a queue of n_scans device clouds): pair i aligns scans[i + 1] (the query) to
+   scans[i] (the reference: `copyPointCloud(*query_, *reference_)` of the previous update), out[0 .. n_scans - 2].  A scan's index is built
+   ONCE -- by this call, or before it by lh_normals_knn_batch -- and kept with the cloud, where lh_gicp_align_batch rebuilds every target
+   (initCompute).  The index is a function of the cloud alone: results identical to lh_gicp_align_batch on the same pairs.
+   guesses: (n_scans - 1) x 16 or NULL. */
+lh_status lh_gicp_align_stream(lh_ctx* ctx, const lh_gicp_params* p, int n_scans, lh_cloud* const* scans, const float* guesses,
+                               lh_gicp_result* out, int max_in_flight);
 
 /* ---- several GPUs from one process (BASELINE configs 4/5) ---------------------------------------------------
    Independent scan pairs shard over GPUs with NO exchange step, so a single C++ process (the LOCUS node is one,

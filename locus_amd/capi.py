@@ -106,7 +106,7 @@ EXPORTS = [
     "lh_cloud_download", "lh_cloud_transform", "lh_cloud_slice", "lh_cloud_concat", "lh_gicp_create", "lh_gicp_destroy", "lh_gicp_set_params",
     "lh_gicp_set_source", "lh_gicp_set_target", "lh_gicp_set_source_cloud", "lh_gicp_set_target_cloud",
     "lh_gicp_promote_source_to_target", "lh_gicp_align", "lh_gicp_fitness", "lh_set_allreduce", "lh_nn1", "lh_nn1_cloud", "lh_knn_cloud",
-    "lh_gicp_align_batch", "lh_gicp_align_batch_out", "lh_device_count", "lh_gicp_align_batch_multi", "lh_gicp_align_batch_multi_views", "lh_cov_knn", "lh_gicp_debug_sweep", "lh_gicp_debug_sweep_fused", "lh_gicp_debug_stats", "lh_debug_traversal_stats", "lh_gicp_debug_cost", "lh_p2plane_information",
+    "lh_gicp_align_batch", "lh_gicp_align_batch_out", "lh_gicp_align_stream", "lh_device_count", "lh_gicp_align_batch_multi", "lh_gicp_align_batch_multi_views", "lh_cov_knn", "lh_gicp_debug_sweep", "lh_gicp_debug_sweep_fused", "lh_gicp_debug_stats", "lh_debug_traversal_stats", "lh_gicp_debug_cost", "lh_p2plane_information",
     "lh_icp_covariance", "lh_voxel_grid", "lh_cloud_voxel_grid", "lh_cloud_voxel_grid_pointf", "lh_cloud_nearest_neighbors", "lh_cloud_crop_box", "lh_default_ndt_params", "lh_ndt_create", "lh_ndt_destroy", "lh_ndt_set_params",
     "lh_ndt_set_source", "lh_ndt_set_target", "lh_ndt_set_source_cloud", "lh_ndt_set_target_cloud", "lh_ndt_align", "lh_ndt_debug_cells",
     "lh_ndt_debug_derivatives", "lh_map_create", "lh_map_destroy", "lh_map_insert", "lh_map_refresh", "lh_map_cloud", "lh_map_size", "lh_normals_knn", "lh_normals_knn_cloud", "lh_normals_knn_batch", "lh_cov_knn_batch",
@@ -162,6 +162,7 @@ def lib():
                                           C.POINTER(GicpResult), i32]
         L.lh_gicp_align_batch_out.argtypes = [vp, C.POINTER(GicpParams), i32, C.POINTER(vp), C.POINTER(vp), vp,
                                               C.POINTER(GicpResult), C.POINTER(vp), i32]
+        L.lh_gicp_align_stream.argtypes = [vp, C.POINTER(GicpParams), i32, C.POINTER(vp), vp, C.POINTER(GicpResult), i32]
         L.lh_device_count.restype = i32
         L.lh_gicp_align_batch_multi.argtypes = [i32, C.POINTER(vp), C.POINTER(GicpParams), i32, C.POINTER(vp), C.POINTER(vp), vp,
                                                 C.POINTER(GicpResult), C.POINTER(vp), i32]
@@ -765,6 +766,18 @@ def align_batch(ctx, params, src_clouds, tgt_clouds, guesses=None, max_in_flight
     if st not in (LH_OK, LH_ETOO_FEW_CORR, LH_ESOLVER, LH_ENO_NN):
         raise LocusHipError(st, "lh_gicp_align_batch")
     return [_result_dict(out[i]) for i in range(n)]
+
+
+def align_stream(ctx, params, scans, guesses=None, max_in_flight=0, raw=False):
+    """lh_gicp_align_stream: pair i = scans[i + 1] -> scans[i]; a scan's index is built once and kept (PointCloudOdometry over a queue)"""
+    n = len(scans)
+    S = (C.c_void_p * n)(*[c.h for c in scans])
+    out = (GicpResult * (n - 1))()
+    g = np.ascontiguousarray(guesses, np.float32).reshape((n - 1) * 16) if guesses is not None else None
+    st = lib().lh_gicp_align_stream(ctx.h, C.byref(params), n, S, _ptr(g), out, max_in_flight)
+    if st not in (LH_OK, LH_ETOO_FEW_CORR, LH_ESOLVER, LH_ENO_NN):
+        raise LocusHipError(st, "lh_gicp_align_stream")
+    return out if raw else [_result_dict(out[i]) for i in range(n - 1)]
 
 
 def align_batch_out(ctx, params, src_clouds, tgt_clouds, guesses=None, max_in_flight=0, aligned=None, raw=False):

@@ -499,8 +499,8 @@ static lh_status cloud_like(const lh_cloud* in, lh_cloud** out) {
   return LH_OK;
 }
 
-lh_status lh_gicp_align_batch_out(lh_ctx* ctx, const lh_gicp_params* p, int n_pairs, lh_cloud* const* src, lh_cloud* const* tgt,
-                                  const float* guesses, lh_gicp_result* out, lh_cloud** aligned, int max_in_flight) {
+static lh_status align_batch_impl(lh_ctx* ctx, const lh_gicp_params* p, int n_pairs, lh_cloud* const* src, lh_cloud* const* tgt,
+                                  const float* guesses, lh_gicp_result* out, lh_cloud** aligned, int max_in_flight, bool rebuild_index) {
   if (!ctx || !p || n_pairs < 0 || !src || !tgt || !out) return LH_EINVAL;
   if (n_pairs == 0) return LH_OK;
   HIPCHK(hipSetDevice(ctx->device));
@@ -539,7 +539,7 @@ lh_status lh_gicp_align_batch_out(lh_ctx* ctx, const lh_gicp_params* p, int n_pa
     memcpy(t.guess, guesses ? guesses + 16 * (size_t)i : I16, sizeof(I16));
     ptrs[i] = &t;
   }
-  st = run_tasks(ctx, ptrs, in_flight, /*rebuild_index=*/true, &ctx->slot_ws);
+  st = run_tasks(ctx, ptrs, in_flight, rebuild_index, &ctx->slot_ws);
   for (int i = 0; i < n_pairs; i++) out[i] = tasks[i].result;
   if (aligned) {  // the output clouds were written on the scheduler streams: complete before the caller touches them
     (void)hipStreamSynchronize(ctx->stream);
@@ -548,9 +548,24 @@ lh_status lh_gicp_align_batch_out(lh_ctx* ctx, const lh_gicp_params* p, int n_pa
   return st;
 }
 
+lh_status lh_gicp_align_batch_out(lh_ctx* ctx, const lh_gicp_params* p, int n_pairs, lh_cloud* const* src, lh_cloud* const* tgt,
+                                  const float* guesses, lh_gicp_result* out, lh_cloud** aligned, int max_in_flight) {
+  return align_batch_impl(ctx, p, n_pairs, src, tgt, guesses, out, aligned, max_in_flight, /*rebuild_index=*/true);
+}
+
 lh_status lh_gicp_align_batch(lh_ctx* ctx, const lh_gicp_params* p, int n_pairs, lh_cloud* const* src, lh_cloud* const* tgt,
                               const float* guesses, lh_gicp_result* out, int max_in_flight) {
   return lh_gicp_align_batch_out(ctx, p, n_pairs, src, tgt, guesses, out, nullptr, max_in_flight);
+}
+
+// The odometry stream (PointCloudOdometry.cc:237-322 over a queue of scans): pair i aligns scans[i + 1] (query) to scans[i] (reference,
+// `copyPointCloud(*query_, *reference_)` of the previous update).  A scan's index is built ONCE -- by this call, or before it by the
+// normal filter (lh_normals_knn_batch) -- and stays with the cloud; lh_gicp_align_batch rebuilds every target like initCompute does.
+// The index is a function of the cloud alone, so the results are those of lh_gicp_align_batch, bit for bit.
+lh_status lh_gicp_align_stream(lh_ctx* ctx, const lh_gicp_params* p, int n_scans, lh_cloud* const* scans, const float* guesses,
+                               lh_gicp_result* out, int max_in_flight) {
+  if (!scans || n_scans < 2) return LH_EINVAL;
+  return align_batch_impl(ctx, p, n_scans - 1, scans + 1, scans, guesses, out, nullptr, max_in_flight, /*rebuild_index=*/false);
 }
 
 int lh_device_count(void) {

@@ -530,9 +530,31 @@ LH_FN int estimate_rigid_bfgs(Fn* fn, int max_inner, float* T16, int* n_inner, d
   if (fn->count() < 4) return -4;  // gicp.hpp:225 (the count is known after the first fused pass)
   do {
     inner++;
+    double x_in[6], p_in[6];
+    Bfgs<Fn>::copy6(x_in, x);
+    Bfgs<Fn>::copy6(p_in, b.p);
+    const double f_in = b.f, df_in = b.delta_f;
+    const int passes_in = fn->passes;
     result = b.one_step(x);
     if (result) break;
     result = (Bfgs<Fn>::norm(b.gradient) < gradient_tol) ? BFGS_SUCCESS : BFGS_RUNNING;  // testGradient
+    // A step that ends in the state it started from -- position, direction, f and delta_f bit for bit: the line search used up its 100
+    // iterations on a cost that is flat to the last bit and left alpha = 0 (Fletcher's sectioning returns `success` then, as GSL's does) -- is
+    // a fixed point of minimizeOneStep: every further inner iteration would replay it evaluation for evaluation, to the same end, until
+    // max_inner_iterations.  (Pairs whose outer loop is forced on after they have converged do this: 20 x 101 evaluations per outer
+    // iteration, 6 ms of one wave in k_solve with the 31 other pairs of its group waiting.)  The replays are skipped; their evaluations are
+    // still counted, so `cost_passes` stays the number the algorithm specifies, and x, f, the inner count and every later decision are
+    // exactly what the replays would have left.
+    if (result == BFGS_RUNNING && inner < max_inner && b.f == f_in && b.delta_f == df_in) {
+      bool same = true;
+#pragma unroll
+      for (int i = 0; i < 6; i++) same = same && x[i] == x_in[i] && b.p[i] == p_in[i];
+      if (same) {
+        fn->passes += (max_inner - inner) * (fn->passes - passes_in);
+        inner = max_inner;
+        break;
+      }
+    }
   } while (result == BFGS_RUNNING && inner < max_inner);
   *n_inner = inner;
   *f_end = b.f;

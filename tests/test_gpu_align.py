@@ -551,3 +551,29 @@ def test_reused_output_cloud_drops_its_stale_index(ctx, capi, oracle):
     idx, d2 = A[0].nn1(q)                         # must search the NEW coordinates
     io, do = oracle.nn1_brute(oracle.xyz4(now), oracle.xyz4(pairs[0][2][:500]))
     assert (idx == io).all() and (d2 == do).all()
+
+
+def test_stream_of_raw_scans_normals_batch_then_align_stream(ctx, capi, oracle):
+    """the streaming path of bench.py's stream_with_normals: raw scans -> ONE batched index build + ONE k-NN launch (lh_normals_knn_batch)
+    -> lh_gicp_align_stream, which keeps the indices the normal filter built.  Bit-identical to the scan-at-a-time path (normals per
+    cloud, lh_gicp_align_batch rebuilding every target), and the first pair against the oracle."""
+    poses = [synth.pose_matrix(0.15 * i, 0.05 * i, 0.0, 0.0, 0.0, 0.02 * i) for i in range(6)]
+    pts = [synth.scan(p, 16, 400, (-15.0, 15.0), 1.0, 0.01, seed=40 + i) for i, p in enumerate(poses)]
+    A = [capi.Cloud(ctx, p) for p in pts]
+    B = [capi.Cloud(ctx, p) for p in pts]
+    P = capi.default_params(max_iterations=20, corr_dist=1.0, transformation_epsilon=1e-3)
+    capi.normals_knn_batch(A, 20)
+    ra = capi.align_stream(ctx, P, A, max_in_flight=8)
+    for b in B:
+        b.normals_knn(20)
+        b.drop_index()
+    rb = capi.align_batch(ctx, P, B[1:], B[:-1], max_in_flight=8)
+    for x, y in zip(ra, rb):
+        assert x["status"] == 0 and (np.asarray(x["T"]) == np.asarray(y["T"])).all() and x["iterations"] == y["iterations"]
+    d0, d1 = A[0].download(), A[1].download()
+    xyz = lambda d: oracle.xyz4(np.stack([d["x"], d["y"], d["z"]], 1))
+    nrm = lambda d: oracle.nrm4(np.stack([d["normal_x"], d["normal_y"], d["normal_z"]], 1))
+    po = oracle.default_params(max_iterations=20, corr_dist=1.0, transformation_epsilon=1e-3)
+    ro = oracle.gicp_align(xyz(d1), nrm(d1), xyz(d0), nrm(d0), po)
+    Tg, To = oracle.T_to_mat(ra[0]["T"]), oracle.T_to_mat(ro["T"])
+    assert np.abs(Tg[:3, 3] - To[:3, 3]).max() < 2e-3 and np.abs(Tg[:3, :3] - To[:3, :3]).max() < 2.5e-3   # the stopping scale (include/locus_hip.h)

@@ -6,7 +6,7 @@ os.environ["LH_HOST_PROF"] = "1"
 import bench
 from locus_amd import capi, synth
 n = int(os.environ.get("N", "129"))
-traj = bench.gen_trajectory_host(n, 64, 1563, 2.0)
+traj = bench.gen_trajectory_host(513, 64, 1563, 2.0)[:n]   # (the first n scans of the 513-scan drive: the step size depends on the total)
 pairs = bench.gen_pairs_host(n - 1, 0, 64, 1563, 2.0)
 ctx = capi.Context(0)
 P = capi.default_params(max_iterations=20, max_inner_iterations=20, corr_dist=1.0, transformation_epsilon=1e-12, rotation_epsilon=1e-12)
