@@ -1,0 +1,110 @@
+"""CPU suite: the C oracle (oracle/locus_oracle.c, the checker every GPU parity test leans on) against the SECOND, independent restatement
+of the same path -- tools/golden.py, numpy + scipy.spatial.cKDTree + scipy.optimize, written from the reference's source and sharing no
+code with the oracle.  The fixture tests/golden/second_restatement.npz holds golden.py's inputs and outputs for the
+reference's own garage scans (multithreaded_gicp/test/*.pcd with test_same_output_different_num_threads.cpp's parameters), the same pair
+with the reference scan's repeated coordinates removed, and BASELINE configs[0]'s 5 k-point pair.
+
+What agreement means here:
+  * k-NN sets, k-NN covariances, first-sweep correspondences, Mahalanobis matrices, f and g of the cost functor: the two restatements
+    implement the same formulas with different tools (own kd-tree / cKDTree, cofactor inverse / LAPACK, Jacobi / LAPACK SVD) -> equal to
+    rounding (1e-9 on matrices, 1e-12 on f and g at the identity, 1e-6 at a rotated state where the float rotation is formed differently).
+  * the outer loop: golden.py has NO pcl::BFGS -- each outer iteration goes to the minimiser of the frozen-correspondence cost.  The oracle
+    restates pcl::BFGS (GSL vector_bfgs2), which stops at gradient norm 1e-2 or when a line search makes no progress.  Per iteration the two
+    are <= 4e-4 m apart and the final poses <= 1e-4 m on configs[0] / <= 6e-4 m on the garage pair, whose reference scan repeats 1 721 of its
+    8 112 coordinates (which coincident point is "the" neighbour is FLANN's unpinned tie rule) and whose tf_eps of 1e-10 stops the
+    reference only when an iterate repeats bit for bit."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FIX = os.path.join(ROOT, "tests", "golden", "second_restatement.npz")
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(FIX)
+
+
+def _case(gold, oracle, name):
+    src, tgt = gold[name + "_src"], gold[name + "_tgt"]
+    k, eps, cd, mi, tf = gold[name + "_params"]
+    return src, tgt, oracle.xyz4(src), oracle.xyz4(tgt), int(k), float(eps), float(cd), int(mi), float(tf)
+
+
+@pytest.mark.parametrize("name", ["garage", "garage_unique", "config1"])
+def test_knn_covariances_agree(gold, oracle, name):
+    src, tgt, s4, t4, k, eps, cd, mi, tf = _case(gold, oracle, name)
+    ts = oracle.Tree(s4)
+    ki, _ = ts.knn(s4, k)
+    assert (np.sort(ki, 1) == np.sort(gold[name + "_knn_src"], 1)).all()          # the same 20 neighbours for every source point
+    cs = oracle.cov_knn(s4, k, eps, tree=ts)
+    assert np.abs(cs - gold[name + "_cov_src"]).max() < 1e-9
+    ct = oracle.cov_knn(t4, k, eps)
+    step = max(1, len(ct) // 512)
+    e = np.abs(ct[::step] - gold[name + "_cov_tgt_sample"]).max(axis=(1, 2))
+    if name == "garage":   # repeated coordinates: 20 neighbours of which >= 18 coincide have a rank-deficient covariance, its null vectors are anybody's choice
+        assert (e < 1e-9).mean() > 0.97
+    else:
+        assert e.max() < 1e-9
+
+
+@pytest.mark.parametrize("name", ["garage", "garage_unique", "config1"])
+def test_first_sweep_and_cost_functor_agree(gold, oracle, name):
+    src, tgt, s4, t4, k, eps, cd, mi, tf = _case(gold, oracle, name)
+    tt = oracle.Tree(t4)
+    cs, ct = oracle.cov_knn(s4, k, eps), oracle.cov_knn(t4, k, eps, tree=tt)
+    I16 = np.eye(4, dtype=np.float32).reshape(16)
+    idx, M = oracle.nn_mahalanobis(s4, tt, cs, ct, I16, np.eye(3).reshape(9), cd)
+    ok, nn, Mg = gold[name + "_ok"], gold[name + "_nn"], gold[name + "_maha"]
+    assert ((idx >= 0) == ok).all()                                    # the same points pass the corr_dist gate
+    assert (tgt[idx[ok]] == tgt[nn[ok]]).all()                        # ... and meet the same neighbour POSITION
+    same = ok & (idx == nn)
+    if name != "garage":
+        assert same.sum() == ok.sum()                                  # no coincident points: the same neighbour index
+    rel = np.abs(M[same] - Mg[same]).max(axis=(1, 2)) / np.abs(Mg[same]).max(axis=(1, 2))
+    if name == "garage":
+        assert (rel < 1e-9).mean() > 0.97                              # (a coincident neighbour of another index brings another degenerate covariance)
+    else:
+        assert rel.max() < 1e-9
+    # the functor on golden.py's own correspondences and matrices: only the arithmetic of gicp.hpp:362-402 is compared
+    si = np.nonzero(ok)[0].astype(np.int32)
+    for tag, x, tol in (("0", np.zeros(6), 1e-12), ("1", gold[name + "_x_probe"], 1e-6)):
+        f, g, _ = oracle.cost_fdf(s4, t4, si, nn[si], Mg, x)
+        assert abs(f - gold[name + "_f" + tag]) <= tol * abs(f), (name, tag)
+        assert np.abs(g - gold[name + "_g" + tag]).max() <= tol * np.abs(g).max(), (name, tag)
+
+
+@pytest.mark.parametrize("name,bar_iter,bar_final", [("garage", 5e-4, 6e-4), ("garage_unique", 5e-4, 6e-4), ("config1", 4e-4, 1e-4)])
+def test_outer_loop_against_the_true_minimisers(gold, oracle, name, bar_iter, bar_final):
+    src, tgt, s4, t4, k, eps, cd, mi, tf = _case(gold, oracle, name)
+    P = oracle.default_params(max_iterations=mi, corr_dist=cd, transformation_epsilon=tf, recompute_source_cov=1, recompute_target_cov=1, k_correspondences=k)
+    r = oracle.gicp_align(s4, None, t4, None, P)
+    assert r["status"] == 0
+    xs, nc = gold[name + "_iter_x"], gold[name + "_iter_ncorr"]
+    tr = r["trace"]
+    for i in range(min(len(xs), len(tr["T"]))):
+        Ti = oracle.T_to_mat(tr["T"][i])
+        assert np.abs(Ti[:3, 3] - xs[i][:3]).max() < bar_iter, (name, i)      # where pcl::BFGS stops vs the minimiser it is heading for
+        if name != "garage":
+            assert tr["n_corr"][i] == nc[i], (name, i)
+    To, Tg = oracle.T_to_mat(r["T"]), gold[name + "_T"].astype(np.float64)
+    assert np.abs(To[:3, 3] - Tg[:3, 3]).max() < bar_final and np.abs(To[:3, :3] - Tg[:3, :3]).max() < bar_final, name
+
+
+def test_fixture_is_what_golden_py_writes(tmp_path, gold):
+    """the committed fixture is the generator's output (numpy + scipy are in the image; nothing of the generator ships)"""
+    env = dict(os.environ, GOLDEN_OUT=str(tmp_path / "again.npz"))
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "golden.py")], env=env, stdout=subprocess.DEVNULL)
+    again = np.load(tmp_path / "again.npz")
+    assert sorted(again.files) == sorted(gold.files)
+    for key in gold.files:
+        a, b = gold[key], again[key]
+        assert a.shape == b.shape, key
+        if a.dtype.kind == "f":
+            assert np.allclose(a, b, rtol=1e-9, atol=1e-12, equal_nan=True), key
+        else:
+            assert (a == b).all(), key
