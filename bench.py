@@ -20,6 +20,10 @@ import time
 # be in the environment before anything (torch, the oracle) loads one
 os.environ.setdefault("OMP_PROC_BIND", "close")
 os.environ.setdefault("OMP_PLACES", "cores")
+# idle OpenMP workers spin this long before they sleep: the CPU leg's optimiser stage is thousands of short parallel regions, and waking a
+# sleeping team for each one was most of its time at high thread counts (a bounded spin, not OMP_WAIT_POLICY=active: a team that spins for
+# ever would sit on the cores the GPU legs' host threads need)
+os.environ.setdefault("GOMP_SPINCOUNT", "300000")
 
 import ctypes as C
 
@@ -122,6 +126,8 @@ _T0 = time.perf_counter()
 _BEAT = [time.perf_counter(), "start"]   # last sign of life, and the leg it came from
 _PARTIAL = [None]                        # the result line as far as it has been measured (rank 0)
 _STALL_LIMIT_S = float(os.environ.get("BENCH_STALL_LIMIT_S", "420"))
+import threading  # noqa: E402
+_PRINT_LOCK = threading.Lock()           # the result line goes out once: from the main thread, or from the watchdog that abandons a hung leg
 
 
 def _beat():
@@ -148,9 +154,11 @@ def _start_watchdog():
                 r = _PARTIAL[0]
                 if r is not None and "roofline" in r and ("cpu_baseline" in r or r.get("cpu_baseline_skipped")):
                     r["incomplete"] = "leg %r made no progress for %.0f s and was abandoned; the fields it would have added are missing" % (_BEAT[1], _STALL_LIMIT_S)
-                    print(json.dumps(r))
-                    sys.stdout.flush()
-                    os._exit(0)
+                    r["all_ok"] = False          # a leg that hangs is a failure of the run: the line still carries what was measured, the exit code says so
+                    with _PRINT_LOCK:
+                        print(json.dumps(r))
+                        sys.stdout.flush()
+                        os._exit(4)
                 os._exit(3)
 
     threading.Thread(target=watch, daemon=True).start()
@@ -217,6 +225,9 @@ def cpu_baseline(S, T, host, P):
 
     poses, rows, t_total = {}, [], 0.0
     plan = [(4, 0, 1, 10), (1, 0, 0, 3), (phys, 0, 1, 5), (phys, 1, 1, 5)]   # threads, parallel cost functor, warm-up pairs, timed pairs
+    for th in (8, 16, 32, 64):   # the sweep between the protocol's points: where is the CPU's best?
+        if th < phys:
+            plan += [(th, 0, 1, 2), (th, 1, 1, 2)]
     for threads, par, warm, timed in plan:
         times, stages = [], []
         for k in range(warm + timed):
@@ -239,10 +250,18 @@ def cpu_baseline(S, T, host, P):
                                         "nn_sweeps": round(float(st[2]), 4), "optimiser": round(float(st[3]), 4)}})
     ref_rows = [r for r in rows if r["cost_functor"].startswith("serial")]
     best = max(ref_rows, key=lambda r: r["pairs_per_s"])
-    par_row = [r for r in rows if not r["cost_functor"].startswith("serial")][0]
+    par_rows = [r for r in rows if not r["cost_functor"].startswith("serial")]
+    par_row = max(par_rows, key=lambda r: r["pairs_per_s"])
+    overall = max(rows, key=lambda r: r["pairs_per_s"])
+    four = [r for r in ref_rows if r["threads"] == 4][0]
     return {"value": best["pairs_per_s"], "unit": "scan-pairs/s", "cores": best["threads"], "kind": "port",
+            "protocol_4_threads": four["pairs_per_s"],
+            "best": {"value": overall["pairs_per_s"], "cores": overall["threads"], "cost_functor": overall["cost_functor"],
+                     "what": "the fastest of every sampled configuration (threads 1 / 4 / 8 / 16 / 32 / 64 / all physical cores, serial and OMP-reduction cost functor): "
+                             "what the '>= 50x' of the north star should be quoted against"},
             "by_threads": {str(r["threads"]): r["pairs_per_s"] for r in ref_rows},
-            "fully_parallel_variant": {"value": par_row["pairs_per_s"], "cores": par_row["threads"]},
+            "fully_parallel_variant": {"value": par_row["pairs_per_s"], "cores": par_row["threads"], "by_threads": {str(r["threads"]): r["pairs_per_s"] for r in par_rows}},
+            "gomp_spincount": os.environ.get("GOMP_SPINCOUNT"),
             "rows": rows, "physical_cores": phys, "omp_proc_bind": os.environ.get("OMP_PROC_BIND"),
             "sample": "median over %d timed pairs of the step's %d-pt pairs at %d OMP threads (1 / 4 / %d physical cores sampled: 3 / 10 / 5 "
                       "timed pairs after a warm-up pair; fully parallel variant 5 pairs; %.1f s of CPU work in all), 20 outer iterations, "
@@ -284,7 +303,7 @@ def trajectory_leg(ctx, P, traj_host, args):
            "ate_vs_ground_truth_m": ate(chain, gt), "max_single_step_translation_err_m": max(step_err),
            "final_position_err_m": float(np.linalg.norm(chain[-1, :3, 3] - gt[-1, :3, 3]))}
     # the CPU path's chain on a prefix (reference arithmetic, 4 OMP threads per pair, the pairs concurrently)
-    n_cpu = min(16, n - 1)
+    n_cpu = min(64, n - 1)
     okw = dict(max_iterations=P.max_iterations, max_inner_iterations=P.max_inner_iterations, corr_dist=P.corr_dist,
                transformation_epsilon=P.transformation_epsilon, rotation_epsilon=P.rotation_epsilon, gicp_epsilon=P.gicp_epsilon)
     dl = [clouds[i].download() for i in range(n_cpu + 1)]
@@ -641,12 +660,25 @@ def main():
             # the dominant kernel: most time among the kernels that fill the GPU (bfgs_solve is one wave per pair running beside the other
             # groups' sweeps: its launches are long but occupy 32 of the chip's 24 576 wave slots; it moves no data and has no byte model)
             name, st = max(((k, v) for k, v in stats.items() if v["bytes"] > 0), key=lambda kv: kv[1]["ms"])
-            achieved = st["bytes"] / 1e9 / (st["ms"] / 1e3) if st["ms"] > 0 else 0.0
             avg_us = 1e3 * st["ms"] / max(1, st["launches"])
+            model = st["bytes"] / 1e9 / (st["ms"] / 1e3) if st["ms"] > 0 else 0.0
+            # The fraction is taken on what THIS design has to move: every sweep streams, per source point, the point (16 B), its normal (16), the
+            # neighbour index (4), the certificate (16) and the neighbour record (32) = 84 B -- whatever the certificates decide.  (The refresh
+            # writes of the points that walk and the tree nodes they visit come on top: `traffic` is the measured total.)  SURVEY 8d's byte model
+            # also counts C1, C2 and M (216 of its 340 B per correspondence), which are never materialised here: a rate on THAT model can exceed
+            # the peak and is kept as a labelled third figure, not as `frac`.
+            comp_bytes = 84.0 * n_pts * prof_in_flight if name == "nn_sweep" else st["bytes"] / max(1, st["launches"])
+            achieved = comp_bytes / 1e9 / (avg_us * 1e-6) if avg_us > 0 else 0.0
             return name, st, stats, {
                 "bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "avg_launch_us": round(avg_us, 2), "launches": st["launches"],
-                "jobs_per_launch": prof_in_flight, "algorithmic_bytes_per_launch": round(st["bytes"] / max(1, st["launches"]), 1),
+                "jobs_per_launch": prof_in_flight,
+                "bytes_per_launch": round(comp_bytes, 1),
+                "bytes_are": ("compulsory stream of this design: 84 B per source point per sweep (point, normal, neighbour index, certificate, neighbour record)"
+                              if name == "nn_sweep" else "the launch's byte model (lh_profile)"),
+                "survey_8d_model": {"achieved": round(model, 2), "frac": round(model / HBM_PEAK_GBS, 5), "bytes_per_launch": round(st["bytes"] / max(1, st["launches"]), 1),
+                                    "note": "20 N + 340 K_t with the measured K_t (SURVEY 8d's B_nn + B_fdf): counts covariance and Mahalanobis matrices this design never "
+                                            "writes or reads, so it is not bounded by the peak; kept for comparison with rounds 1-3"},
                 "kernels_ms": {k: round(v["ms"], 3) for k, v in sorted(stats.items(), key=lambda kv: -kv[1]["ms"])}}
 
         name, st, stats, roofline = roofline_leg(None, "profile_leg", max(1, min(args.steps, 2)))
@@ -661,7 +693,7 @@ def main():
             except Exception:
                 traffic = None
         # hbm_frac_real: the kernel's MEASURED DRAM traffic (PMC, profiles/pmc_latest.json) / its launch time / peak -- how busy HBM
-        # really is.  A fused kernel legitimately moves fewer bytes than the algorithmic model, so this sits below `frac`.
+        # really is (the compulsory stream + the walkers' refresh writes + tree nodes that miss the L2): it sits above `frac`.
         roofline["traffic"] = traffic
         roofline["hbm_frac_real"] = round(traffic / (roofline["avg_launch_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 5) if traffic else None
         roofline["traffic_source"] = ("carried from profiles/pmc_latest.json (rocprofv3 --pmc passes of tools/pmc_traffic.sh on this kernel, a builder-side "
@@ -723,20 +755,37 @@ def main():
                             L.lo_set_cost_variant(0)
                         Af, Bf = np.asarray(rf["T"], np.float64).reshape(4, 4).T, np.asarray(poses[k], np.float64).reshape(4, 4).T
                         outliers.append({"pair": int(k), "dt_m": d, "reference_fma_vs_nonfma_dt_m": float(np.abs(Af[:3, 3] - Bf[:3, 3]).max())})
+            # getFitnessScore: the GPU's score of its pose against the CPU path's score of its own (relative 1e-4), same pairs
+            gf = capi.Gicp(ctx, P)
+            fits = []
+            with ThreadPoolExecutor(max(1, min(len(keys), physical_cores() // 4))) as ex:
+                cpu_fit = dict(zip(keys, ex.map(lambda k: O.fitness((ins[k] if k in ins else oracle_inputs(k))[0], poses[k],
+                                                                    O.Tree((ins[k] if k in ins else oracle_inputs(k))[2]), threads=4), keys)))
+            for k in keys:
+                gf.set_source(S[k])
+                gf.set_target(T[k])
+                T[k].drop_index()
+                rk = gf.align(want_trace=False)
+                assert (np.asarray(rk["T"]) == np.asarray(out[k]["T"])).all()   # one at a time == the timed batch, bit for bit
+                fits.append(abs(gf.fitness() - cpu_fit[k]) / cpu_fit[k])
+            gf.close()
             q50, q90 = float(np.median(dts)), float(np.quantile(dts, 0.9))
             if args.cost_mode == 0:   # reference arithmetic, only the summation order differs: the same quantile shape one decade lower (tests: median 0.0)
                 parity_ok = q50 <= 1e-6 and q90 <= 1e-4 and max(dts) <= PARITY_P90_T and max(drs) <= 1e-4
             else:
                 parity_ok = (q50 <= PARITY_MEDIAN_T and q90 <= PARITY_P90_T and max(drs) <= PARITY_TOL_R and max(dts) <= PARITY_HARD_T and
-                             all(o["reference_fma_vs_nonfma_dt_m"] > PARITY_P90_T for o in outliers))
+                             all(o["reference_fma_vs_nonfma_dt_m"] > PARITY_P90_T for o in outliers) and
+                             float(np.median(fits)) <= 1e-4 and float(np.quantile(fits, 0.9)) <= 5e-4 and max(fits) <= 2e-3)
             result["parity"] = {
                 "against": "CPU path (reference arithmetic, oracle) on %d of the step's own pairs: the ones the CPU leg timed + the rest of the first %d, "
                            "4 OMP threads each" % (len(dts), PARITY_PAIRS),
                 "bars": {"median_dt_m": PARITY_MEDIAN_T, "p90_dt_m": PARITY_P90_T, "max_dR": PARITY_TOL_R, "hard_max_dt_m": PARITY_HARD_T,
                          "beyond_p90_bar": "only pairs on which the reference's own FMA / non-FMA builds part by more than the bar (listed)"},
                 "median_dt_m": q50, "p90_dt_m": q90, "max_dt_m": max(dts), "max_dR": max(drs), "n_pairs": len(dts),
+                "fitness_rel": {"median": float(np.median(fits)), "p90": float(np.quantile(fits, 0.9)), "max": float(max(fits)),
+                                "bars": {"median": 1e-4, "p90": 5e-4, "max": 2e-3}},
                 "pairs_within_1e-4": int(sum(d <= 1e-4 for d in dts)), "pairs_beyond_p90_bar": outliers,
-                "distribution_over_64_pairs": "profiles/r03_fullsize_parity.json", "ok": bool(parity_ok)}
+                "distribution_over_64_pairs": "profiles/r04_parity_distributions.json (both stopping rules: pose, fitness, per-iteration, iteration counts)", "ok": bool(parity_ok)}
         if args.no_cpu_baseline or world != 1:
             result["cpu_baseline_skipped"] = True
         _PARTIAL[0] = result
@@ -787,15 +836,44 @@ def main():
 
             stepn()
             ctx.synchronize()
-            t1 = time.perf_counter()
-            outn = stepn()
-            ctx.synchronize()
-            dtn = time.perf_counter() - t1
+            dtn = None
+            for _ in range(2):   # two timed steps, the faster one (a 25-ms step is at the mercy of a single host hiccup)
+                t1 = time.perf_counter()
+                outn = stepn()
+                ctx.synchronize()
+                dtn = min(dtn or 1e9, time.perf_counter() - t1)
             itn = [int(o["iterations"]) for o in outn]
             result["natural_convergence"] = {
                 "value": round(pairs_here / dtn, 2), "unit": "scan-pairs/s", "iterations_min_mean_max": [min(itn), float(np.mean(itn)), max(itn)],
                 "all_converged": bool(all(o["converged"] == 1 for o in outn)),
                 "max_abs_pose_diff_vs_20_forced_iterations": float(max(np.abs(np.asarray(a["T"]) - np.asarray(b["T"])).max() for a, b in zip(outn, out)))}
+            # ... against the CPU path under the SAME rule, on the first 16 pairs (4 OMP threads each, concurrently): the regime LOCUS runs in
+            if not args.no_cpu_baseline:
+                from concurrent.futures import ThreadPoolExecutor
+                from oracle import oracle as O
+                okn = dict(max_iterations=Pn.max_iterations, max_inner_iterations=Pn.max_inner_iterations, corr_dist=Pn.corr_dist,
+                           transformation_epsilon=Pn.transformation_epsilon, rotation_epsilon=Pn.rotation_epsilon, gicp_epsilon=Pn.gicp_epsilon)
+                kn = list(range(min(16, len(S))))
+
+                def cpu_nat(k):
+                    a, b = S[k].download(), T[k].download()
+                    return O.gicp_align(O.xyz4(np.stack([a["x"], a["y"], a["z"]], 1)), O.nrm4(np.stack([a["normal_x"], a["normal_y"], a["normal_z"]], 1)),
+                                        O.xyz4(np.stack([b["x"], b["y"], b["z"]], 1)), O.nrm4(np.stack([b["normal_x"], b["normal_y"], b["normal_z"]], 1)),
+                                        O.default_params(num_threads=4, **okn), want_trace=False)
+                with ThreadPoolExecutor(max(1, min(len(kn), physical_cores() // 4))) as ex:
+                    cn = list(ex.map(cpu_nat, kn))
+                ndt, ndr, nit = [], [], []
+                for k, r in zip(kn, cn):
+                    A_, B_ = np.asarray(outn[k]["T"], np.float64).reshape(4, 4).T, np.asarray(r["T"], np.float64).reshape(4, 4).T
+                    ndt.append(float(np.abs(A_[:3, 3] - B_[:3, 3]).max()))
+                    ndr.append(float(np.abs(A_[:3, :3] - B_[:3, :3]).max()))
+                    nit.append(int(outn[k]["iterations"]) - int(r["iterations"]))
+                nat_ok = float(np.median(ndt)) <= 5e-4 and float(np.quantile(ndt, 0.9)) <= 3e-3 and max(ndt) <= 2e-2 and max(ndr) <= 5e-4
+                result["natural_convergence"]["vs_cpu_path"] = {
+                    "n_pairs": len(kn), "median_dt_m": float(np.median(ndt)), "p90_dt_m": float(np.quantile(ndt, 0.9)), "max_dt_m": max(ndt), "max_dR": max(ndr),
+                    "iteration_count_differs_on": int(sum(1 for d in nit if d != 0)), "bars": {"median_dt_m": 5e-4, "p90_dt_m": 3e-3, "max_dt_m": 2e-2, "max_dR": 5e-4},
+                    "reference_own_two_builds_64_pairs": "median 2.1e-4, p90 3.2e-3, max 2.1e-2 (profiles/r04_parity_distributions.json: under this rule the result is defined to the stopping scale)",
+                    "ok": bool(nat_ok)}
             # ... and the roofline of ITS dominant kernel (nearly every sweep of this regime is an all-walk sweep + the index build and seed pass)
             _, _, _, rn = roofline_leg(Pn, "profile_leg_natural", 1)
             result["natural_convergence"]["roofline"] = rn
@@ -825,10 +903,14 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(result))
-        sys.stdout.flush()
+        with _PRINT_LOCK:
+            print(json.dumps(result))
+            sys.stdout.flush()
         if "parity" in result:   # a fast kernel whose results differ from the reference's is not done
             assert result["parity"]["ok"], "GPU vs CPU pose parity outside the stated tolerance: %r" % (result["parity"],)
+        nv = result.get("natural_convergence", {}).get("vs_cpu_path")
+        if nv:
+            assert nv["ok"], "GPU vs CPU pose parity under the production stopping rule outside the stated quantiles: %r" % (nv,)
 
 
 if __name__ == "__main__":
