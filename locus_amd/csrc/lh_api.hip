@@ -26,13 +26,20 @@ lh_status upload_view(lh_ctx* c, const lh_cloud_view* v, lh_cloud** out, bool sy
   cl->ctx = c;
   cl->n = (int)n;
   cl->n_pad = round_up(cl->n, 256);
-  // the host array goes over AS IT IS (one copy of n x stride bytes) and is taken apart on the device (k_unpack_view)
+  // the host array goes over AS IT IS (one copy) and is taken apart on the device (k_unpack_view).  Only the bytes up to the end of the LAST
+  // point's last field are read: a strided view whose final point ends the caller's buffer (a column slice of a wider record, a stride
+  // larger than the fields used) is not over-read by the tail of a stride.
+  size_t used = (size_t)v->off_xyz + 12;
+  if (has_n) used = std::max(used, (size_t)v->off_normal + 12);
+  if (has_i) used = std::max(used, (size_t)v->off_intensity + 4);
+  if (has_n && v->off_curvature != UINT32_MAX) used = std::max(used, (size_t)v->off_curvature + 4);
+  const size_t raw_bytes = (n - 1) * (size_t)v->stride + used;
   void* raw = nullptr;
   hipError_t e = lhMalloc(&raw, n * (size_t)v->stride);
   if (e == hipSuccess) e = lhMalloc(&cl->xyz, sizeof(float4) * (size_t)cl->n_pad);
   if (e == hipSuccess && has_n) e = lhMalloc(&cl->nrm, sizeof(float4) * (size_t)cl->n_pad);
   if (e == hipSuccess && has_i) e = lhMalloc(&cl->intensity, sizeof(float) * (size_t)cl->n_pad);
-  if (e == hipSuccess) e = hipMemcpyAsync(raw, v->base, n * (size_t)v->stride, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(raw, v->base, raw_bytes, hipMemcpyHostToDevice, c->stream);
   if (e == hipSuccess) {
     launch_unpack_view(raw, cl->n, v->stride, v->off_xyz, has_n ? v->off_normal : 0u, has_i ? v->off_intensity : 0u, has_n ? v->off_curvature : UINT32_MAX,
                        cl->xyz, cl->nrm, cl->intensity, c->stream);

@@ -59,8 +59,14 @@ namespace lh {
 
 constexpr int LEAF_CAP = 8;     // max points per leaf (128 B = one cache line of sorted points)
 constexpr int LDS_STACK = 12;   // traversal-stack entries (64-bit) a thread keeps in LDS; deeper entries spill to private memory
-constexpr int SPILL_MAX = 80;   // structural bound: binary depth <= 30 key bits + 28 tie-break bits => 4-ary depth <= 29,
-                                // at most 3 pushes per level + 1 => 88 <= LDS_STACK + SPILL_MAX entries for any cloud < 2^31 points
+constexpr int MAX_POINT_BITS = 27; // a cloud holds at most 2^27 points (leaf references keep 27 bits of sorted position; build_indices checks)
+constexpr int GRID_CELL_ROOTS = 3; // levels of the start grid (a cell root is kept as a child instead of being adopted: one 4-ary level for ONE binary level)
+// The traversal stack is unchecked.  Its structural bound: the binary radix tree is at most 30 key bits + MAX_POINT_BITS tie-break bits deep
+// (runs of identical keys are split by leaf index); a 4-ary node adopts its grandchildren, so a 4-ary level covers two binary levels except
+// at the (at most three) cell roots on a path => ceil((57 + 3) / 2) = 30 levels; a visit stacks at most 3 siblings and descends into the
+// fourth child => 3 * 30 + 1 = 91 entries for a walk from the root.  A walk that starts in the grid stacks <= 7 neighbour cells and then
+// begins at a level-5 cell root, >= 7 levels down: 7 + 3 * 23 + 1 = 77.  LDS_STACK + SPILL_MAX = 92.
+constexpr int SPILL_MAX = 80;
 constexpr int MAX_DEPTH = 12;   // (size of the instrumentation histogram; only slot 0 is used by the explicit tree)
 
 // child reference: >= 0 internal node index (cloud-local); < 0 leaf: ~ref = (first sorted position << 4) | (count - 1)
@@ -79,6 +85,8 @@ struct alignas(16) NodeX {
   int32_t child[4];    // absent child: NO_CHILD (its boxes are unused)
 };
 static_assert(sizeof(NodeX) == 64, "NodeX is half a 128-B line");
+static_assert(3 * ((30 + MAX_POINT_BITS + GRID_CELL_ROOTS + 1) / 2) + 1 <= LDS_STACK + SPILL_MAX,
+              "the unchecked traversal stack must hold the deepest walk of the largest cloud");
 constexpr float QUANT_STEPS = 65532.0f;  // grid steps across the cloud's largest extent: 0 .. 65532, +-1 of outward rounding <= 65535
 struct TreeHeader {
   int32_t root;       // child reference of the root (a leaf reference for clouds of <= LEAF_CAP points)

@@ -29,7 +29,7 @@ lh_status build_indices(lh_ctx* x, lh_cloud* const* clouds, int n_clouds, hipStr
     for (int k = 0; k < nb; k++) {
       lh_cloud* c = clouds[o + k];
       if (!c || c->n <= 0 || c->ctx != x) return LH_EINVAL;
-      if (c->n > (1 << 27)) return LH_EINVAL;  // leaf references keep 27 bits of sorted position
+      if (c->n > (1 << MAX_POINT_BITS)) return LH_EINVAL;  // leaf references keep 27 bits of sorted position; the traversal stack is sized for it (lh_device.hpp)
       if (c->n > c->index_cap) {
         (void)hipStreamSynchronize(x->stream);
         x->sync_side_streams();
@@ -53,6 +53,9 @@ lh_status build_indices(lh_ctx* x, lh_cloud* const* clouds, int n_clouds, hipStr
       x->sync_side_streams();
       (void)lhFree(x->k64a); (void)lhFree(x->k64b); (void)lhFree(x->v32a); (void)lhFree(x->v32b); (void)lhFree(x->sort64_temp);
       (void)lhFree(x->tree_tmp); (void)lhFree(x->scan_tmp); (void)lhFree(x->k32a); (void)lhFree(x->k32b); (void)lhFree(x->rs_hist);
+      // (a failed allocation below must not leave the old capacity standing over freed buffers)
+      x->k64a = x->k64b = nullptr; x->v32a = x->v32b = nullptr; x->sort64_temp = nullptr; x->tree_tmp = nullptr; x->scan_tmp = nullptr;
+      x->k32a = x->k32b = nullptr; x->rs_hist = nullptr; x->idx_cap = 0;
       int cap = round_up((int)std::min<long>(total + total / 4, 0x7fffff00L), 1024);
       HIPCHK(hipMalloc(&x->k64a, sizeof(uint64_t) * (size_t)cap));
       HIPCHK(hipMalloc(&x->k64b, sizeof(uint64_t) * (size_t)cap));

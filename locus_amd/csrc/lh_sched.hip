@@ -46,6 +46,11 @@ lh_status ctx_ensure_slots(lh_ctx* c, int n_slots, int max_n) {
   if (c->partials_host) (void)hipHostFree(c->partials_host);
   if (c->states_host) (void)hipHostFree(c->states_host);
   if (c->states_init) (void)hipHostFree(c->states_init);
+  // nothing is left half-described: if an allocation below fails, the context holds NO slot buffers and says so (n_slots = 0), so the next
+  // call -- whatever it asks for -- allocates afresh instead of passing the capacity check above and launching on freed memory
+  c->descs_dev = nullptr; c->mom_partials_dev = nullptr; c->wmask_dev = nullptr; c->states_dev = nullptr; c->chunks_dev = nullptr;
+  c->descs_host = nullptr; c->partials_host = nullptr; c->states_host = nullptr; c->states_init = nullptr;
+  c->n_slots = 0; c->partials_per_slot = 0; c->mom_stride = 0; c->mask_stride = 0;
   HIPCHK(hipMalloc(&c->descs_dev, sizeof(PairDesc) * n_slots));
   HIPCHK(hipMalloc(&c->mom_partials_dev, sizeof(double) * (size_t)mom_stride * n_slots));
   HIPCHK(hipMalloc(&c->wmask_dev, sizeof(unsigned long long) * (size_t)mask_stride * n_slots));
