@@ -247,6 +247,12 @@ lh_status lh_gicp_debug_stats(lh_gicp* g, uint64_t out[2], int reset);
 /* instrumentation of the tree traversal (1-NN of T*q; cand = optional warm-start candidate per query, leaf_prescan = look at
    the candidate's leaf first): out = {sum node visits, sum leaf visits, sum over waves of the per-wave max visits, number of
    waves, max visits of any query} */
+/* debug: the index as it lies in HBM -- sorted4: (n + 8) x 4 floats (x, y, z, original index; 8 pads), nodes: min(nodes_capacity, n) 64-byte 4-ary
+   nodes (only those reachable from the root are meaningful), header64: the 64-byte tree header.  lh_debug_small_index(enable): clouds of at
+   most 4 096 points are indexed by ONE launch of one workgroup (LOCUS's ~3 000-point operating point) -- 0 sends every cloud through the general
+   build, 1 restores the default, a negative value only queries; returns the previous setting.  The two builds give identical trees. */
+lh_status lh_debug_index_dump(lh_cloud* c, float* sorted4, void* nodes, uint32_t nodes_capacity, void* header64);
+int lh_debug_small_index(int enable);
 lh_status lh_debug_traversal_stats(lh_cloud* target, const lh_cloud* q, const float T[16], const int32_t* cand, int leaf_prescan,
                                    uint64_t out[5]);
 /* K5: one cost-functor pass fdf(x) (gicp.hpp:362-402) on the correspondences of the last sweep */

@@ -106,7 +106,7 @@ EXPORTS = [
     "lh_cloud_download", "lh_cloud_transform", "lh_cloud_slice", "lh_cloud_concat", "lh_gicp_create", "lh_gicp_destroy", "lh_gicp_set_params",
     "lh_gicp_set_source", "lh_gicp_set_target", "lh_gicp_set_source_cloud", "lh_gicp_set_target_cloud",
     "lh_gicp_promote_source_to_target", "lh_gicp_align", "lh_gicp_fitness", "lh_set_allreduce", "lh_nn1", "lh_nn1_cloud", "lh_knn_cloud",
-    "lh_gicp_align_batch", "lh_gicp_align_batch_out", "lh_gicp_align_stream", "lh_device_count", "lh_gicp_align_batch_multi", "lh_gicp_align_batch_multi_views", "lh_cov_knn", "lh_gicp_debug_sweep", "lh_gicp_debug_sweep_fused", "lh_gicp_debug_stats", "lh_debug_traversal_stats", "lh_gicp_debug_cost", "lh_p2plane_information",
+    "lh_gicp_align_batch", "lh_gicp_align_batch_out", "lh_gicp_align_stream", "lh_device_count", "lh_gicp_align_batch_multi", "lh_gicp_align_batch_multi_views", "lh_cov_knn", "lh_gicp_debug_sweep", "lh_gicp_debug_sweep_fused", "lh_gicp_debug_stats", "lh_debug_traversal_stats", "lh_debug_index_dump", "lh_debug_small_index", "lh_gicp_debug_cost", "lh_p2plane_information",
     "lh_icp_covariance", "lh_voxel_grid", "lh_cloud_voxel_grid", "lh_cloud_voxel_grid_pointf", "lh_cloud_nearest_neighbors", "lh_cloud_crop_box", "lh_default_ndt_params", "lh_ndt_create", "lh_ndt_destroy", "lh_ndt_set_params",
     "lh_ndt_set_source", "lh_ndt_set_target", "lh_ndt_set_source_cloud", "lh_ndt_set_target_cloud", "lh_ndt_align", "lh_ndt_debug_cells",
     "lh_ndt_debug_derivatives", "lh_map_create", "lh_map_destroy", "lh_map_insert", "lh_map_refresh", "lh_map_cloud", "lh_map_size", "lh_normals_knn", "lh_normals_knn_cloud", "lh_normals_knn_batch", "lh_cov_knn_batch",
@@ -182,6 +182,9 @@ def lib():
         L.lh_cloud_nearest_neighbors.argtypes = [vp, vp, C.POINTER(vp)]
         L.lh_normals_knn.argtypes = [vp, C.POINTER(CloudView), i32, vp]
         L.lh_normals_knn_cloud.argtypes = [vp, i32]
+        L.lh_debug_index_dump.argtypes = [vp, vp, vp, u32, vp]
+        L.lh_debug_small_index.argtypes = [i32]
+        L.lh_debug_small_index.restype = i32
         L.lh_normals_knn_batch.argtypes = [C.POINTER(vp), i32, i32]
         L.lh_cov_knn_batch.argtypes = [C.POINTER(vp), i32, i32, dbl]
         L.lh_cloud_slice.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(vp)]
@@ -279,6 +282,11 @@ def view_of(points, with_normals=None):
     assert a.ndim == 2 and a.shape[1] in (3, 4)
     v = CloudView(_ptr(a), a.shape[0], a.shape[1] * 4, 0, UINT32_MAX, UINT32_MAX, UINT32_MAX)
     return v, a
+
+
+def small_index(enable):
+    """lh_debug_small_index: switch the one-launch build of small clouds off (0) / on (1); returns the previous setting"""
+    return lib().lh_debug_small_index(int(enable))
 
 
 def normals_knn_batch(clouds, k=20):
@@ -498,6 +506,15 @@ class Cloud:
         n, w = len(query_cloud), int(out[3])
         return {"nodes_per_query": out[0] / n, "leaves_per_query": out[1] / n, "wave_max_visits_avg": out[2] / max(w, 1),
                 "max_visits": int(out[4])}
+
+    def index_dump(self):
+        """(sorted (n + 8, 4) float32, nodes (n, 16) uint32, header (16,) uint32) of the cloud's NN index (built if missing)"""
+        n = len(self)
+        srt = np.empty((n + 8, 4), np.float32)
+        nodes = np.zeros((max(n, 1), 16), np.uint32)
+        hdr = np.zeros(16, np.uint32)
+        _check(lib().lh_debug_index_dump(self.h, _ptr(srt), _ptr(nodes), n, _ptr(hdr)), "lh_debug_index_dump")
+        return srt, nodes, hdr
 
     def cov_knn(self, k=20, eps=1e-3):
         cov = np.empty((len(self), 3, 3), np.float64)

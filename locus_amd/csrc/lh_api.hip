@@ -179,6 +179,23 @@ lh_status lh_cloud_drop_index(lh_cloud* c) {
   c->cov_k = 0;
   return LH_OK;
 }
+// debug: the index as it lies in HBM (tests compare the one-launch build of small clouds with the general build, byte for byte)
+lh_status lh_debug_index_dump(lh_cloud* c, float* sorted4, void* nodes, uint32_t nodes_capacity, void* header64) {
+  if (!c || !sorted4 || !nodes || !header64) return LH_EINVAL;
+  HIPCHK(hipSetDevice(c->ctx->device));
+  if (!c->has_index) { lh_status st = cloud_build_index(c); if (st) return st; }
+  const uint32_t nn = std::min<uint32_t>(nodes_capacity, (uint32_t)c->n);
+  HIPCHK(hipMemcpyAsync(sorted4, c->sorted, sizeof(float4) * ((size_t)c->n + LEAF_CAP), hipMemcpyDeviceToHost, c->ctx->stream));
+  HIPCHK(hipMemcpyAsync(nodes, c->nodes(), sizeof(NodeX) * (size_t)nn, hipMemcpyDeviceToHost, c->ctx->stream));
+  HIPCHK(hipMemcpyAsync(header64, c->hdr(), sizeof(TreeHeader), hipMemcpyDeviceToHost, c->ctx->stream));
+  HIPCHK(hipStreamSynchronize(c->ctx->stream));
+  return LH_OK;
+}
+int lh_debug_small_index(int enable) {
+  const bool was = g_small_index.load();
+  if (enable >= 0) g_small_index.store(enable != 0);
+  return was ? 1 : 0;
+}
 lh_status lh_cloud_download(const lh_cloud* c, void* out_base, uint32_t stride, uint32_t off_xyz, uint32_t off_normal,
                             uint32_t off_intensity, uint32_t off_curvature) {
   if (!c || !out_base || stride < 12) return LH_EINVAL;

@@ -1,6 +1,10 @@
 // lh_index.hip -- K2: the batched NN-index build (replaces tree_->setInputCloud of pcl::Registration::initCompute) and the k-NN
 // covariances of a cloud (gicp.hpp:85-154), host side (see lh_runtime.hpp; kernels in lh_kernels.hip / lh_radix.hip).
+#include <atomic>
+
 #include "lh_runtime.hpp"
+
+std::atomic<bool> g_small_index{[]() { const char* e = getenv("LH_SMALL_INDEX"); return !e || atoi(e) != 0; }()};
 
 // K2: Morton sort + cell-aligned radix tree with 4-ary nodes (replaces tree_->setInputCloud of pcl::Registration::initCompute).
 // All clouds of a batch are built by the same launches, one radix sort and one scan (see lh_kernels.hpp "K2 batched").
@@ -26,9 +30,21 @@ lh_status build_indices(lh_ctx* x, lh_cloud* const* clouds, int n_clouds, hipStr
     x->idx_stage = (x->idx_stage + 1) % lh_ctx::IDX_STAGE;
     IndexDesc* const stage_host = x->idx_descs_host + (size_t)stage * MAX_INDEX_BATCH;
     HIPCHK(hipEventSynchronize(x->idx_copy_done[stage]));   // (an event that was never recorded is complete)
+    // the chunk's clouds: the large ones first (their sorted positions must be one contiguous run for the batched launches), then the small
+    // ones, which are built by one launch of one workgroup each (lh_index_small.hip) on their own slices of the same scratch
+    const bool small_path = g_small_index.load();   // (lh_debug_small_index / LH_SMALL_INDEX=0: every cloud through the general build -- A/B, tests)
+    std::vector<lh_cloud*> ordered;
+    for (int pass = 0; pass < 2; pass++)
+      for (int k = 0; k < nb; k++) {
+        lh_cloud* c = clouds[o + k];
+        if (!c || c->n <= 0 || c->ctx != x) return LH_EINVAL;
+        const bool small = small_path && c->n <= SMALL_INDEX_MAX_N;
+        if (small == (pass == 1)) ordered.push_back(c);
+      }
+    int n_big = 0;
+    long total_big = 0;
     for (int k = 0; k < nb; k++) {
-      lh_cloud* c = clouds[o + k];
-      if (!c || c->n <= 0 || c->ctx != x) return LH_EINVAL;
+      lh_cloud* c = ordered[k];
       if (c->n > (1 << MAX_POINT_BITS)) return LH_EINVAL;  // leaf references keep 27 bits of sorted position; the traversal stack is sized for it (lh_device.hpp)
       if (c->n > c->index_cap) {
         (void)hipStreamSynchronize(x->stream);
@@ -43,9 +59,14 @@ lh_status build_indices(lh_ctx* x, lh_cloud* const* clouds, int n_clouds, hipStr
       d.xyz = c->xyz; d.sorted = c->sorted; d.nodes = c->nodes(); d.hdr = c->hdr(); d.pos = nullptr;
       d.n = c->n; d.offset = (int)total;
       d.tile0 = tile0; d.pad = 0;
-      tile0 += segsort_tiles(c->n);
+      const bool small = small_path && c->n <= SMALL_INDEX_MAX_N;
+      if (!small) {
+        tile0 += segsort_tiles(c->n);
+        n_big++;
+        total_big += c->n;
+        max_n = std::max(max_n, c->n);
+      }
       total += c->n;
-      max_n = std::max(max_n, c->n);
     }
     if (total > 0x7ffffff0L) return LH_EINVAL;
     if ((int)total > x->idx_cap) {
@@ -89,54 +110,60 @@ lh_status build_indices(lh_ctx* x, lh_cloud* const* clouds, int n_clouds, hipStr
       ts.tsum = reinterpret_cast<uint32_t*>(p); p += 4 * (cap / 4096 + 16);
       ts.toff = reinterpret_cast<uint32_t*>(p); p += 4 * (cap / 4096 + 16);
       ts.keys = x->k64b;
-      ts.total = (int)total;
+      ts.total = (int)total_big;   // the batched launches cover the large clouds' positions [0, total_big)
     }
     HIPCHK(hipStreamWaitEvent(s, x->idx_build_done, 0));  // the shared build scratch may still be in use on the other stream
     HIPCHK(hipMemcpyAsync(x->idx_descs_dev, stage_host, sizeof(IndexDesc) * nb, hipMemcpyHostToDevice, s));
     HIPCHK(hipEventRecord(x->idx_copy_done[stage], s));
     int id_bits = 0;
-    while ((1 << id_bits) < nb) id_bits++;
+    while ((1 << id_bits) < std::max(n_big, 1)) id_bits++;
+    if (n_big > 0) {
     // LH_SORT=generic: the one-segment 64-bit sort over the whole concatenated array instead of the segmented one (A/B);
     // LH_SORT=check: both, compared element by element (tests: two independent code paths must give the same stable order)
     static const int sort_cfg = []() { const char* e = getenv("LH_SORT"); return !e ? 0 : (strcmp(e, "generic") == 0 ? 1 : (strcmp(e, "check") == 0 ? 2 : 0)); }();
-    { ProfScope p(x, "index_bbox_keys", 16.0 * total * 2, s);
-      launch_index_keys(x->idx_descs_dev, nb, max_n, x->idx_bbox, x->k32a, sort_cfg ? x->k64a : nullptr, sort_cfg ? x->v32a : nullptr, s); }
+    { ProfScope p(x, "index_bbox_keys", 16.0 * total_big * 2, s);
+      launch_index_keys(x->idx_descs_dev, n_big, max_n, x->idx_bbox, x->k32a, sort_cfg ? x->k64a : nullptr, sort_cfg ? x->v32a : nullptr, s); }
     {
       if (sort_cfg == 1) {
-        ProfScope p(x, "index_radix_sort", 12.0 * total * 2 * 4, s);
-        sort_pairs_u64(x->sort64_temp, x->sort64_temp_bytes, x->k64a, x->k64b, x->v32a, x->v32b, (int)total, 32 + id_bits, s);
+        ProfScope p(x, "index_radix_sort", 12.0 * total_big * 2 * 4, s);
+        sort_pairs_u64(x->sort64_temp, x->sort64_temp_bytes, x->k64a, x->k64b, x->v32a, x->v32b, (int)total_big, 32 + id_bits, s);
       } else {
         std::vector<uint64_t> kref;
         std::vector<uint32_t> vref;
         if (sort_cfg == 2) {  // reference first
-          sort_pairs_u64(x->sort64_temp, x->sort64_temp_bytes, x->k64a, x->k64b, x->v32a, x->v32b, (int)total, 32 + id_bits, s);
-          kref.resize(total); vref.resize(total);
-          HIPCHK(hipMemcpyAsync(kref.data(), x->k64b, sizeof(uint64_t) * total, hipMemcpyDeviceToHost, s));
-          HIPCHK(hipMemcpyAsync(vref.data(), x->v32b, sizeof(uint32_t) * total, hipMemcpyDeviceToHost, s));
+          sort_pairs_u64(x->sort64_temp, x->sort64_temp_bytes, x->k64a, x->k64b, x->v32a, x->v32b, (int)total_big, 32 + id_bits, s);
+          kref.resize(total_big); vref.resize(total_big);
+          HIPCHK(hipMemcpyAsync(kref.data(), x->k64b, sizeof(uint64_t) * total_big, hipMemcpyDeviceToHost, s));
+          HIPCHK(hipMemcpyAsync(vref.data(), x->v32b, sizeof(uint32_t) * total_big, hipMemcpyDeviceToHost, s));
           HIPCHK(hipStreamSynchronize(s));
         }
-        { ProfScope p(x, "index_radix_sort", 8.0 * total * 3 * 2, s);
-          segsort_pairs(x->idx_descs_dev, nb, max_n, x->k32a, x->k32b, x->k64b, x->v32b, x->rs_hist, s); }
+        { ProfScope p(x, "index_radix_sort", 8.0 * total_big * 3 * 2, s);
+          segsort_pairs(x->idx_descs_dev, n_big, max_n, x->k32a, x->k32b, x->k64b, x->v32b, x->rs_hist, s); }
         if (sort_cfg == 2) {
-          std::vector<uint64_t> kk(total);
-          std::vector<uint32_t> vv(total);
-          HIPCHK(hipMemcpyAsync(kk.data(), x->k64b, sizeof(uint64_t) * total, hipMemcpyDeviceToHost, s));
-          HIPCHK(hipMemcpyAsync(vv.data(), x->v32b, sizeof(uint32_t) * total, hipMemcpyDeviceToHost, s));
+          std::vector<uint64_t> kk(total_big);
+          std::vector<uint32_t> vv(total_big);
+          HIPCHK(hipMemcpyAsync(kk.data(), x->k64b, sizeof(uint64_t) * total_big, hipMemcpyDeviceToHost, s));
+          HIPCHK(hipMemcpyAsync(vv.data(), x->v32b, sizeof(uint32_t) * total_big, hipMemcpyDeviceToHost, s));
           HIPCHK(hipStreamSynchronize(s));
           long bad = 0;
-          for (long i = 0; i < total; i++)
+          for (long i = 0; i < total_big; i++)
             if (kk[i] != kref[i] || vv[i] != vref[i]) bad++;
           if (bad) {
-            fprintf(stderr, "[locus_hip] LH_SORT=check: %ld of %ld sorted elements differ between the segmented and the one-segment sort\n", bad, total);
+            fprintf(stderr, "[locus_hip] LH_SORT=check: %ld of %ld sorted elements differ between the segmented and the one-segment sort\n", bad, total_big);
             return LH_EDEVICE;
           }
         }
       }
     }
-    { ProfScope p(x, "index_leaves", 8.0 * total * 3 + 48.0 * total, s); launch_index_leaves(x->idx_descs_dev, nb, ts, x->v32b, x->idx_bbox, s); }
-    { ProfScope p(x, "index_box_tables", 24.0 * total, s); launch_index_trees(x->idx_descs_dev, nb, max_n, ts, s, 0); }
-    { ProfScope p(x, "index_radix_tree", 8.0 * total, s); launch_index_trees(x->idx_descs_dev, nb, max_n, ts, s, 1); }
-    { ProfScope p(x, "index_nodes", 32.0 * total, s); launch_index_trees(x->idx_descs_dev, nb, max_n, ts, s, 2); }
+    { ProfScope p(x, "index_leaves", 8.0 * total_big * 3 + 48.0 * total_big, s); launch_index_leaves(x->idx_descs_dev, n_big, ts, x->v32b, x->idx_bbox, s); }
+    { ProfScope p(x, "index_box_tables", 24.0 * total_big, s); launch_index_trees(x->idx_descs_dev, n_big, max_n, ts, s, 0); }
+    { ProfScope p(x, "index_radix_tree", 8.0 * total_big, s); launch_index_trees(x->idx_descs_dev, n_big, max_n, ts, s, 1); }
+    { ProfScope p(x, "index_nodes", 32.0 * total_big, s); launch_index_trees(x->idx_descs_dev, n_big, max_n, ts, s, 2); }
+    }
+    if (nb > n_big) {   // the small clouds: the whole build in one launch, one workgroup per cloud
+      ProfScope p(x, "index_small", 120.0 * (total - total_big), s);
+      launch_index_small(x->idx_descs_dev + n_big, nb - n_big, ts, s);
+    }
     HIPCHK(hipEventRecord(x->idx_build_done, s));
     HIPCHK(hipGetLastError());
     for (int k = 0; k < nb; k++) clouds[o + k]->has_index = true;

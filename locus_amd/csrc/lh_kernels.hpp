@@ -117,6 +117,10 @@ struct TreeScratch {
 };
 constexpr size_t TREE_SCRATCH_BYTES_PER_POINT = 4 + 4 + 8 + 4 + 32 + 2 + 32 + 8 + 8 + 4 + 4 + 1;  // flag lid lkey lstart lbox a1+a2 ibox ichild irange iparent icom tsum
 constexpr int MAX_INDEX_BATCH = 64;
+// clouds of at most this many points are indexed by ONE launch of one workgroup each (lh_index_small.hip): LOCUS's operating point is ~3 000
+// points per scan, where the general build's 13 launches are 122 us of launch latency around microseconds of work
+constexpr int SMALL_INDEX_MAX_N = 4096;
+void launch_index_small(const IndexDesc* descs_dev, int n_clouds, const TreeScratch& t, hipStream_t s);
 // the build's own sort (lh_radix.hip): segmented 3 x 10-bit LSD radix sort of the 30-bit keys, every cloud inside its segment
 int segsort_tiles(int n);
 size_t segsort_hist_elems(long total_points, int n_clouds);

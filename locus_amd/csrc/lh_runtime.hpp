@@ -312,6 +312,7 @@ lh_status ctx_ensure_slots(lh_ctx* c, int n_slots, int max_n);
 // K2 (lh_index.hip): the NN indexes of several clouds by the same launches; k-NN covariances of a cloud
 lh_status build_indices(lh_ctx* x, lh_cloud* const* clouds, int n_clouds, hipStream_t s_in = nullptr);
 static inline lh_status cloud_build_index(lh_cloud* c) { return build_indices(c->ctx, &c, 1); }
+extern std::atomic<bool> g_small_index;   // clouds of <= SMALL_INDEX_MAX_N points take the one-launch build (lh_index_small.hip); off: the general build for all
 lh_status cloud_ensure_cov(lh_cloud* c, int k, double eps);
 // K3 for a batch of clouds: ONE index build for those that have none and ONE block k-NN launch per MAX_INDEX_BATCH clouds.
 // mode = KNN_MODE_NORMALS (fills lh_cloud::nrm), KNN_MODE_COV (lh_cloud::cov6) or KNN_MODE_RAW (one cloud: idx_dev / d2_dev, n * k each)

@@ -140,6 +140,65 @@ def test_normals_and_covariances_batch_equals_one_by_one(ctx, capi, oracle):
     assert np.quantile(np.abs((out * ref[:, :3]).sum(1)), 0.01) > 1 - 1e-4
 
 
+def _reachable_tree(srt, nodes, hdr):
+    """the index as a comparable value: header fields, sorted points, and every node reachable from the root (unreached slots hold leftovers)"""
+    root = int(hdr.view(np.int32)[0])
+    out = {"hdr": hdr[:11].tobytes(), "sorted": srt.tobytes(), "nodes": {}}
+    stack = [root] if root >= 0 else []
+    while stack:
+        i = stack.pop()
+        nd = nodes[i]
+        out["nodes"][i] = nd.tobytes()
+        for c in nd[12:16].view(np.int32):
+            if 0 <= c < 0x7fffffff:
+                stack.append(int(c))
+    return out
+
+
+@pytest.mark.parametrize("n", [1, 2, 7, 8, 9, 33, 64, 100, 1000, 2933, 4095, 4096])
+def test_small_cloud_index_is_the_general_build_byte_for_byte(ctx, capi, oracle, n):
+    """clouds of <= 4 096 points (LOCUS's operating point: ~3 000) are indexed by ONE launch of one workgroup (lh_index_small.hip): the same
+    tree as the 13-launch general build -- header, sorted array and every reachable 4-ary node compared as bytes -- on a lidar sweep, on a cloud
+    with duplicates and runs of identical points, and the neighbours it gives against the oracle"""
+    rng = np.random.default_rng(n)
+    base = _cloud_pts(40 + n, max(n, 8), dup=True)
+    clouds = [base[:n], np.repeat((rng.normal(size=(max(1, n // 12), 3)) * [5, 3, 1]).astype(np.float32), 12, axis=0)[:n],
+              synth.scan(rings=16, azimuths=300, scale=1.0, seed=n)[:n]]
+    for pts in clouds:
+        if len(pts) < n:
+            pts = np.concatenate([pts, base[: n - len(pts)]])
+        prev = capi.small_index(1)
+        try:
+            a = capi.Cloud(ctx, pts)
+            ta = _reachable_tree(*a.index_dump())
+            capi.small_index(0)
+            b = capi.Cloud(ctx, pts)
+            tb = _reachable_tree(*b.index_dump())
+        finally:
+            capi.small_index(prev)
+        assert ta["hdr"] == tb["hdr"] and ta["sorted"] == tb["sorted"]
+        assert ta["nodes"].keys() == tb["nodes"].keys() and all(ta["nodes"][k] == tb["nodes"][k] for k in ta["nodes"])
+        q = (pts[: min(n, 200)] + rng.normal(scale=0.05, size=(min(n, 200), 3))).astype(np.float32)
+        idx, d2 = a.nn1(capi.Cloud(ctx, q))
+        io, do = oracle.nn1_brute(oracle.xyz4(pts), oracle.xyz4(q))
+        assert (idx == io).all() and (d2 == do).all()
+
+
+def test_small_and_large_clouds_in_one_batched_build(ctx, capi, oracle):
+    """a batch that mixes both kinds: the large clouds go through the batched launches, the small ones through the one-workgroup build, on
+    disjoint slices of the same scratch"""
+    sizes = [30000, 300, 9000, 8, 4096, 4097, 1, 2500]
+    pts = [_cloud_pts(60 + i, max(n, 8), dup=n > 100)[:n] + np.float32(2.0 * i) for i, n in enumerate(sizes)]
+    C_ = [capi.Cloud(ctx, p) for p in pts]
+    capi.normals_knn_batch([c for c, p in zip(C_, pts) if len(p) >= 3], 5)   # ONE build for all of them
+    rng = np.random.default_rng(0)
+    for c, p in zip(C_, pts):
+        q = (p[: min(len(p), 300)] + rng.normal(scale=0.05, size=(min(len(p), 300), 3))).astype(np.float32)
+        idx, d2 = c.nn1(capi.Cloud(ctx, q))
+        io, do = oracle.nn1_brute(oracle.xyz4(p), oracle.xyz4(q))
+        assert (idx == io).all() and (d2 == do).all(), len(p)
+
+
 def test_knn_more_neighbours_than_points(ctx, capi, oracle):
     pts = _cloud_pts(4, 8, dup=False)[:5]
     tgt = capi.Cloud(ctx, pts)
