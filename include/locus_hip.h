@@ -181,6 +181,15 @@ lh_status lh_gicp_fitness(lh_gicp* g, double* fitness);
    Not for lh_gicp_align_batch (ranks hold different pairs there: no exchange step at all). */
 typedef int (*lh_allreduce_fn)(double* sums, int n, void* user);
 lh_status lh_set_allreduce(lh_ctx* ctx, lh_allreduce_fn fn, void* user);
+/* The same exchange WITHOUT leaving the device (cost_mode 1): with this hook the sharded pair runs the device-driven loop (k_solve) and the
+   library calls fn between the moment reduction and the solve of every outer iteration, with the pair's 8 x 76 chunk sums where they lie in
+   HBM and the HIP stream the iteration is queued on.  fn ENQUEUES an in-place SUM over the ranks on that stream -- for RCCL:
+   ncclAllReduce(dev_sums, dev_sums, n, ncclDouble, ncclSum, comm, (hipStream_t)stream) -- and returns without synchronising: no host copy,
+   no host synchronisation per iteration.  Every rank ends with the same bits, so every rank's k_solve takes the same decisions.  The host
+   hook above still serves what is summed on the host (cost_mode 0, lh_gicp_fitness); install both (lh_rccl_install_sum_hook does).
+   NULL removes the hook. */
+typedef int (*lh_device_allreduce_fn)(double* dev_sums, int n, void* stream, void* user);
+lh_status lh_set_device_allreduce(lh_ctx* ctx, lh_device_allreduce_fn fn, void* user);
 /* getSearchMethodTarget()->nearestKSearch(pt, 1, ...) for every point of q (PointCloudLocalization.cc:327-336) */
 lh_status lh_nn1(lh_gicp* g, const lh_cloud_view* q, int32_t* idx, float* d2);
 lh_status lh_nn1_cloud(lh_cloud* target, const lh_cloud* q, int32_t* idx, float* d2);

@@ -32,7 +32,12 @@ int lh_rccl_world(const lh_rccl* r);
 
 /* the lh_allreduce_fn of lh_set_allreduce (user = the lh_rccl*): in-place SUM of n doubles over the ranks */
 int lh_rccl_sum_hook(double* sums, int n, void* user);
-/* lh_set_allreduce(ctx, lh_rccl_sum_hook, r); r == NULL removes the hook */
+/* the lh_device_allreduce_fn of lh_set_device_allreduce (user = the lh_rccl*): ncclAllReduce(SUM) of n doubles IN HBM, enqueued on `stream`
+   (the stream the library's iteration is queued on); returns without synchronising */
+int lh_rccl_device_sum_hook(double* dev_sums, int n, void* stream, void* user);
+/* lh_set_allreduce(ctx, lh_rccl_sum_hook, r) + lh_set_device_allreduce(ctx, lh_rccl_device_sum_hook, r): a source-sharded pair then runs the
+   device-driven loop with the exchange on the device (one all-reduce per outer iteration, no host copy in the loop); r == NULL
+   removes both hooks */
 lh_status lh_rccl_install_sum_hook(lh_ctx* ctx, lh_rccl* r);
 
 /* every rank contributes n_local results (the counts may differ); `all` (capacity `cap` records) receives the concatenation

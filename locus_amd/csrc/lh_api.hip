@@ -459,6 +459,13 @@ lh_status lh_set_allreduce(lh_ctx* ctx, lh_allreduce_fn fn, void* user) {
   return LH_OK;
 }
 
+lh_status lh_set_device_allreduce(lh_ctx* ctx, lh_device_allreduce_fn fn, void* user) {
+  if (!ctx) return LH_EINVAL;
+  ctx->dev_reduce_fn = fn;
+  ctx->dev_reduce_user = user;
+  return LH_OK;
+}
+
 lh_status lh_gicp_fitness(lh_gicp* g, double* fitness) {
   if (!g || !fitness || !g->src || !g->tgt || !g->have_result) return LH_EINVAL;
   HIPCHK(hipSetDevice(g->ctx->device));

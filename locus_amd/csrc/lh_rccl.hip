@@ -106,9 +106,19 @@ int lh_rccl_sum_hook(double* sums, int n, void* user) {
   return 0;
 }
 
+// ... and on the device: the device-driven loop hands over the chunk sums where they lie and the stream the iteration is queued on; the
+// all-reduce is enqueued there, between k_moments_final and k_solve -- no staging buffer, no copy, no synchronisation
+int lh_rccl_device_sum_hook(double* dev_sums, int n, void* stream, void* user) {
+  lh_rccl* r = static_cast<lh_rccl*>(user);
+  if (!r || !dev_sums || n <= 0) return 1;
+  return ncclAllReduce(dev_sums, dev_sums, (size_t)n, ncclDouble, ncclSum, r->comm, static_cast<hipStream_t>(stream)) == ncclSuccess ? 0 : 1;
+}
+
 lh_status lh_rccl_install_sum_hook(lh_ctx* ctx, lh_rccl* r) {
   if (!ctx) return LH_EINVAL;
-  return r ? lh_set_allreduce(ctx, lh_rccl_sum_hook, r) : lh_set_allreduce(ctx, nullptr, nullptr);
+  lh_status st = r ? lh_set_allreduce(ctx, lh_rccl_sum_hook, r) : lh_set_allreduce(ctx, nullptr, nullptr);
+  if (st) return st;
+  return r ? lh_set_device_allreduce(ctx, lh_rccl_device_sum_hook, r) : lh_set_device_allreduce(ctx, nullptr, nullptr);
 }
 
 lh_status lh_rccl_allgather_results(lh_rccl* r, const lh_gicp_result* local, int n_local, lh_gicp_result* all, int cap, int* counts) {

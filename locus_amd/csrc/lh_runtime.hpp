@@ -202,6 +202,8 @@ struct lh_ctx {
   // source-sharded single pair: in-place sum of the cost/moment sums over the ranks that hold the other shards
   lh_allreduce_fn reduce_fn = nullptr;
   void* reduce_user = nullptr;
+  lh_device_allreduce_fn dev_reduce_fn = nullptr;   // ... and its device-side form: the device-driven loop sums the chunk sums over the ranks in HBM, on the iteration's own stream
+  void* dev_reduce_user = nullptr;
   uint64_t epoch = 0;          // one per scheduler run (run_tasks_*): see lh_cloud::built_epoch
   // profiling
   bool prof = false;

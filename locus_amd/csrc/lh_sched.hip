@@ -462,6 +462,11 @@ static lh_status dev_enqueue(lh_ctx* c, DevGroup& g, int rounds) {
         ca.pad = (int)(~split_mask & (a.njobs >= 32 ? 0xffffffffu : ((1u << a.njobs) - 1u)));   // the jobs whose rows the fused sweep left
         launch_moments_final(c->descs_dev, ca, c->mom_partials_dev, c->mom_stride, c->chunks_dev, c->states_dev, c->wmask_dev, c->mask_stride, st);
       }
+      if (c->dev_reduce_fn) {   // the source-sharded pair: the chunk sums are summed over the ranks where they lie, on this stream, before k_solve reads them
+        ProfScope p(c, "moments_allreduce", 0.0, st);
+        for (int j = 0; j < a.njobs; j++)
+          if (c->dev_reduce_fn(c->chunks_dev + (size_t)sa.slot[j] * (FINAL_CHUNKS * MOM_ROW), FINAL_CHUNKS * MOM_ROW, (void*)st, c->dev_reduce_user) != 0) return LH_EDEVICE;
+      }
       {
         ProfScope p(c, "bfgs_solve", 0.0, st);
         launch_solve(c->descs_dev, sa, c->chunks_dev, FINAL_CHUNKS * MOM_ROW, c->states_dev, st);
@@ -745,13 +750,17 @@ static lh_status run_tasks_host(lh_ctx* c, std::vector<Task*>& tasks, int in_fli
 // sums cross ranks through a host callback) and the debug-statistics sweeps.  Both loops give bit-identical results.
 constexpr int DEVICE_LOOP_MIN_IN_FLIGHT = 8;
 lh_status run_tasks(lh_ctx* c, std::vector<Task*>& tasks, int in_flight, bool rebuild_index, std::vector<Workspace>* slot_ws) {
-  bool device_loop = !c->reduce_fn;
+  // a host SUM hook needs the host between the reduction and the solve; a device SUM hook keeps the loop on the device (and asks for it:
+  // without the host hook a host-driven loop would solve on this rank's shard alone)
+  bool device_loop = !c->reduce_fn || c->dev_reduce_fn;
+  const bool forced_by_hook = c->dev_reduce_fn != nullptr;
   bool forced = false;
   for (Task* t : tasks) {
     if (t->P.cost_mode != 1 || t->P.solver == 1 || t->count_stats || t->P.max_iterations < 1) device_loop = false;
     if (t->P.solver == 2) forced = true;
   }
-  if (device_loop && !forced && std::min<size_t>(in_flight, tasks.size()) < (size_t)DEVICE_LOOP_MIN_IN_FLIGHT) device_loop = false;
+  if (device_loop && !forced && !forced_by_hook && std::min<size_t>(in_flight, tasks.size()) < (size_t)DEVICE_LOOP_MIN_IN_FLIGHT) device_loop = false;
+  if (!device_loop && forced_by_hook && !c->reduce_fn) return LH_EINVAL;   // only a device hook, and a mode the device loop does not run (cost_mode 0, solver 1, debug counters): the shards could not be summed
   return device_loop ? run_tasks_device(c, tasks, in_flight, rebuild_index, slot_ws) : run_tasks_host(c, tasks, in_flight, rebuild_index, slot_ws);
 }
 

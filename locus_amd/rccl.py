@@ -8,7 +8,7 @@ import numpy as np
 from . import capi
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "liblocus_hip_rccl.so")
-EXPORTS = ["lh_rccl_get_unique_id", "lh_rccl_create", "lh_rccl_destroy", "lh_rccl_rank", "lh_rccl_world", "lh_rccl_sum_hook",
+EXPORTS = ["lh_rccl_get_unique_id", "lh_rccl_create", "lh_rccl_destroy", "lh_rccl_rank", "lh_rccl_world", "lh_rccl_sum_hook", "lh_rccl_device_sum_hook",
            "lh_rccl_install_sum_hook", "lh_rccl_allgather_results", "lh_rccl_max_double", "lh_rccl_barrier"]
 ID_BYTES = 128
 _lib = None

@@ -42,7 +42,7 @@ def test_rccl_library_exports_every_declared_symbol(capi):
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     syms = sorted(set(re.findall(r"\b(lh_rccl_[a-z0-9_]+)\s*\(", txt)))
     L = rccl.lib()
-    assert len(syms) == 10 and sorted(rccl.EXPORTS) == syms
+    assert len(syms) == 11 and sorted(rccl.EXPORTS) == syms
     assert not [s for s in syms if not hasattr(L, s)]
     assert rccl.ID_BYTES == 128
     if not _has_gpu():   # argument validation happens before any device or RCCL call

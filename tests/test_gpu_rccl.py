@@ -42,8 +42,13 @@ def _rank_body(rank, world, uid, device, q=None):
     g = capi.Gicp(ctx, capi.default_params(max_iterations=10, corr_dist=1.0, transformation_epsilon=1e-12, rotation_epsilon=1e-12))
     g.set_target(capi.make_pointf(tgt, nt))
     g.set_source(capi.make_pointf(src[a:b], ns[a:b]))
-    comm.install_sum_hook(ctx)
+    comm.install_sum_hook(ctx)   # the host hook AND the device hook: the sharded pair runs the device-driven loop, its exchange stays in HBM
+    ctx.profile(True)
+    ctx.profile_reset()
     r = g.align(want_trace=False)
+    stats = ctx.profile_get()
+    ctx.profile(False)
+    out["device_allreduces"] = (stats.get("moments_allreduce", {}).get("launches", 0), stats.get("bfgs_solve", {}).get("launches", 0), r["iterations"])
     fit = g.fitness()
     comm.remove_sum_hook(ctx)
     g.set_source(capi.make_pointf(src, ns))
@@ -69,6 +74,8 @@ def _check(outs, world):
         assert np.abs(Ts - Tw).max() < 1e-5 and abs(fs - fw) <= 1e-6 * abs(fw)
         if world == 1:
             assert (Ts == Tw).all() and fs == fw                        # a world of one: the hook is the identity
+        n_red, n_solve, its_ = o["device_allreduces"]
+        assert n_red >= its_ and n_red == n_solve        # one device-side all-reduce in front of every k_solve launch: no host copy in the loop
         assert o["tmax"] == float(world)
 
 
