@@ -603,6 +603,23 @@ def main():
     elapsed = time.perf_counter() - t0
     roctx.pop()
     elapsed = ldist.max_over_ranks(elapsed, world, device=ddev)
+    strong = None
+    if world > 1 and not args.strong:
+        # the same line read the other way (BASELINE configs[3]: a FIXED queue of --pairs pairs over the N GPUs): every rank aligns its 1 / N share,
+        # barrier-bracketed like the timed region, so that the driver's per-N values can be read as weak AND strong scaling
+        k = max(1, args.pairs // world)
+        for _ in range(1 + 2):
+            if _ == 1:
+                barrier()
+                ts = time.perf_counter()
+            for t in T[:k]:
+                t.drop_index()
+            raw_s, _a = capi.align_batch_out(ctx, P, S[:k], T[:k], max_in_flight=min(args.in_flight, k), aligned=A[:k], raw=True)
+            ldist.gather_records(raw_s, world, device=ddev)
+        barrier()
+        el_s = ldist.max_over_ranks(time.perf_counter() - ts, world, device=ddev)
+        strong = {"total_pairs": k * world, "pairs_per_gpu": k, "pairs_in_flight_per_gpu": min(args.in_flight, k), "value": round(2 * k * world / el_s, 2), "unit": "scan-pairs/s",
+                  "what": "the same pairs as a fixed queue of %d split over the %d GPUs (two timed steps after a warm-up, barrier-bracketed, max over ranks)" % (k * world, world)}
     if world > 1:   # the gathered table holds this rank's records at its own offset, bit for bit
         mine = bytes(bytearray(out))
         got = bytes(gathered[0].cpu().numpy().tobytes())[rank * len(mine):(rank + 1) * len(mine)]
@@ -714,7 +731,10 @@ def main():
             "all_ok": bool(ok), "outer_iterations_min_mean_max": [min(iters), float(np.mean(iters)), max(iters)],
             "cost_mode": args.cost_mode, "mean_cost_evaluations_per_pair": passes, "max_translation_err_vs_truth_m": float(np.max(errs)),
             "roofline": roofline,
+            "pairs_in_flight_per_gpu": min(args.in_flight, pairs_here),
         }
+        if strong is not None:
+            result["strong_scaling_same_pairs"] = strong
         _leg("CPU baseline + parity")
         if world == 1 and not args.no_cpu_baseline:
             cb, poses = cpu_baseline(S, T, host, P)
