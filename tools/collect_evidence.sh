@@ -2,7 +2,8 @@
 cd $GRAFT_REPO_ROOT
 E=gpurun_out/evidence
 mkdir -p $E
-python bench.py --steps 20 --warmup 5 > $E/bench_final.json 2> $E/bench_final.err
+python bench.py > $E/bench_driver_style.json 2> $E/bench_driver_style.err
+python bench.py --steps 20 --warmup 5 --no-trajectory > $E/bench_final.json 2> $E/bench_final.err
 bash tools/profile_bench.sh > $E/profile_bench.log 2>&1
 cp gpurun_out/prof/kernel_stats.csv $E/bench_kernel_stats.csv
 cp gpurun_out/prof/profile_leg_kernels.txt $E/bench_profile_leg_kernels.txt
