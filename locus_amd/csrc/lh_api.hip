@@ -124,14 +124,16 @@ void lh_destroy(lh_ctx* c) {
   c->prof_flush();
   for (auto e : c->ev_pool) (void)hipEventDestroy(e);
   (void)lhFree(c->keys0); (void)lhFree(c->keys1); (void)lhFree(c->vals0); (void)lhFree(c->vals1);
-  (void)lhFree(c->k64a); (void)lhFree(c->k64b); (void)lhFree(c->v32a); (void)lhFree(c->v32b); (void)lhFree(c->sort64_temp);
-  (void)lhFree(c->tree_tmp); (void)lhFree(c->scan_tmp); (void)lhFree(c->k32a); (void)lhFree(c->k32b); (void)lhFree(c->rs_hist);
-  (void)lhFree(c->idx_bbox); (void)lhFree(c->idx_descs_dev);
+  for (lh_ctx::IndexScratch& X : c->idx_sets) {
+    (void)lhFree(X.k64a); (void)lhFree(X.k64b); (void)lhFree(X.v32a); (void)lhFree(X.v32b); (void)lhFree(X.sort64_temp);
+    (void)lhFree(X.tree_tmp); (void)lhFree(X.k32a); (void)lhFree(X.k32b); (void)lhFree(X.rs_hist);
+    (void)lhFree(X.bbox); (void)lhFree(X.descs_dev);
+    if (X.descs_host) (void)hipHostFree(X.descs_host);
+    for (hipEvent_t e : X.copy_done)
+      if (e) (void)hipEventDestroy(e);
+    if (X.build_done) (void)hipEventDestroy(X.build_done);
+  }
   (void)lhFree(c->knn_descs_dev); (void)lhFree(c->knn_redo_cnt); (void)lhFree(c->knn_redo); (void)lhFree(c->knn_soa);
-  if (c->idx_descs_host) (void)hipHostFree(c->idx_descs_host);
-  for (hipEvent_t e : c->idx_copy_done)
-    if (e) (void)hipEventDestroy(e);
-  if (c->idx_build_done) (void)hipEventDestroy(c->idx_build_done);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
   if (c->stream3) (void)hipStreamDestroy(c->stream3);
   if (c->stream4) (void)hipStreamDestroy(c->stream4);

@@ -8,28 +8,29 @@ std::atomic<bool> g_small_index{[]() { const char* e = getenv("LH_SMALL_INDEX");
 
 // K2: Morton sort + cell-aligned radix tree with 4-ary nodes (replaces tree_->setInputCloud of pcl::Registration::initCompute).
 // All clouds of a batch are built by the same launches, one radix sort and one scan (see lh_kernels.hpp "K2 batched").
-lh_status build_indices(lh_ctx* x, lh_cloud* const* clouds, int n_clouds, hipStream_t s_in) {
+lh_status build_indices(lh_ctx* x, lh_cloud* const* clouds, int n_clouds, hipStream_t s_in, int set) {
   if (n_clouds <= 0) return LH_OK;
   hipStream_t s = s_in ? s_in : x->stream;
+  lh_ctx::IndexScratch& X = x->idx_sets[((set % lh_ctx::IDX_SETS) + lh_ctx::IDX_SETS) % lh_ctx::IDX_SETS];   // the build scratch this call owns (lh_runtime.hpp)
   for (int o = 0; o < n_clouds; o += MAX_INDEX_BATCH) {
     int nb = std::min(MAX_INDEX_BATCH, n_clouds - o);
     long total = 0;
     int max_n = 0, tile0 = 0;
-    if (!x->idx_descs_dev) {
-      HIPCHK(hipMalloc(&x->idx_descs_dev, sizeof(IndexDesc) * MAX_INDEX_BATCH));
-      HIPCHK(hipHostMalloc(&x->idx_descs_host, sizeof(IndexDesc) * MAX_INDEX_BATCH * lh_ctx::IDX_STAGE, hipHostMallocDefault));
-      HIPCHK(hipMalloc(&x->idx_bbox, sizeof(uint32_t) * 8 * MAX_INDEX_BATCH));
-      launch_index_bbox_init(x->idx_bbox, s);   // (every build then leaves the slots reset for the next one)
-      for (int k = 0; k < lh_ctx::IDX_STAGE; k++) HIPCHK(hipEventCreateWithFlags(&x->idx_copy_done[k], hipEventDisableTiming));
-      HIPCHK(hipEventCreateWithFlags(&x->idx_build_done, hipEventDisableTiming));
+    if (!X.descs_dev) {
+      HIPCHK(hipMalloc(&X.descs_dev, sizeof(IndexDesc) * MAX_INDEX_BATCH));
+      HIPCHK(hipHostMalloc(&X.descs_host, sizeof(IndexDesc) * MAX_INDEX_BATCH * lh_ctx::IndexScratch::STAGES, hipHostMallocDefault));
+      HIPCHK(hipMalloc(&X.bbox, sizeof(uint32_t) * 8 * MAX_INDEX_BATCH));
+      launch_index_bbox_init(X.bbox, s);   // (every build then leaves the slots reset for the next one)
+      for (int k = 0; k < lh_ctx::IndexScratch::STAGES; k++) HIPCHK(hipEventCreateWithFlags(&X.copy_done[k], hipEventDisableTiming));
+      HIPCHK(hipEventCreateWithFlags(&X.build_done, hipEventDisableTiming));
     }
-    // The descriptors are staged in a ring: the upload of a build is queued behind the previous build on the GPU (shared scratch), so
-    // waiting for the PREVIOUS upload before refilling one staging buffer tied the scheduling thread to the GPU's index builds
-    // (1.6 ms per group of 32 with sixteen groups in flight: 25 of a 60-ms step).  Only the upload IDX_STAGE builds ago is waited for.
-    const int stage = x->idx_stage;
-    x->idx_stage = (x->idx_stage + 1) % lh_ctx::IDX_STAGE;
-    IndexDesc* const stage_host = x->idx_descs_host + (size_t)stage * MAX_INDEX_BATCH;
-    HIPCHK(hipEventSynchronize(x->idx_copy_done[stage]));   // (an event that was never recorded is complete)
+    // The descriptors are staged in a ring: the upload of a build is queued behind the previous build of the same set on the GPU, so
+    // waiting for the PREVIOUS upload before refilling one staging buffer would tie the calling thread to the GPU's index builds (with
+    // one shared scratch, round 3: 1.6 ms per group of 32, 25 of a 60-ms step).  Only the upload STAGES builds ago is waited for.
+    const int stage = X.stage;
+    X.stage = (X.stage + 1) % lh_ctx::IndexScratch::STAGES;
+    IndexDesc* const stage_host = X.descs_host + (size_t)stage * MAX_INDEX_BATCH;
+    HIPCHK(hipEventSynchronize(X.copy_done[stage]));   // (an event that was never recorded is complete)
     // the chunk's clouds: the large ones first (their sorted positions must be one contiguous run for the batched launches), then the small
     // ones, which are built by one launch of one workgroup each (lh_index_small.hip) on their own slices of the same scratch
     const bool small_path = g_small_index.load();   // (lh_debug_small_index / LH_SMALL_INDEX=0: every cloud through the general build -- A/B, tests)
@@ -69,32 +70,32 @@ lh_status build_indices(lh_ctx* x, lh_cloud* const* clouds, int n_clouds, hipStr
       total += c->n;
     }
     if (total > 0x7ffffff0L) return LH_EINVAL;
-    if ((int)total > x->idx_cap) {
+    if ((int)total > X.cap) {
       (void)hipStreamSynchronize(x->stream);
       x->sync_side_streams();
-      (void)lhFree(x->k64a); (void)lhFree(x->k64b); (void)lhFree(x->v32a); (void)lhFree(x->v32b); (void)lhFree(x->sort64_temp);
-      (void)lhFree(x->tree_tmp); (void)lhFree(x->scan_tmp); (void)lhFree(x->k32a); (void)lhFree(x->k32b); (void)lhFree(x->rs_hist);
+      (void)lhFree(X.k64a); (void)lhFree(X.k64b); (void)lhFree(X.v32a); (void)lhFree(X.v32b); (void)lhFree(X.sort64_temp);
+      (void)lhFree(X.tree_tmp); (void)lhFree(X.k32a); (void)lhFree(X.k32b); (void)lhFree(X.rs_hist);
       // (a failed allocation below must not leave the old capacity standing over freed buffers)
-      x->k64a = x->k64b = nullptr; x->v32a = x->v32b = nullptr; x->sort64_temp = nullptr; x->tree_tmp = nullptr; x->scan_tmp = nullptr;
-      x->k32a = x->k32b = nullptr; x->rs_hist = nullptr; x->idx_cap = 0;
+      X.k64a = X.k64b = nullptr; X.v32a = X.v32b = nullptr; X.sort64_temp = nullptr; X.tree_tmp = nullptr;
+      X.k32a = X.k32b = nullptr; X.rs_hist = nullptr; X.cap = 0;
       int cap = round_up((int)std::min<long>(total + total / 4, 0x7fffff00L), 1024);
-      HIPCHK(hipMalloc(&x->k64a, sizeof(uint64_t) * (size_t)cap));
-      HIPCHK(hipMalloc(&x->k64b, sizeof(uint64_t) * (size_t)cap));
-      HIPCHK(hipMalloc(&x->v32a, sizeof(uint32_t) * (size_t)cap));
-      HIPCHK(hipMalloc(&x->v32b, sizeof(uint32_t) * (size_t)cap));
-      HIPCHK(hipMalloc(&x->k32a, sizeof(uint64_t) * (size_t)cap));
-      HIPCHK(hipMalloc(&x->k32b, sizeof(uint64_t) * (size_t)cap));
-      HIPCHK(hipMalloc(&x->rs_hist, sizeof(uint32_t) * segsort_hist_elems(cap, MAX_INDEX_BATCH)));
-      x->sort64_temp_bytes = sort64_temp_bytes(cap);
-      HIPCHK(hipMalloc(&x->sort64_temp, x->sort64_temp_bytes ? x->sort64_temp_bytes : 16));
-      HIPCHK(hipMalloc(&x->tree_tmp, TREE_SCRATCH_BYTES_PER_POINT * ((size_t)cap + 16) + 4096));
-      HIPCHK(hipMemsetAsync(x->tree_tmp, 0, TREE_SCRATCH_BYTES_PER_POINT * ((size_t)cap + 16) + 4096, s));   // (the per-tile leaf counts must start at zero; every build leaves them so)
-      x->idx_cap = cap;
+      HIPCHK(hipMalloc(&X.k64a, sizeof(uint64_t) * (size_t)cap));
+      HIPCHK(hipMalloc(&X.k64b, sizeof(uint64_t) * (size_t)cap));
+      HIPCHK(hipMalloc(&X.v32a, sizeof(uint32_t) * (size_t)cap));
+      HIPCHK(hipMalloc(&X.v32b, sizeof(uint32_t) * (size_t)cap));
+      HIPCHK(hipMalloc(&X.k32a, sizeof(uint64_t) * (size_t)cap));
+      HIPCHK(hipMalloc(&X.k32b, sizeof(uint64_t) * (size_t)cap));
+      HIPCHK(hipMalloc(&X.rs_hist, sizeof(uint32_t) * segsort_hist_elems(cap, MAX_INDEX_BATCH)));
+      X.sort64_temp_bytes = sort64_temp_bytes(cap);
+      HIPCHK(hipMalloc(&X.sort64_temp, X.sort64_temp_bytes ? X.sort64_temp_bytes : 16));
+      HIPCHK(hipMalloc(&X.tree_tmp, TREE_SCRATCH_BYTES_PER_POINT * ((size_t)cap + 16) + 4096));
+      HIPCHK(hipMemsetAsync(X.tree_tmp, 0, TREE_SCRATCH_BYTES_PER_POINT * ((size_t)cap + 16) + 4096, s));   // (the per-tile leaf counts must start at zero; every build leaves them so)
+      X.cap = cap;
     }
     TreeScratch ts;
     {
-      size_t cap = (size_t)x->idx_cap + 16;
-      char* p = x->tree_tmp;
+      size_t cap = (size_t)X.cap + 16;
+      char* p = X.tree_tmp;
       ts.lkey = reinterpret_cast<uint64_t*>(p); p += 8 * cap;       // 16-byte aligned arrays first (cap is a multiple of 16)
       ts.lbox = reinterpret_cast<float4*>(p); p += 32 * cap;
       ts.a1box = reinterpret_cast<float4*>(p); p += 32 * (cap / 32 + 16);
@@ -109,12 +110,12 @@ lh_status build_indices(lh_ctx* x, lh_cloud* const* clouds, int n_clouds, hipStr
       ts.lstart = reinterpret_cast<uint32_t*>(p); p += 4 * cap;
       ts.tsum = reinterpret_cast<uint32_t*>(p); p += 4 * (cap / 4096 + 16);
       ts.toff = reinterpret_cast<uint32_t*>(p); p += 4 * (cap / 4096 + 16);
-      ts.keys = x->k64b;
+      ts.keys = X.k64b;
       ts.total = (int)total_big;   // the batched launches cover the large clouds' positions [0, total_big)
     }
-    HIPCHK(hipStreamWaitEvent(s, x->idx_build_done, 0));  // the shared build scratch may still be in use on the other stream
-    HIPCHK(hipMemcpyAsync(x->idx_descs_dev, stage_host, sizeof(IndexDesc) * nb, hipMemcpyHostToDevice, s));
-    HIPCHK(hipEventRecord(x->idx_copy_done[stage], s));
+    HIPCHK(hipStreamWaitEvent(s, X.build_done, 0));  // the previous build of this set may still be running on another stream
+    HIPCHK(hipMemcpyAsync(X.descs_dev, stage_host, sizeof(IndexDesc) * nb, hipMemcpyHostToDevice, s));
+    HIPCHK(hipEventRecord(X.copy_done[stage], s));
     int id_bits = 0;
     while ((1 << id_bits) < std::max(n_big, 1)) id_bits++;
     if (n_big > 0) {
@@ -122,28 +123,28 @@ lh_status build_indices(lh_ctx* x, lh_cloud* const* clouds, int n_clouds, hipStr
     // LH_SORT=check: both, compared element by element (tests: two independent code paths must give the same stable order)
     static const int sort_cfg = []() { const char* e = getenv("LH_SORT"); return !e ? 0 : (strcmp(e, "generic") == 0 ? 1 : (strcmp(e, "check") == 0 ? 2 : 0)); }();
     { ProfScope p(x, "index_bbox_keys", 16.0 * total_big * 2, s);
-      launch_index_keys(x->idx_descs_dev, n_big, max_n, x->idx_bbox, x->k32a, sort_cfg ? x->k64a : nullptr, sort_cfg ? x->v32a : nullptr, s); }
+      launch_index_keys(X.descs_dev, n_big, max_n, X.bbox, X.k32a, sort_cfg ? X.k64a : nullptr, sort_cfg ? X.v32a : nullptr, s); }
     {
       if (sort_cfg == 1) {
         ProfScope p(x, "index_radix_sort", 12.0 * total_big * 2 * 4, s);
-        sort_pairs_u64(x->sort64_temp, x->sort64_temp_bytes, x->k64a, x->k64b, x->v32a, x->v32b, (int)total_big, 32 + id_bits, s);
+        sort_pairs_u64(X.sort64_temp, X.sort64_temp_bytes, X.k64a, X.k64b, X.v32a, X.v32b, (int)total_big, 32 + id_bits, s);
       } else {
         std::vector<uint64_t> kref;
         std::vector<uint32_t> vref;
         if (sort_cfg == 2) {  // reference first
-          sort_pairs_u64(x->sort64_temp, x->sort64_temp_bytes, x->k64a, x->k64b, x->v32a, x->v32b, (int)total_big, 32 + id_bits, s);
+          sort_pairs_u64(X.sort64_temp, X.sort64_temp_bytes, X.k64a, X.k64b, X.v32a, X.v32b, (int)total_big, 32 + id_bits, s);
           kref.resize(total_big); vref.resize(total_big);
-          HIPCHK(hipMemcpyAsync(kref.data(), x->k64b, sizeof(uint64_t) * total_big, hipMemcpyDeviceToHost, s));
-          HIPCHK(hipMemcpyAsync(vref.data(), x->v32b, sizeof(uint32_t) * total_big, hipMemcpyDeviceToHost, s));
+          HIPCHK(hipMemcpyAsync(kref.data(), X.k64b, sizeof(uint64_t) * total_big, hipMemcpyDeviceToHost, s));
+          HIPCHK(hipMemcpyAsync(vref.data(), X.v32b, sizeof(uint32_t) * total_big, hipMemcpyDeviceToHost, s));
           HIPCHK(hipStreamSynchronize(s));
         }
         { ProfScope p(x, "index_radix_sort", 8.0 * total_big * 3 * 2, s);
-          segsort_pairs(x->idx_descs_dev, n_big, max_n, x->k32a, x->k32b, x->k64b, x->v32b, x->rs_hist, s); }
+          segsort_pairs(X.descs_dev, n_big, max_n, X.k32a, X.k32b, X.k64b, X.v32b, X.rs_hist, s); }
         if (sort_cfg == 2) {
           std::vector<uint64_t> kk(total_big);
           std::vector<uint32_t> vv(total_big);
-          HIPCHK(hipMemcpyAsync(kk.data(), x->k64b, sizeof(uint64_t) * total_big, hipMemcpyDeviceToHost, s));
-          HIPCHK(hipMemcpyAsync(vv.data(), x->v32b, sizeof(uint32_t) * total_big, hipMemcpyDeviceToHost, s));
+          HIPCHK(hipMemcpyAsync(kk.data(), X.k64b, sizeof(uint64_t) * total_big, hipMemcpyDeviceToHost, s));
+          HIPCHK(hipMemcpyAsync(vv.data(), X.v32b, sizeof(uint32_t) * total_big, hipMemcpyDeviceToHost, s));
           HIPCHK(hipStreamSynchronize(s));
           long bad = 0;
           for (long i = 0; i < total_big; i++)
@@ -155,16 +156,16 @@ lh_status build_indices(lh_ctx* x, lh_cloud* const* clouds, int n_clouds, hipStr
         }
       }
     }
-    { ProfScope p(x, "index_leaves", 8.0 * total_big * 3 + 48.0 * total_big, s); launch_index_leaves(x->idx_descs_dev, n_big, ts, x->v32b, x->idx_bbox, s); }
-    { ProfScope p(x, "index_box_tables", 24.0 * total_big, s); launch_index_trees(x->idx_descs_dev, n_big, max_n, ts, s, 0); }
-    { ProfScope p(x, "index_radix_tree", 8.0 * total_big, s); launch_index_trees(x->idx_descs_dev, n_big, max_n, ts, s, 1); }
-    { ProfScope p(x, "index_nodes", 32.0 * total_big, s); launch_index_trees(x->idx_descs_dev, n_big, max_n, ts, s, 2); }
+    { ProfScope p(x, "index_leaves", 8.0 * total_big * 3 + 48.0 * total_big, s); launch_index_leaves(X.descs_dev, n_big, ts, X.v32b, X.bbox, s); }
+    { ProfScope p(x, "index_box_tables", 24.0 * total_big, s); launch_index_trees(X.descs_dev, n_big, max_n, ts, s, 0); }
+    { ProfScope p(x, "index_radix_tree", 8.0 * total_big, s); launch_index_trees(X.descs_dev, n_big, max_n, ts, s, 1); }
+    { ProfScope p(x, "index_nodes", 32.0 * total_big, s); launch_index_trees(X.descs_dev, n_big, max_n, ts, s, 2); }
     }
     if (nb > n_big) {   // the small clouds: the whole build in one launch, one workgroup per cloud
       ProfScope p(x, "index_small", 120.0 * (total - total_big), s);
-      launch_index_small(x->idx_descs_dev + n_big, nb - n_big, ts, s);
+      launch_index_small(X.descs_dev + n_big, nb - n_big, ts, s);
     }
-    HIPCHK(hipEventRecord(x->idx_build_done, s));
+    HIPCHK(hipEventRecord(X.build_done, s));
     HIPCHK(hipGetLastError());
     for (int k = 0; k < nb; k++) clouds[o + k]->has_index = true;
   }

@@ -226,8 +226,8 @@ __global__ void __launch_bounds__(256) k_leaves_b(const IndexDesc* __restrict__ 
       t.lkey[lid] = ~0ull;
     }
   }
-  // the bounding-box slots of this batch have been consumed (k_key_b): reset them for the NEXT build (builds are serialised on the
-  // shared scratch), which saves every build its own init launch
+  // the bounding-box slots of this batch have been consumed (k_key_b): reset them for the NEXT build of this scratch set (builds on one
+  // set are serialised), which saves every build its own init launch
   if (blockIdx.x == 0)
     for (int k = threadIdx.x; k < MAX_INDEX_BATCH * 8; k += 256) bbox_next[k] = (k & 7) < 3 ? 0xffffffffu : 0u;
 }

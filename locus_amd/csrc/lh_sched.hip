@@ -577,14 +577,14 @@ static lh_status run_tasks_device(lh_ctx* c, std::vector<Task*>& tasks, int in_f
         }
         if (!to_build.empty()) {
           const double hb = hp_now();
-          st = build_indices(c, to_build.data(), (int)to_build.size(), g.stream);
+          // each group builds in its own scratch set: the builds of the sixteen groups overlap instead of queueing on one scratch
+          st = build_indices(c, to_build.data(), (int)to_build.size(), g.stream, gi);
           if (st) return fail(st);
           for (lh_cloud* tg : to_build) tg->built_epoch = epoch;
           hp_build += hp_now() - hb;
-        } else if (built_elsewhere && c->idx_build_done) {
-          // builds are chained through idx_build_done (shared scratch), so the latest record covers every earlier build of this call
-          if (hipStreamWaitEvent(g.stream, c->idx_build_done, 0) != hipSuccess) return fail(LH_EDEVICE);
         }
+        // a target another group built: that build was enqueued earlier in this call, on that group's stream and scratch set
+        if (built_elsewhere && (st = wait_index_builds(c, g.stream))) return fail(st);
         const double hpp = hp_now();
         std::vector<int> admitted;
         while (next < tasks.size() && !g.free_slots.empty()) {
@@ -709,12 +709,11 @@ static lh_status run_tasks_host(lh_ctx* c, std::vector<Task*>& tasks, int in_fli
           if ((rebuild_index || !tg->has_index) && std::find(to_build.begin(), to_build.end(), tg) == to_build.end()) to_build.push_back(tg);
         }
         if (!to_build.empty()) {
-          st = build_indices(c, to_build.data(), (int)to_build.size(), g.stream);
+          st = build_indices(c, to_build.data(), (int)to_build.size(), g.stream, gi);
           if (st) return fail(st);
           for (lh_cloud* tg : to_build) tg->built_epoch = epoch;
-        } else if (built_elsewhere && c->idx_build_done) {
-          if (hipStreamWaitEvent(g.stream, c->idx_build_done, 0) != hipSuccess) return fail(LH_EDEVICE);
         }
+        if (built_elsewhere && (st = wait_index_builds(c, g.stream))) return fail(st);
         while (next < tasks.size() && !g.free_slots.empty()) {
           Task* t = tasks[next++];
           t->slot = g.free_slots.back();
