@@ -24,6 +24,10 @@ os.environ.setdefault("OMP_PLACES", "cores")
 # sleeping team for each one was most of its time at high thread counts (a bounded spin, not OMP_WAIT_POLICY=active: a team that spins for
 # ever would sit on the cores the GPU legs' host threads need)
 os.environ.setdefault("GOMP_SPINCOUNT", "300000")
+# sixteen groups of pairs run on sixteen HIP streams; the runtime's default of four hardware queues would serialise them four deep.  Read
+# once, when HIP initialises, so it is set before torch is imported (locus_amd/__init__.py does the same for any user of the package;
+# lh_api.hip lh_runtime_defaults for a C++ host).  Reported in the JSON line as config.gpu_max_hw_queues.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 
 import ctypes as C
 
@@ -732,6 +736,7 @@ def main():
             "cost_mode": args.cost_mode, "mean_cost_evaluations_per_pair": passes, "max_translation_err_vs_truth_m": float(np.max(errs)),
             "roofline": roofline,
             "pairs_in_flight_per_gpu": min(args.in_flight, pairs_here),
+            "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),   # HIP runtime setting (streams -> hardware queues), set at the top of this file
         }
         if strong is not None:
             result["strong_scaling_same_pairs"] = strong

@@ -95,6 +95,15 @@ void lh_default_gicp_params(lh_gicp_params* p) {
   p->solver = 0;
 }
 
+// The scheduler keeps up to sixteen groups of pairs in flight, each on its own HIP stream, and counts on their kernels overlapping (one
+// group's single-workgroup k_solve under the other groups' sweeps).  The HIP runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues --
+// four by default -- and streams that share a queue run one after the other.  Measured on the 512-pair bench queue: 4 / 8 / 16 / 24 / 32 / 64
+// queues -> 9 740 / 10 150 / 10 990 / 12 220 / 12 140 / 12 180 pairs/s (round 4).  The runtime reads the variable when it initialises, i.e. at
+// the process's first HIP call, so it is set here, when the library is loaded, unless the deployment already chose a value; a process that
+// initialised HIP before loading this library keeps whatever it had ("knobs").
+// (priority 101: before this library's own kernel registration)
+__attribute__((constructor(101))) static void lh_runtime_defaults() { (void)setenv("GPU_MAX_HW_QUEUES", "24", 0); }
+
 lh_status lh_create(lh_ctx** out, int device_id) {
   if (!out) return LH_EINVAL;
   int ndev = 0;
