@@ -579,6 +579,16 @@ struct SweepPoint {
 // while the certificate and the neighbour record of this workspace slot are a former pair's: neither is read, every point searches,
 // and the record is (re)written whatever the search finds.  (The seed pass used to write a zero certificate and the record for every
 // point: 52 B per source point of stores, 110 us per 32 pairs, for one sweep's use.)
+// The neighbour record of a source point -- position and normal of target point prev_nn[i] -- as two planes of packed 12-byte triples
+// (PairDesc::rec: positions at rec, normals at rec + 3 n_pad): a wave's load is 768 contiguous bytes, and the late sweeps, which stream the
+// record of every point once per iteration and are bound by exactly that stream, read 24 bytes per point instead of two float4.
+struct __attribute__((packed, aligned(4))) Pk3 { float x, y, z; };
+__device__ __forceinline__ float4 rec_pos(const PairDesc& d, int i) { const Pk3 v = gld(reinterpret_cast<const Pk3*>(d.rec) + i); return make_float4(v.x, v.y, v.z, 0.f); }
+__device__ __forceinline__ float4 rec_nrm(const PairDesc& d, int i) { const Pk3 v = gld(reinterpret_cast<const Pk3*>(d.rec + 3 * (size_t)d.n_pad) + i); return make_float4(v.x, v.y, v.z, 0.f); }
+__device__ __forceinline__ void rec_put(const PairDesc& d, int i, const float4& t, const float4& tn) {
+  gst(reinterpret_cast<Pk3*>(d.rec) + i, Pk3{t.x, t.y, t.z});
+  gst(reinterpret_cast<Pk3*>(d.rec + 3 * (size_t)d.n_pad) + i, Pk3{tn.x, tn.y, tn.z});
+}
 template <bool kRank1 = false, int kStride = 256>
 __device__ __forceinline__ void sweep_point(const PairDesc& d, const float* __restrict__ T, int i, uint64_t* stack, SweepPoint& o, float cm, bool cold = false) {
   // first round of loads: everything whose address only depends on i goes out together (the certificate and, in the fused
@@ -595,8 +605,8 @@ __device__ __forceinline__ void sweep_point(const PairDesc& d, const float* __re
     // ... and so does the candidate itself: rec[i] holds the position and normal of target point prev_nn[i] (kept in step with
     // prev_nn by every writer), so the gather through w -- a second, dependent memory round -- is gone from every sweep
     if (!cold) {
-      t = gld(d.rec + 2 * (size_t)i);
-      tn = gld(d.rec + 2 * (size_t)i + 1);
+      t = rec_pos(d, i);
+      tn = rec_nrm(d, i);
     } else if (w >= 0)
       t = gld(d.tgt_xyz + w);   // the seed: its position only (it is a bound, not yet a neighbour)
   }
@@ -626,7 +636,8 @@ __device__ __forceinline__ void sweep_point(const PairDesc& d, const float* __re
   o.searched = need_search;
   if (need_search) {
     tree_search<Nn1CertCollector, true>(tv, qx, qy, qz, col, stack, kStride);
-    gst(d.cert + i, make_float4(qx, qy, qz, col.lb));
+    // (a search that found nothing -- a non-finite query -- leaves a certificate that can never hold: k_late tests it without reading prev_nn)
+    gst(d.cert + i, make_float4(qx, qy, qz, nn_index(col.bi, col.bd) >= 0 ? col.lb : -1.0f));
     if (d.stats) atomicAdd(&d.stats[0], 1ull);  // instrumentation only (lh_gicp_debug_sweep): contended atomics
   }
   if (d.stats) atomicAdd(&d.stats[1], 1ull);
@@ -637,10 +648,7 @@ __device__ __forceinline__ void sweep_point(const PairDesc& d, const float* __re
     t = gld(d.tgt_xyz + j);
     if (d.tgt_nrm) tn = gld(d.tgt_nrm + j);
     if constexpr (kRank1) nn = gld(d.src_nrm + i);   // re-read after a walk, so that the normal is not live across it
-    if ((j != w || cold) && d.rec) {                 // the record follows prev_nn
-      gst(d.rec + 2 * (size_t)i, t);
-      gst(d.rec + 2 * (size_t)i + 1, tn);
-    }
+    if ((j != w || cold) && d.rec) rec_put(d, i, t, tn);   // the record follows prev_nn
   }
   o.j = j;
   o.matched = j >= 0 && (double)col.bd < d.corr_dist2;  // gicp.hpp:483
@@ -858,10 +866,12 @@ __device__ __forceinline__ void gram_accumulate(double* wl, const double (&av)[1
     for (int s = 0; s < 2; s++) {  // sixteen points per step: block b takes points 16 s + 4 b .. + 3
       const double* row = wl + (16 * s + 4 * b + kk) * GRAM_RS;
       const double A0 = row[ij], A1 = row[4 + ij], A2 = (ij < 3) ? row[8 + ij] : 0.0;
-      const double x = row[11], y = row[12], z = row[13], o = row[14];
-      const double u = ij == 0 ? x : (ij == 1 ? y : (ij == 2 ? z : o));     // C0: x y z 1
-      const double B1 = (ij == 3 ? y : x) * (ij == 3 ? y : u);             // C1: xx xy xz yy
-      const double B2 = ij == 0 ? y * z : (ij == 1 ? z * z : 0.0);         // C2: yz zz 0 0
+      // the lane's operands of b are fetched from the staged row at per-lane offsets (x y z 1 sit at 11..14) rather than picked out of
+      // all four by compare-and-select: sixteen v_cndmask per step were a seventh of the late sweep's vector instructions
+      const double u = row[11 + ij];                                       // C0: x y z 1
+      const double B1 = row[ij == 3 ? 12 : 11] * row[ij == 3 ? 12 : 11 + ij];   // C1: xx xy xz yy
+      const double yz = row[ij == 1 ? 13 : 12] * row[13];
+      const double B2 = ij < 2 ? yz : 0.0;                                 // C2: yz zz 0 0
       g.t[0] = __builtin_amdgcn_mfma_f64_4x4x4f64(A0, u, g.t[0], 0, 0, 0);
       g.t[1] = __builtin_amdgcn_mfma_f64_4x4x4f64(A0, B1, g.t[1], 0, 0, 0);
       g.t[2] = __builtin_amdgcn_mfma_f64_4x4x4f64(A0, B2, g.t[2], 0, 0, 0);
@@ -1080,23 +1090,21 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))
   bool walker = false, matched = false;
   float4 p = make_float4(0.f, 0.f, 0.f, 0.f), nn = p, t = p, tn = p;
   if (i < d.n) {
-    // ONE round of loads: the point, its normal, its neighbour's index, the certificate of the last search and the neighbour itself
+    // ONE round of loads: the point, its normal, the certificate of the last search and the neighbour's record -- 72 bytes per point
+    // (the neighbour's index is not needed: a point without a neighbour carries a negative bound in its certificate)
     p = gld(d.src + i);
-    const int w = gld(d.prev_nn + i);
     const float4 cq = gld(d.cert + i);
     nn = gld(d.src_nrm + i);
-    t = gld(d.rec + 2 * (size_t)i);
-    tn = gld(d.rec + 2 * (size_t)i + 1);
+    t = rec_pos(d, i);
+    tn = rec_nrm(d, i);
     float qx, qy, qz;
     xform_pt(T, p.x, p.y, p.z, qx, qy, qz);  // gicp.hpp:469
-    bool ok = false;
-    float bd = 0.f;
-    if (w >= 0) {  // the certificate test of sweep_point: the neighbour of the last search is provably still the nearest
-      bd = d2f(qx, qy, qz, t.x, t.y, t.z);
-      float e = sqrt_bound(d2f(qx, qy, qz, cq.x, cq.y, cq.z));
-      float dw = sqrt_bound(bd), lo = sqrt_bound(cq.w);
-      ok = dw * (1.0f + a.cert_rel) + e * (1.0f + a.cert_rel) + 1e-12f < lo * (1.0f - a.cert_rel);
-    }
+    // the certificate test of sweep_point: the neighbour of the last search is provably still the nearest
+    const float bd = d2f(qx, qy, qz, t.x, t.y, t.z);
+    const float e = sqrt_bound(d2f(qx, qy, qz, cq.x, cq.y, cq.z));
+    const float dw = sqrt_bound(bd), lo = sqrt_bound(cq.w);
+    // (one test, no branch: a short-circuit on the sign made the compiler fetch the certificate in two dependent rounds)
+    const bool ok = (int)(cq.w >= 0.0f) & (int)(dw * (1.0f + a.cert_rel) + e * (1.0f + a.cert_rel) + 1e-12f < lo * (1.0f - a.cert_rel));
     walker = !ok;
     matched = ok && (double)bd < d.corr_dist2;  // gicp.hpp:483
   }
@@ -1206,8 +1214,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) k
         if (idle) {
           if (qi >= 0) {  // the search that has just ended: its neighbour and certificate
             const int i = i0 + qi;
-            gst(d.cert + i, make_float4(qx, qy, qz, col.lb));
-            gst(d.prev_nn + i, nn_index(col.bi, col.bd));
+            const int j = nn_index(col.bi, col.bd);
+            gst(d.cert + i, make_float4(qx, qy, qz, j >= 0 ? col.lb : -1.0f));
+            gst(d.prev_nn + i, j);
             qi = -1;
           }
           const int slot = head + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(im >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)im, 0u));
@@ -1219,7 +1228,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) k
             xform_pt(T, p.x, p.y, p.z, qx, qy, qz);  // gicp.hpp:469
             col = Nn1CertCollector{INFINITY, 0x7fffffff, INFINITY};
             if (w >= 0) {  // warm start: the previous neighbour is a valid candidate => tight initial bound, still exact
-              const float4 t0 = gld(d.rec + 2 * (size_t)i);
+              const float4 t0 = rec_pos(d, i);
               col.bd = d2f(qx, qy, qz, t0.x, t0.y, t0.z);
               col.bi = w;
             }
@@ -1260,8 +1269,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) k
       if (j >= 0) {
         t = gld(d.tgt_xyz + j);
         tn = gld(d.tgt_nrm + j);
-        gst(d.rec + 2 * (size_t)i, t);   // the record follows prev_nn
-        gst(d.rec + 2 * (size_t)i + 1, tn);
+        rec_put(d, i, t, tn);   // the record follows prev_nn
         float qx, qy, qz;
         xform_pt(T, p.x, p.y, p.z, qx, qy, qz);
         matched = (double)d2f(qx, qy, qz, t.x, t.y, t.z) < d.corr_dist2;  // gicp.hpp:483 (the same float the search ended with)

@@ -28,9 +28,9 @@ struct PairDesc {
   const NodeX* tgt_nodes;
   const TreeHeader* tgt_hdr;
   int32_t* prev_nn;         // warm-start NN index per source point                      [n]
-  float4* cert;             // (query x,y,z at the last full search, lower bound on the other points' d2) [n]
-  float4* rec;              // per source point the neighbour prev_nn points at, gathered: (tgt xyz, id), (tgt normal, curvature) [2 n]
-                            // -- written whenever prev_nn changes, so a sweep whose certificates hold reads ONE round of loads
+  float4* cert;             // (query x,y,z at the last full search, lower bound on the other points' d2; < 0: that search found no neighbour) [n]
+  float* rec;               // per source point the neighbour prev_nn points at, gathered: positions as packed triples [3 n_pad], then the
+                            // normals [3 n_pad] -- written whenever prev_nn changes, so a sweep whose certificates hold reads ONE round of loads
   unsigned long long* stats; // [0] += queries that ran the tree traversal, [1] += queries (instrumentation)
   float4* corr;             // per source point: (tgt x, y, z, bitcast tgt idx | -1)     [n]
   double* maha6;            // 6 planes of n_pad doubles: M00 M01 M02 M11 M12 M22

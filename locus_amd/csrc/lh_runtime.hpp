@@ -128,7 +128,7 @@ struct Workspace {
   double* maha6 = nullptr;
   int32_t* prev_nn = nullptr;
   float4* cert = nullptr;     // NN certificates (see Nn1CertCollector)
-  float4* rec = nullptr;      // the neighbour prev_nn points at, gathered (position, normal): 2 float4 per source point
+  float* rec = nullptr;       // the neighbour prev_nn points at, gathered: positions then normals, packed triples (PairDesc::rec)
   unsigned long long* stats = nullptr;  // 2 counters
   float4* out_xyz = nullptr;  // guess * input when guess != I
   int n_pad = 0;

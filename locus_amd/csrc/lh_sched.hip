@@ -15,7 +15,7 @@ lh_status Workspace::ensure(lh_ctx* c, int n) {
   HIPCHK(hipMalloc(&prev_nn, sizeof(int32_t) * (size_t)ncap));
   HIPCHK(hipMalloc(&out_xyz, sizeof(float4) * (size_t)ncap));
   HIPCHK(hipMalloc(&cert, sizeof(float4) * (size_t)ncap));
-  HIPCHK(hipMalloc(&rec, sizeof(float4) * 2 * (size_t)ncap));
+  HIPCHK(hipMalloc(&rec, sizeof(float) * 6 * (size_t)ncap));   // two planes of packed triples (PairDesc::rec)
   if (!stats) { HIPCHK(hipMalloc(&stats, 16)); HIPCHK(hipMemset(stats, 0, 16)); }
   cap = ncap;
   n_pad = ncap;
