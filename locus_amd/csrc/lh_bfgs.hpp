@@ -579,12 +579,31 @@ struct OuterState {
   int n_corr_last, passes, n_inner, pad;
   double f_end, delta;
   double corr_sum;  // correspondences summed over the iterations (instrumentation: the algorithmic bytes of SURVEY 8d scale with it)
+  // T in the form the late sweeps (k_late) use it, made by whoever sets T (pose_of_transform below): eighteen doubles every wave would
+  // otherwise re-derive from the floats with vector instructions, read there with scalar loads into SGPRs
+  double poseT[12];  // double(T), row-major 3x4
+  double poseG[6];   // R R^T + I of its rotation block: 00 01 02 11 12 22
 };
+// (explicit fused multiply-adds: the sweep kernels derive the same values from the same floats and must get the same bits)
+LH_FN void pose_of_transform(const float* T12, double* poseT, double* poseG) {   // T12: row-major 3x4
+#pragma unroll
+  for (int k = 0; k < 12; k++) poseT[k] = (double)T12[k];
+  int q = 0;
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int c = r; c < 3; c++) {
+      const double rr = __builtin_fma(poseT[r * 4 + 2], poseT[c * 4 + 2], __builtin_fma(poseT[r * 4 + 1], poseT[c * 4 + 1], poseT[r * 4 + 0] * poseT[c * 4 + 0]));
+      poseG[q++] = r == c ? rr + 1.0 : rr;
+    }
+}
 LH_FN void outer_state_init(OuterState* s) {
 #pragma unroll
   for (int i = 0; i < 16; i++) { s->T[i] = (i % 5 == 0) ? 1.0f : 0.0f; s->prev[i] = s->T[i]; }  // align() resets transformation_ to identity
   s->iter = 0; s->done = 0; s->converged = 0; s->status = 0; s->n_corr_last = 0; s->passes = 0; s->n_inner = 0; s->pad = 0;
   s->f_end = 0.0; s->delta = 0.0; s->corr_sum = 0.0;
+  const float I12[12] = {1.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f};
+  pose_of_transform(I12, s->poseT, s->poseG);
 }
 // fn = the functor of THIS iteration's correspondences (a fresh cache)
 template <class Fn, class M>

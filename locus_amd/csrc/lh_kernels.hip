@@ -579,6 +579,64 @@ struct SweepPoint {
 // while the certificate and the neighbour record of this workspace slot are a former pair's: neither is read, every point searches,
 // and the record is (re)written whatever the search finds.  (The seed pass used to write a zero certificate and the record for every
 // point: 52 B per source point of stores, 110 us per 32 pairs, for one sweep's use.)
+// ---- cost_mode 1 with covariances from normals: the per-point terms, ONE implementation for the fused sweep, k_late and k_walk ----------
+// (the translation unit is compiled without FMA contraction because the float NN distances must round like the oracle's; this
+// double-precision evaluation exists only in cost_mode 1, whose parity bar is the reference's own FMA / non-FMA floor.  The fused
+// multiply-adds are written out: which kernel evaluates a point depends on the iteration, and every one of them must produce the same bits)
+struct PoseD { double T[12]; double G[6]; };   // OuterState::poseT / poseG
+__device__ __forceinline__ void pose_from_T(const float* T, PoseD& P) { pose_of_transform(T, P.T, P.G); }
+// 1 / d to (nearly) the last bit without the correctly-rounded division's ten instructions: v_rcp_f64 is good to 2^-23, two Newton steps
+// square that twice.  d is the determinant of a symmetric positive definite matrix of order one: no scaling, no special cases.
+__device__ __forceinline__ double rcp_newton(double d) {
+  double r = __builtin_amdgcn_rcp(d);
+  r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+  r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+  return r;
+}
+// The Mahalanobis matrix M = (C2 + R C1 R^T)^-1 (gicp.hpp:488-493) for C = I - (1 - eps) n n^T / |n|^2 (cov_from_normal), rank-one form:
+//   A = (R R^T + I) - k1 u u^T - k2 v v^T,  u = R n1, v = n2, k_i = (1 - eps) / |n_i|^2 (0 for a zero / non-finite normal: C = I).
+// Evaluated as l1 l2 A = l1 l2 G - (kap l2) u u^T - (kap l1) v v^T and M = l1 l2 cof / det: ONE reciprocal instead of three divisions.
+// G = R R^T + I comes with the pose (uniform over the wave).  M6: 00 01 02 11 12 22.
+__device__ __forceinline__ void maha_rank1(const double* R, int rs, const double* G, double kap, const float4& nn, const float4& tn, double (&M6)[6]) {
+  const double n1[3] = {(double)nn.x, (double)nn.y, (double)nn.z}, v[3] = {(double)tn.x, (double)tn.y, (double)tn.z};
+  const double l1 = __builtin_fma(n1[2], n1[2], __builtin_fma(n1[1], n1[1], n1[0] * n1[0]));
+  const double l2 = __builtin_fma(v[2], v[2], __builtin_fma(v[1], v[1], v[0] * v[0]));
+  const bool ok1 = l1 > 0.0 && l1 < 1.0e300, ok2 = l2 > 0.0 && l2 < 1.0e300;
+  const double l1s = ok1 ? l1 : 1.0, l2s = ok2 ? l2 : 1.0;
+  const double w = l1s * l2s, a1 = ok1 ? kap * l2s : 0.0, a2 = ok2 ? kap * l1s : 0.0;
+  double u[3];
+#pragma unroll
+  for (int r = 0; r < 3; r++) u[r] = __builtin_fma(R[r * rs + 2], n1[2], __builtin_fma(R[r * rs + 1], n1[1], R[r * rs + 0] * n1[0]));
+  const double ku[3] = {a1 * u[0], a1 * u[1], a1 * u[2]}, kv[3] = {a2 * v[0], a2 * v[1], a2 * v[2]};
+  double A[6];
+  {
+    int q = 0;
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int cc = r; cc < 3; cc++) {
+        A[q] = __builtin_fma(-kv[r], v[cc], __builtin_fma(-ku[r], u[cc], w * G[q]));
+        q++;
+      }
+  }
+  // symmetric cofactors
+  const double c00 = __builtin_fma(A[3], A[5], -(A[4] * A[4])), c01 = __builtin_fma(A[2], A[4], -(A[1] * A[5])), c02 = __builtin_fma(A[1], A[4], -(A[2] * A[3]));
+  const double c11 = __builtin_fma(A[0], A[5], -(A[2] * A[2])), c12 = __builtin_fma(A[1], A[2], -(A[0] * A[4])), c22 = __builtin_fma(A[0], A[3], -(A[1] * A[1]));
+  const double det = __builtin_fma(A[2], c02, __builtin_fma(A[1], c01, A[0] * c00));
+  const double id = w * rcp_newton(det);
+  M6[0] = c00 * id; M6[1] = c01 * id; M6[2] = c02 * id; M6[3] = c11 * id; M6[4] = c12 * id; M6[5] = c22 * id;
+}
+// residual a = T p - t about the sweep's transform (gicp.hpp:382-384 in double), M a and a^T M a
+__device__ __forceinline__ void resid_terms(const double* T0, const double (&M6)[6], const double (&pt)[3], const float4& t, double (&Ma)[3], double& aMa) {
+  const double a0 = (__builtin_fma(T0[2], pt[2], __builtin_fma(T0[1], pt[1], T0[0] * pt[0])) + T0[3]) - (double)t.x;
+  const double a1 = (__builtin_fma(T0[6], pt[2], __builtin_fma(T0[5], pt[1], T0[4] * pt[0])) + T0[7]) - (double)t.y;
+  const double a2 = (__builtin_fma(T0[10], pt[2], __builtin_fma(T0[9], pt[1], T0[8] * pt[0])) + T0[11]) - (double)t.z;
+  Ma[0] = __builtin_fma(M6[2], a2, __builtin_fma(M6[1], a1, M6[0] * a0));
+  Ma[1] = __builtin_fma(M6[4], a2, __builtin_fma(M6[3], a1, M6[1] * a0));
+  Ma[2] = __builtin_fma(M6[5], a2, __builtin_fma(M6[4], a1, M6[2] * a0));
+  aMa = __builtin_fma(a2, Ma[2], __builtin_fma(a1, Ma[1], a0 * Ma[0]));
+}
+
 // The neighbour record of a source point -- position and normal of target point prev_nn[i] -- as two planes of packed 12-byte triples
 // (PairDesc::rec: positions at rec, normals at rec + 3 n_pad): a wave's load is 768 contiguous bytes, and the late sweeps, which stream the
 // record of every point once per iteration and are bound by exactly that stream, read 24 bytes per point instead of two float4.
@@ -669,37 +727,21 @@ __device__ __forceinline__ void sweep_point(const PairDesc& d, const float* __re
                            (double)T[r * 4 + 2] * d.guess3[2 * 3 + cc]) + (double)T[r * 4 + 3] * 0.0;
     }
     if constexpr (kRank1) {  // (the launch guarantees that neither cloud of any job carries k-NN covariances)
-#pragma clang fp contract(fast)   // see point_terms
-      const double kap = 1.0 - d.gicp_eps;
-      double n1[3] = {(double)nn.x, (double)nn.y, (double)nn.z}, v[3] = {(double)tn.x, (double)tn.y, (double)tn.z};
-      double l1 = (n1[0] * n1[0] + n1[1] * n1[1]) + n1[2] * n1[2], l2 = (v[0] * v[0] + v[1] * v[1]) + v[2] * v[2];
-      double k1 = (l1 > 0.0 && l1 < 1.0e300) ? kap / l1 : 0.0;   // zero / non-finite normal => C = I (cov_from_normal)
-      double k2 = (l2 > 0.0 && l2 < 1.0e300) ? kap / l2 : 0.0;
-      double u[3];
-#pragma unroll
-      for (int r = 0; r < 3; r++) u[r] = (R[r * 3 + 0] * n1[0] + R[r * 3 + 1] * n1[1]) + R[r * 3 + 2] * n1[2];
-      double ku[3] = {k1 * u[0], k1 * u[1], k1 * u[2]}, kv[3] = {k2 * v[0], k2 * v[1], k2 * v[2]};
-      // A = R R^T + I - ku u^T - kv v^T, symmetric: (00 01 02 11 12 22)
-      double A[6];
+      double G[6], M6[6];
       {
         int q = 0;
 #pragma unroll
         for (int r = 0; r < 3; r++)
 #pragma unroll
-          for (int cc = r; cc < 3; cc++) {
-            double rr = (R[r * 3 + 0] * R[cc * 3 + 0] + R[r * 3 + 1] * R[cc * 3 + 1]) + R[r * 3 + 2] * R[cc * 3 + 2];
-            if (r == cc) rr += 1.0;
-            A[q++] = (rr - ku[r] * u[cc]) - kv[r] * v[cc];
+          for (int cc = r; cc < 3; cc++) {   // R R^T + I, like pose_of_transform (R = double(T) when the guess is the identity)
+            const double rr = __builtin_fma(R[r * 3 + 2], R[cc * 3 + 2], __builtin_fma(R[r * 3 + 1], R[cc * 3 + 1], R[r * 3 + 0] * R[cc * 3 + 0]));
+            G[q++] = r == cc ? rr + 1.0 : rr;
           }
       }
-      // symmetric cofactor inverse
-      double c00 = A[3] * A[5] - A[4] * A[4], c01 = A[2] * A[4] - A[1] * A[5], c02 = A[1] * A[4] - A[2] * A[3];
-      double c11 = A[0] * A[5] - A[2] * A[2], c12 = A[1] * A[2] - A[0] * A[4], c22 = A[0] * A[3] - A[1] * A[1];
-      double det = (A[0] * c00 + A[1] * c01) + A[2] * c02;
-      double id = 1.0 / det;
-      o.M[0] = c00 * id; o.M[1] = c01 * id; o.M[2] = c02 * id;
-      o.M[3] = o.M[1];   o.M[4] = c11 * id; o.M[5] = c12 * id;
-      o.M[6] = o.M[2];   o.M[7] = o.M[5];   o.M[8] = c22 * id;
+      maha_rank1(R, 3, G, 1.0 - d.gicp_eps, nn, tn, M6);
+      o.M[0] = M6[0]; o.M[1] = M6[1]; o.M[2] = M6[2];
+      o.M[3] = M6[1]; o.M[4] = M6[3]; o.M[5] = M6[4];
+      o.M[6] = M6[2]; o.M[7] = M6[4]; o.M[8] = M6[5];
       o.tgt = t;
       return;
     }
@@ -761,19 +803,17 @@ __device__ __forceinline__ double mom_value(int k, const double* M6, const doubl
 }
 // the moment contributions of one matched point, added to acc[0..73] (acc must be zero-initialised by the caller)
 __device__ __forceinline__ void moments_of_point(const float* __restrict__ T, const SweepPoint& sp, double* M6, double* Ma, double& aMa, double* pt, double* pp) {
-#pragma clang fp contract(fast)   // see point_terms (cost_mode 1 only)
   pt[0] = (double)sp.p.x; pt[1] = (double)sp.p.y; pt[2] = (double)sp.p.z; pt[3] = 1.0;
   double T0[12];
 #pragma unroll
   for (int k = 0; k < 12; k++) T0[k] = (double)T[k];
-  double a0 = (((T0[0] * pt[0] + T0[1] * pt[1]) + T0[2] * pt[2]) + T0[3]) - (double)sp.tgt.x;
-  double a1 = (((T0[4] * pt[0] + T0[5] * pt[1]) + T0[6] * pt[2]) + T0[7]) - (double)sp.tgt.y;
-  double a2 = (((T0[8] * pt[0] + T0[9] * pt[1]) + T0[10] * pt[2]) + T0[11]) - (double)sp.tgt.z;
-  M6[0] = sp.M[0]; M6[1] = sp.M[1]; M6[2] = sp.M[2]; M6[3] = sp.M[4]; M6[4] = sp.M[5]; M6[5] = sp.M[8];
-  Ma[0] = (M6[0] * a0 + M6[1] * a1) + M6[2] * a2;
-  Ma[1] = (M6[1] * a0 + M6[3] * a1) + M6[4] * a2;
-  Ma[2] = (M6[2] * a0 + M6[4] * a1) + M6[5] * a2;
-  aMa = (a0 * Ma[0] + a1 * Ma[1]) + a2 * Ma[2];
+  const double m6[6] = {sp.M[0], sp.M[1], sp.M[2], sp.M[4], sp.M[5], sp.M[8]};
+  const double p3[3] = {pt[0], pt[1], pt[2]};
+  double ma[3];
+  resid_terms(T0, m6, p3, sp.tgt, ma, aMa);
+#pragma unroll
+  for (int k = 0; k < 6; k++) M6[k] = m6[k];
+  Ma[0] = ma[0]; Ma[1] = ma[1]; Ma[2] = ma[2];
   int t = 0;
 #pragma unroll
   for (int cc = 0; cc < 4; cc++)
@@ -1021,59 +1061,35 @@ __global__ void __launch_bounds__(FUSED_WG) __attribute__((amdgpu_waves_per_eu(6
 // (1.2 -> 1.5 ms for 20 iterations).  Tried and dropped: the walks inside k_late by the last wave of a span to finish (a device-wide counter
 // needs agent-scope release/acquire = L2 write-back: 1.4 ms per launch; a workgroup-wide one keeps the workgroup's LDS and
 // registers while one wave walks: walking iterations 40 % slower).
-// Mahalanobis matrix (rank-one form, see sweep_point<true>) and moment operands of one matched pair of points; guess = I
-__device__ __forceinline__ void point_terms(const PairDesc& d, const float* __restrict__ T, const float4& p, const float4& nn, const float4& t,
-                                            const float4& tn, double (&av)[11]) {
-  // (the translation unit is compiled without FMA contraction because the float NN distances must round like the oracle's; this
-  // double-precision evaluation exists only here, in cost_mode 1, whose parity bar is the reference's own FMA / non-FMA floor:
-  // fused multiply-adds are a quarter fewer vector instructions in a kernel that sits at 70 % of its VALU bound)
-#pragma clang fp contract(fast)
-  double R[9];
-#pragma unroll
-  for (int r = 0; r < 3; r++)
-#pragma unroll
-    for (int cc = 0; cc < 3; cc++) R[r * 3 + cc] = (double)T[r * 4 + cc];
-  const double kap = 1.0 - d.gicp_eps;
-  double n1[3] = {(double)nn.x, (double)nn.y, (double)nn.z}, v[3] = {(double)tn.x, (double)tn.y, (double)tn.z};
-  double l1 = (n1[0] * n1[0] + n1[1] * n1[1]) + n1[2] * n1[2], l2 = (v[0] * v[0] + v[1] * v[1]) + v[2] * v[2];
-  double k1 = (l1 > 0.0 && l1 < 1.0e300) ? kap / l1 : 0.0;   // zero / non-finite normal => C = I (cov_from_normal)
-  double k2 = (l2 > 0.0 && l2 < 1.0e300) ? kap / l2 : 0.0;
-  double u[3];
-#pragma unroll
-  for (int r = 0; r < 3; r++) u[r] = (R[r * 3 + 0] * n1[0] + R[r * 3 + 1] * n1[1]) + R[r * 3 + 2] * n1[2];
-  double ku[3] = {k1 * u[0], k1 * u[1], k1 * u[2]}, kv[3] = {k2 * v[0], k2 * v[1], k2 * v[2]};
-  double A[6];
-  {
-    int q = 0;
-#pragma unroll
-    for (int r = 0; r < 3; r++)
-#pragma unroll
-      for (int cc = r; cc < 3; cc++) {
-        double rr = (R[r * 3 + 0] * R[cc * 3 + 0] + R[r * 3 + 1] * R[cc * 3 + 1]) + R[r * 3 + 2] * R[cc * 3 + 2];
-        if (r == cc) rr += 1.0;
-        A[q++] = (rr - ku[r] * u[cc]) - kv[r] * v[cc];
-      }
-  }
-  double c00 = A[3] * A[5] - A[4] * A[4], c01 = A[2] * A[4] - A[1] * A[5], c02 = A[1] * A[4] - A[2] * A[3];
-  double c11 = A[0] * A[5] - A[2] * A[2], c12 = A[1] * A[2] - A[0] * A[4], c22 = A[0] * A[3] - A[1] * A[1];
-  double det = (A[0] * c00 + A[1] * c01) + A[2] * c02;
-  double id = 1.0 / det;
-  const double M6[6] = {c00 * id, c01 * id, c02 * id, c11 * id, c12 * id, c22 * id};
-  // residual about T0 = T (double), M a, a^T M a
-  double pt[3] = {(double)p.x, (double)p.y, (double)p.z};
-  double a0 = ((((double)T[0] * pt[0] + (double)T[1] * pt[1]) + (double)T[2] * pt[2]) + (double)T[3]) - (double)t.x;
-  double a1 = ((((double)T[4] * pt[0] + (double)T[5] * pt[1]) + (double)T[6] * pt[2]) + (double)T[7]) - (double)t.y;
-  double a2 = ((((double)T[8] * pt[0] + (double)T[9] * pt[1]) + (double)T[10] * pt[2]) + (double)T[11]) - (double)t.z;
-  double Ma0 = (M6[0] * a0 + M6[1] * a1) + M6[2] * a2;
-  double Ma1 = (M6[1] * a0 + M6[3] * a1) + M6[4] * a2;
-  double Ma2 = (M6[2] * a0 + M6[4] * a1) + M6[5] * a2;
+// Mahalanobis matrix (maha_rank1) and moment operands of one matched pair of points; guess = I
+__device__ __forceinline__ void point_terms(const PairDesc& d, const PoseD& P, const float4& p, const float4& nn, const float4& t, const float4& tn, double (&av)[11]) {
+  double M6[6], Ma[3], aMa;
+  maha_rank1(P.T, 4, P.G, 1.0 - d.gicp_eps, nn, tn, M6);
+  const double pt[3] = {(double)p.x, (double)p.y, (double)p.z};
+  resid_terms(P.T, M6, pt, t, Ma, aMa);
 #pragma unroll
   for (int k = 0; k < 6; k++) av[k] = M6[k];
-  av[6] = Ma0; av[7] = Ma1; av[8] = Ma2;
-  av[9] = (a0 * Ma0 + a1 * Ma1) + a2 * Ma2;
+  av[6] = Ma[0]; av[7] = Ma[1]; av[8] = Ma[2];
+  av[9] = aMa;
   av[10] = 1.0;
 }
+// the pose of a pair in the device-driven loop: k_solve left it in the pair's state (scalar loads, like job_transform's)
+__device__ __forceinline__ void pose_load(const SweepJob& job, const OuterState* __restrict__ states, PoseD& P) {
+  typedef const __attribute__((address_space(4))) OuterState* ConstState;
+  ConstState st = (ConstState)(uintptr_t)(states + job.slot);
+#pragma unroll
+  for (int k = 0; k < 12; k++) P.T[k] = st->poseT[k];
+#pragma unroll
+  for (int k = 0; k < 6; k++) P.G[k] = st->poseG[k];
+  // (pinned here: left alone the compiler sinks the loads into the matched-points branch, where every wave then waits for them)
+#pragma unroll
+  for (int k = 0; k < 12; k++) asm volatile("" : "+s"(P.T[k]));
+#pragma unroll
+  for (int k = 0; k < 6; k++) asm volatile("" : "+s"(P.G[k]));
+}
 
+// kDev: launched by the device-driven loop (states != nullptr) -- the pose comes from the pair's state instead of being derived per wave
+template <bool kDev>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) k_late(const PairDesc* __restrict__ descs, SweepArgs a, double* __restrict__ partials,
                                                                                    int partials_stride, const OuterState* __restrict__ states,
                                                                                    unsigned long long* __restrict__ wmask, int mask_stride) {
@@ -1085,6 +1101,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))
   if (blk * 256 >= d.n) return;
   float T[12];
   if (!job_transform(job, states, T)) return;
+  PoseD P;
+  if constexpr (kDev) pose_load(job, states, P);   // (scalar loads, issued beside the transform's)
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int i = blk * 256 + tid;
   bool walker = false, matched = false;
@@ -1124,8 +1142,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))
     if (lane < MOM_ROW - 64) myrow[64 + lane] = (lane == MOM_NSUM - 64) ? (double)__popcll(mask) : 0.0;
   } else {
     double av[11];
-    if (matched) point_terms(d, T, p, nn, t, tn, av);  // gicp.hpp:488-498
-    else {
+    if (matched) {   // gicp.hpp:488-498
+      if constexpr (!kDev) pose_from_T(T, P);
+      point_terms(d, P, p, nn, t, tn, av);
+    } else {
 #pragma unroll
       for (int k = 0; k < 11; k++) av[k] = 0.0;
     }
@@ -1284,8 +1304,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) k
       asm volatile("" : "+s"(Tl[k]));
     }
     double av[11];
-    if (matched) point_terms(d, Tl, p, nn, t, tn, av);
-    else {
+    if (matched) {
+      PoseD P;
+      pose_from_T(Tl, P);
+      point_terms(d, P, p, nn, t, tn, av);
+    } else {
 #pragma unroll
       for (int k = 0; k < 11; k++) av[k] = 0.0;
       if (nonn) av[10] = NO_NN_MARK;
@@ -1338,8 +1361,12 @@ void launch_sweep_fused(const PairDesc* descs, SweepArgs& a, uint32_t split_mask
   }
   if (sp.njobs > 0) {
     sp.bpj = (max_n + 255) / 256;
-    hipLaunchKernelGGL(k_late, dim3(xcd_grid(sp.njobs, sp.bpj)), dim3(256), sizeof(double) * 4 * 32 * GRAM_RS, s, descs, sp, partials_dev, partials_stride, states,
-                       wmask, mask_stride);
+    if (states)
+      hipLaunchKernelGGL(k_late<true>, dim3(xcd_grid(sp.njobs, sp.bpj)), dim3(256), sizeof(double) * 4 * 32 * GRAM_RS, s, descs, sp, partials_dev, partials_stride, states,
+                         wmask, mask_stride);
+    else
+      hipLaunchKernelGGL(k_late<false>, dim3(xcd_grid(sp.njobs, sp.bpj)), dim3(256), sizeof(double) * 4 * 32 * GRAM_RS, s, descs, sp, partials_dev, partials_stride, states,
+                         wmask, mask_stride);
     sp.bpj = ((max_n + sp.span - 1) / sp.span + 3) / 4;
     hipLaunchKernelGGL(k_walk, dim3(xcd_grid(sp.njobs, sp.bpj)), dim3(256), 0, s, descs, sp, partials_dev, partials_stride, states, wmask, mask_stride);
   }
@@ -1625,6 +1652,14 @@ __global__ void __launch_bounds__(64) k_solve(const PairDesc* __restrict__ descs
   const int before = s.passes, it = s.iter;
   outer_step<Fn, PortableMath>(&fn, P, &s);
   s.corr_sum += mom.count();
+  {  // the next sweep's transform as doubles (k_late reads them with scalar loads)
+    float T12[12];
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int c = 0; c < 4; c++) T12[r * 4 + c] = s.T[c * 4 + r];
+    pose_of_transform(T12, s.poseT, s.poseG);
+  }
   if (lane == 0) {
     *sp = s;
     lh_gicp_trace* tr = d->trace;
