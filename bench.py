@@ -49,7 +49,8 @@ def _pool_map(fn, jobs, workers, chunk):
     pool = mp.get_context("fork").Pool(workers)
     try:
         res = pool.map_async(fn, jobs, chunksize=chunk).get(timeout=60.0 + 1.0 * len(jobs))
-        pool.close()
+        pool.terminate()   # (the results are in: nothing of the pool is left for interpreter exit to wait on)
+        pool.join()
         return res
     except mp.TimeoutError:
         print("[bench] worker pool stalled: generating %d scans in this process" % len(jobs), file=sys.stderr, flush=True)

@@ -58,7 +58,10 @@ __host__ __device__ __forceinline__ V gload16(const void* p) {
 namespace lh {
 
 constexpr int LEAF_CAP = 8;     // max points per leaf (128 B = one cache line of sorted points)
-constexpr int LDS_STACK = 12;   // traversal-stack entries (64-bit) a thread keeps in LDS; deeper entries spill to private memory
+#ifndef LH_LDS_STACK
+#define LH_LDS_STACK 12
+#endif
+constexpr int LDS_STACK = LH_LDS_STACK;   // traversal-stack entries (64-bit) a thread keeps in LDS; deeper entries spill to private memory (-DLH_LDS_STACK: A/B builds)
 constexpr int MAX_POINT_BITS = 27; // a cloud holds at most 2^27 points (leaf references keep 27 bits of sorted position; build_indices checks)
 constexpr int GRID_CELL_ROOTS = 3; // levels of the start grid (a cell root is kept as a child instead of being adopted: one 4-ary level for ONE binary level)
 // The traversal stack is unchecked.  Its structural bound: the binary radix tree is at most 30 key bits + MAX_POINT_BITS tie-break bits deep
@@ -66,7 +69,7 @@ constexpr int GRID_CELL_ROOTS = 3; // levels of the start grid (a cell root is k
 // at the (at most three) cell roots on a path => ceil((57 + 3) / 2) = 30 levels; a visit stacks at most 3 siblings and descends into the
 // fourth child => 3 * 30 + 1 = 91 entries for a walk from the root.  A walk that starts in the grid stacks <= 7 neighbour cells and then
 // begins at a level-5 cell root, >= 7 levels down: 7 + 3 * 23 + 1 = 77.  LDS_STACK + SPILL_MAX = 92.
-constexpr int SPILL_MAX = 80;
+constexpr int SPILL_MAX = 92 - LDS_STACK;   // (80 with the default LDS_STACK)
 constexpr int MAX_DEPTH = 12;   // (size of the instrumentation histogram; only slot 0 is used by the explicit tree)
 
 // child reference: >= 0 internal node index (cloud-local); < 0 leaf: ~ref = (first sorted position << 4) | (count - 1)

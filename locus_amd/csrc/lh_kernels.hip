@@ -984,7 +984,10 @@ __device__ __forceinline__ void wg_row_sum(const double* lds_rows, int wave_stri
 constexpr int FUSED_WG = LH_FUSED_WG;
 static_assert(FUSED_WG == 256 || FUSED_WG == 64, "LH_FUSED_WG");
 template <bool kNormals>
-__global__ void __launch_bounds__(FUSED_WG) __attribute__((amdgpu_waves_per_eu(6))) k_sweep_fused(const PairDesc* __restrict__ descs, SweepArgs a, double* __restrict__ partials,
+#ifndef LH_FUSED_WAVES
+#define LH_FUSED_WAVES 6
+#endif
+__global__ void __launch_bounds__(FUSED_WG) __attribute__((amdgpu_waves_per_eu(LH_FUSED_WAVES))) k_sweep_fused(const PairDesc* __restrict__ descs, SweepArgs a, double* __restrict__ partials,
                                                      int partials_stride, const OuterState* __restrict__ states) {
   extern __shared__ __attribute__((aligned(16))) uint64_t lds_stack[];  // [entries][FUSED_WG], later reused as the Gram staging rows
   int jb, blk;
