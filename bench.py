@@ -685,18 +685,19 @@ def main():
             avg_us = 1e3 * st["ms"] / max(1, st["launches"])
             model = st["bytes"] / 1e9 / (st["ms"] / 1e3) if st["ms"] > 0 else 0.0
             # The fraction is taken on what THIS design has to move: every sweep streams, per source point, the point (16 B), its normal (16), the
-            # neighbour index (4), the certificate (16) and the neighbour record (32) = 84 B -- whatever the certificates decide.  (The refresh
+            # certificate (16) and the neighbour record (24: two packed triples) = 72 B -- whatever the certificates decide (84 B until round 4's
+            # packed record; the fused sweeps of the first three iterations also read the neighbour index, 4 B).  (The refresh
             # writes of the points that walk and the tree nodes they visit come on top: `traffic` is the measured total.)  SURVEY 8d's byte model
             # also counts C1, C2 and M (216 of its 340 B per correspondence), which are never materialised here: a rate on THAT model can exceed
             # the peak and is kept as a labelled third figure, not as `frac`.
-            comp_bytes = 84.0 * n_pts * prof_in_flight if name == "nn_sweep" else st["bytes"] / max(1, st["launches"])
+            comp_bytes = 72.0 * n_pts * prof_in_flight if name == "nn_sweep" else st["bytes"] / max(1, st["launches"])
             achieved = comp_bytes / 1e9 / (avg_us * 1e-6) if avg_us > 0 else 0.0
             return name, st, stats, {
                 "bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "avg_launch_us": round(avg_us, 2), "launches": st["launches"],
                 "jobs_per_launch": prof_in_flight,
                 "bytes_per_launch": round(comp_bytes, 1),
-                "bytes_are": ("compulsory stream of this design: 84 B per source point per sweep (point, normal, neighbour index, certificate, neighbour record)"
+                "bytes_are": ("compulsory stream of this design: 72 B per source point per sweep (point, normal, certificate, neighbour record as two packed triples)"
                               if name == "nn_sweep" else "the launch's byte model (lh_profile)"),
                 "survey_8d_model": {"achieved": round(model, 2), "frac": round(model / HBM_PEAK_GBS, 5), "bytes_per_launch": round(st["bytes"] / max(1, st["launches"]), 1),
                                     "note": "20 N + 340 K_t with the measured K_t (SURVEY 8d's B_nn + B_fdf): counts covariance and Mahalanobis matrices this design never "
