@@ -91,6 +91,24 @@ def test_missing_library_fails_loudly():
     assert r.returncode != 0 and "no CPU fallback" in r.stderr.replace("\n", " ")
 
 
+def test_library_load_sets_the_hardware_queue_default_and_keeps_a_chosen_value():
+    """lh_api.hip lh_runtime_defaults: the scheduler's sixteen streams need more than the HIP runtime's default of four hardware queues;
+    the variable is read at the first HIP call, so the library sets it when it is loaded -- unless the deployment chose a value."""
+    code = ("import ctypes, os, sys\n"
+            "libc = ctypes.CDLL(None); libc.getenv.restype = ctypes.c_char_p\n"
+            "ctypes.CDLL(%r)\n"
+            "print(libc.getenv(b'GPU_MAX_HW_QUEUES').decode())" % os.path.join(ROOT, "locus_amd", "csrc", "liblocus_hip.so"))
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    r = subprocess.run(["python", "-c", code], capture_output=True, text=True, env=env)
+    assert r.returncode == 0 and r.stdout.strip() == "24", (r.stdout, r.stderr)
+    r = subprocess.run(["python", "-c", code], capture_output=True, text=True, env=dict(env, GPU_MAX_HW_QUEUES="6"))
+    assert r.returncode == 0 and r.stdout.strip() == "6", (r.stdout, r.stderr)
+    # the Python package does the same before anything can have initialised HIP
+    code2 = "import os, sys; sys.path.insert(0, %r); import locus_amd; print(os.environ['GPU_MAX_HW_QUEUES'])" % ROOT
+    r = subprocess.run(["python", "-c", code2], capture_output=True, text=True, env=env)
+    assert r.returncode == 0 and r.stdout.strip() == "24", (r.stdout, r.stderr)
+
+
 def test_host_side_covariance_conditioning_matches_oracle(capi, oracle):
     # lh_icp_covariance is 6x6 host arithmetic (H2) -- callable without a device
     rng = np.random.default_rng(5)
