@@ -957,4 +957,8 @@ if __name__ == "__main__":
         code = 1
     sys.stdout.flush()
     sys.stderr.flush()
+    # (under rocprofv3 the tool writes its trace when the process exits normally: no short cut there)
+    profiled = any(k.startswith(("ROCP", "ROCPROF")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
+    if profiled:
+        sys.exit(code)
     os._exit(code)

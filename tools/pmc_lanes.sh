@@ -1,10 +1,12 @@
 # lane utilisation of the walking kernels: SQ_THREAD_CYCLES_VALU / SQ_INSTS_VALU per dispatch (the average number of
 # active lanes of a vector instruction) for the fused sweep and for k_walk, plus VALU busy.  Program: tools/probe_iter_times.py.
 cd /tmp && export TMPDIR=/tmp
+# (counter passes run with the runtime's default of four hardware queues: the program keeps one scheduler group in flight, so the queue count
+# does not enter what is measured, and it is the configuration these passes have always been collected in)
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out/pmc
 rm -rf /tmp/pmcl
-timeout 250 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES SQ_WAVE_CYCLES -d /tmp/pmcl -o run --output-format csv -- python $R/tools/probe_iter_times.py > /tmp/pmcl.log 2>&1
+GPU_MAX_HW_QUEUES=4 timeout 150 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES SQ_WAVE_CYCLES -d /tmp/pmcl -o run --output-format csv -- python $R/tools/probe_iter_times.py > /tmp/pmcl.log 2>&1
 f=$(find /tmp/pmcl -name "*counter_collection.csv" | head -1)
 python - "$f" <<'PY' | tee $R/gpurun_out/pmc/lanes.txt
 import csv, sys, collections

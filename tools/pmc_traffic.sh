@@ -3,13 +3,15 @@
 # FETCH_SIZE, which tallies 128-B requests at 64 B on gfx950.  Program: tools/probe_iter_times.py (32 pairs; the profiled alignment runs in
 # one scheduler group = launches of 32 jobs, the warm-up in four groups of 8).  Writes gpurun_out/pmc/traffic.json + the raw per-dispatch values.
 cd /tmp && export TMPDIR=/tmp
+# (counter passes run with the runtime's default of four hardware queues: the program keeps one scheduler group in flight, so the queue count
+# does not enter what is measured, and it is the configuration these passes have always been collected in)
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out/pmc
 i=0
 for set in "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
   rm -rf /tmp/pmct_$i
-  timeout 250 rocprofv3 --kernel-trace --pmc $set -d /tmp/pmct_$i -o run --output-format csv -- python $R/tools/probe_iter_times.py > /tmp/pmct_$i.log 2>&1
+  GPU_MAX_HW_QUEUES=4 timeout 150 rocprofv3 --kernel-trace --pmc $set -d /tmp/pmct_$i -o run --output-format csv -- python $R/tools/probe_iter_times.py > /tmp/pmct_$i.log 2>&1
   cp $(find /tmp/pmct_$i -name "*counter_collection.csv" | head -1) $R/gpurun_out/pmc/traffic_pass$i.csv
 done
 python - <<'PY'
