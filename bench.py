@@ -26,7 +26,7 @@ os.environ.setdefault("OMP_PLACES", "cores")
 os.environ.setdefault("GOMP_SPINCOUNT", "300000")
 # sixteen groups of pairs run on sixteen HIP streams; the runtime's default of four hardware queues would serialise them four deep.  Read
 # once, when HIP initialises, so it is set before torch is imported (locus_amd/__init__.py does the same for any user of the package;
-# lh_api.hip lh_runtime_defaults for a C++ host).  Reported in the JSON line as config.gpu_max_hw_queues.
+# lh_api.hip lh_runtime_defaults for a C++ host).  Reported in the JSON line as gpu_max_hw_queues.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 
 import ctypes as C
