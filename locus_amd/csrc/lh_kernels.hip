@@ -1093,7 +1093,10 @@ __device__ __forceinline__ void pose_load(const SweepJob& job, const OuterState*
 
 // kDev: launched by the device-driven loop (states != nullptr) -- the pose comes from the pair's state instead of being derived per wave
 template <bool kDev>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) k_late(const PairDesc* __restrict__ descs, SweepArgs a, double* __restrict__ partials,
+#ifndef LH_LATE_WAVES
+#define LH_LATE_WAVES 7, 8
+#endif
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LH_LATE_WAVES))) k_late(const PairDesc* __restrict__ descs, SweepArgs a, double* __restrict__ partials,
                                                                                    int partials_stride, const OuterState* __restrict__ states,
                                                                                    unsigned long long* __restrict__ wmask, int mask_stride) {
   extern __shared__ __attribute__((aligned(16))) double lds_gram[];  // [4 waves][32 rows][GRAM_RS]
