@@ -123,7 +123,12 @@ int lh_abi_version(void);
 const char* lh_status_string(lh_status s);
 /* One context per GPU per process is the supported configuration (the host classes share it, locus_amd/host): calls on a
  * context are issued in order on its stream, and temporary device buffers are recycled in that order.  Two contexts on
- * the SAME device must not have asynchronous work in flight at the same time (call lh_synchronize between them). */
+ * the SAME device must not have asynchronous work in flight at the same time (call lh_synchronize between them).
+ * HIP runtime setting: the batch entry points keep up to sixteen groups of pairs in flight on as many HIP streams and count on their
+ * kernels overlapping; the runtime spreads a process's streams over GPU_MAX_HW_QUEUES hardware queues (default 4) and reads the variable
+ * at the process's FIRST HIP call.  Loading this library sets GPU_MAX_HW_QUEUES=24 unless the variable is already set (9.7 k -> 12.2 k
+ * scan-pairs/s on the 512-pair bench queue); a process that has initialised HIP before loading the library must set it itself
+ * (INTEGRATION.md section 5). */
 lh_status lh_create(lh_ctx** out, int device_id);
 void lh_destroy(lh_ctx* ctx);
 lh_status lh_synchronize(lh_ctx* ctx);
