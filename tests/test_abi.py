@@ -146,6 +146,19 @@ def test_traversal_device_functions_on_host():
     assert "TRAVERSAL_CHECK_OK" in out.stdout
 
 
+def test_per_point_terms_match_the_reference_formula_on_oracle_covariances():
+    """lh_terms.hpp (cost_mode 1: rank-one Mahalanobis matrix with one reciprocal, residual terms, the pose's doubles -- shared by the fused
+    sweep, k_late and k_walk) against M = (C2 + R C1 R^T)^-1 (gicp.hpp:488-493) on the oracle's covariances from normals: unit,
+    unnormalised, zero and non-finite normals, float rotations (tests/host_emu/terms_check.cpp)."""
+    obj, oo, exe = "/tmp/lh_terms_check.o", "/tmp/lh_terms_oracle.o", "/tmp/lh_terms_check"
+    subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-fopenmp", "-c", os.path.join(ROOT, "oracle", "locus_oracle.c"), "-o", oo])
+    subprocess.check_call(["hipcc", "-O2", "-std=c++17", "-ffp-contract=off", "--offload-arch=gfx950", "-c",
+                           os.path.join(ROOT, "tests", "host_emu", "terms_check.cpp"), "-o", obj])
+    subprocess.check_call(["hipcc", obj, oo, "-fopenmp", "-lm", "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and "TERMS_CHECK_OK" in out.stdout, out.stdout + out.stderr
+
+
 def test_block_knn_search_on_host():
     """The block k-NN search of K3 (lh_knn_block.hpp: one wave per 64 Morton-consecutive queries, sorted-key lists, window + one shared
     tree walk, second pass, redo list) stepped lane by lane on the host with the product's own per-lane functions and networks: every
