@@ -959,6 +959,6 @@ if __name__ == "__main__":
     sys.stderr.flush()
     # (under rocprofv3 the tool writes its trace when the process exits normally: no short cut there)
     profiled = any(k.startswith(("ROCP", "ROCPROF")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
-    if profiled:
+    if profiled or os.environ.get("BENCH_NORMAL_EXIT"):   # (BENCH_NORMAL_EXIT: tools/probe_exit_hang.sh looks for the teardown that hung)
         sys.exit(code)
     os._exit(code)
