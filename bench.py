@@ -7,8 +7,10 @@ GICP iterations with BFGS) over one batch of `--pairs` independent synthetic 100
 in HBM before the timed region.  value = pairs aligned by all ranks / max-over-ranks time.
 
     python bench.py --gpus 1 --steps 3 --warmup 1
+    python bench.py --gpus N --steps K --warmup W          # starts its own N ranks (locus_amd/launch.py), or equivalently
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
+A launcher that brings up another number of ranks than --gpus is a hard failure.
 """
 import argparse
 import json
@@ -38,6 +40,7 @@ sys.path.insert(0, ROOT)
 
 from locus_amd import capi, synth  # noqa: E402
 from locus_amd import dist as ldist  # noqa: E402
+from locus_amd import launch as llaunch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
@@ -526,6 +529,9 @@ def main():
                     help="functional check of the N > 1 code path on a 1-GPU box: every rank uses cuda:0 (needs --dist-backend gloo); "
                          "the printed rate is meaningless")
     args = ap.parse_args()
+    # `python bench.py --gpus N` with no launcher around it starts its own N ranks (re-exec under torch.distributed.run, 127.0.0.1, a free
+    # port); a launcher that started another number of ranks than --gpus is a hard failure (locus_amd/launch.py)
+    llaunch.maybe_self_launch(os.path.abspath(__file__), sys.argv[1:], args.gpus)
     _start_watchdog()
 
     # safety net: a rank that stops making progress dumps every thread's Python stack and exits instead of hanging the box
@@ -561,7 +567,8 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend="gloo")
-    assert world == args.gpus or world == 1, (world, args.gpus)
+    rccl_world = dist.get_world_size() if world > 1 else 1
+    llaunch.check_world(args.gpus, world, rccl_world)
 
     ctx = capi.Context(local_rank)
     # forced 20 outer iterations: eps = 0 would divide by zero in the ratio, use a vanishing eps instead
@@ -657,10 +664,11 @@ def main():
                 capi.align_batch(ctx, Pq, S, T, max_in_flight=args.in_flight)
             ctx.synchronize()
             nat = round(2 * pairs_here / (time.perf_counter() - tq), 1)
-        print(json.dumps({"value": round(value, 2), "natural": nat, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "solver": args.solver,
+        print(json.dumps({"value": round(value, 2), "n_gpus": world, "rccl_world": rccl_world, "self_launched": bool(os.environ.get("LH_BENCH_SELF_LAUNCHED")),
+                          "pairs_in_flight_per_gpu": min(args.in_flight, pairs_here), "strong_scaling_same_pairs": strong, "natural": nat, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "solver": args.solver,
                           "iters": [min(iters), float(np.mean(iters)), max(iters)], "env": {k: v for k, v in os.environ.items() if k.startswith("LH_")}}))
-        return
-    if rank == 0:
+        sys.stdout.flush()
+    if rank == 0 and not args.quick:
         _leg("timed region done; roofline leg")
         # ---- roofline leg: the same steps again with HIP-event timing of every launch on the library's stream ----
         # Profiling runs ONE scheduler group so kernels never overlap; to time launches of the same shape as the timed
@@ -731,7 +739,8 @@ def main():
                                    "overlap); the timed region overlaps sixteen groups, where the same kernels take longer per launch")
         result = {
             "metric": "GICP scan-pairs/s (100k-pt clouds, 20 iters)", "value": round(value, 3), "unit": "scan-pairs/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "n_gpus": world, "rccl_world": rccl_world, "dist_backend": (args.dist_backend if world > 1 else None),
+            "self_launched": bool(os.environ.get("LH_BENCH_SELF_LAUNCHED")), "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "f32 geometry / f64 cost",
             "data": "synthetic",
             "config": {"workload": "configs[1]: 100k-pt Velodyne-style scan-to-scan GICP, 20 outer iterations (stopping thresholds "
@@ -935,7 +944,7 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    if rank == 0:
+    if rank == 0 and result is not None:
         with _PRINT_LOCK:
             print(json.dumps(result))
             sys.stdout.flush()

@@ -154,6 +154,7 @@ void lh_destroy(lh_ctx* c) {
   if (c->states_init) (void)hipHostFree(c->states_init);
   for (int k = 0; k < lh_ctx::MAX_GROUPS; k++)
     if (c->group_ev[k]) (void)hipEventDestroy(c->group_ev[k]);
+  if (c->entry_ev) (void)hipEventDestroy(c->entry_ev);
   if (c->descs_host) (void)hipHostFree(c->descs_host);
   if (c->partials_host) (void)hipHostFree(c->partials_host);
   if (c->small_host) (void)hipHostFree(c->small_host);

@@ -231,7 +231,8 @@ lh_status knn_block_batch(lh_ctx* x, lh_cloud* const* clouds, int n_clouds, int 
       x->knn_redo = nullptr; x->knn_soa = nullptr; x->knn_redo_cap = 0;
       const long cap = pts + pts / 4 + 1024;
       HIPCHK(lhMalloc(&x->knn_redo, sizeof(uint2) * (size_t)cap));
-      HIPCHK(lhMalloc(&x->knn_soa, sizeof(float) * 3 * ((size_t)cap + (size_t)16 * MAX_INDEX_BATCH)));
+      // a cloud's arrays take round_up16(n + LEAF_CAP) <= n + LEAF_CAP + 15 floats each: room for the padding of a full batch whatever its sizes
+      HIPCHK(lhMalloc(&x->knn_soa, sizeof(float) * 3 * ((size_t)cap + (size_t)(LEAF_CAP + 16) * MAX_INDEX_BATCH)));
       x->knn_redo_cap = cap;
     }
     {

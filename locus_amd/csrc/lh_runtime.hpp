@@ -199,6 +199,7 @@ struct lh_ctx {
   OuterState* states_init = nullptr;   // pinned: initial states (separate from the download target: uploads and downloads overlap)
   double* chunks_dev = nullptr;        // [n_slots][FINAL_CHUNKS * MOM_ROW]
   hipEvent_t group_ev[MAX_GROUPS] = {};
+  hipEvent_t entry_ev = nullptr;       // fork point of a scheduler run: the side streams wait for what earlier calls left on `stream`
   // batch mode: one workspace per scheduler slot.  They live here (not in a thread-local) so that they are tied to this
   // context's device, reused by every thread that drives the context, and released by lh_destroy.
   std::vector<Workspace> slot_ws;
@@ -324,6 +325,17 @@ static inline lh_status wait_index_builds(lh_ctx* x, hipStream_t s) {
   for (lh_ctx::IndexScratch& X : x->idx_sets)
     if (X.build_done && hipStreamWaitEvent(s, X.build_done, 0) != hipSuccess) return LH_EDEVICE;
   return LH_OK;
+}
+// Calls on a context are issued in order (include/locus_hip.h): whatever earlier calls enqueued on the primary stream without waiting for it
+// (lh_normals_knn_batch: index build + normals; uploads) is complete
+// before a scheduler group's side stream (non-blocking, otherwise unordered against `stream`) reads a tree, a normal or a cloud.
+static inline lh_status fork_side_streams(lh_ctx* x, hipStream_t* const* side, int n_side) {
+  if (n_side <= 0) return LH_OK;
+  if (!x->entry_ev && hipEventCreateWithFlags(&x->entry_ev, hipEventDisableTiming) != hipSuccess) return LH_EDEVICE;
+  if (hipEventRecord(x->entry_ev, x->stream) != hipSuccess) return LH_EDEVICE;
+  for (int k = 0; k < n_side; k++)
+    if (hipStreamWaitEvent(*side[k], x->entry_ev, 0) != hipSuccess) return LH_EDEVICE;
+  return LH_OK;   // (index builds inside a scheduler run are complete when the run returns: every pair retires behind its group's build)
 }
 static inline lh_status cloud_build_index(lh_cloud* c) { return build_indices(c->ctx, &c, 1); }
 extern std::atomic<bool> g_small_index;   // clouds of <= SMALL_INDEX_MAX_N points take the one-launch build (lh_index_small.hip); off: the general build for all

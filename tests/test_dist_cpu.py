@@ -165,8 +165,11 @@ def test_bench_rank0_only_block_calls_no_collective():
     src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")).read()
     tree = ast.parse(src)
     main = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "main")
-    blocks = [n for n in ast.walk(main) if isinstance(n, ast.If) and isinstance(n.test, ast.Compare)
-              and isinstance(n.test.left, ast.Name) and n.test.left.id == "rank" and isinstance(n.test.ops[0], ast.Eq)]
+    def is_rank0(t):   # `rank == 0` or `rank == 0 and ...`
+        if isinstance(t, ast.BoolOp) and isinstance(t.op, ast.And):
+            t = t.values[0]
+        return isinstance(t, ast.Compare) and isinstance(t.left, ast.Name) and t.left.id == "rank" and isinstance(t.ops[0], ast.Eq)
+    blocks = [n for n in ast.walk(main) if isinstance(n, ast.If) and is_rank0(n.test)]
     assert blocks, "rank == 0 block not found"
     big = max(blocks, key=lambda n: n.end_lineno - n.lineno)
     assert big.end_lineno - big.lineno > 30  # the roofline leg, not the final print

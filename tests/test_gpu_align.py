@@ -640,3 +640,29 @@ def test_stream_of_raw_scans_normals_batch_then_align_stream(ctx, capi, oracle):
     ro = oracle.gicp_align(xyz(d1), nrm(d1), xyz(d0), nrm(d0), po)
     Tg, To = oracle.T_to_mat(ra[0]["T"]), oracle.T_to_mat(ro["T"])
     assert np.abs(Tg[:3, 3] - To[:3, 3]).max() < 2e-3 and np.abs(Tg[:3, :3] - To[:3, :3]).max() < 2.5e-3   # the stopping scale (include/locus_hip.h)
+
+
+def test_align_stream_right_behind_the_normal_filter_many_groups_no_synchronise(ctx, capi, oracle):
+    """Calls on a context are issued in order (include/locus_hip.h): lh_normals_knn_batch returns with its index build and k-NN launch still
+    queued on the context's stream, and lh_gicp_align_stream with >= 32 pairs in flight spreads its groups over SIDE streams that read those
+    trees and normals.  The scheduler forks its side streams from the primary stream (fork_side_streams), so the result is the one of the
+    synchronised sequence, bit for bit -- 100 k-point scans make the filter's launch long enough for a missing dependency to show."""
+    n = 49
+    poses = [synth.pose_matrix(0.12 * i, 0.02 * i, 0.0, 0.0, 0.0, 0.01 * i) for i in range(n)]
+    pts = [synth.scan(p, 32, 1200, (-25.0, 15.0), 2.0, 0.02, seed=700 + i) for i, p in enumerate(poses)]
+    P = capi.default_params(max_iterations=6, corr_dist=1.0, transformation_epsilon=1e-12, rotation_epsilon=1e-12)
+    A = [capi.Cloud(ctx, p) for p in pts]
+    capi.normals_knn_batch(A, 20)
+    ctx.synchronize()
+    ref = capi.align_stream(ctx, P, A, max_in_flight=48)      # everything the filter left is complete: the reference result
+    ctx.synchronize()
+    for rep in range(3):
+        B = [capi.Cloud(ctx, p) for p in pts]
+        capi.normals_knn_batch(B, 20)                         # NO synchronise: the k-NN launch is still running when the groups start
+        got = capi.align_stream(ctx, P, B, max_in_flight=48)  # 48 in flight: two or more groups, all but the first on side streams
+        for x, y in zip(got, ref):
+            assert x["status"] == 0 and (np.asarray(x["T"]) == np.asarray(y["T"])).all() and x["iterations"] == y["iterations"]
+        for b in B:
+            b.close()
+    for a in A:
+        a.close()
