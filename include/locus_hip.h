@@ -126,9 +126,23 @@ const char* lh_status_string(lh_status s);
  * the SAME device must not have asynchronous work in flight at the same time (call lh_synchronize between them).
  * HIP runtime setting: the batch entry points keep up to sixteen groups of pairs in flight on as many HIP streams and count on their
  * kernels overlapping; the runtime spreads a process's streams over GPU_MAX_HW_QUEUES hardware queues (default 4) and reads the variable
- * at the process's FIRST HIP call.  Loading this library sets GPU_MAX_HW_QUEUES=24 unless the variable is already set (9.7 k -> 12.2 k
- * scan-pairs/s on the 512-pair bench queue); a process that has initialised HIP before loading the library must set it itself
- * (INTEGRATION.md section 5). */
+ * at the process's FIRST HIP call (9.7 k -> 12.2 k scan-pairs/s on the 512-pair bench queue with 24).  The library does NOT touch the
+ * environment on its own (no equivalent of the reference's omp_set_num_threads side effect, gicp.h:138): see lh_runtime_init /
+ * lh_runtime_info below and INTEGRATION.md section 5. */
+/* Optional, explicit: GPU_MAX_HW_QUEUES = max_hw_queues (0: the library's recommendation, 24) unless the deployment already set the variable.
+ * Only effective BEFORE the process's first HIP call; call it from the main thread before other threads exist (it is setenv).  Returns
+ * LH_EINVAL for a value outside 0..128. */
+lh_status lh_runtime_init(int max_hw_queues);
+typedef struct {
+  int hw_queues_env;          /* GPU_MAX_HW_QUEUES as this process sees it now (-1: unset) */
+  int streams_probed;         /* 16 */
+  double stream_concurrency;  /* MEASURED: how many of sixteen one-wave kernels on sixteen streams ran at once (16 = all; ~4 = the runtime's default) */
+  int adequate;               /* stream_concurrency >= 12: batches of >= 64 pairs get the overlap the scheduler counts on */
+  int reserved;
+} lh_runtime_info_t;
+/* What the HIP runtime actually gives this process (a 16-stream overlap probe, ~1 ms, measured once per device and cached).  The scheduler runs
+ * the same probe the first time a batch spreads over more than four streams and reports a shortfall once on stderr. */
+lh_status lh_runtime_info(lh_ctx* ctx, lh_runtime_info_t* out);
 lh_status lh_create(lh_ctx** out, int device_id);
 void lh_destroy(lh_ctx* ctx);
 lh_status lh_synchronize(lh_ctx* ctx);

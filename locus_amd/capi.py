@@ -111,10 +111,20 @@ EXPORTS = [
     "lh_ndt_set_source", "lh_ndt_set_target", "lh_ndt_set_source_cloud", "lh_ndt_set_target_cloud", "lh_ndt_align", "lh_ndt_debug_cells",
     "lh_ndt_debug_derivatives", "lh_map_create", "lh_map_destroy", "lh_map_insert", "lh_map_refresh", "lh_map_cloud", "lh_map_size", "lh_normals_knn", "lh_normals_knn_cloud", "lh_normals_knn_batch", "lh_cov_knn_batch",
     "lh_normals_radius", "lh_normals_radius_cloud", "lh_cloud_remove_nan_normals", "lh_profile_enable",
-    "lh_profile_reset", "lh_profile_get",
+    "lh_profile_reset", "lh_profile_get", "lh_runtime_init", "lh_runtime_info",
 ]
 
+class RuntimeInfo(C.Structure):
+    _fields_ = [("hw_queues_env", C.c_int), ("streams_probed", C.c_int), ("stream_concurrency", C.c_double), ("adequate", C.c_int), ("reserved", C.c_int)]
+
+
 _lib = None
+
+
+def lib_sha256():
+    """sha256 of the library file the binding loads: the stamp counter files (profiles/pmc_latest.json) carry to say which build they describe"""
+    import hashlib
+    return hashlib.sha256(open(LIB_PATH, "rb").read()).hexdigest()
 
 
 def lib():
@@ -133,6 +143,8 @@ def lib():
         L.lh_destroy.argtypes = [vp]
         L.lh_destroy.restype = None
         L.lh_synchronize.argtypes = [vp]
+        L.lh_runtime_init.argtypes = [i32]
+        L.lh_runtime_info.argtypes = [vp, C.POINTER(RuntimeInfo)]
         L.lh_default_gicp_params.argtypes = [C.POINTER(GicpParams)]
         L.lh_default_gicp_params.restype = None
         L.lh_cloud_create.argtypes = [vp, C.POINTER(CloudView), C.POINTER(vp)]
@@ -330,6 +342,12 @@ class Context:
 
     def synchronize(self):
         _check(lib().lh_synchronize(self.h), "lh_synchronize")
+
+    def runtime_info(self):
+        """lh_runtime_info: GPU_MAX_HW_QUEUES as the process sees it and the MEASURED concurrency of sixteen streams"""
+        ri = RuntimeInfo()
+        _check(lib().lh_runtime_info(self.h, C.byref(ri)), "lh_runtime_info")
+        return {"hw_queues_env": ri.hw_queues_env, "streams_probed": ri.streams_probed, "stream_concurrency": ri.stream_concurrency, "adequate": bool(ri.adequate)}
 
     def set_allreduce(self, fn):
         """source-sharded single pair: fn(numpy float64 view) sums in place over the ranks; None removes it"""

@@ -8,6 +8,9 @@
 // The scheduler resumes every in-flight pair, batches their requests into ONE launch per kind (grid.y = pair),
 // synchronises once per round and feeds the results back.  A single lh_gicp_align is the same machinery with one
 // task.  No CPU fallback exists: without a HIP device every entry point returns LH_EDEVICE.
+#include <atomic>
+#include <chrono>
+#include <mutex>
 #include "lh_runtime.hpp"
 
 // host <-> device cloud conversion
@@ -60,6 +63,53 @@ lh_status upload_view(lh_ctx* c, const lh_cloud_view* v, lh_cloud** out, bool sy
 
 // =========================================================================================================
 #pragma GCC visibility push(default)   // the C ABI is the library's ONLY exported surface (the TUs are compiled -fvisibility=hidden)
+// one wave that stays resident for `ticks` of the 100-MHz wall clock: the probe's unit of work
+__global__ void __launch_bounds__(64) k_probe_spin(unsigned long long ticks, unsigned int* sink) {
+  const unsigned long long t0 = wall_clock64();
+  unsigned int it = 0;
+  while (wall_clock64() - t0 < ticks) it++;
+  if (sink && threadIdx.x == 0 && it == 0xffffffffu) *sink = it;
+}
+static std::mutex g_probe_mu;
+static double g_probe_concurrency[64] = {};   // per device; 0 = not measured yet
+// How many of sixteen one-wave kernels on sixteen streams the runtime runs at once (wall clock): 16 x the kernel's length / the time all took.
+static double probe_stream_concurrency(int device) {
+  std::lock_guard<std::mutex> lk(g_probe_mu);
+  if (device >= 0 && device < 64 && g_probe_concurrency[device] > 0) return g_probe_concurrency[device];
+  constexpr int NS = 16;
+  const double spin_s = 400e-6;
+  hipStream_t st[NS] = {};
+  bool ok = true;
+  for (int k = 0; k < NS && ok; k++) ok = hipStreamCreateWithFlags(&st[k], hipStreamNonBlocking) == hipSuccess;
+  double conc = 0.0;
+  if (ok) {
+    for (int k = 0; k < NS; k++) hipLaunchKernelGGL(k_probe_spin, dim3(1), dim3(64), 0, st[k], 100ull, (unsigned int*)nullptr);   // warm-up: code object, queues
+    for (int k = 0; k < NS; k++) (void)hipStreamSynchronize(st[k]);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int k = 0; k < NS; k++) hipLaunchKernelGGL(k_probe_spin, dim3(1), dim3(64), 0, st[k], (unsigned long long)(spin_s * 1e8), (unsigned int*)nullptr);
+    for (int k = 0; k < NS; k++) ok = ok && hipStreamSynchronize(st[k]) == hipSuccess;
+    const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (ok && wall > 0) conc = std::min((double)NS, NS * spin_s / wall);
+  }
+  for (int k = 0; k < NS; k++)
+    if (st[k]) (void)hipStreamDestroy(st[k]);
+  (void)hipGetLastError();
+  if (device >= 0 && device < 64) g_probe_concurrency[device] = conc;
+  return conc;
+}
+// called by the scheduler the first time a batch spreads over more than four streams
+void runtime_check_streams(lh_ctx* c, int groups) {
+  static std::atomic<bool> said{false};
+  if (groups <= 4 || said.load()) return;
+  const double conc = probe_stream_concurrency(c->device);
+  if (conc > 0 && conc < 0.7 * std::min(groups, 16) && !said.exchange(true)) {
+    const char* e = getenv("GPU_MAX_HW_QUEUES");
+    fprintf(stderr, "[locus_hip] this process runs %d scheduler streams about %.0f deep: the HIP runtime gave it too few hardware queues (GPU_MAX_HW_QUEUES=%s, read at "
+                    "the process's first HIP call).  Batches of >= 64 pairs run about 20 %% slower than they could: call lh_runtime_init(0) before the first HIP "
+                    "call, or export GPU_MAX_HW_QUEUES=24 (INTEGRATION.md section 5).\n", groups, 16.0 / conc, e ? e : "unset");
+  }
+}
+
 extern "C" {
 
 
@@ -99,11 +149,30 @@ void lh_default_gicp_params(lh_gicp_params* p) {
 // group's single-workgroup k_solve under the other groups' sweeps).  The HIP runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues --
 // four by default -- and streams that share a queue run one after the other.  Measured on the 512-pair bench queue: 4 / 8 / 16 / 24 / 32 / 64
 // queues -> 9 740 / 10 150 / 10 990 / 12 220 / 12 140 / 12 180 pairs/s (round 4).  The runtime reads the variable when it initialises, i.e. at
-// the process's first HIP call, so it is set here, when the library is loaded, unless the deployment already chose a value; a process that
-// initialised HIP before loading this library keeps whatever it had ("knobs").
-// (priority 101: before this library's own kernel registration)
-__attribute__((constructor(101))) static void lh_runtime_defaults() { (void)setenv("GPU_MAX_HW_QUEUES", "24", 0); }
+// the process's first HIP call.  Round 4 set it from a load-time constructor; a library must not edit its host's environment behind its
+// back (setenv races getenv in other threads, and it changes the queues of every other HIP user of the process -- the kind of side effect
+// SURVEY 8b told this build not to copy from omp_set_num_threads, gicp.h:138).  Now: lh_runtime_init() is the explicit form, called by the
+// host before its first HIP call and before it starts threads; lh_runtime_info() MEASURES what the process got, and the scheduler says so
+// once on stderr when a batch wants more concurrent streams than the runtime gives it.
+lh_status lh_runtime_init(int max_hw_queues) {
+  if (max_hw_queues < 0 || max_hw_queues > 128) return LH_EINVAL;
+  char buf[16];
+  snprintf(buf, sizeof buf, "%d", max_hw_queues ? max_hw_queues : 24);
+  return setenv("GPU_MAX_HW_QUEUES", buf, 0) == 0 ? LH_OK : LH_EINVAL;   // (overwrite = 0: a value the deployment chose stays)
+}
 
+lh_status lh_runtime_info(lh_ctx* c, lh_runtime_info_t* out) {
+  if (!c || !out) return LH_EINVAL;
+  HIPCHK(hipSetDevice(c->device));
+  memset(out, 0, sizeof *out);
+  const char* e = getenv("GPU_MAX_HW_QUEUES");
+  out->hw_queues_env = e ? atoi(e) : -1;
+  out->streams_probed = 16;
+  out->stream_concurrency = probe_stream_concurrency(c->device);
+  if (!(out->stream_concurrency > 0)) return LH_EDEVICE;
+  out->adequate = out->stream_concurrency >= 12.0;
+  return LH_OK;
+}
 lh_status lh_create(lh_ctx** out, int device_id) {
   if (!out) return LH_EINVAL;
   int ndev = 0;

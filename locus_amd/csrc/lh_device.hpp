@@ -111,11 +111,21 @@ static_assert(sizeof(TreeHeader) == 64, "TreeHeader occupies one NodeX slot in f
 // owes the rest of the cloud only the neighbour cells its candidate's distance ball reaches: their subtrees go on the traversal
 // stack with the cell's box distance as key, and everything else is bounded by the distance to the faces it does not cross.
 // Layout: [TreeHeader][GRID_ENTRIES x int32][nodes ...] in one buffer, so the tables need no pointer of their own.
-constexpr int GRID_LEVELS = 3;                       // levels 5, 4, 3: cells of 32, 64, 128 key cells (2.5 / 5 / 10 m on an 80-m scene)
-constexpr int GRID_OFF5 = 0, GRID_OFF4 = 32768, GRID_OFF3 = 32768 + 4096;
-constexpr int GRID_ENTRIES = 32768 + 4096 + 512;     // 37 376 entries = 146 KB
+#ifndef LH_GRID_FINEST
+#define LH_GRID_FINEST 5
+#endif
+constexpr int GRID_FINEST = LH_GRID_FINEST;          // finest table level (5: 32^3; the host model of tools/model tries 6 and 7)
+constexpr int GRID_LEVELS = GRID_FINEST - 2;         // levels GRID_FINEST .. 3: cells of 32, 64, 128 key cells (2.5 / 5 / 10 m on an 80-m scene) at 5, 4, 3
+LH_HD constexpr int grid_off(int level) {            // tables in order of decreasing level: entries of the finer tables come first
+  int off = 0;
+  for (int l = GRID_FINEST; l > level; l--) off += 1 << (3 * l);
+  return off;
+}
+constexpr int GRID_OFF5 = grid_off(5), GRID_OFF4 = grid_off(4), GRID_OFF3 = grid_off(3);
+constexpr int GRID_ENTRIES = grid_off(3) + 512;      // 37 376 entries = 146 KB with three levels
 constexpr int GRID_NODEX = GRID_ENTRIES * 4 / 64;    // the same in NodeX slots (2 336)
 static_assert(GRID_NODEX * 64 == GRID_ENTRIES * 4, "the grid fills whole node slots");
+static_assert(GRID_FINEST != 5 || (GRID_OFF5 == 0 && GRID_OFF4 == 32768 && GRID_OFF3 == 32768 + 4096 && GRID_ENTRIES == 37376), "three-level layout");
 constexpr int32_t GRID_EMPTY = (int32_t)0x80000000;  // no point of the cloud lies in the cell (never a valid reference)
 constexpr int GRID_MIN_POINTS = 8192;                // smaller clouds: the tree is shallow, the tables would cost more than they save
 constexpr float GRID_SLACK = 4e-3f;                  // key cells (0.3 mm on an 80-m scene): ten times the float rounding of a key coordinate
@@ -372,8 +382,7 @@ LH_HD void scan_leaf(const TreeView& t, int32_t ref, float qx, float qy, float q
 
 // ---- start grid (see TreeHeader) --------------------------------------------------------------------------------------------
 LH_HD int grid_index(int level, int cx, int cy, int cz) {
-  const int off = level == 5 ? GRID_OFF5 : (level == 4 ? GRID_OFF4 : GRID_OFF3);
-  return off + (((cx << level) | cy) << level | cz);
+  return grid_off(level) + (((cx << level) | cy) << level | cz);
 }
 constexpr int32_t GRID_USE_ROOT = NO_CHILD - 1;   // grid_start: the candidate is too far for the coarsest table, walk from the root
 // Where a WARM 1-NN walk starts.  `col` holds a real candidate at squared distance bd (finite).  The table level is the finest one
@@ -393,11 +402,13 @@ LH_HD int32_t grid_start(const float* org, float key_sc, float key_inv, const in
   const float bd = col.bound();
   const float ru = sqrt_bound(bd) * key_sc * 1.000001f + 2.0f * GRID_SLACK;   // the ball's radius in key cells, rounded up
   if (!(ru < 63.5f)) return GRID_USE_ROOT;
-  const int sh = 5 + (ru >= 15.5f ? 1 : 0) + (ru >= 31.5f ? 1 : 0);      // key-cell bits inside one table cell: wider than the ball
+  int sh = 5 + (ru >= 15.5f ? 1 : 0) + (ru >= 31.5f ? 1 : 0);            // key-cell bits inside one table cell: wider than the ball
+  if (GRID_FINEST >= 6 && ru < 7.5f) sh = 4;
+  if (GRID_FINEST >= 7 && ru < 3.5f) sh = 3;
   const int level = 10 - sh, G = 1 << level;
   const float cell = (float)(1 << sh);
   const float q[3] = {qx, qy, qz};
-  int home = level == 5 ? GRID_OFF5 : (level == 4 ? GRID_OFF4 : GRID_OFF3);
+  int home = grid_off(level);
   int cm = 0, dstep[3];
   float sq[3];   // squared metres to the crossed face (a lower bound), per axis
 #pragma unroll
@@ -768,7 +779,12 @@ LH_HD void radix_node(const uint64_t* __restrict__ lkey, int n_leaves, int i, in
 // -1 for a node that joins two clouds, 30 for identical keys
 LH_HD int key_common(int delta) { return delta < 34 ? -1 : (delta > 64 ? 30 : delta - 34); }
 // how many of the start grid's levels (3, 4, 5 = 9, 12, 15 prefix bits) a node with `com` common bits lies inside a cell of
-LH_HD int grid_depth(int com) { return (com >= 9 ? 1 : 0) + (com >= 12 ? 1 : 0) + (com >= 15 ? 1 : 0); }
+LH_HD int grid_depth(int com) {
+  int d = (com >= 9 ? 1 : 0) + (com >= 12 ? 1 : 0) + (com >= 15 ? 1 : 0);
+  if (GRID_FINEST >= 6) d += com >= 18 ? 1 : 0;
+  if (GRID_FINEST >= 7) d += com >= 21 ? 1 : 0;
+  return d;
+}
 // Start-grid entries contributed by ONE child of binary node i (com_i common key bits); called for both children of every node of
 // a cloud.  An internal child whose keys share >= 3 l bits while i's do not IS the level-l cell of its keys: the keys of a radix-tree
 // node are all keys with its prefix, so the child holds exactly the cloud's points inside that cell.  A LEAF child is the cell of
@@ -786,7 +802,7 @@ LH_HD bool grid_child_cells(int l, int com_i, bool child_is_leaf, int com_c, uin
 }
 LH_HD void grid_fill_child(int32_t* grid, int com_i, bool child_is_leaf, int com_c, uint32_t key30_c, int32_t ref_c) {
 #pragma unroll
-  for (int l = 5; l >= 3; l--) {
+  for (int l = GRID_FINEST; l >= 3; l--) {
     uint32_t lo3[3], hi3[3];
     if (!grid_child_cells(l, com_i, child_is_leaf, com_c, key30_c, lo3, hi3)) continue;
     for (uint32_t x = lo3[0]; x <= hi3[0]; x++)
@@ -797,7 +813,7 @@ LH_HD void grid_fill_child(int32_t* grid, int com_i, bool child_is_leaf, int com
 // ... and by the cloud's root, for the levels at which the WHOLE cloud lies inside one cell
 LH_HD void grid_fill_root(int32_t* grid, int com_root, uint32_t key30, int32_t ref_root) {
 #pragma unroll
-  for (int l = 5; l >= 3; l--) {
+  for (int l = GRID_FINEST; l >= 3; l--) {
     if (com_root < 3 * l) continue;
     uint32_t c0[3], c1[3];
     morton_cell(key30, 3 * l, c0, c1);

@@ -315,6 +315,7 @@ struct DevGuard {
 };
 
 
+void runtime_check_streams(lh_ctx* c, int groups);   // lh_api.hip: one-time report when the runtime serialises the scheduler's streams
 lh_status ctx_ensure_scratch(lh_ctx* c, int n);
 lh_status ctx_ensure_small(lh_ctx* c, size_t doubles);
 lh_status ctx_ensure_slots(lh_ctx* c, int n_slots, int max_n);

@@ -501,6 +501,7 @@ static lh_status run_tasks_device(lh_ctx* c, std::vector<Task*>& tasks, int in_f
   for (int gi = 1; gi < G; gi++)
     if (!*extra[gi - 1]) HIPCHK(hipStreamCreateWithFlags(extra[gi - 1], hipStreamNonBlocking));
   { lh_status fst = fork_side_streams(c, extra, G - 1); if (fst) return fst; }
+  runtime_check_streams(c, G);
   DevGroup groups[lh_ctx::MAX_GROUPS];
   groups[0].stream = c->stream;
   for (int gi = 1; gi < G; gi++) groups[gi].stream = *extra[gi - 1];
@@ -671,6 +672,7 @@ static lh_status run_tasks_host(lh_ctx* c, std::vector<Task*>& tasks, int in_fli
   for (int gi = 1; gi < G; gi++)
     if (!*extra[gi - 1]) HIPCHK(hipStreamCreateWithFlags(extra[gi - 1], hipStreamNonBlocking));
   { lh_status fst = fork_side_streams(c, extra, G - 1); if (fst) return fst; }
+  runtime_check_streams(c, G);
   std::vector<Group> groups(G);
   groups[0].stream = c->stream;
   for (int gi = 1; gi < G; gi++) groups[gi].stream = *extra[gi - 1];

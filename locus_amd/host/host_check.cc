@@ -61,6 +61,7 @@ static void Inverse4(const float* Tc, double* inv /*row-major*/) {  // rigid inv
 }
 
 int main() {
+  (void)lh_runtime_init(0);   // what a nodelet manager does first: the hardware-queue setting, before the process's first HIP call
   lh_ctx* ctx = nullptr;
   if (lh_create(&ctx, 0) != LH_OK) { printf("no HIP device: the host mirror has no CPU fallback\n"); return 2; }
   const double epsiliond = 1e-2, epsilion = 1e-4;

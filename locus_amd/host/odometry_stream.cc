@@ -21,6 +21,7 @@ using namespace locus_hip;
 int main(int argc, char** argv) {
   if (argc < 2) { fprintf(stderr, "usage: odometry_stream scans.bin [warmup]\n"); return 2; }
   const int warm = argc > 2 ? atoi(argv[2]) : 3;
+  (void)lh_runtime_init(0);   // what a nodelet manager does first: the hardware-queue setting, before the process's first HIP call
   FILE* f = fopen(argv[1], "rb");
   if (!f) { fprintf(stderr, "cannot open %s\n", argv[1]); return 2; }
   int32_t n_scans = 0;

@@ -91,22 +91,51 @@ def test_missing_library_fails_loudly():
     assert r.returncode != 0 and "no CPU fallback" in r.stderr.replace("\n", " ")
 
 
-def test_library_load_sets_the_hardware_queue_default_and_keeps_a_chosen_value():
-    """lh_api.hip lh_runtime_defaults: the scheduler's sixteen streams need more than the HIP runtime's default of four hardware queues;
-    the variable is read at the first HIP call, so the library sets it when it is loaded -- unless the deployment chose a value."""
+def test_runtime_init_is_explicit_and_keeps_a_chosen_value():
+    """The scheduler's sixteen streams need more than the HIP runtime's default of four hardware queues, and the variable is read at the
+    process's first HIP call.  LOADING the library must not touch the environment (round 4's constructor did); lh_runtime_init() is the
+    explicit form and leaves a value the deployment chose alone; the Python package sets the default before anything can initialise HIP."""
+    lib = os.path.join(ROOT, "locus_amd", "csrc", "liblocus_hip.so")
     code = ("import ctypes, os, sys\n"
             "libc = ctypes.CDLL(None); libc.getenv.restype = ctypes.c_char_p\n"
-            "ctypes.CDLL(%r)\n"
-            "print(libc.getenv(b'GPU_MAX_HW_QUEUES').decode())" % os.path.join(ROOT, "locus_amd", "csrc", "liblocus_hip.so"))
+            "L = ctypes.CDLL(%r)\n"
+            "a = libc.getenv(b'GPU_MAX_HW_QUEUES')\n"
+            "rc = L.lh_runtime_init(int(sys.argv[1]))\n"
+            "b = libc.getenv(b'GPU_MAX_HW_QUEUES')\n"
+            "print(a.decode() if a else 'unset', rc, b.decode() if b else 'unset')" % lib)
     env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
-    r = subprocess.run(["python", "-c", code], capture_output=True, text=True, env=env)
-    assert r.returncode == 0 and r.stdout.strip() == "24", (r.stdout, r.stderr)
-    r = subprocess.run(["python", "-c", code], capture_output=True, text=True, env=dict(env, GPU_MAX_HW_QUEUES="6"))
-    assert r.returncode == 0 and r.stdout.strip() == "6", (r.stdout, r.stderr)
-    # the Python package does the same before anything can have initialised HIP
+    r = subprocess.run(["python", "-c", code, "0"], capture_output=True, text=True, env=env)
+    assert r.returncode == 0 and r.stdout.split() == ["unset", "0", "24"], (r.stdout, r.stderr)       # loading alone: untouched; init(0): 24
+    r = subprocess.run(["python", "-c", code, "16"], capture_output=True, text=True, env=env)
+    assert r.returncode == 0 and r.stdout.split() == ["unset", "0", "16"], (r.stdout, r.stderr)
+    r = subprocess.run(["python", "-c", code, "0"], capture_output=True, text=True, env=dict(env, GPU_MAX_HW_QUEUES="6"))
+    assert r.returncode == 0 and r.stdout.split() == ["6", "0", "6"], (r.stdout, r.stderr)            # the deployment's value stays
+    r = subprocess.run(["python", "-c", code, "1000"], capture_output=True, text=True, env=env)
+    assert r.returncode == 0 and r.stdout.split() == ["unset", "-1", "unset"], (r.stdout, r.stderr)   # LH_EINVAL
+    # the Python package sets the default before anything can have initialised HIP
     code2 = "import os, sys; sys.path.insert(0, %r); import locus_amd; print(os.environ['GPU_MAX_HW_QUEUES'])" % ROOT
     r = subprocess.run(["python", "-c", code2], capture_output=True, text=True, env=env)
     assert r.returncode == 0 and r.stdout.strip() == "24", (r.stdout, r.stderr)
+
+
+@pytest.mark.gpu
+def test_runtime_info_measures_the_stream_concurrency():
+    """lh_runtime_info in fresh processes: with the package's default of 24 hardware queues the sixteen probe kernels overlap (adequate); with
+    the runtime's default of 4 they run about four deep and the report says so -- the knob is observable, not an article of faith."""
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from locus_amd import capi\n"
+            "import json; print(json.dumps(capi.Context(0).runtime_info()))" % ROOT)
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    import json
+    r = subprocess.run(["python", "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-1000:]
+    hi = json.loads(r.stdout.strip().splitlines()[-1])
+    assert hi["hw_queues_env"] == 24 and hi["streams_probed"] == 16 and hi["adequate"] and hi["stream_concurrency"] >= 12.0, hi
+    r = subprocess.run(["python", "-c", code], capture_output=True, text=True, env=dict(env, GPU_MAX_HW_QUEUES="4"), timeout=300)
+    assert r.returncode == 0, r.stderr[-1000:]
+    lo = json.loads(r.stdout.strip().splitlines()[-1])
+    assert lo["hw_queues_env"] == 4 and not lo["adequate"] and lo["stream_concurrency"] < 8.0, lo
+    print("stream concurrency: 24 queues %.1f, 4 queues %.1f" % (hi["stream_concurrency"], lo["stream_concurrency"]))
 
 
 def test_host_side_covariance_conditioning_matches_oracle(capi, oracle):

@@ -129,10 +129,10 @@ int main(int argc, char** argv) {
   for (int i = 0; i < m; i++) tp[i] = make_float4(tg[3 * i], tg[3 * i + 1], tg[3 * i + 2], 1.f);
   HostTree t = build(tp);   // (fills the start grid with the product's grid_fill_child / grid_fill_root)
   TreeView tv = t.view();
-  long set5 = 0, set4 = 0, set3 = 0;
+  long set5 = 0, set4 = 0, set3 = 0, setf = 0;
   for (int k = 0; k < GRID_ENTRIES; k++)
-    if (t.grid()[k] != GRID_EMPTY) (k < GRID_OFF4 ? set5 : (k < GRID_OFF3 ? set4 : set3))++;
-  printf("target %d points, %d leaves; start grid: %ld / %ld / %ld cells set at levels 5 / 4 / 3\n", m, t.n_leaves, set5, set4, set3);
+    if (t.grid()[k] != GRID_EMPTY) (k < GRID_OFF5 ? setf : (k < GRID_OFF4 ? set5 : (k < GRID_OFF3 ? set4 : set3)))++;
+  printf("target %d points, %d leaves; start grid (finest level %d): %ld / %ld / %ld cells set at levels 5 / 4 / 3, %ld at the finer levels\n", m, t.n_leaves, GRID_FINEST, set5, set4, set3, setf);
   const TreeHeader h = t.hdr();
   std::vector<int> prev(n, -1);
   for (int s = 0; s < np; s++) {

@@ -5,7 +5,8 @@
 cd /tmp && export TMPDIR=/tmp
 # (counter passes run with the runtime's default of four hardware queues: the program keeps one scheduler group in flight, so the queue count
 # does not enter what is measured, and it is the configuration these passes have always been collected in)
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+export GRAFT_REPO_ROOT=$R
 mkdir -p $R/gpurun_out/pmc
 i=0
 for set in "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_HIT_sum TCC_MISS_sum"; do
@@ -72,6 +73,8 @@ for pat, name in (("k_seed", "nn_seed"), ("k_moments_final", "moments_final")):
 out["_method"] = ("rocprofv3 --kernel-trace --output-format csv --pmc <set> (two separate passes, no sys/hip traces) on tools/probe_iter_times.py (32 pairs, one scheduler group); bytes = "
                   "128*RDREQ_128B + 64*RDREQ_64B + 32*RDREQ_32B + 64*(other reads) + 64*WRREQ_64B + 32*(WRREQ - WRREQ_64B), TCC_EA0 counters summed over the XCDs; "
                   "nn_sweep.hbm_bytes_per_launch = all bytes of k_sweep_fused + k_late + k_walk of the profiled alignment / its 20 sweeps (32 jobs each)")
+import hashlib
+out["_lib_sha256"] = hashlib.sha256(open(os.environ.get("LH_LIB") or (R + "/locus_amd/csrc/liblocus_hip.so"), "rb").read()).hexdigest()   # which binary these counters describe
 json.dump(out, open(R + "/gpurun_out/pmc/traffic.json", "w"), indent=1)
 print(json.dumps(out, indent=1)[:3000])
 PY
