@@ -20,8 +20,11 @@ import time
 
 # the CPU leg runs with OMP_PROC_BIND=close; the variable is read when the OpenMP runtime starts, so it has to
 # be in the environment before anything (torch, the oracle) loads one
-os.environ.setdefault("OMP_PROC_BIND", "close")
-os.environ.setdefault("OMP_PLACES", "cores")
+# (the CPU farm's worker processes -- CpuFarm below -- must NOT be bound: dozens of independent 4-thread teams bound `close` all land on the
+# same first cores)
+if not os.environ.get("LH_BENCH_WORKER"):
+    os.environ.setdefault("OMP_PROC_BIND", "close")
+    os.environ.setdefault("OMP_PLACES", "cores")
 # idle OpenMP workers spin this long before they sleep: the CPU leg's optimiser stage is thousands of short parallel regions, and waking a
 # sleeping team for each one was most of its time at high thread counts (a bounded spin, not OMP_WAIT_POLICY=active: a team that spins for
 # ever would sit on the cores the GPU legs' host threads need)
@@ -43,6 +46,97 @@ from locus_amd import dist as ldist  # noqa: E402
 from locus_amd import launch as llaunch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+# ---- the CPU farm: the checker's (oracle's) UNTIMED concurrent runs -------------------------------------------------------------------------
+# Parity and ATE need hundreds of CPU alignments of 100 k-point pairs (4 OMP threads each, dozens at once).  They cannot run as threads of this
+# process: the timed CPU baseline is bound (OMP_PROC_BIND=close), and libgomp binds the team of EVERY thread that opens a parallel
+# region to the same first places -- 32 concurrent 4-thread teams shared four cores (measured: 175 s for the trajectory's 512 pairs).  So they run
+# in spawned worker processes without the binding; scans travel once, as .npy files in /dev/shm.
+def _farm_init():
+    os.environ["LH_BENCH_WORKER"] = "1"
+
+
+def _farm_load(key):
+    return np.load(key + "_xyz.npy"), np.load(key + "_nrm.npy")
+
+
+def _farm_align(a):
+    from oracle import oracle as O
+    src_key, tgt_key, kw, threads = a
+    s4, sn = _farm_load(src_key)
+    t4, tn = _farm_load(tgt_key)
+    r = O.gicp_align(s4, sn, t4, tn, O.default_params(num_threads=threads, **kw), want_trace=False)
+    return np.asarray(r["T"], np.float32), int(r["iterations"]), int(r["status"])
+
+
+def _farm_fitness(a):
+    from oracle import oracle as O
+    src_key, tgt_key, T16, threads = a
+    s4, _ = _farm_load(src_key)
+    t4, _ = _farm_load(tgt_key)
+    return float(O.fitness(s4, np.asarray(T16, np.float32), O.Tree(t4), threads=threads))
+
+
+def _farm_ping(_):
+    from oracle import oracle as O
+    O.lib()
+    return os.getpid()
+
+
+class CpuFarm:
+    def __init__(self, workers, threads=4):
+        import multiprocessing as mp
+        from concurrent.futures import ProcessPoolExecutor
+        self.threads = threads
+        self.dir = "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"
+        self.files = []
+        saved = {k: os.environ.pop(k) for k in ("OMP_PROC_BIND", "OMP_PLACES") if k in os.environ}
+        os.environ["LH_BENCH_WORKER"] = "1"
+        try:
+            self.ex = ProcessPoolExecutor(workers, mp_context=mp.get_context("spawn"), initializer=_farm_init)
+            list(self.ex.map(_farm_ping, range(4 * workers)))   # every worker is up (and has loaded the oracle) before the environment goes back
+        finally:
+            os.environ.pop("LH_BENCH_WORKER", None)
+            os.environ.update(saved)
+
+    def put(self, tag, download):
+        """a downloaded cloud (pcl::PointXYZINormal records) as the oracle's two arrays, in shared memory; returns its key"""
+        from oracle import oracle as O
+        key = os.path.join(self.dir, "lhbench_%d_%s" % (os.getpid(), tag))
+        np.save(key + "_xyz.npy", O.xyz4(np.stack([download["x"], download["y"], download["z"]], 1)))
+        np.save(key + "_nrm.npy", O.nrm4(np.stack([download["normal_x"], download["normal_y"], download["normal_z"]], 1)))
+        self.files += [key + "_xyz.npy", key + "_nrm.npy"]
+        return key
+
+    def drop(self, key):
+        for f in (key + "_xyz.npy", key + "_nrm.npy"):
+            try:
+                os.unlink(f)
+                self.files.remove(f)
+            except (OSError, ValueError):
+                pass
+
+    def align(self, jobs, kw):
+        """jobs: [(src_key, tgt_key)] -> [{"T", "iterations", "status"}] in order"""
+        out = self.ex.map(_farm_align, [(a, b, kw, self.threads) for a, b in jobs])
+        return [{"T": T, "iterations": it, "status": st} for T, it, st in out]
+
+    def fitness(self, jobs):
+        """jobs: [(src_key, tgt_key, T16)] -> [float]"""
+        return list(self.ex.map(_farm_fitness, [(a, b, np.asarray(T, np.float32), self.threads) for a, b, T in jobs]))
+
+    def close(self):
+        try:
+            self.ex.shutdown(wait=True, cancel_futures=True)
+        except Exception:
+            pass
+        for f in list(self.files):
+            try:
+                os.unlink(f)
+            except OSError:
+                pass
+        self.files = []
 
 
 def _pool_map(fn, jobs, workers, chunk):
@@ -503,7 +597,7 @@ def cpu_baseline(S, T, host, P):
                       % (best["pairs_timed"], len(S[0]), best["threads"], phys, t_total)}, poses
 
 
-def trajectory_leg(ctx, P, traj_host, args):
+def trajectory_leg(ctx, P, traj_host, args, farm):
     """BASELINE metric '...; ATE vs ref' / SURVEY 8d config 4: 513 consecutive scans along a smooth trajectory, the 512 pairs (i-1, i)
     aligned as ONE batch (they are independent: PointCloudOdometry.cc:243-267), poses chained with PoseUpdate (:308-309);
     ATE = RMSE of the chained positions against ground truth (all 513 poses) and against the CPU path's chain on a prefix.
@@ -536,33 +630,37 @@ def trajectory_leg(ctx, P, traj_host, args):
            "pairs_per_s": round((n - 1) / dt, 2), "path_length_m": float(np.sum(np.linalg.norm(np.diff(gt[:, :3, 3], axis=0), axis=1))),
            "ate_vs_ground_truth_m": ate(chain, gt), "max_single_step_translation_err_m": max(step_err),
            "final_position_err_m": float(np.linalg.norm(chain[-1, :3, 3] - gt[-1, :3, 3]))}
-    # the CPU path's chain (reference arithmetic, 4 OMP threads per pair, the pairs concurrently) over ALL the pairs, 64 at a time so that only
-    # 65 scans are on the host at once
-    n_cpu = min(int(args.cpu_chain_pairs), n - 1)
+    # the CPU path's chain (reference arithmetic, 4 OMP threads per pair, the pairs concurrently in the CPU farm's worker processes) over ALL the pairs
+    n_cpu = min(int(args.cpu_chain_pairs), n - 1) if farm is not None else 0
     okw = dict(max_iterations=P.max_iterations, max_inner_iterations=P.max_inner_iterations, corr_dist=P.corr_dist,
                transformation_epsilon=P.transformation_epsilon, rotation_epsilon=P.rotation_epsilon, gicp_epsilon=P.gicp_epsilon)
 
-    def inp(d):
-        return O.xyz4(np.stack([d["x"], d["y"], d["z"]], 1)), O.nrm4(np.stack([d["normal_x"], d["normal_y"], d["normal_z"]], 1))
     cpu, t_cpu = [], time.perf_counter()
     carry = None
-    for c0 in range(0, n_cpu, 64):
-        c1 = min(n_cpu, c0 + 64)
-        ins = ([carry] if carry is not None else [inp(clouds[c0].download())]) + [inp(clouds[i].download()) for i in range(c0 + 1, c1 + 1)]
-        carry = ins[-1]
-        with ThreadPoolExecutor(max(1, min(c1 - c0, physical_cores() // 4))) as ex:
-            cpu += list(ex.map(lambda k: O.gicp_align(ins[k + 1][0], ins[k + 1][1], ins[k][0], ins[k][1], O.default_params(num_threads=4, **okw), want_trace=False), range(c1 - c0)))
+    for c0 in range(0, n_cpu, 128):    # 128 pairs at a time: 129 scans in shared memory at once
+        c1 = min(n_cpu, c0 + 128)
+        keys = ([carry] if carry is not None else [farm.put("traj%d" % c0, clouds[c0].download())]) + [farm.put("traj%d" % i, clouds[i].download()) for i in range(c0 + 1, c1 + 1)]
+        cpu += farm.align([(keys[k + 1], keys[k]) for k in range(c1 - c0)], okw)
+        for key in keys[:-1]:
+            farm.drop(key)
+        carry = keys[-1]
         _beat()
+    if carry is not None:
+        farm.drop(carry)
     t_cpu = time.perf_counter() - t_cpu
-    cchain = ldist.chain_poses(np.stack([r["T"] for r in cpu]))
-    step_dt = [_pose_diff(o["T"], r["T"])[0] for o, r in zip(out, cpu)]
-    res["cpu_chain_pairs"] = n_cpu
-    res["cpu_chain_s"] = round(t_cpu, 2)
-    res["ate_vs_cpu_chain_m"] = ate(chain[: n_cpu + 1], cchain)
-    res["cpu_chain_ate_vs_ground_truth_m"] = ate(cchain, gt[: n_cpu + 1])
-    res["gpu_chain_ate_vs_ground_truth_m"] = ate(chain[: n_cpu + 1], gt[: n_cpu + 1])
-    res["per_pair_dt_vs_cpu_m"] = {"median": float(np.median(step_dt)), "p90": float(np.quantile(step_dt, 0.9)), "max": float(max(step_dt)),
-                                   "pairs_within_1e-4": int(sum(d <= 1e-4 for d in step_dt))}
+    if n_cpu == 0:
+        res["cpu_chain_pairs"] = 0
+        cpu = None
+    cchain = ldist.chain_poses(np.stack([r["T"] for r in cpu])) if cpu else None
+    if cpu:
+        step_dt = [_pose_diff(o["T"], r["T"])[0] for o, r in zip(out, cpu)]
+        res["cpu_chain_pairs"] = n_cpu
+        res["cpu_chain_s"] = round(t_cpu, 2)
+        res["ate_vs_cpu_chain_m"] = ate(chain[: n_cpu + 1], cchain)
+        res["cpu_chain_ate_vs_ground_truth_m"] = ate(cchain, gt[: n_cpu + 1])
+        res["gpu_chain_ate_vs_ground_truth_m"] = ate(chain[: n_cpu + 1], gt[: n_cpu + 1])
+        res["per_pair_dt_vs_cpu_m"] = {"median": float(np.median(step_dt)), "p90": float(np.quantile(step_dt, 0.9)), "max": float(max(step_dt)),
+                                       "pairs_within_1e-4": int(sum(d <= 1e-4 for d in step_dt))}
     # PCIe-inclusive: the same stream handed over as HOST PointXYZINormal arrays (what the ROS node holds): every scan uploaded once
     # (scan i is the source of pair i and the target of pair i + 1), aligned, only the 96-byte results come back
     n_pc = min(129, n)
@@ -1018,6 +1116,11 @@ def main():
         }
         if strong is not None:
             result["strong_scaling_same_pairs"] = strong
+        farm, pair_keys = None, {}
+        if world == 1 and not args.no_cpu_baseline:
+            _leg("CPU farm (spawned, unbound oracle workers)")
+            farm = CpuFarm(max(1, min(64, physical_cores() // 4)), threads=4)
+            _STATE["farm"] = farm
         _leg("CPU baseline + parity")
         if world == 1 and not args.no_cpu_baseline:
             cb, poses = cpu_baseline(S, T, host, P)
@@ -1035,10 +1138,12 @@ def main():
                         O.xyz4(np.stack([b["x"], b["y"], b["z"]], 1)), O.nrm4(np.stack([b["normal_x"], b["normal_y"], b["normal_z"]], 1)))
 
             extra = [k for k in range(min(PARITY_PAIRS, len(S))) if k not in poses]
-            ins = {k: oracle_inputs(k) for k in extra}
-            with ThreadPoolExecutor(max(1, min(len(extra), physical_cores() // 4))) as ex:
-                for k, r in zip(extra, ex.map(lambda k: O.gicp_align(*ins[k], O.default_params(num_threads=4, **okw), want_trace=False), extra)):
-                    poses[k] = r["T"]
+            ins = {}
+            # (the untimed runs go to the CPU farm: unbound worker processes, 4 OMP threads each; the pairs' scans stay in shared memory for the
+            # fitness and production-stopping checks below)
+            pair_keys = {k: (farm.put("s%d" % k, S[k].download()), farm.put("t%d" % k, T[k].download())) for k in range(min(PARITY_PAIRS, len(S)))}
+            for k, r in zip(extra, farm.align([pair_keys[k] for k in extra], okw)):
+                poses[k] = r["T"]
             keys = sorted(poses)
             dts, drs = [], []
             for k in keys:
@@ -1061,9 +1166,10 @@ def main():
             # getFitnessScore: the GPU's score of its pose against the CPU path's score of its own (relative 1e-4), same pairs
             gf = capi.Gicp(ctx, P)
             fits = []
-            with ThreadPoolExecutor(max(1, min(len(keys), physical_cores() // 4))) as ex:
-                cpu_fit = dict(zip(keys, ex.map(lambda k: O.fitness((ins[k] if k in ins else oracle_inputs(k))[0], poses[k],
-                                                                    O.Tree((ins[k] if k in ins else oracle_inputs(k))[2]), threads=4), keys)))
+            for k in keys:
+                if k not in pair_keys:
+                    pair_keys[k] = (farm.put("s%d" % k, S[k].download()), farm.put("t%d" % k, T[k].download()))
+            cpu_fit = dict(zip(keys, farm.fitness([(pair_keys[k][0], pair_keys[k][1], poses[k]) for k in keys])))
             for k in keys:
                 gf.set_source(S[k])
                 gf.set_target(T[k])
@@ -1158,13 +1264,10 @@ def main():
                            transformation_epsilon=Pn.transformation_epsilon, rotation_epsilon=Pn.rotation_epsilon, gicp_epsilon=Pn.gicp_epsilon)
                 kn = list(range(min(PARITY_PAIRS, len(S))))
 
-                def cpu_nat(k):
-                    a, b = S[k].download(), T[k].download()
-                    return O.gicp_align(O.xyz4(np.stack([a["x"], a["y"], a["z"]], 1)), O.nrm4(np.stack([a["normal_x"], a["normal_y"], a["normal_z"]], 1)),
-                                        O.xyz4(np.stack([b["x"], b["y"], b["z"]], 1)), O.nrm4(np.stack([b["normal_x"], b["normal_y"], b["normal_z"]], 1)),
-                                        O.default_params(num_threads=4, **okn), want_trace=False)
-                with ThreadPoolExecutor(max(1, min(len(kn), physical_cores() // 4))) as ex:
-                    cn = list(ex.map(cpu_nat, kn))
+                for k in kn:
+                    if k not in pair_keys:
+                        pair_keys[k] = (farm.put("s%d" % k, S[k].download()), farm.put("t%d" % k, T[k].download()))
+                cn = farm.align([pair_keys[k] for k in kn], okn)
 
                 def nat_vs_cpu(outs):
                     ndt, ndr, nit = [], [], []
@@ -1225,7 +1328,7 @@ def main():
                                           "what": "the timed step with max_in_flight = 64 (configs[3]'s per-GPU load: 512 pairs over 8 GPUs)"}
         _leg("trajectory")
         if world == 1 and traj_host is not None:
-            result["trajectory"] = trajectory_leg(ctx, P, traj_host, args)
+            result["trajectory"] = trajectory_leg(ctx, P, traj_host, args, farm)
             _PARTIAL[0] = result
             _leg("stream with normals")
             sw, sw_out = stream_leg(ctx, P, traj_host, args)
@@ -1285,6 +1388,9 @@ def _teardown(code, state):
         faulthandler.cancel_dump_traceback_later()
     except Exception:
         pass
+    if state.get("farm") is not None:
+        phase("CPU farm shutdown")
+        state["farm"].close()
     phase("closing %d clouds" % len(state.get("clouds", [])))
     for c in state.get("clouds", []):
         try:

@@ -136,11 +136,12 @@ lh_status lh_runtime_init(int max_hw_queues);
 typedef struct {
   int hw_queues_env;          /* GPU_MAX_HW_QUEUES as this process sees it now (-1: unset) */
   int streams_probed;         /* 16 */
-  double stream_concurrency;  /* MEASURED: how many of sixteen one-wave kernels on sixteen streams ran at once (16 = all; ~4 = the runtime's default) */
+  double stream_concurrency;  /* MEASURED: how many of sixteen one-wave kernels on the context's sixteen streams were resident at the same instant (16 = all; ~4 = the runtime's default) */
   int adequate;               /* stream_concurrency >= 12: batches of >= 64 pairs get the overlap the scheduler counts on */
   int reserved;
 } lh_runtime_info_t;
-/* What the HIP runtime actually gives this process (a 16-stream overlap probe, ~1 ms, measured once per device and cached).  The scheduler runs
+/* What the HIP runtime actually gives this process (an overlap probe on the context's own sixteen scheduler streams -- created if the scheduler has
+ * not needed them yet -- ~2 ms, measured once per device and cached).  The scheduler runs
  * the same probe the first time a batch spreads over more than four streams and reports a shortfall once on stderr. */
 lh_status lh_runtime_info(lh_ctx* ctx, lh_runtime_info_t* out);
 lh_status lh_create(lh_ctx** out, int device_id);

@@ -63,37 +63,53 @@ lh_status upload_view(lh_ctx* c, const lh_cloud_view* v, lh_cloud** out, bool sy
 
 // =========================================================================================================
 #pragma GCC visibility push(default)   // the C ABI is the library's ONLY exported surface (the TUs are compiled -fvisibility=hidden)
-// one wave that stays resident for `ticks` of the 100-MHz wall clock: the probe's unit of work
-__global__ void __launch_bounds__(64) k_probe_spin(unsigned long long ticks, unsigned int* sink) {
+// one wave that stays resident for `ticks` of the 100-MHz wall clock and says when it ran: the probe's unit of work
+__global__ void __launch_bounds__(64) k_probe_spin(unsigned long long ticks, unsigned long long* __restrict__ span) {
   const unsigned long long t0 = wall_clock64();
-  unsigned int it = 0;
-  while (wall_clock64() - t0 < ticks) it++;
-  if (sink && threadIdx.x == 0 && it == 0xffffffffu) *sink = it;
+  while (wall_clock64() - t0 < ticks) {}
+  if (span && threadIdx.x == 0) { span[0] = t0; span[1] = wall_clock64(); }
 }
 static std::mutex g_probe_mu;
 static double g_probe_concurrency[64] = {};   // per device; 0 = not measured yet
-// How many of sixteen one-wave kernels on sixteen streams the runtime runs at once (wall clock): 16 x the kernel's length / the time all took.
-static double probe_stream_concurrency(int device) {
+// How many of sixteen one-wave kernels on the CONTEXT'S OWN sixteen streams are resident at the same instant (their own wall-clock stamps; the
+// largest overlap of the sixteen intervals).  The scheduler's streams, not new ones: the runtime hands hardware queues to streams as they are
+// created, and a process with more streams than queues runs far worse than one with fewer (round 4: 24 groups 3.8 k pairs/s against 12.2 k
+// with 16) -- a probe that created sixteen streams of its own next to the scheduler's cost exactly that.
+static double probe_stream_concurrency(lh_ctx* c) {
   std::lock_guard<std::mutex> lk(g_probe_mu);
+  const int device = c->device;
   if (device >= 0 && device < 64 && g_probe_concurrency[device] > 0) return g_probe_concurrency[device];
   constexpr int NS = 16;
-  const double spin_s = 400e-6;
-  hipStream_t st[NS] = {};
-  bool ok = true;
-  for (int k = 0; k < NS && ok; k++) ok = hipStreamCreateWithFlags(&st[k], hipStreamNonBlocking) == hipSuccess;
-  double conc = 0.0;
-  if (ok) {
-    for (int k = 0; k < NS; k++) hipLaunchKernelGGL(k_probe_spin, dim3(1), dim3(64), 0, st[k], 100ull, (unsigned int*)nullptr);   // warm-up: code object, queues
-    for (int k = 0; k < NS; k++) (void)hipStreamSynchronize(st[k]);
-    const auto t0 = std::chrono::steady_clock::now();
-    for (int k = 0; k < NS; k++) hipLaunchKernelGGL(k_probe_spin, dim3(1), dim3(64), 0, st[k], (unsigned long long)(spin_s * 1e8), (unsigned int*)nullptr);
-    for (int k = 0; k < NS; k++) ok = ok && hipStreamSynchronize(st[k]) == hipSuccess;
-    const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    if (ok && wall > 0) conc = std::min((double)NS, NS * spin_s / wall);
+  hipStream_t* side[lh_ctx::MAX_GROUPS - 1] = {&c->stream2, &c->stream3, &c->stream4};
+  for (int k = 0; k < lh_ctx::MAX_GROUPS - 4; k++) side[3 + k] = &c->stream_more[k];
+  hipStream_t st[NS];
+  st[0] = c->stream;
+  for (int k = 1; k < NS; k++) {
+    if (!*side[k - 1] && hipStreamCreateWithFlags(side[k - 1], hipStreamNonBlocking) != hipSuccess) return 0.0;
+    st[k] = *side[k - 1];
   }
-  for (int k = 0; k < NS; k++)
-    if (st[k]) (void)hipStreamDestroy(st[k]);
+  unsigned long long* span = nullptr;
+  if (hipMalloc(&span, sizeof(unsigned long long) * 2 * NS) != hipSuccess) return 0.0;
+  const unsigned long long ticks = 200000ull;   // 2 ms of the 100-MHz clock: sixteen launches are issued in a fraction of that
+  bool ok = true;
+  for (int k = 0; k < NS; k++) hipLaunchKernelGGL(k_probe_spin, dim3(1), dim3(64), 0, st[k], 100ull, (unsigned long long*)nullptr);   // warm-up: code object, queues
+  for (int k = 0; k < NS; k++) ok = ok && hipStreamSynchronize(st[k]) == hipSuccess;
+  for (int k = 0; k < NS; k++) hipLaunchKernelGGL(k_probe_spin, dim3(1), dim3(64), 0, st[k], ticks, span + 2 * k);
+  for (int k = 0; k < NS; k++) ok = ok && hipStreamSynchronize(st[k]) == hipSuccess;
+  unsigned long long h[2 * NS] = {};
+  ok = ok && hipMemcpy(h, span, sizeof h, hipMemcpyDeviceToHost) == hipSuccess;
+  (void)hipFree(span);
   (void)hipGetLastError();
+  double conc = 0.0;
+  if (ok) {   // the largest number of intervals [start, end) that contain a common instant: try every start
+    int best = 0;
+    for (int a = 0; a < NS; a++) {
+      int n = 0;
+      for (int b = 0; b < NS; b++) n += (h[2 * b] <= h[2 * a] && h[2 * a] < h[2 * b + 1]) ? 1 : 0;
+      best = std::max(best, n);
+    }
+    conc = (double)best;
+  }
   if (device >= 0 && device < 64) g_probe_concurrency[device] = conc;
   return conc;
 }
@@ -101,12 +117,12 @@ static double probe_stream_concurrency(int device) {
 void runtime_check_streams(lh_ctx* c, int groups) {
   static std::atomic<bool> said{false};
   if (groups <= 4 || said.load()) return;
-  const double conc = probe_stream_concurrency(c->device);
+  const double conc = probe_stream_concurrency(c);
   if (conc > 0 && conc < 0.7 * std::min(groups, 16) && !said.exchange(true)) {
     const char* e = getenv("GPU_MAX_HW_QUEUES");
-    fprintf(stderr, "[locus_hip] this process runs %d scheduler streams about %.0f deep: the HIP runtime gave it too few hardware queues (GPU_MAX_HW_QUEUES=%s, read at "
+    fprintf(stderr, "[locus_hip] of %d scheduler streams only about %.0f run at once: the HIP runtime gave this process too few hardware queues (GPU_MAX_HW_QUEUES=%s, read at "
                     "the process's first HIP call).  Batches of >= 64 pairs run about 20 %% slower than they could: call lh_runtime_init(0) before the first HIP "
-                    "call, or export GPU_MAX_HW_QUEUES=24 (INTEGRATION.md section 5).\n", groups, 16.0 / conc, e ? e : "unset");
+                    "call, or export GPU_MAX_HW_QUEUES=24 (INTEGRATION.md section 5).\n", groups, conc, e ? e : "unset");
   }
 }
 
@@ -168,7 +184,7 @@ lh_status lh_runtime_info(lh_ctx* c, lh_runtime_info_t* out) {
   const char* e = getenv("GPU_MAX_HW_QUEUES");
   out->hw_queues_env = e ? atoi(e) : -1;
   out->streams_probed = 16;
-  out->stream_concurrency = probe_stream_concurrency(c->device);
+  out->stream_concurrency = probe_stream_concurrency(c);
   if (!(out->stream_concurrency > 0)) return LH_EDEVICE;
   out->adequate = out->stream_concurrency >= 12.0;
   return LH_OK;
