@@ -36,6 +36,11 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 
 import ctypes as C
 
+try:
+    _CPUS_AT_START = os.sched_getaffinity(0)   # before any OpenMP runtime exists in this process (see _farm_init)
+except AttributeError:
+    _CPUS_AT_START = set(range(os.cpu_count() or 1))
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -53,8 +58,14 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured 
 # process: the timed CPU baseline is bound (OMP_PROC_BIND=close), and libgomp binds the team of EVERY thread that opens a parallel
 # region to the same first places -- 32 concurrent 4-thread teams shared four cores (measured: 175 s for the trajectory's 512 pairs).  So they run
 # in spawned worker processes without the binding; scans travel once, as .npy files in /dev/shm.
-def _farm_init():
+def _farm_init(cpus):
+    # the parent's main thread was bound to ONE core by its own OpenMP runtime (OMP_PROC_BIND=close binds the initial thread) and a child
+    # inherits that mask: without this every worker of the farm -- and every thread of its team -- shares that core (measured: 383 s for 512 pairs)
     os.environ["LH_BENCH_WORKER"] = "1"
+    try:
+        os.sched_setaffinity(0, cpus)
+    except (OSError, AttributeError):
+        pass
 
 
 def _farm_load(key):
@@ -94,7 +105,7 @@ class CpuFarm:
         saved = {k: os.environ.pop(k) for k in ("OMP_PROC_BIND", "OMP_PLACES") if k in os.environ}
         os.environ["LH_BENCH_WORKER"] = "1"
         try:
-            self.ex = ProcessPoolExecutor(workers, mp_context=mp.get_context("spawn"), initializer=_farm_init)
+            self.ex = ProcessPoolExecutor(workers, mp_context=mp.get_context("spawn"), initializer=_farm_init, initargs=(_CPUS_AT_START,))
             list(self.ex.map(_farm_ping, range(4 * workers)))   # every worker is up (and has loaded the oracle) before the environment goes back
         finally:
             os.environ.pop("LH_BENCH_WORKER", None)

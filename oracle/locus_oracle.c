@@ -975,6 +975,34 @@ int lo_estimate_rigid_bfgs(const float* out_xyz4, const float* tgt_xyz4, const i
   return st;
 }
 
+/* The same solve with its inner steps written down (tests/test_second_restatement.py: held against tools/golden.py's independently written
+ * vector_bfgs2 + Fletcher line search): after minimizeInit (row 0) and after every minimizeOneStep that returned success, the state x, the
+ * cost f, the gradient norm and the number of functor evaluations so far.  Returns the number of rows; *result = the last step's return
+ * value (BFGS_SUCCESS = gradient below 1e-2, BFGS_NOPROGRESS, BFGS_RUNNING = max_inner reached). */
+int lo_estimate_rigid_bfgs_trace(const float* out_xyz4, const float* tgt_xyz4, const int32_t* src_idx, const int32_t* tgt_idx, int m,
+                                 const double* maha9, int max_inner, const double* x_start6, double* xs, double* fs, double* gnorms, int* evals,
+                                 int cap, int* result) {
+  cost_ctx c = {out_xyz4, tgt_xyz4, src_idx, tgt_idx, m, maha9, 0, 1, 0};
+  double x[6];
+  memcpy(x, x_start6, sizeof x);
+  bfgs_t b;
+  memset(&b, 0, sizeof(b));
+  b.sigma = 0.01; b.rho = 0.01; b.tau1 = 9; b.tau2 = 0.05; b.tau3 = 0.5; b.order = 3;
+  b.step_size = 1; b.bracket_iters = 100; b.section_iters = 100;
+  int rows = 0, inner = 0, res;
+  bfgs_init(&b, &c, x);
+  if (rows < cap) { memcpy(xs, x, sizeof x); fs[0] = b.f; gnorms[0] = norm6(b.gradient); evals[0] = (int)c.passes; rows = 1; }
+  do {
+    inner++;
+    res = bfgs_one_step(&b, x);
+    if (res) break;
+    if (rows < cap) { memcpy(xs + 6 * rows, x, sizeof x); fs[rows] = b.f; gnorms[rows] = norm6(b.gradient); evals[rows] = (int)c.passes; rows++; }
+    res = (norm6(b.gradient) < 1e-2) ? BFGS_SUCCESS : BFGS_RUNNING;
+  } while (res == BFGS_RUNNING && inner < max_inner);
+  if (result) *result = res;
+  return rows;
+}
+
 /* ------------------------------------------------------------------------------------------
  * a3 + a6: pcl::Registration::align -> computeTransformation (gicp.hpp:406-617)
  * ------------------------------------------------------------------------------------------ */

@@ -100,6 +100,12 @@ void lo_cost_fdf(const float* out_xyz4, const float* tgt_xyz4, const int32_t* sr
 /* estimateRigidTransformationBFGS (gicp.hpp:218-287) on given correspondences; T16 in/out */
 int lo_estimate_rigid_bfgs(const float* out_xyz4, const float* tgt_xyz4, const int32_t* src_idx, const int32_t* tgt_idx, int m,
                            const double* maha9, int max_inner, float* T16, int* n_inner, double* f_end, int* passes);
+/* ... and the same solve from state x_start6 with its inner steps recorded (row 0 = after minimizeInit, then one row per successful
+ * minimizeOneStep): xs [cap][6], fs, gnorms, evals (functor evaluations so far).  Returns the rows written; *result = the last step's status
+ * (0 success: gradient below 1e-2, 1 no progress, -1 still running when max_inner was reached). */
+int lo_estimate_rigid_bfgs_trace(const float* out_xyz4, const float* tgt_xyz4, const int32_t* src_idx, const int32_t* tgt_idx, int m,
+                                 const double* maha9, int max_inner, const double* x_start6, double* xs, double* fs, double* gnorms, int* evals,
+                                 int cap, int* result);
 /* applyState (gicp.hpp:619-634): T = [Rz(x5)Ry(x4)Rx(x3) | x0..2] in float, column-major out */
 void lo_apply_state(const double* x6, float* T16);
 

@@ -264,6 +264,23 @@ def cost_fdf(out4, tgt4, src_idx, tgt_idx, maha, x6):
     return f.value, g, sums
 
 
+def bfgs_trace(out4, tgt4, src_idx, tgt_idx, maha, x_start, max_inner=20, cap=256):
+    """estimateRigidTransformationBFGS's solve (gicp.hpp:249-271 + the restated pcl::BFGS) from state x_start with its inner steps recorded:
+    row 0 after minimizeInit, then one row per successful minimizeOneStep"""
+    out4, tgt4 = _f4(out4), _f4(tgt4)
+    src_idx = np.ascontiguousarray(src_idx, np.int32)
+    tgt_idx = np.ascontiguousarray(tgt_idx, np.int32)
+    maha = np.ascontiguousarray(maha, np.float64)
+    x0 = np.ascontiguousarray(x_start, np.float64)
+    xs, fs, gn, ev = np.zeros((cap, 6)), np.zeros(cap), np.zeros(cap), np.zeros(cap, np.int32)
+    res = C.c_int()
+    L = lib()
+    L.lo_estimate_rigid_bfgs_trace.restype = C.c_int
+    rows = L.lo_estimate_rigid_bfgs_trace(_p(out4), _p(tgt4), _p(src_idx), _p(tgt_idx), C.c_int(src_idx.shape[0]), _p(maha), C.c_int(max_inner), _p(x0),
+                                          _p(xs), _p(fs), _p(gn), _p(ev), C.c_int(cap), C.byref(res))
+    return {"x": xs[:rows], "f": fs[:rows], "gnorm": gn[:rows], "evals": ev[:rows], "result": res.value}
+
+
 def apply_state(x6):
     x6 = np.ascontiguousarray(x6, np.float64)
     T = np.empty(16, np.float32)

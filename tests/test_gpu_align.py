@@ -238,7 +238,6 @@ def test_batch_multi_contexts_and_views(ctx, capi, oracle):
 # bit-different evaluation of the same cost and is held to max(1e-4, floor): every pair inside the floor's maximum, the
 # typical pair inside its 15-of-16 value.
 FLOOR_T_MAX, FLOOR_R_MAX, FLOOR_T_TYPICAL = 2.5e-3, 1.3e-4, 2.4e-4
-ITERATE_SANITY = 2e-2   # intermediate iterates (a line search that stopped elsewhere on the valley floor): order-of-magnitude check only
 N_BENCH_PAIRS = 32
 BENCH_SEEDS = tuple(10 + 2 * p for p in range(N_BENCH_PAIRS))   # bench.py gen_pairs_host(), rank 0, pairs 0..31
 # Quantile bars of the benched mode over those pairs (profiles/r03_fullsize_parity.json: the same table over 64 pairs, next to the
@@ -392,7 +391,7 @@ def test_bench_pairs_full_size_vs_oracle(ctx, capi, oracle, bench_pairs, cost_mo
     pairs = pairs[:4]   # with their per-iteration traces, one at a time (the other tests take all of them as a batch)
     P = capi.default_params(cost_mode=cost_mode, **kw)
     batch = capi.align_batch(ctx, P, [p["cs"] for p in pairs], [p["ct"] for p in pairs], max_in_flight=4)
-    dts, drs = [], []
+    dts, drs, iter_dts = [], [], []
     for p, rb in zip(pairs, batch):
         ro = p["ro"]
         g = capi.Gicp(ctx, P)
@@ -421,7 +420,7 @@ def test_bench_pairs_full_size_vs_oracle(ctx, capi, oracle, bench_pairs, cost_mo
         else:                # moment model: inside the reference's own noise floor at this configuration
             assert dt <= max(TOL_T, FLOOR_T_MAX) and dR <= max(TOL_R, FLOOR_R_MAX), (p["seed"], dt, dR)
             assert abs(fit - p["fo"]) <= 2e-3 * p["fo"]
-            assert dT_it.max() <= ITERATE_SANITY   # measured up to 7.6e-3 mid-way (the reference's two builds: 3.4e-3)
+            iter_dts.append(float(dT_it.max()))   # held below to the per-iteration quantile bars of the 32-pair test (measured up to 7.6e-3 mid-way; the reference's two builds: 3.4e-3)
             # the cost at the end of each solve: the same valley (mid-way the two line searches stop at different heights: 2 %
             # measured), the same floor at the end
             assert np.allclose(r["trace"]["f_end"][:k], ro["trace"]["f_end"][:k], rtol=5e-2)
@@ -431,6 +430,9 @@ def test_bench_pairs_full_size_vs_oracle(ctx, capi, oracle, bench_pairs, cost_mo
         assert np.abs(Tm[:3, 3] - p["delta"][:3, 3]).max() < 0.02
     if cost_mode == 1:
         assert np.median(dts) <= max(TOL_T, FLOOR_T_TYPICAL), dts
+        # north_star's "per-iteration results match": the same quantile bars as test_bench_pairs_device_loop_32_in_flight_vs_oracle (the largest
+        # |dT| of any iteration of a pair: median <= 1.5e-3, and with four pairs "nine in ten" means every one of them <= 1e-2)
+        assert np.median(iter_dts) <= Q_ITER_MEDIAN and max(iter_dts) <= Q_ITER_P90, iter_dts
 
 
 def test_full_size_properties_100k(ctx, capi, oracle):

@@ -2,9 +2,11 @@
 """SECOND, independent restatement of the GICP hot path in numpy + scipy -- written from the reference's source
 (/root/reference/multithreaded_gicp/include/multithreaded_gicp/gicp.hpp, cited per function), sharing NO code with oracle/locus_oracle.c:
 neighbours from scipy.spatial.cKDTree instead of the oracle's own kd-tree, 3x3 inverses / SVDs from LAPACK instead of hand-written
-cofactors / Jacobi sweeps, and -- the part the C oracle restates "as recalled" -- NO pcl::BFGS at all: every outer iteration minimises
-the frozen-correspondence cost with scipy.optimize (BFGS with an analytic gradient, tight tolerance), i.e. it goes to the minimiser the
-reference's inner loop is heading for instead of imitating where that loop stops.
+cofactors / Jacobi sweeps.  The outer loop contains NO pcl::BFGS: every outer iteration minimises the frozen-correspondence cost with
+scipy.optimize (BFGS with an analytic gradient, tight tolerance), i.e. it goes to the minimiser the reference's inner loop is heading for
+instead of imitating where that loop stops.  Separately (round 5) the part the C oracle restates "as recalled" -- pcl::BFGS = GSL
+vector_bfgs2 + Fletcher's line search -- is written here a second time from the published algorithm, with PCL's known or suspected
+deviations as switches, and the first solve of two cases is recorded step by step for the oracle to be held against.
 
 It writes tests/golden/second_restatement.npz (inputs + expected outputs); tests/test_second_restatement.py then holds the C oracle to
 it on the CPU:  first-sweep correspondences and Mahalanobis matrices, k-NN covariances, f and g of the cost functor, the
@@ -180,7 +182,308 @@ def gicp(src, tgt, C1, C2, corr_dist, max_iterations, tf_eps, rot_eps=2e-3):
     return T, first, trace
 
 
-def case(name, src, tgt, k, eps, corr_dist, max_iterations, tf_eps):
+# ---- pcl::BFGS, written a second time ------------------------------------------------------------------------------------------------------
+# estimateRigidTransformationBFGS (gicp.hpp:249-271) drives pcl::BFGS<OptimizationFunctorWithIndices> -- PCL's Eigen port of GSL's
+# multimin/vector_bfgs2.c + linear_minimize.c (Fletcher, "Practical Methods of Optimization", 2nd ed., algorithms 2.6.2 / 2.6.4), not in
+# /root/reference.  The C oracle restates it; this is a SECOND restatement written from the GSL algorithm as published (state layout,
+# names and control structure are this file's own), so that tests/test_second_restatement.py can hold the oracle's INNER steps -- x, f, |g|,
+# evaluation count after every minimizeOneStep -- against it.  The places where PCL's port is known or suspected to deviate from GSL are
+# switches (`quirks`), because no copy of pcl/registration/bfgs.h exists here to settle them; the test reports how far each moves the solve.
+QUIRKS_AS_THE_ORACLE = dict(
+    roots="plain",        # roots of the cubic's derivative: "plain" (-b -+ sqrt(disc)) / 2a  (PCL's PolynomialSolver<Scalar, 2> specialisation) | "stable" (gsl_poly_solve_quadratic)
+    dir_zero="keep",      # sign of the new direction when p . g == 0 exactly: "keep" (PCL: `> 0 ? -1 : 1`) | "flip" (GSL: `>= 0 ? -1 : 1`)
+    quad_curv="c>0",      # quadratic interpolation accepts its stationary point if "c>0" (GSL) | "c>a" (reported PCL typo)
+    poly_eval="horner")   # cubic evaluated by "horner" (GSL cubic()) | "eigen" (Eigen::poly_eval: reverse Horner for |z| > 1)
+
+
+def quat_state_matrix(x):
+    """applyState (gicp.hpp:619-634) on the identity: Eigen::AngleAxisf(z) * AngleAxisf(y) * AngleAxisf(x) -> Quaternionf products ->
+    toRotationMatrix, all in float32 (Eigen's documented scalar formulas); translation = float(x[0:3]).  Returns a float32 4x4."""
+    def aa(angle, axis):   # Quaternion(AngleAxis): w = cos(a / 2), vec = sin(a / 2) * axis   (a = float(angle))
+        ha = F32(0.5) * F32(angle)
+        c, sn = F32(np.cos(np.float64(ha))), F32(np.sin(np.float64(ha)))   # cosf / sinf: correctly rounded from double
+        v = [F32(0), F32(0), F32(0)]
+        v[axis] = sn
+        return (c, v[0], v[1], v[2])
+
+    def mul(a, b):         # Eigen quat_product, scalar path
+        aw, ax, ay, az = a
+        bw, bx, by, bz = b
+        return (F32(F32(F32(aw * bw - ax * bx) - ay * by) - az * bz), F32(F32(F32(aw * bx + ax * bw) + ay * bz) - az * by),
+                F32(F32(F32(aw * by + ay * bw) + az * bx) - ax * bz), F32(F32(F32(aw * bz + az * bw) + ax * by) - ay * bx))
+    w, qx, qy, qz = mul(mul(aa(x[5], 2), aa(x[4], 1)), aa(x[3], 0))
+    tx, ty, tz = F32(2) * qx, F32(2) * qy, F32(2) * qz
+    twx, twy, twz = tx * w, ty * w, tz * w
+    txx, txy, txz = tx * qx, ty * qx, tz * qx
+    tyy, tyz, tzz = ty * qy, tz * qy, tz * qz
+    T = np.eye(4, dtype=F32)
+    T[0, 0], T[0, 1], T[0, 2] = F32(1) - (tyy + tzz), txy - twz, txz + twy
+    T[1, 0], T[1, 1], T[1, 2] = txy + twz, F32(1) - (txx + tzz), tyz - twx
+    T[2, 0], T[2, 1], T[2, 2] = txz - twy, tyz + twx, F32(1) - (txx + tyy)
+    T[0, 3], T[1, 3], T[2, 3] = F32(x[0]), F32(x[1]), F32(x[2])
+    return T
+
+
+class SerialFunctor:
+    """OptimizationFunctorWithIndices::fdf (gicp.hpp:362-402) the way the reference adds it up: one correspondence after the other (cumsum is a
+    sequential scan), every 3-term product as (a + b) + c, the residual a FLOAT subtraction of two floats (:384)"""
+
+    def __init__(self, src, tgt, nn, ok, M):
+        ii = np.nonzero(ok)[0]
+        self.p, self.t, self.M, self.m = src[ii].astype(F32), tgt[nn[ii]].astype(F32), M[ii], len(ii)
+        self.evals = 0
+
+    def __call__(self, x):
+        self.evals += 1
+        T = quat_state_matrix(x)
+        p, t, M = self.p, self.t, self.M
+        pp = np.stack([((T[r, 0] * p[:, 0] + T[r, 1] * p[:, 1]) + T[r, 2] * p[:, 2]) + T[r, 3] for r in range(3)], 1).astype(F32)
+        res = (pp - t).astype(np.float64)
+        temp = np.stack([(M[:, r, 0] * res[:, 0] + M[:, r, 1] * res[:, 1]) + M[:, r, 2] * res[:, 2] for r in range(3)], 1)
+        ser = lambda v: float(np.cumsum(v)[-1])                      # noqa: E731  (serial sum, in order)
+        f = ser((res[:, 0] * temp[:, 0] + res[:, 1] * temp[:, 1]) + res[:, 2] * temp[:, 2]) / self.m
+        s = 2.0 / self.m
+        g = np.zeros(6)
+        g[0], g[1], g[2] = ser(temp[:, 0]) * s, ser(temp[:, 1]) * s, ser(temp[:, 2]) * s
+        pd = p.astype(np.float64)
+        R = np.array([[ser(pd[:, a] * temp[:, b]) * s for b in range(3)] for a in range(3)])   # R += p_src3 * temp^T, then R *= 2 / m
+        dphi, dth, dpsi = d_euler(x)
+        # matricesInnerProd (gicp.h:361-370): r += mat1(j, i) * mat2(i, j), i outer, j inner
+        for k, dm in ((3, dphi), (4, dth), (5, dpsi)):
+            r = 0.0
+            for i in range(3):
+                for j in range(3):
+                    r += dm[j, i] * R[i, j]
+            g[k] = r
+        return f, g
+
+
+class Fletcher:
+    """one-dimensional minimisation along x0 + alpha p with GSL's cached wrapper (f and df at the last alpha are not recomputed)"""
+
+    def __init__(self, fn, quirks):
+        self.fn, self.q = fn, quirks
+
+    # -- the wrapper (vector_bfgs2.c wrap_f / wrap_df / wrap_fdf): one cache entry per quantity, keyed by alpha
+    def prepare(self, x0, f0, g0, p):
+        self.x0, self.p = x0.copy(), p.copy()
+        self.x_a, self.g_a = x0.copy(), g0.copy()
+        self.f_a, self.df_a = f0, float(np.dot(g0, p))
+        self.kx = self.kf = self.kg = self.kdf = 0.0
+
+    def _move(self, alpha):
+        if alpha != self.kx:
+            self.x_a = self.x0 + alpha * self.p
+            self.kx = alpha
+
+    def f(self, alpha):
+        if alpha != self.kf:
+            self._move(alpha)
+            self.f_a, _ = self.fn(self.x_a)
+            self.kf = alpha
+        return self.f_a
+
+    def df(self, alpha):
+        if alpha != self.kdf:
+            self._move(alpha)
+            if alpha != self.kg:
+                _, self.g_a = self.fn(self.x_a)
+                self.kg = alpha
+            self.df_a = float(np.dot(self.g_a, self.p))
+            self.kdf = alpha
+        return self.df_a
+
+    def fdf(self, alpha):
+        if alpha == self.kf and alpha == self.kdf:
+            return self.f_a, self.df_a
+        if alpha == self.kf or alpha == self.kdf:
+            return self.f(alpha), self.df(alpha)
+        self._move(alpha)
+        self.f_a, self.g_a = self.fn(self.x_a)
+        self.kf = self.kg = alpha
+        self.df_a = float(np.dot(self.g_a, self.p))
+        self.kdf = alpha
+        return self.f_a, self.df_a
+
+    # -- interpolation (linear_minimize.c)
+    def _cubic(self, c, z):
+        if self.q["poly_eval"] == "eigen" and z * z > 1.0:
+            val, inv = c[0], 1.0 / z
+            for k in (1, 2, 3):
+                val = val * inv + c[k]
+            return (z ** 3) * val
+        return c[0] + z * (c[1] + z * (c[2] + z * c[3]))
+
+    def _derivative_roots(self, c):
+        qa, qb, qc = 3 * c[3], 2 * c[2], c[1]
+        disc = qb * qb - 4 * qa * qc
+        if self.q["roots"] == "stable":
+            if qa == 0:
+                return [] if qb == 0 else [-qc / qb]
+            if disc > 0:
+                if qb == 0:
+                    r = np.sqrt(-qc / qa)
+                    return [-r, r]
+                tmp = -0.5 * (qb + (1 if qb > 0 else -1) * np.sqrt(disc))
+                return sorted([tmp / qa, qc / tmp])
+            return [-0.5 * qb / qa] if disc == 0 else []
+        if disc > 0:
+            sd = np.sqrt(disc)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                return sorted([float(np.float64(-qb - sd) / np.float64(2 * qa)), float(np.float64(-qb + sd) / np.float64(2 * qa))], key=lambda v: (v != v, v))
+        if disc == 0:
+            with np.errstate(divide="ignore", invalid="ignore"):
+                return [float(np.float64(-qb) / np.float64(2 * qa))]
+        return []
+
+    def interpolate(self, a, fa, fpa, b, fb, fpb, xmin, xmax, order=3):
+        ymin, ymax = (xmin - a) / (b - a), (xmax - a) / (b - a)
+        if ymin > ymax:
+            ymin, ymax = ymax, ymin
+        if order > 2 and np.isfinite(fpb):
+            fpa, fpb = fpa * (b - a), fpb * (b - a)
+            c = (fa, fpa, 3 * (fb - fa) - 2 * fpa - fpb, fpa + fpb - 2 * (fb - fa))
+            y, fmin = ymin, self._cubic(c, ymin)
+            cand = [ymax] + [z for z in self._derivative_roots(c) if z > ymin and z < ymax]
+            for z in cand:
+                v = self._cubic(c, z)
+                if v < fmin:
+                    y, fmin = z, v
+        else:
+            fpa = fpa * (b - a)
+            quad = lambda z: fa + z * (fpa + z * (fb - fa - fpa))   # noqa: E731
+            y, fmin = ymin, quad(ymin)
+            if quad(ymax) < fmin:
+                y, fmin = ymax, quad(ymax)
+            curv = 2 * (fb - fa - fpa)
+            if curv > (a if self.q["quad_curv"] == "c>a" else 0.0):
+                z = -fpa / curv
+                if z > ymin and z < ymax and quad(z) < fmin:
+                    y = z
+        return a + y * (b - a)
+
+    # -- Fletcher's line search: bracketing, then sectioning (minimize() of linear_minimize.c); returns (status, alpha)
+    def minimize(self, alpha1, rho=0.01, sigma=0.01, tau1=9.0, tau2=0.05, tau3=0.5, order=3):
+        f0, fp0 = self.fdf(0.0)
+        alpha, alpha_prev, f_prev, fp_prev = alpha1, 0.0, f0, fp0
+        a, b, fa, fb, fpa, fpb = 0.0, alpha, f0, 0.0, fp0, 0.0
+        i = 0
+        while i < 100:
+            i += 1
+            fal = self.f(alpha)
+            if fal > f0 + alpha * rho * fp0 or fal >= f_prev:
+                a, fa, fpa, b, fb, fpb = alpha_prev, f_prev, fp_prev, alpha, fal, np.nan
+                break
+            fpal = self.df(alpha)
+            if abs(fpal) <= -sigma * fp0:
+                return "success", alpha
+            if fpal >= 0:
+                a, fa, fpa, b, fb, fpb = alpha, fal, fpal, alpha_prev, f_prev, fp_prev
+                break
+            delta = alpha - alpha_prev
+            nxt = self.interpolate(alpha_prev, f_prev, fp_prev, alpha, fal, fpal, alpha + delta, alpha + tau1 * delta, order)
+            alpha_prev, f_prev, fp_prev, alpha = alpha, fal, fpal, nxt
+        else:
+            i += 1          # (C's `while (i++ < n)` leaves i one past n when the loop runs out)
+        while i < 100:
+            i += 1
+            delta = b - a
+            alpha = self.interpolate(a, fa, fpa, b, fb, fpb, a + tau2 * delta, b - tau3 * delta, order)
+            fal = self.f(alpha)
+            if (a - alpha) * fpa <= np.finfo(np.float64).eps:
+                return "noprogress", alpha
+            if fal > f0 + rho * alpha * fp0 or fal >= fa:
+                b, fb, fpb = alpha, fal, np.nan
+            else:
+                fpal = self.df(alpha)
+                if abs(fpal) <= -sigma * fp0:
+                    return "success", alpha
+                if ((b - a) >= 0 and fpal >= 0) or ((b - a) <= 0 and fpal <= 0):
+                    b, fb, fpb = a, fa, fpa
+                a, fa, fpa = alpha, fal, fpal
+        return "success", alpha
+
+
+def vector_bfgs2(fn, x_start, max_inner, quirks=QUIRKS_AS_THE_ORACLE, gradient_tol=1e-2, step_size=1.0):
+    """gsl_multimin_fdfminimizer_vector_bfgs2 as pcl::BFGS::minimizeInit / minimizeOneStep / testGradient are driven by gicp.hpp:259-271.
+    Returns the rows (x, f, |g|, evaluations so far) after the initialisation and after every successful step, and how the loop ended."""
+    x = np.asarray(x_start, np.float64).copy()
+    f, g = fn(x)
+    x0, g0 = x.copy(), g.copy()
+    g0norm = float(np.sqrt(np.dot(g0, g0)))
+    p = g * (-1.0 / g0norm)
+    pnorm, fp0, delta_f = float(np.sqrt(np.dot(p, p))), -g0norm, 0.0
+    ls = Fletcher(fn, quirks)
+    ls.prepare(x0, f, g0, p)
+    rows = [(x.copy(), f, g0norm, fn.evals)]
+    end, inner = "running", 0
+    while True:
+        inner += 1
+        if pnorm == 0.0 or g0norm == 0.0 or fp0 == 0.0:
+            end = "noprogress"
+            break
+        f_before = f
+        if delta_f < 0:
+            alpha1 = min(1.0, 2.0 * max(-delta_f, 10 * np.finfo(np.float64).eps * abs(f_before)) / (-fp0))
+        else:
+            alpha1 = abs(step_size)
+        status, alpha = ls.minimize(alpha1)
+        if status != "success":
+            end = status
+            break
+        ls.fdf(alpha)                                   # update_position: x, f, g at the accepted alpha (from the cache)
+        x, f, g = ls.x_a.copy(), ls.f_a, ls.g_a.copy()
+        delta_f = f - f_before
+        dx, dg = x - x0, g - g0
+        dxg, dgg, dxdg, dgn = float(np.dot(dx, g)), float(np.dot(dg, g)), float(np.dot(dx, dg)), float(np.sqrt(np.dot(dg, dg)))
+        if dxdg != 0:
+            B = dxg / dxdg
+            A = -(1.0 + dgn * dgn / dxdg) * B + dgg / dxdg
+        else:
+            A = B = 0.0
+        p = (g - A * dx) - B * dg                      # p = g; p -= A dx; p -= B dg
+        g0, x0 = g.copy(), x.copy()
+        g0norm, pnorm = float(np.sqrt(np.dot(g0, g0))), float(np.sqrt(np.dot(p, p)))
+        pg = float(np.dot(p, g))
+        sign = -1.0 if (pg > 0 or (pg == 0 and quirks["dir_zero"] == "flip")) else 1.0
+        p = p * (sign / pnorm)
+        pnorm, fp0 = float(np.sqrt(np.dot(p, p))), float(np.dot(p, g0))
+        ls.prepare(x0, f, g0, p)                       # change_direction
+        rows.append((x.copy(), f, g0norm, fn.evals))
+        if g0norm < gradient_tol:                      # testGradient
+            end = "success"
+            break
+        if inner >= max_inner:
+            break
+    return rows, end
+
+
+def bfgs_case(name, src, tgt, nn, ok, M, max_inner):
+    """the FIRST outer iteration's solve (transformation_ = identity, the first sweep's correspondences and matrices) step by step, and where
+    the same solve ends under each single deviation PCL's port may or may not have"""
+    out = {}
+    fn = SerialFunctor(src, tgt, nn, ok, M)
+    rows, end = vector_bfgs2(fn, np.zeros(6), max_inner)
+    out[name + "_bfgs_x"] = np.array([r[0] for r in rows])
+    out[name + "_bfgs_f"] = np.array([r[1] for r in rows])
+    out[name + "_bfgs_gnorm"] = np.array([r[2] for r in rows])
+    out[name + "_bfgs_evals"] = np.array([r[3] for r in rows], np.int32)
+    out[name + "_bfgs_end"] = np.array([{"success": 0, "noprogress": 1, "running": -1}[end]], np.int32)
+    var_x, var_names = [], []
+    for key, alt in (("roots", "stable"), ("dir_zero", "flip"), ("quad_curv", "c>a"), ("poly_eval", "eigen")):
+        q = dict(QUIRKS_AS_THE_ORACLE)
+        q[key] = alt
+        r2, _ = vector_bfgs2(SerialFunctor(src, tgt, nn, ok, M), np.zeros(6), max_inner, quirks=q)
+        var_x.append(r2[-1][0])
+        var_names.append(key + "=" + alt)
+    out[name + "_bfgs_variant_x"] = np.array(var_x)
+    out[name + "_bfgs_variants"] = np.array(var_names)
+    print("%s: vector_bfgs2 from the identity: %d steps, %d evaluations, |g| %.2e, ends `%s`; variants move the end point by %s m"
+          % (name, len(rows) - 1, rows[-1][3], rows[-1][2], end, ["%.1e" % np.abs(v[:3] - rows[-1][0][:3]).max() for v in var_x]))
+    return out
+
+
+def case(name, src, tgt, k, eps, corr_dist, max_iterations, tf_eps, max_inner=None):
     C1, nn1 = knn_covariances(src, k, eps)
     C2, nn2 = knn_covariances(tgt, k, eps)
     T, (nn, d2, ok, M), trace = gicp(src, tgt, C1, C2, corr_dist, max_iterations, tf_eps)
@@ -188,7 +491,8 @@ def case(name, src, tgt, k, eps, corr_dist, max_iterations, tf_eps):
     f0, g0 = cost_fdf(np.zeros(6), src, tgt, nn, ok, M)
     f1, g1 = cost_fdf(x_probe, src, tgt, nn, ok, M)
     print("%s: %d -> %d points, %d correspondences in the first sweep, %d outer iterations, final t = %s" % (name, len(src), len(tgt), int(ok.sum()), len(trace), T[:3, 3]))
-    return {name + "_src": src, name + "_tgt": tgt, name + "_params": np.array([k, eps, corr_dist, max_iterations, tf_eps]),
+    extra = bfgs_case(name, src, tgt, nn, ok, M, max_inner) if max_inner else {}
+    return {**extra, name + "_src": src, name + "_tgt": tgt, name + "_params": np.array([k, eps, corr_dist, max_iterations, tf_eps]),
             name + "_cov_src": C1, name + "_cov_tgt_sample": C2[:: max(1, len(C2) // 512)], name + "_knn_src": nn1.astype(np.int32),
             name + "_nn": nn, name + "_d2": d2, name + "_ok": ok, name + "_maha": M,
             name + "_x_probe": x_probe, name + "_f0": f0, name + "_g0": g0, name + "_f1": f1, name + "_g1": g1,
@@ -205,11 +509,11 @@ def main():
     # neighbour is FLANN's unpinned tie rule, and it decides which (degenerate) covariance enters.  The same pair with every coordinate kept
     # once (first occurrence, input order) has no such freedom.
     _, keep = np.unique(r, axis=0, return_index=True)
-    out.update(case("garage_unique", q, r[np.sort(keep)], 20, 1e-3, 0.2, 50, 1e-10))
+    out.update(case("garage_unique", q, r[np.sort(keep)], 20, 1e-3, 0.2, 50, 1e-10, max_inner=50))   # (max_inner 50: test_same_output...cpp:36)
     src, tgt, _ = synth.config1_pair()
     vs, vt = voxel_grid_xyz(src, 0.25), voxel_grid_xyz(tgt, 0.25)
     # BASELINE configs[0]: the 5 k-point plumbing pair, odometry parameters (parameters.yaml: corr_dist 1.0, tf_eps 1e-3, 20 iterations), recompute branch
-    out.update(case("config1", vs, vt, 20, 1e-3, 1.0, 20, 1e-3))
+    out.update(case("config1", vs, vt, 20, 1e-3, 1.0, 20, 1e-3, max_inner=20))
     path = os.environ.get("GOLDEN_OUT") or os.path.join(gold, "second_restatement.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, "%.0f KB" % (os.path.getsize(path) / 1024))
