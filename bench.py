@@ -77,9 +77,7 @@ def _farm_align(a):
     src_key, tgt_key, kw, threads = a
     s4, sn = _farm_load(src_key)
     t4, tn = _farm_load(tgt_key)
-    # skip_replays: these runs are the checker's, never timed -- an inner BFGS step that is a bit-for-bit fixed point is counted, not re-executed
-    # (oracle/locus_oracle.h lo_params.skip_replays: same pose, iterations, traces; tests/test_oracle_kats.py).  The timed CPU baseline never sets it.
-    r = O.gicp_align(s4, sn, t4, tn, O.default_params(num_threads=threads, skip_replays=1, **kw), want_trace=False)
+    r = O.gicp_align(s4, sn, t4, tn, O.default_params(num_threads=threads, **kw), want_trace=False)
     return np.asarray(r["T"], np.float32), int(r["iterations"]), int(r["status"])
 
 

@@ -369,21 +369,30 @@ static lh_status voxel_segments(lh_ctx* c, const float4* d_in, int n, float leaf
   if (e != hipSuccess) { vs->release(); return LH_EDEVICE; }
   return LH_OK;
 }
+// d_inten / d_out_inten (device clouds): d_in is a cloud's xyz array (w = 1) with the intensities beside it, and the centroids leave as a cloud's
+// two arrays (n_pad entries each) -- the filter reads and writes the cloud layout itself instead of a packed copy
 static lh_status voxel_grid_device(lh_ctx* c, const float4* d_in, int n, float leaf, int limit_axis, double lo, double hi,
-                                   float4** d_out, uint32_t* total_out, const float4* d_nrm = nullptr, float4** d_out_nrm = nullptr) {
+                                   float4** d_out, uint32_t* total_out, const float4* d_nrm = nullptr, float4** d_out_nrm = nullptr,
+                                   const float* d_inten = nullptr, float** d_out_inten = nullptr) {
   *d_out = nullptr;
   *total_out = 0;
   if (d_out_nrm) *d_out_nrm = nullptr;
+  if (d_out_inten) *d_out_inten = nullptr;
   VoxelSegments vs;
   lh_status st = voxel_segments(c, d_in, n, leaf, limit_axis, lo, hi, &vs);
   if (st) return st;
   if (vs.total > 0) {
-    if (lhMalloc(d_out, sizeof(float4) * (size_t)vs.total) != hipSuccess) { vs.release(); return LH_ENOMEM; }
-    if (d_nrm && d_out_nrm && lhMalloc(d_out_nrm, sizeof(float4) * (size_t)round_up((int)vs.total, 256)) != hipSuccess) {  // n_pad entries, like every cloud's normals
-      (void)lhFree(*d_out); *d_out = nullptr; vs.release(); return LH_ENOMEM;
+    const size_t n_pad = (size_t)round_up((int)vs.total, 256);
+    if (lhMalloc(d_out, sizeof(float4) * (d_out_inten ? n_pad : (size_t)vs.total)) != hipSuccess) { vs.release(); return LH_ENOMEM; }
+    if (d_out_inten && lhMalloc(d_out_inten, sizeof(float) * n_pad) != hipSuccess) { (void)lhFree(*d_out); *d_out = nullptr; vs.release(); return LH_ENOMEM; }
+    if (d_nrm && d_out_nrm && lhMalloc(d_out_nrm, sizeof(float4) * n_pad) != hipSuccess) {  // n_pad entries, like every cloud's normals
+      (void)lhFree(*d_out); *d_out = nullptr;
+      if (d_out_inten) { (void)lhFree(*d_out_inten); *d_out_inten = nullptr; }
+      vs.release(); return LH_ENOMEM;
     }
     ProfScope p(c, "voxel_centroids", (d_nrm ? 64.0 : 32.0) * n);
-    launch_voxel_centroids(d_in, d_nrm, c->keys1, c->vals1, vs.heads, vs.rank, n, *d_out, d_out_nrm ? *d_out_nrm : nullptr, vs.total, c->stream);
+    launch_voxel_centroids(d_in, d_nrm, c->keys1, c->vals1, vs.heads, vs.rank, n, *d_out, d_out_nrm ? *d_out_nrm : nullptr, vs.total, c->stream, d_inten,
+                           d_out_inten ? *d_out_inten : nullptr);
   }
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
@@ -423,47 +432,29 @@ lh_status lh_voxel_grid(lh_ctx* c, const lh_cloud_view* in, float leaf, int limi
 }
 
 // device-resident variant: cloud in -> new cloud out (x, y, z, intensity centroids; no normals), nothing crosses PCIe
-__global__ void __launch_bounds__(256) k_pack_xyzi(const float4* __restrict__ xyz, const float* __restrict__ inten, int n, float4* __restrict__ out) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float4 p = xyz[i];
-  out[i] = make_float4(p.x, p.y, p.z, inten ? inten[i] : 0.0f);
-}
-__global__ void __launch_bounds__(256) k_unpack_xyzi(const float4* __restrict__ in, int n, float4* __restrict__ xyz, float* __restrict__ inten) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float4 p = in[i];
-  xyz[i] = make_float4(p.x, p.y, p.z, 1.0f);
-  inten[i] = p.w;
-}
 static lh_status cloud_voxel_grid(const lh_cloud* in, float leaf, int limit_axis, double lo, double hi, bool all_fields, lh_cloud** out) {
   if (!in || !out || !(leaf > 0.0f) || limit_axis > 2 || in->n <= 0) return LH_EINVAL;
   if (all_fields && !in->nrm) return LH_EINVAL;  // the PointXYZINormal flavour needs the normal / curvature fields
   lh_ctx* c = in->ctx;
   HIPCHK(hipSetDevice(c->device));
-  float4 *d_in = nullptr, *d_out = nullptr, *d_out_nrm = nullptr;
-  HIPCHK(lhMalloc(&d_in, sizeof(float4) * (size_t)in->n));
-  hipLaunchKernelGGL(k_pack_xyzi, dim3((in->n + 255) / 256), dim3(256), 0, c->stream, in->xyz, in->intensity, in->n, d_in);
+  float4 *d_out = nullptr, *d_out_nrm = nullptr;
+  float* d_out_inten = nullptr;
   uint32_t total = 0;
-  lh_status st = voxel_grid_device(c, d_in, in->n, leaf, limit_axis, lo, hi, &d_out, &total, all_fields ? in->nrm : nullptr,
-                                   all_fields ? &d_out_nrm : nullptr);
-  (void)lhFree(d_in);
-  DevGuard guard;
-  guard.bufs.push_back(d_out);
-  if (st) { (void)lhFree(d_out_nrm); return st; }
-  if (total == 0) { (void)lhFree(d_out_nrm); return LH_EINVAL; }  // every point was filtered out: no cloud to return
+  // the cloud's own arrays in, a cloud's arrays out (round 5: the pack / unpack passes around the filter are gone)
+  lh_status st = voxel_grid_device(c, in->xyz, in->n, leaf, limit_axis, lo, hi, &d_out, &total, all_fields ? in->nrm : nullptr,
+                                   all_fields ? &d_out_nrm : nullptr, in->intensity, &d_out_inten);
+  if (st || total == 0) {
+    (void)lhFree(d_out); (void)lhFree(d_out_nrm); (void)lhFree(d_out_inten);
+    return st ? st : LH_EINVAL;  // every point was filtered out: no cloud to return
+  }
   lh_cloud* o = new lh_cloud();
-  guard.cloud = o;
   o->ctx = c;
   o->n = (int)total;
   o->n_pad = round_up(o->n, 256);
+  o->xyz = d_out;
+  o->intensity = d_out_inten;
   o->nrm = d_out_nrm;
-  HIPCHK(lhMalloc(&o->xyz, sizeof(float4) * (size_t)o->n_pad));
-  HIPCHK(lhMalloc(&o->intensity, sizeof(float) * (size_t)o->n_pad));
-  hipLaunchKernelGGL(k_unpack_xyzi, dim3((o->n + 255) / 256), dim3(256), 0, c->stream, d_out, o->n, o->xyz, o->intensity);
-  HIPCHK(hipGetLastError());
-  HIPCHK(hipStreamSynchronize(c->stream));
-  *out = guard.keep_cloud();
+  *out = o;
   return LH_OK;
 }
 lh_status lh_cloud_voxel_grid(const lh_cloud* in, float leaf, int limit_axis, double lo, double hi, lh_cloud** out) {

@@ -273,7 +273,8 @@ void launch_voxel_heads(const uint32_t* keys, int n, uint32_t* heads, hipStream_
 // one thread per voxel head: sequential float centroid of the segment in sorted (= input) order
 // (nrm / out_nrm non-null: the PointXYZINormal flavour -- normals summed and normalised, curvature averaged)
 void launch_voxel_centroids(const float4* xyzi, const float4* nrm, const uint32_t* keys, const uint32_t* vals, const uint32_t* heads,
-                            const uint32_t* rank_incl, int n, float4* out, float4* out_nrm, uint32_t out_cap, hipStream_t s);
+                            const uint32_t* rank_incl, int n, float4* out, float4* out_nrm, uint32_t out_cap, hipStream_t s, const float* in_inten = nullptr,
+                            float* out_inten = nullptr);
 size_t sort_keys64_temp_bytes(int n);
 void sort_keys_u64(void* temp, size_t temp_bytes, const uint64_t* keys_in, uint64_t* keys_out, int n, hipStream_t s);
 size_t scan_temp_bytes(int n);

@@ -42,7 +42,6 @@ void lo_default_params(lo_params* p) {
   p->recompute_target_cov = 0;
   p->num_threads = 1;
   p->parallel_cost = 0;
-  p->skip_replays = 0;
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -937,11 +936,7 @@ static int bfgs_one_step(bfgs_t* b, double* x) { /* BFGS::minimizeOneStep */
 }
 
 /* estimateRigidTransformationBFGS (gicp.hpp:218-287). T16 in/out column-major float. */
-static int estimate_rigid_bfgs_ex(cost_ctx* c, int max_inner, float* T16, int* n_inner, double* f_end, int skip_replays);
 static int estimate_rigid_bfgs(cost_ctx* c, int max_inner, float* T16, int* n_inner, double* f_end) {
-  return estimate_rigid_bfgs_ex(c, max_inner, T16, n_inner, f_end, 0);
-}
-static int estimate_rigid_bfgs_ex(cost_ctx* c, int max_inner, float* T16, int* n_inner, double* f_end, int skip_replays) {
   if (c->m < 4) return LO_ETOO_FEW; /* gicp.hpp:225 */
 #define TM(r, col) ((double)T16[(col) * 4 + (r)])
   double x[6];
@@ -959,22 +954,9 @@ static int estimate_rigid_bfgs_ex(cost_ctx* c, int max_inner, float* T16, int* n
   bfgs_init(&b, c, x);
   do {
     inner++;
-    double x_in[6], p_in[6];
-    memcpy(x_in, x, sizeof x_in);
-    memcpy(p_in, b.p, sizeof p_in);
-    const double f_in = b.f, df_in = b.delta_f;
-    const long passes_in = c->passes;
     result = bfgs_one_step(&b, x);
     if (result) break;
     result = (norm6(b.gradient) < gradient_tol) ? BFGS_SUCCESS : BFGS_RUNNING; /* testGradient */
-    /* lo_params.skip_replays (untimed checker runs): a step that left x, p, f and delta_f exactly as it found them will be repeated
-       identically by every remaining inner iteration -- count them, do not run them */
-    if (skip_replays && result == BFGS_RUNNING && inner < max_inner && memcmp(&b.f, &f_in, 8) == 0 && memcmp(&b.delta_f, &df_in, 8) == 0 &&
-        memcmp(x, x_in, sizeof x_in) == 0 && memcmp(b.p, p_in, sizeof p_in) == 0) {
-      c->passes += (long)(max_inner - inner) * (c->passes - passes_in);
-      inner = max_inner;
-      break;
-    }
   } while (result == BFGS_RUNNING && inner < max_inner);
   *n_inner = inner;
   *f_end = b.f;
@@ -1116,7 +1098,7 @@ int lo_gicp_align(const float* src_xyz4, const float* src_nrm4, int n, const flo
       cost_ctx c = {output, tgt_xyz4, src_idx, tgt_idx, cnt, maha, P->parallel_cost, threads, 0};
       int n_inner = 0;
       double f_end = 0;
-      int st = estimate_rigid_bfgs_ex(&c, P->max_inner_iterations, transformation, &n_inner, &f_end, P->skip_replays);
+      int st = estimate_rigid_bfgs(&c, P->max_inner_iterations, transformation, &n_inner, &f_end);
       res->t_opt += now_s() - t0;
       res->total_passes += c.passes;
       res->n_corr_last = cnt;

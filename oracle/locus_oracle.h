@@ -42,13 +42,6 @@ typedef struct {
   int num_threads;               /* gicp.h:134-141; OMP on the two loops the reference parallelises */
   int parallel_cost;             /* 0 = serial cost functor like the reference (gicp.hpp:291-402);
                                     1 = "fully parallel CPU" variant (OMP reduction), reported separately */
-  int skip_replays;              /* 0 = every minimizeOneStep is executed, like the reference (timed runs: always 0).
-                                    1 = untimed checker runs only: an inner step that ends in the state it began in -- x, direction, f and
-                                    delta_f bit for bit -- is a fixed point of minimizeOneStep (a deterministic function of exactly that
-                                    state), so the remaining inner iterations would replay it evaluation for evaluation; they are counted
-                                    but not executed.  Same x, f, inner count, passes and every later decision (tests/test_oracle_kats.py);
-                                    a pair whose outer loop is forced on after it converged otherwise spends 20 x 101 serial cost
-                                    evaluations per outer iteration (40 s of one core) telling the checker what it already knows. */
 } lo_params;
 
 #define LO_MAX_TRACE 256

@@ -28,7 +28,6 @@ class LoParams(C.Structure):
         ("recompute_target_cov", C.c_int),
         ("num_threads", C.c_int),
         ("parallel_cost", C.c_int),
-        ("skip_replays", C.c_int),
     ]
 
 
