@@ -515,7 +515,7 @@ def pmc_traffic_live(lib_sha):
     try:
         if os.path.exists(out):
             os.remove(out)
-        env = {k: v for k, v in os.environ.items() if not k.startswith(("ROCP", "ROCPROF"))}
+        env = {k: v for k, v in os.environ.items() if not k.startswith(("ROCP", "ROCPROF")) and not (k == "LD_PRELOAD" and "rocprof" in v)}
         env["GRAFT_REPO_ROOT"] = ROOT
         subprocess.run(["bash", os.path.join(ROOT, "tools", "pmc_traffic.sh")], env=env, timeout=400, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         doc = json.load(open(out))
@@ -1080,7 +1080,8 @@ def main():
         traffic, traffic_source = None, None
         lib_sha = capi.lib_sha256()
         ent = None
-        if world == 1 and not args.no_pmc:
+        profiled = any(k.startswith(("ROCP", "ROCPROF")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")   # (no profiler inside a profiler)
+        if world == 1 and not args.no_pmc and not profiled:
             _leg("PMC traffic passes (rocprofv3 child process)")
             ent = pmc_traffic_live(lib_sha)
             if ent is not None:

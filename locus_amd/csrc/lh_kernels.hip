@@ -517,13 +517,18 @@ __global__ void __launch_bounds__(256) k_seed(const PairDesc* __restrict__ descs
   Nn1Collector col{INFINITY, 0x7fffffff};
   tree_descend<Nn1Collector, true>(tv, qx, qy, qz, col);   // the nearest point of the nearest leaf (below the query's own grid cell): no stack, no backtracking, a third of an exact cold search
   const int j = (col.bi == 0x7fffffff) ? -1 : col.bi;
-  // only the candidate: the sweep that follows is launched `cold` (SweepJob::pad) and reads neither certificate nor record
+  // only the candidate: the sweep that follows is launched `cold` (SweepJob::pad = the group size) and reads neither certificate nor record.
+  // The whole group gets j; the cold sweep itself lets point e of the group choose between j and j + e (sweep_point).
   for (int e = 0; e < group; e++)
     if (i + e < d.n) d.prev_nn[i + e] = j;
 }
 
-void launch_seed(const PairDesc* descs, SweepArgs& a, int max_n, hipStream_t s) {
+static int seed_group_size() {
   static const int seed_group = []() { const char* e = getenv("LH_SEED_GROUP"); int v = e ? atoi(e) : SEED_GROUP; return v < 1 ? 1 : v; }();
+  return seed_group;
+}
+void launch_seed(const PairDesc* descs, SweepArgs& a, int max_n, hipStream_t s) {
+  const int seed_group = seed_group_size();
   a.pad = seed_group;
   int groups = (max_n + seed_group - 1) / seed_group;
   a.bpj = (groups + 255) / 256;
@@ -591,12 +596,27 @@ __device__ __forceinline__ void rec_put(const PairDesc& d, int i, const float4& 
   gst(reinterpret_cast<Pk3*>(d.rec + 3 * (size_t)d.n_pad) + i, Pk3{tn.x, tn.y, tn.z});
 }
 template <bool kRank1 = false, int kStride = 256>
-__device__ __forceinline__ void sweep_point(const PairDesc& d, const float* __restrict__ T, int i, uint64_t* stack, SweepPoint& o, float cm, bool cold = false) {
+__device__ __forceinline__ void sweep_point(const PairDesc& d, const float* __restrict__ T, int i, uint64_t* stack, SweepPoint& o, float cm, int cold = 0) {
   // first round of loads: everything whose address only depends on i goes out together (the certificate and, in the fused
   // kernel, the source normal as well: each was its own dependent memory round behind the candidate before, and the late
   // sweeps are bound by exactly that chain -- a workgroup lives for two memory latencies instead of three)
   o.p = gld(d.src + i);
   int w = gld(d.prev_nn + i);
+  // `cold` = the seed pass's group size (the pair's FIRST sweep).  Point e of a group may start from target point w + e instead of the group's
+  // shared seed w (round 5): source and target are scans of the same kind of sensor, consecutive returns of a ring are consecutive in both, so
+  // the neighbour of the e-th next source point is near the e-th next target point.  ANY target point is a valid candidate -- no result depends
+  // on it, only how tight the cold walk's first bound is -- and the nearer of the two is taken, so a target in some other order (a voxelised
+  // cloud, a map) loses nothing.  Host model (tools/model/seed_model.cpp, bench pair seed 10): groups of 16 with w + e walk as little (17.3 wave
+  // iterations per 64 queries) as groups of 4 sharing w (17.8; groups of 16 sharing w: 19.2) -- a quarter of the seed pass's descents.
+  int w_alt = -1;
+  float4 t_alt = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (cold > 1 && w >= 0) {
+    const int e = i % cold;
+    if (e > 0) {
+      w_alt = min(d.m - 1, w + e);
+      t_alt = gld(d.tgt_xyz + w_alt);
+    }
+  }
   float4 cq = make_float4(0.f, 0.f, 0.f, 0.f);
   if (!cold) cq = gld(d.cert + i);   // only meaningful when w >= 0; the buffer always holds n entries
   float4 nn = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -616,6 +636,13 @@ __device__ __forceinline__ void sweep_point(const PairDesc& d, const float* __re
   TreeView tv{d.tgt_sorted, d.tgt_nodes, d.tgt_hdr, d.m};
   Nn1CertCollector col{INFINITY, 0x7fffffff, INFINITY};
   bool need_search = true;
+  if (w_alt >= 0) {   // cold sweep: the nearer of the group's seed and its e-th successor (ties: the seed)
+    const float4 t0 = kRank1 ? t : gld(d.tgt_xyz + w);
+    if (d2f(qx, qy, qz, t_alt.x, t_alt.y, t_alt.z) < d2f(qx, qy, qz, t0.x, t0.y, t0.z)) {
+      w = w_alt;
+      if constexpr (kRank1) t = t_alt;
+    }
+  }
   if (w >= 0) {
     // warm start: last sweep's neighbour is a valid candidate => tight initial bound, still exact
     if constexpr (!kRank1) {
@@ -644,7 +671,7 @@ __device__ __forceinline__ void sweep_point(const PairDesc& d, const float* __re
   if (d.stats) atomicAdd(&d.stats[1], 1ull);
   int j = nn_index(col.bi, col.bd);
   o.nonn = j < 0;
-  if (j != w) gst(d.prev_nn + i, j);
+  if (j != w || cold) gst(d.prev_nn + i, j);   // (cold: w may be the group seed's successor, not what prev_nn holds)
   if (need_search && j >= 0) {
     t = gld(d.tgt_xyz + j);
     if (d.tgt_nrm) tn = gld(d.tgt_nrm + j);
@@ -720,7 +747,7 @@ __global__ void __launch_bounds__(256) k_sweep(const PairDesc* __restrict__ desc
   int i = blk * 256 + threadIdx.x;
   if (i >= d.n) return;
   SweepPoint sp;
-  sweep_point(d, job.T, i, lds_stack + threadIdx.x, sp, a.cert_rel, job.pad != 0);
+  sweep_point(d, job.T, i, lds_stack + threadIdx.x, sp, a.cert_rel, job.pad);
   float4 c = make_float4(0.f, 0.f, 0.f, __int_as_float(sp.nonn ? -2 : -1));   // -1: gated out; -2: no neighbour at all (the failure path)
   if (sp.matched) {
     d.maha6[(size_t)0 * d.n_pad + i] = sp.M[0];
@@ -949,7 +976,7 @@ __global__ void __launch_bounds__(FUSED_WG) __attribute__((amdgpu_waves_per_eu(L
   // does a sweep's time follow the number of LANES that walk (request-bound) or the number of WAVES that do (bound per wave step)?
   // Measured (round 3): a quarter of the lanes -> 25 / 13 / 14 % less time in the three all-walk sweeps: per wave step.
   const bool exp_skip = a.pad2 != 0 && (threadIdx.x & (a.pad2 == 1 ? 1 : 3)) != 0;
-  if (i < d.n && !exp_skip) sweep_point<kNormals, FUSED_WG>(d, T, i, lds_stack + threadIdx.x, sp, a.cert_rel, job.pad != 0);
+  if (i < d.n && !exp_skip) sweep_point<kNormals, FUSED_WG>(d, T, i, lds_stack + threadIdx.x, sp, a.cert_rel, job.pad);
   double M6[6] = {0, 0, 0, 0, 0, 0}, Ma[3] = {0, 0, 0}, pt[4] = {0, 0, 0, 0}, pp[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, aMa = 0.0;
   if (sp.matched) moments_of_point(T, sp, M6, Ma, aMa, pt, pp);
   const double live = sp.matched ? 1.0 : (sp.nonn ? NO_NN_MARK : 0.0);
@@ -1296,6 +1323,8 @@ void launch_sweep_fused(const PairDesc* descs, SweepArgs& a, uint32_t split_mask
   static const int refill = []() { const char* e = getenv("LH_WALK_REFILL"); int v = e ? atoi(e) : 16; return v < 1 ? 1 : (v > 64 ? 64 : v); }();
   a.span = sweep_walk_span();
   a.cert_rel = cert_margin();
+  for (int j = 0; j < a.njobs; j++)
+    if (a.job[j].pad) a.job[j].pad = seed_group_size();   // a cold job: the sweep is told the seed pass's group size (sweep_point)
   static const int exp_lanes = []() { const char* e = getenv("LH_EXP_LANES"); return e ? atoi(e) : 0; }();
   a.pad2 = exp_lanes;
   a.refill = refill;
@@ -1322,6 +1351,8 @@ void launch_sweep_fused(const PairDesc* descs, SweepArgs& a, uint32_t split_mask
 }
 void launch_sweep(const PairDesc* descs, SweepArgs& a, int max_n, hipStream_t s) {
   a.cert_rel = cert_margin();
+  for (int j = 0; j < a.njobs; j++)
+    if (a.job[j].pad) a.job[j].pad = seed_group_size();
   a.bpj = (max_n + 255) / 256;
   hipLaunchKernelGGL(k_sweep, dim3(xcd_grid(a.njobs, a.bpj)), dim3(256), stack_lds_bytes(a.max_depth, 256), s, descs, a);
 }

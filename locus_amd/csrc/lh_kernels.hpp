@@ -162,7 +162,7 @@ constexpr int FUSED_CHUNK = 64;   // one 74-double partial per WAVE of the fused
 constexpr int FINAL_CHUNKS = 8;   // the final sum leaves FINAL_CHUNKS x 74 chunk sums per job for the host to add (in chunk order)
 // cold-start helper: the nearest point of the leaf nearest to every 4th source point, written as the warm-start candidate of its group
 void launch_seed(const PairDesc* descs, SweepArgs& a, int max_n, hipStream_t s);
-constexpr int SEED_GROUP = 4;
+constexpr int SEED_GROUP = 16;   // (4 until round 5: see k_seed)
 __host__ __device__ inline int cost_blocks(int n) { return (n + COST_CHUNK - 1) / COST_CHUNK; }
 // one pass of the cost functor: per-block sums in partials_dev[slot * partials_stride + block * COST_NSUM + k], then their sum in block
 // order in out[job.out_offset + k] (k < COST_NSUM; pinned host memory for the host-driven loop)

@@ -1,10 +1,11 @@
-# Does a full bench.py run hang in teardown AFTER printing its line (seen once in round 4)?  Runs the bench with the normal interpreter exit
-# (BENCH_NORMAL_EXIT=1) a few times; a run still alive 40 s after its line gets its threads' names, states and kernel wait channels dumped.
+# Does a full bench.py run hang in teardown AFTER printing its line (seen once in round 4)?  Runs the bench a few times (it tears down normally
+# since round 5, bounded by tools/exitguard; BENCH_TEARDOWN_LIMIT_S=600 here so that the guard does not end a hang before it is looked at);
+# a run still alive 40 s after its line gets its threads' names, states and kernel wait channels dumped.
 # usage (GPU box): bash tools/probe_exit_hang.sh [runs=3]
 cd $GRAFT_REPO_ROOT
 for r in $(seq 1 ${1:-3}); do
   rm -f /tmp/b_$r.json
-  BENCH_NORMAL_EXIT=1 python bench.py > /tmp/b_$r.json 2> /tmp/b_$r.err &
+  BENCH_TEARDOWN_LIMIT_S=600 python bench.py > /tmp/b_$r.json 2> /tmp/b_$r.err &
   pid=$!
   for i in $(seq 1 240); do sleep 1; [ -s /tmp/b_$r.json ] && break; kill -0 $pid 2>/dev/null || break; done
   t0=$(date +%s)

@@ -3,7 +3,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out/prof
 rm -rf /tmp/bprof
-(cd $R && timeout 200 rocprofv3 --kernel-trace --marker-trace --stats -d /tmp/bprof -o run --output-format csv -- python bench.py --no-cpu-baseline --no-trajectory > $R/gpurun_out/prof/bench_line.json 2> $R/gpurun_out/prof/bench.err)
+(cd $R && timeout 200 rocprofv3 --kernel-trace --marker-trace --stats -d /tmp/bprof -o run --output-format csv -- python bench.py --no-cpu-baseline --no-trajectory --no-pmc --no-configs > $R/gpurun_out/prof/bench_line.json 2> $R/gpurun_out/prof/bench.err)
 ls /tmp/bprof/* | head -20 > $R/gpurun_out/prof/files.txt
 ks=$(find /tmp/bprof -name "*kernel_stats.csv" | head -1); kt=$(find /tmp/bprof -name "*kernel_trace.csv" | head -1); mt=$(find /tmp/bprof -name "*marker_api_trace.csv" | head -1)
 cp $ks $R/gpurun_out/prof/kernel_stats.csv
