@@ -9,7 +9,10 @@ lh_status Workspace::ensure(lh_ctx* c, int n) {
   c->sync_side_streams();
   (void)lhFree(corr); (void)lhFree(maha6); (void)lhFree(prev_nn); (void)lhFree(out_xyz); (void)lhFree(cert); (void)lhFree(rec);
   corr = nullptr; maha6 = nullptr; prev_nn = nullptr; out_xyz = nullptr; cert = nullptr; rec = nullptr; cap = 0;
-  int ncap = round_up(n, 256);
+  // a quarter of headroom (round 5): a stream's scans differ by a few per cent from one to the next (the adaptive voxel filter aims at a point
+  // COUNT, Locus.cc:780-810), and with exact capacities every scan that was a little larger than all before it re-allocated the slot's six buffers
+  // -- 2 ms of hipFree / hipMalloc on a 0.27-ms update (the production leg's p-max), 3.4 instead of 1.4 ms per 218 k-point frame of configs[4]
+  int ncap = round_up(n + n / 4, 256);
   HIPCHK(hipMalloc(&corr, sizeof(float4) * (size_t)ncap));
   HIPCHK(hipMalloc(&maha6, sizeof(double) * 6 * (size_t)ncap));
   HIPCHK(hipMalloc(&prev_nn, sizeof(int32_t) * (size_t)ncap));
@@ -27,6 +30,11 @@ void Workspace::release() {
 }
 
 lh_status ctx_ensure_slots(lh_ctx* c, int n_slots, int max_n) {
+  {  // already large enough for this call?  (checked on the exact size; an allocation below is made with a quarter of headroom, like the slots' own buffers)
+    const size_t need_slot = std::max<size_t>((size_t)cost_blocks(max_n) * COST_NSUM, (size_t)FINAL_CHUNKS * MOM_ROW);
+    if (n_slots <= c->n_slots && need_slot <= c->partials_per_slot && sweep_rows(max_n) * MOM_ROW <= c->mom_stride && ((max_n + 255) / 256) * 4 <= c->mask_stride) return LH_OK;
+  }
+  max_n = max_n + max_n / 4;
   size_t per_slot = std::max<size_t>((size_t)cost_blocks(max_n) * COST_NSUM, (size_t)FINAL_CHUNKS * MOM_ROW);
   int mom_stride = sweep_rows(max_n) * MOM_ROW;  // one partial row per 256-point workgroup of the sweep + the walk rows
   int mask_stride = ((max_n + 255) / 256) * 4;
