@@ -19,5 +19,6 @@ bash tools/trace_index.sh > $E/index_kernel_trace.txt 2>&1
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 2 --same-gpu --dist-backend gloo --quick --pairs 64 --in-flight 64 --steps 2 --warmup 1 > $E/bench_two_ranks_one_gpu.json 2> $E/bench_two_ranks_one_gpu.err
 python bench.py --gpus 2 --same-gpu --dist-backend gloo --quick --pairs 64 --in-flight 64 --steps 2 --warmup 1 > $E/bench_self_launched_two_ranks.json 2> $E/bench_self_launched_two_ranks.err
 python bench.py --gpus 2 --same-gpu --dist-backend gloo --pairs 32 --in-flight 32 --steps 2 --warmup 1 --no-trajectory --no-configs > $E/bench_two_ranks_full_line.json 2> $E/bench_two_ranks_full_line.err
+bash tools/trace_production.sh > $E/production_update_trace.txt 2>&1
 python tests/perf/bench_ndt.py > $E/ndt.json 2> $E/ndt.err
 ls -la $E
