@@ -126,32 +126,77 @@ __global__ void __launch_bounds__(SMALL_THREADS) k_index_small(const IndexDesc* 
     for (int k = 0; k < 5; k++) fr.pad[k] = 0;
   }
   // ---- B: keys (k_key_b) ----
-  int P = 1;
-  while (P < n) P <<= 1;
-  for (int i = tid; i < P; i += SMALL_THREADS) {
-    uint64_t k = ~0ull;
-    if (i < n) {
-      const float4 p = d.xyz[i];
-      k = ((uint64_t)spatial_key30(p.x, p.y, p.z, bb[0], bb[1], bb[2], bb[3], bb[4], bb[5]) << 32) | (uint32_t)i;
-    }
-    skey[i] = k;
+  for (int i = tid; i < n; i += SMALL_THREADS) {
+    const float4 p = d.xyz[i];
+    skey[i] = ((uint64_t)spatial_key30(p.x, p.y, p.z, bb[0], bb[1], bb[2], bb[3], bb[4], bb[5]) << 32) | (uint32_t)i;
   }
   __syncthreads();
-  // ---- C: sort.  (key, original index) pairs are distinct, and their order is the order a stable sort by key leaves: bitonic network in LDS ----
-  // Thread q of a stage compares positions i(q) and i(q) | j.  For j <= 64 a wave's 64 pairs lie inside its own run of 128 positions, stage after
-  // stage, so those stages need no workgroup barrier (a wave's LDS operations complete in order): 20 barriers instead of 78 for 4 096 keys.
-  for (int k = 2; k <= P; k <<= 1)
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int q = tid; q < (P >> 1); q += SMALL_THREADS) {
-        const int i = ((q & ~(j - 1)) << 1) | (q & (j - 1));   // the lower index of the q-th pair at distance j
-        const int l = i | j;
-        const uint64_t a = skey[i], b = skey[l];
-        const bool up = (i & k) == 0;
-        if ((a > b) == up) { skey[i] = b; skey[l] = a; }
+  // ---- C: sort by the 30-bit key, stable (equal keys keep ascending original index: the order a sort of the (key, index) pairs leaves).
+  // Round 5: a least-significant-digit radix sort in LDS, four passes of 8 bits, instead of the bitonic network (78 stages for 4 096 keys:
+  // 31 of the build's 63 us on a 3 k-point cloud, tools/probe_small_index.py).  Wave w owns positions [256 w, 256 w + 256) in four batches of 64
+  // consecutive elements; per batch eight ballots give every lane the mask of the lanes that hold its digit (rank = the set bits below it), a
+  // per-(digit, wave) counter in LDS takes the batch's group sizes in batch order, one workgroup-wide exclusive scan in (digit, wave) order turns
+  // the counters into first positions, and every element goes to first position + (its group's offset inside the wave) + rank.  The same scheme
+  // as k_rs_scatter (lh_radix.hip) with the whole array in one workgroup.  Buffers: skey <-> lkey (free until phase G), counters in lid.
+  {
+    uint64_t* src = skey;
+    uint64_t* dst = lkey;
+    uint32_t* const cnt = lid;                 // [256 digits][16 waves]
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int shift = 0; shift < 32; shift += 8) {
+      uint4* const cnt4 = reinterpret_cast<uint4*>(cnt);
+      cnt4[tid] = make_uint4(0u, 0u, 0u, 0u);  // 1 024 threads x 4 counters
+      __syncthreads();
+      uint64_t e[4];
+      uint32_t where[4];                       // digit << 16 | (offset of the element among its wave's elements of that digit)
+#pragma unroll
+      for (int bt = 0; bt < 4; bt++) {
+        const int i = wave * 256 + bt * 64 + lane;
+        const bool live = i < n;
+        e[bt] = live ? src[i] : ~0ull;
+        const uint32_t dg = (uint32_t)(e[bt] >> (32 + shift)) & 255u;
+        unsigned long long same = __ballot(live);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          const bool bit = (dg >> k) & 1u;
+          const unsigned long long m = __ballot(bit);
+          same &= bit ? m : ~m;
+        }
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(same >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)same, 0u));
+        uint32_t base = 0;
+        if (live) {
+          base = cnt[dg * 16 + wave];                                   // what the wave's earlier batches put there (a wave's LDS operations complete in order)
+          if (rank == 0) cnt[dg * 16 + wave] = base + (uint32_t)__popcll(same);
+        }
+        where[bt] = (dg << 16) | (base + rank);
       }
-      if (j > 64 || j == 1) __syncthreads();            // (j == 1: the next k starts with a cross-wave stage, or the sort ends)
-      else __builtin_amdgcn_wave_barrier();
+      __syncthreads();
+      {  // exclusive scan of the 4 096 counters in (digit, wave) order: four consecutive ones per thread
+        const uint4 v = cnt4[tid];
+        const uint32_t mine = v.x + v.y + v.z + v.w;
+        uint32_t inc = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const uint32_t u = __shfl_up(inc, o, 64);
+          if (lane >= o) inc += u;
+        }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        uint32_t b0 = inc - mine;
+        for (int w = 0; w < wave; w++) b0 += wsum[w];
+        cnt4[tid] = make_uint4(b0, b0 + v.x, b0 + v.x + v.y, b0 + v.x + v.y + v.z);
+        __syncthreads();
+      }
+#pragma unroll
+      for (int bt = 0; bt < 4; bt++) {
+        const int i = wave * 256 + bt * 64 + lane;
+        if (i < n) dst[cnt[(where[bt] >> 16) * 16 + wave] + (where[bt] & 0xffffu)] = e[bt];
+      }
+      __syncthreads();
+      uint64_t* const sw = src; src = dst; dst = sw;
     }
+    // (four passes: the sorted pairs are back in skey)
+  }
   // ---- D: sorted keys in the build's form (cloud id above the 30-bit key) + the permutation ----
   for (int g = tid; g < n; g += SMALL_THREADS) {
     const uint64_t s = skey[g];
