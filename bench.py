@@ -150,6 +150,43 @@ class CpuFarm:
         self.files = []
 
 
+class InProcessFarm:
+    """the same interface on threads of this process: the fallback when worker processes cannot be spawned (correct, but the teams are bound:
+    see CpuFarm)"""
+
+    def __init__(self, workers, threads=4):
+        self.workers, self.threads, self.store = workers, threads, {}
+
+    def put(self, tag, download):
+        from oracle import oracle as O
+        self.store[tag] = (O.xyz4(np.stack([download["x"], download["y"], download["z"]], 1)),
+                           O.nrm4(np.stack([download["normal_x"], download["normal_y"], download["normal_z"]], 1)))
+        return tag
+
+    def drop(self, key):
+        self.store.pop(key, None)
+
+    def align(self, jobs, kw):
+        from concurrent.futures import ThreadPoolExecutor
+        from oracle import oracle as O
+
+        def one(j):
+            (s4, sn), (t4, tn) = self.store[j[0]], self.store[j[1]]
+            r = O.gicp_align(s4, sn, t4, tn, O.default_params(num_threads=self.threads, **kw), want_trace=False)
+            return {"T": np.asarray(r["T"], np.float32), "iterations": int(r["iterations"]), "status": int(r["status"])}
+        with ThreadPoolExecutor(self.workers) as ex:
+            return list(ex.map(one, jobs))
+
+    def fitness(self, jobs):
+        from concurrent.futures import ThreadPoolExecutor
+        from oracle import oracle as O
+        with ThreadPoolExecutor(self.workers) as ex:
+            return list(ex.map(lambda j: float(O.fitness(self.store[j[0]][0], np.asarray(j[2], np.float32), O.Tree(self.store[j[1]][0]), threads=self.threads)), jobs))
+
+    def close(self):
+        self.store = {}
+
+
 def _pool_map(fn, jobs, workers, chunk):
     """pool.map over forked workers; a pool that does not deliver (a worker forked while another thread held a lock) is abandoned
     after a generous wait and the jobs run here instead"""
@@ -1131,7 +1168,11 @@ def main():
         farm, pair_keys = None, {}
         if world == 1 and not args.no_cpu_baseline:
             _leg("CPU farm (spawned, unbound oracle workers)")
-            farm = CpuFarm(max(1, min(64, physical_cores() // 4)), threads=4)
+            try:
+                farm = CpuFarm(max(1, min(64, physical_cores() // 4)), threads=4)
+            except Exception as e:   # (no spawn, no /dev/shm ...: the checker still runs, on threads of this process)
+                print("[bench] CPU farm not available (%r): the checker's concurrent runs stay in this process" % (e,), file=sys.stderr, flush=True)
+                farm = InProcessFarm(max(1, min(64, physical_cores() // 4)), threads=4)
             _STATE["farm"] = farm
         _leg("CPU baseline + parity")
         if world == 1 and not args.no_cpu_baseline:
@@ -1210,152 +1251,160 @@ def main():
         if args.no_cpu_baseline or world != 1:
             result["cpu_baseline_skipped"] = True
         _PARTIAL[0] = result
-        _leg("single-pair latency")
-        if not args.no_single_latency:
-            g = capi.Gicp(ctx, P)
-            g.set_source(S[0])
-            g.set_target(T[0])
-            T[0].drop_index()
-            g.align(want_trace=False)
-            t1 = time.perf_counter()
-            for _ in range(5):
+        # The legs from here on are extras of the line: a failure in one of them must not lose the BASELINE metric, its roofline, the CPU baseline and
+        # the parity check measured above -- the error is recorded in the line (extras_error, all_ok false), the traceback goes to stderr, the exit code says so.
+        try:
+            _leg("single-pair latency")
+            if not args.no_single_latency:
+                g = capi.Gicp(ctx, P)
+                g.set_source(S[0])
+                g.set_target(T[0])
                 T[0].drop_index()
                 g.align(want_trace=False)
-            result["single_pair_latency_ms"] = round(1e3 * (time.perf_counter() - t1) / 5, 3)
-        _leg("cost_mode 0")
-        if world == 1 and args.cost_mode == 1:
-            # the same workload in the reference-arithmetic mode (one device pass per BFGS evaluation, float T*p): the strict
-            # parity mode (<= 1e-4 m vs the CPU path); reported next to the headline, never as `value`
-            P0 = capi.default_params(max_iterations=20, max_inner_iterations=20, corr_dist=1.0, transformation_epsilon=1e-12,
-                                     rotation_epsilon=1e-12, cost_mode=0)
-
-            def step0():
-                for t in T:
-                    t.drop_index()
-                return capi.align_batch(ctx, P0, S, T, max_in_flight=args.in_flight)
-
-            step0()
-            ctx.synchronize()
-            t1 = time.perf_counter()
-            out0 = step0()
-            ctx.synchronize()
-            dt0 = time.perf_counter() - t1
-            result["cost_mode0"] = {"value": round(pairs_here / dt0, 2), "unit": "scan-pairs/s",
-                                    "max_abs_pose_diff_vs_mode1": float(max(np.abs(np.asarray(a["T"]) - np.asarray(b["T"])).max()
-                                                                            for a, b in zip(out0, out)))}
-        _leg("natural convergence")
-        if world == 1:
-            # SURVEY 8d "natural convergence" run: the same pairs with the production stopping rule (tf_eps 1e-3, rot_eps 2e-3,
-            # gicp.h:119, parameters.yaml) instead of 20 forced iterations: iterations to converge, rate, distance to the forced result
-            Pn = capi.default_params(max_iterations=20, max_inner_iterations=20, corr_dist=1.0, transformation_epsilon=1e-3,
-                                     rotation_epsilon=2e-3, cost_mode=args.cost_mode)
-
-            def stepn():
-                for t in T:
-                    t.drop_index()
-                return capi.align_batch(ctx, Pn, S, T, max_in_flight=args.in_flight)
-
-            stepn()
-            ctx.synchronize()
-            dtn = None
-            for _ in range(2):   # two timed steps, the faster one (a 25-ms step is at the mercy of a single host hiccup)
                 t1 = time.perf_counter()
-                outn = stepn()
+                for _ in range(5):
+                    T[0].drop_index()
+                    g.align(want_trace=False)
+                result["single_pair_latency_ms"] = round(1e3 * (time.perf_counter() - t1) / 5, 3)
+            _leg("cost_mode 0")
+            if world == 1 and args.cost_mode == 1:
+                # the same workload in the reference-arithmetic mode (one device pass per BFGS evaluation, float T*p): the strict
+                # parity mode (<= 1e-4 m vs the CPU path); reported next to the headline, never as `value`
+                P0 = capi.default_params(max_iterations=20, max_inner_iterations=20, corr_dist=1.0, transformation_epsilon=1e-12,
+                                         rotation_epsilon=1e-12, cost_mode=0)
+
+                def step0():
+                    for t in T:
+                        t.drop_index()
+                    return capi.align_batch(ctx, P0, S, T, max_in_flight=args.in_flight)
+
+                step0()
                 ctx.synchronize()
-                dtn = min(dtn or 1e9, time.perf_counter() - t1)
-            itn = [int(o["iterations"]) for o in outn]
-            result["natural_convergence"] = {
-                "value": round(pairs_here / dtn, 2), "unit": "scan-pairs/s", "iterations_min_mean_max": [min(itn), float(np.mean(itn)), max(itn)],
-                "all_converged": bool(all(o["converged"] == 1 for o in outn)),
-                "max_abs_pose_diff_vs_20_forced_iterations": float(max(np.abs(np.asarray(a["T"]) - np.asarray(b["T"])).max() for a, b in zip(outn, out)))}
-            # ... against the CPU path under the SAME rule, on the first 16 pairs (4 OMP threads each, concurrently): the regime LOCUS runs in
-            if not args.no_cpu_baseline:
-                from concurrent.futures import ThreadPoolExecutor
-                from oracle import oracle as O
-                okn = dict(max_iterations=Pn.max_iterations, max_inner_iterations=Pn.max_inner_iterations, corr_dist=Pn.corr_dist,
-                           transformation_epsilon=Pn.transformation_epsilon, rotation_epsilon=Pn.rotation_epsilon, gicp_epsilon=Pn.gicp_epsilon)
-                kn = list(range(min(PARITY_PAIRS, len(S))))
+                t1 = time.perf_counter()
+                out0 = step0()
+                ctx.synchronize()
+                dt0 = time.perf_counter() - t1
+                result["cost_mode0"] = {"value": round(pairs_here / dt0, 2), "unit": "scan-pairs/s",
+                                        "max_abs_pose_diff_vs_mode1": float(max(np.abs(np.asarray(a["T"]) - np.asarray(b["T"])).max()
+                                                                                for a, b in zip(out0, out)))}
+            _leg("natural convergence")
+            if world == 1:
+                # SURVEY 8d "natural convergence" run: the same pairs with the production stopping rule (tf_eps 1e-3, rot_eps 2e-3,
+                # gicp.h:119, parameters.yaml) instead of 20 forced iterations: iterations to converge, rate, distance to the forced result
+                Pn = capi.default_params(max_iterations=20, max_inner_iterations=20, corr_dist=1.0, transformation_epsilon=1e-3,
+                                         rotation_epsilon=2e-3, cost_mode=args.cost_mode)
 
-                for k in kn:
-                    if k not in pair_keys:
-                        pair_keys[k] = (farm.put("s%d" % k, S[k].download()), farm.put("t%d" % k, T[k].download()))
-                cn = farm.align([pair_keys[k] for k in kn], okn)
+                def stepn():
+                    for t in T:
+                        t.drop_index()
+                    return capi.align_batch(ctx, Pn, S, T, max_in_flight=args.in_flight)
 
-                def nat_vs_cpu(outs):
-                    ndt, ndr, nit = [], [], []
-                    for k, r in zip(kn, cn):
-                        dt_, dr_ = _pose_diff(outs[k]["T"], r["T"])
-                        ndt.append(dt_)
-                        ndr.append(dr_)
-                        nit.append(int(outs[k]["iterations"]) - int(r["iterations"]))
-                    return ndt, ndr, nit
-                ndt, ndr, nit = nat_vs_cpu(outn)
-                nat_ok = float(np.median(ndt)) <= 5e-4 and float(np.quantile(ndt, 0.9)) <= 3e-3 and max(ndt) <= 2e-2 and max(ndr) <= 5e-4 and max(abs(d) for d in nit) <= 3
-                result["natural_convergence"]["vs_cpu_path"] = {
-                    "n_pairs": len(kn), "median_dt_m": float(np.median(ndt)), "p90_dt_m": float(np.quantile(ndt, 0.9)), "max_dt_m": max(ndt), "max_dR": max(ndr),
-                    "iteration_count_differs_on": int(sum(1 for d in nit if d != 0)), "iteration_count_max_abs_diff": int(max(abs(d) for d in nit)),
-                    "bars": {"median_dt_m": 5e-4, "p90_dt_m": 3e-3, "max_dt_m": 2e-2, "max_dR": 5e-4, "iteration_count_max_abs_diff": 3},
-                    "reference_own_two_builds_64_pairs": "median 2.1e-4, p90 3.2e-3, max 2.1e-2 (profiles/r04_parity_distributions.json: under this rule the result is defined to the stopping scale)",
-                    "ok": bool(nat_ok)}
-                # the STRICT mode (cost_mode 0: every per-point operation the reference's, one device pass per BFGS evaluation) where LOCUS runs it:
-                # the production stopping rule.  Rate, and its parity against the same CPU runs (bars of tests/test_gpu_align.py:
-                # median <= 1e-6, p90 <= 3e-4, every pair <= 1e-3, iteration count equal on every pair)
-                if args.cost_mode == 1:
-                    P0n = capi.default_params(max_iterations=20, max_inner_iterations=20, corr_dist=1.0, transformation_epsilon=1e-3, rotation_epsilon=2e-3, cost_mode=0)
-
-                    def step0n():
-                        for t in T:
-                            t.drop_index()
-                        return capi.align_batch(ctx, P0n, S, T, max_in_flight=args.in_flight)
-                    step0n()
-                    ctx.synchronize()
-                    _beat()
+                stepn()
+                ctx.synchronize()
+                dtn = None
+                for _ in range(2):   # two timed steps, the faster one (a 25-ms step is at the mercy of a single host hiccup)
                     t1 = time.perf_counter()
-                    out0n = step0n()
+                    outn = stepn()
                     ctx.synchronize()
-                    dt0n = time.perf_counter() - t1
-                    zdt, zdr, zit = nat_vs_cpu(out0n)
-                    it0 = [int(o["iterations"]) for o in out0n]
-                    z_ok = float(np.median(zdt)) <= 1e-6 and float(np.quantile(zdt, 0.9)) <= 3e-4 and max(zdt) <= 1e-3 and max(zdr) <= 1e-4 and all(d == 0 for d in zit)
-                    result.setdefault("cost_mode0", {})["natural_convergence"] = {
-                        "value": round(pairs_here / dt0n, 2), "unit": "scan-pairs/s", "iterations_min_mean_max": [min(it0), float(np.mean(it0)), max(it0)],
-                        "mean_cost_evaluations_per_pair": float(np.mean([o["cost_passes"] for o in out0n])),
-                        "vs_cpu_path": {"n_pairs": len(kn), "median_dt_m": float(np.median(zdt)), "p90_dt_m": float(np.quantile(zdt, 0.9)), "max_dt_m": max(zdt), "max_dR": max(zdr),
-                                        "pairs_bit_identical_pose": int(sum(1 for d, r_ in zip(zdt, zdr) if d == 0.0 and r_ == 0.0)),
-                                        "iteration_count_differs_on": int(sum(1 for d in zit if d != 0)),
-                                        "bars": {"median_dt_m": 1e-6, "p90_dt_m": 3e-4, "max_dt_m": 1e-3, "max_dR": 1e-4, "iteration_count": "equal on every pair"}, "ok": bool(z_ok)},
-                        "what": "the strict mode (the only one that meets SURVEY 8d's 1e-4 on every quantile) under LOCUS's own stopping rule (tf_eps 1e-3, rotation_epsilon 2e-3)"}
-            # ... and the roofline of ITS dominant kernel (nearly every sweep of this regime is an all-walk sweep + the index build and seed pass)
-            _, _, _, rn = roofline_leg(Pn, "profile_leg_natural", 1)
-            result["natural_convergence"]["roofline"] = rn
-            # BASELINE configs[3] gives each GPU 64 pairs: the same step with 64 pairs in flight (two scheduler streams) instead of 512
-            if args.in_flight > 64 and pairs_here >= 64:
-                step(64, exchange=False)
-                ctx.synchronize()
-                t1 = time.perf_counter()
-                for _ in range(2):
+                    dtn = min(dtn or 1e9, time.perf_counter() - t1)
+                itn = [int(o["iterations"]) for o in outn]
+                result["natural_convergence"] = {
+                    "value": round(pairs_here / dtn, 2), "unit": "scan-pairs/s", "iterations_min_mean_max": [min(itn), float(np.mean(itn)), max(itn)],
+                    "all_converged": bool(all(o["converged"] == 1 for o in outn)),
+                    "max_abs_pose_diff_vs_20_forced_iterations": float(max(np.abs(np.asarray(a["T"]) - np.asarray(b["T"])).max() for a, b in zip(outn, out)))}
+                # ... against the CPU path under the SAME rule, on the first 16 pairs (4 OMP threads each, concurrently): the regime LOCUS runs in
+                if not args.no_cpu_baseline:
+                    from concurrent.futures import ThreadPoolExecutor
+                    from oracle import oracle as O
+                    okn = dict(max_iterations=Pn.max_iterations, max_inner_iterations=Pn.max_inner_iterations, corr_dist=Pn.corr_dist,
+                               transformation_epsilon=Pn.transformation_epsilon, rotation_epsilon=Pn.rotation_epsilon, gicp_epsilon=Pn.gicp_epsilon)
+                    kn = list(range(min(PARITY_PAIRS, len(S))))
+
+                    for k in kn:
+                        if k not in pair_keys:
+                            pair_keys[k] = (farm.put("s%d" % k, S[k].download()), farm.put("t%d" % k, T[k].download()))
+                    cn = farm.align([pair_keys[k] for k in kn], okn)
+
+                    def nat_vs_cpu(outs):
+                        ndt, ndr, nit = [], [], []
+                        for k, r in zip(kn, cn):
+                            dt_, dr_ = _pose_diff(outs[k]["T"], r["T"])
+                            ndt.append(dt_)
+                            ndr.append(dr_)
+                            nit.append(int(outs[k]["iterations"]) - int(r["iterations"]))
+                        return ndt, ndr, nit
+                    ndt, ndr, nit = nat_vs_cpu(outn)
+                    nat_ok = float(np.median(ndt)) <= 5e-4 and float(np.quantile(ndt, 0.9)) <= 3e-3 and max(ndt) <= 2e-2 and max(ndr) <= 5e-4 and max(abs(d) for d in nit) <= 3
+                    result["natural_convergence"]["vs_cpu_path"] = {
+                        "n_pairs": len(kn), "median_dt_m": float(np.median(ndt)), "p90_dt_m": float(np.quantile(ndt, 0.9)), "max_dt_m": max(ndt), "max_dR": max(ndr),
+                        "iteration_count_differs_on": int(sum(1 for d in nit if d != 0)), "iteration_count_max_abs_diff": int(max(abs(d) for d in nit)),
+                        "bars": {"median_dt_m": 5e-4, "p90_dt_m": 3e-3, "max_dt_m": 2e-2, "max_dR": 5e-4, "iteration_count_max_abs_diff": 3},
+                        "reference_own_two_builds_64_pairs": "median 2.1e-4, p90 3.2e-3, max 2.1e-2 (profiles/r04_parity_distributions.json: under this rule the result is defined to the stopping scale)",
+                        "ok": bool(nat_ok)}
+                    # the STRICT mode (cost_mode 0: every per-point operation the reference's, one device pass per BFGS evaluation) where LOCUS runs it:
+                    # the production stopping rule.  Rate, and its parity against the same CPU runs (bars of tests/test_gpu_align.py:
+                    # median <= 1e-6, p90 <= 3e-4, every pair <= 1e-3, iteration count equal on every pair)
+                    if args.cost_mode == 1:
+                        P0n = capi.default_params(max_iterations=20, max_inner_iterations=20, corr_dist=1.0, transformation_epsilon=1e-3, rotation_epsilon=2e-3, cost_mode=0)
+
+                        def step0n():
+                            for t in T:
+                                t.drop_index()
+                            return capi.align_batch(ctx, P0n, S, T, max_in_flight=args.in_flight)
+                        step0n()
+                        ctx.synchronize()
+                        _beat()
+                        t1 = time.perf_counter()
+                        out0n = step0n()
+                        ctx.synchronize()
+                        dt0n = time.perf_counter() - t1
+                        zdt, zdr, zit = nat_vs_cpu(out0n)
+                        it0 = [int(o["iterations"]) for o in out0n]
+                        z_ok = float(np.median(zdt)) <= 1e-6 and float(np.quantile(zdt, 0.9)) <= 3e-4 and max(zdt) <= 1e-3 and max(zdr) <= 1e-4 and all(d == 0 for d in zit)
+                        result.setdefault("cost_mode0", {})["natural_convergence"] = {
+                            "value": round(pairs_here / dt0n, 2), "unit": "scan-pairs/s", "iterations_min_mean_max": [min(it0), float(np.mean(it0)), max(it0)],
+                            "mean_cost_evaluations_per_pair": float(np.mean([o["cost_passes"] for o in out0n])),
+                            "vs_cpu_path": {"n_pairs": len(kn), "median_dt_m": float(np.median(zdt)), "p90_dt_m": float(np.quantile(zdt, 0.9)), "max_dt_m": max(zdt), "max_dR": max(zdr),
+                                            "pairs_bit_identical_pose": int(sum(1 for d, r_ in zip(zdt, zdr) if d == 0.0 and r_ == 0.0)),
+                                            "iteration_count_differs_on": int(sum(1 for d in zit if d != 0)),
+                                            "bars": {"median_dt_m": 1e-6, "p90_dt_m": 3e-4, "max_dt_m": 1e-3, "max_dR": 1e-4, "iteration_count": "equal on every pair"}, "ok": bool(z_ok)},
+                            "what": "the strict mode (the only one that meets SURVEY 8d's 1e-4 on every quantile) under LOCUS's own stopping rule (tf_eps 1e-3, rotation_epsilon 2e-3)"}
+                # ... and the roofline of ITS dominant kernel (nearly every sweep of this regime is an all-walk sweep + the index build and seed pass)
+                _, _, _, rn = roofline_leg(Pn, "profile_leg_natural", 1)
+                result["natural_convergence"]["roofline"] = rn
+                # BASELINE configs[3] gives each GPU 64 pairs: the same step with 64 pairs in flight (two scheduler streams) instead of 512
+                if args.in_flight > 64 and pairs_here >= 64:
                     step(64, exchange=False)
-                ctx.synchronize()
-                result["in_flight_64"] = {"value": round(2 * pairs_here / (time.perf_counter() - t1), 2), "unit": "scan-pairs/s",
-                                          "what": "the timed step with max_in_flight = 64 (configs[3]'s per-GPU load: 512 pairs over 8 GPUs)"}
-        _leg("trajectory")
-        if world == 1 and traj_host is not None:
-            result["trajectory"] = trajectory_leg(ctx, P, traj_host, args, farm)
-            _PARTIAL[0] = result
-            _leg("stream with normals")
-            sw, sw_out = stream_leg(ctx, P, traj_host, args)
-            result["stream_with_normals"] = sw
-            _leg("voxel filter")
-            result["filter_k1"] = filter_k1_leg(ctx)
-        if world == 1 and extra_host is not None:
-            _PARTIAL[0] = result
-            _leg("configs[2]: scan vs 2 M-point map")
-            result["config3_submap"] = config3_submap_leg(ctx, extra_host, not args.no_cpu_baseline)
-            _leg("configs[4]: 1 M-point merged cloud")
-            result["config5_merged1m"] = config5_merged1m_leg(ctx, extra_host, not args.no_cpu_baseline)
-        _leg("production operating point")
-        if world == 1 and not args.no_cpu_baseline:
-            result["production_operating_point"] = production_leg(ctx)
+                    ctx.synchronize()
+                    t1 = time.perf_counter()
+                    for _ in range(2):
+                        step(64, exchange=False)
+                    ctx.synchronize()
+                    result["in_flight_64"] = {"value": round(2 * pairs_here / (time.perf_counter() - t1), 2), "unit": "scan-pairs/s",
+                                              "what": "the timed step with max_in_flight = 64 (configs[3]'s per-GPU load: 512 pairs over 8 GPUs)"}
+            _leg("trajectory")
+            if world == 1 and traj_host is not None:
+                result["trajectory"] = trajectory_leg(ctx, P, traj_host, args, farm)
+                _PARTIAL[0] = result
+                _leg("stream with normals")
+                sw, sw_out = stream_leg(ctx, P, traj_host, args)
+                result["stream_with_normals"] = sw
+                _leg("voxel filter")
+                result["filter_k1"] = filter_k1_leg(ctx)
+            if world == 1 and extra_host is not None:
+                _PARTIAL[0] = result
+                _leg("configs[2]: scan vs 2 M-point map")
+                result["config3_submap"] = config3_submap_leg(ctx, extra_host, not args.no_cpu_baseline)
+                _leg("configs[4]: 1 M-point merged cloud")
+                result["config5_merged1m"] = config5_merged1m_leg(ctx, extra_host, not args.no_cpu_baseline)
+            _leg("production operating point")
+            if world == 1 and not args.no_cpu_baseline:
+                result["production_operating_point"] = production_leg(ctx)
+        except Exception as e:   # noqa: BLE001
+            import traceback
+            traceback.print_exc()
+            result["extras_error"] = "%s in leg %r: %r" % (type(e).__name__, _BEAT[1], e)
+            result["all_ok"] = False
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -1371,6 +1420,7 @@ def main():
         zv = result.get("cost_mode0", {}).get("natural_convergence", {}).get("vs_cpu_path")
         if zv:
             assert zv["ok"], "cost_mode 0 vs CPU path under the production stopping rule outside the stated bars: %r" % (zv,)
+        assert "extras_error" not in result, "a leg behind the headline failed: %s" % result.get("extras_error")
         for leg in ("config3_submap", "config5_merged1m"):
             cv = result.get(leg, {}).get("vs_cpu_path")
             if cv:
