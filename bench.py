@@ -1083,27 +1083,42 @@ def main():
             name, st = max(((k, v) for k, v in stats.items() if v["bytes"] > 0), key=lambda kv: kv[1]["ms"])
             avg_us = 1e3 * st["ms"] / max(1, st["launches"])
             model = st["bytes"] / 1e9 / (st["ms"] / 1e3) if st["ms"] > 0 else 0.0
-            # The fraction is taken on what THIS design has to move.  A late sweep (k_late + k_walk: every sweep of a pair from its fourth on) streams,
-            # per source point, the point (16 B), its normal (16), the certificate (16) and the neighbour record (24: two packed triples) = 72 B
-            # whatever the certificates decide (84 B until round 4's packed record).  A fused sweep (a pair's first three: everybody walks) reads the
-            # same stream plus the neighbour index (4) and must write back what the late sweeps will read -- certificate 16, record 24, index 4 --
-            # for every point whose neighbour was searched: 120 B.  With 20 forced iterations a group's launches are 3 fused + 17 late.  The tree
-            # nodes and leaf points the walks visit come on top: `traffic` is the measured total.  SURVEY 8d's byte model also counts C1, C2 and M
-            # (216 of its 340 B per correspondence), which are never materialised here: a rate on THAT model can exceed the peak and is kept as a
-            # labelled third figure, not as `frac`.
+            # `frac` follows SURVEY 8(d)'s algorithmic bytes of a fused design: 64 B per correspondence per sweep (source point 16 + its normal 16 +
+            # target point 16 + its normal 16; one correspondence per source point), x the points one launch sweeps, / the launch's average duration
+            # (HIP events on the library's stream), / the HBM peak.  What THIS design must move on top of that -- the certificate (16 B) and the packed
+            # neighbour record instead of a gather (24 instead of 32 B) in a late sweep: 72 B per point; in an all-walk sweep the write-back of
+            # certificate, record and index as well: 120 B -- is kept as the labelled figure `design_compulsory`, the measured DRAM traffic as `traffic`.
+            # SURVEY's literal 20 N + 340 K_t also counts C1, C2 and M (never materialised here): a rate on THAT model can exceed the peak
+            # (`survey_8d_model`).
             batches = reps * ((pairs_here + prof_in_flight - 1) // prof_in_flight)   # groups of pairs the leg ran, one after the other
             sweeps_per_batch = st["launches"] / max(1, batches) if name == "nn_sweep" else 20.0   # (20 here; 4-5 under production stopping)
             n_fused = min(3.0, sweeps_per_batch)   # LH_SPLIT_FROM (lh_kernels.hip), the scheduler's fixed rule
             per_point = (120.0 * n_fused + 72.0 * (sweeps_per_batch - n_fused)) / max(1.0, sweeps_per_batch)
+            ALGO_B = 64.0
+            algo_bytes = ALGO_B * n_pts * prof_in_flight if name == "nn_sweep" else st["bytes"] / max(1, st["launches"])
             comp_bytes = per_point * n_pts * prof_in_flight if name == "nn_sweep" else st["bytes"] / max(1, st["launches"])
-            achieved = comp_bytes / 1e9 / (avg_us * 1e-6) if avg_us > 0 else 0.0
+            achieved = algo_bytes / 1e9 / (avg_us * 1e-6) if avg_us > 0 else 0.0
+            design = comp_bytes / 1e9 / (avg_us * 1e-6) if avg_us > 0 else 0.0
+            # the same fraction per KIND of sweep launch (the scheduler's nested profile scopes): an all-walk sweep (k_sweep_coop: a pair's first
+            # three), a late sweep (k_late + k_walk: from the fourth on)
+            per_kernel = {}
+            for key, label in (("nn_sweep_allwalk", "k_sweep_coop (all-walk sweep)"), ("nn_sweep_late_walk", "k_late + k_walk (late sweep)"), ("nn_sweep_mixed", "mixed launch")):
+                v = stats.get(key)
+                if v and v["launches"] > 0 and v["ms"] > 0:
+                    us = 1e3 * v["ms"] / v["launches"]
+                    per_kernel[key] = {"kernels": label, "launches": v["launches"], "avg_launch_us": round(us, 2),
+                                       "achieved": round(ALGO_B * n_pts * prof_in_flight / 1e9 / (us * 1e-6), 2),
+                                       "frac": round(ALGO_B * n_pts * prof_in_flight / 1e9 / (us * 1e-6) / HBM_PEAK_GBS, 5)}
             return name, st, stats, {
                 "bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "avg_launch_us": round(avg_us, 2), "launches": st["launches"],
                 "jobs_per_launch": prof_in_flight,
-                "bytes_per_launch": round(comp_bytes, 1),
-                "bytes_are": ("compulsory traffic of this design per sweep launch, averaged over this leg's sweeps (%.1f per group of pairs, the first %.0f of them fused): a late sweep streams 72 B per source point (point, normal, certificate, neighbour record as two packed triples), a fused all-walk sweep reads 76 B and writes back certificate, record and index (44 B): %.1f B per point" % (sweeps_per_batch, n_fused, per_point)
-                              if name == "nn_sweep" else "the launch's byte model (lh_profile)"),
+                "bytes_per_launch": round(algo_bytes, 1),
+                "bytes_are": ("SURVEY 8(d): 64 B per correspondence per sweep (source point + normal, target point + normal; one correspondence per source point) x %d points x %d pairs per launch"
+                              % (n_pts, prof_in_flight) if name == "nn_sweep" else "the launch's byte model (lh_profile)"),
+                "per_kernel": per_kernel,
+                "design_compulsory": {"achieved": round(design, 2), "frac": round(design / HBM_PEAK_GBS, 5), "bytes_per_launch": round(comp_bytes, 1),
+                                      "bytes_are": "what this design must move per sweep launch, averaged over the leg's sweeps (%.1f per group of pairs, the first %.0f of them all-walk): a late sweep streams 72 B per source point (point, normal, certificate, neighbour record as two packed triples), an all-walk sweep reads 76 B and writes back certificate, record and index (44 B): %.1f B per point" % (sweeps_per_batch, n_fused, per_point)},
                 "survey_8d_model": {"achieved": round(model, 2), "frac": round(model / HBM_PEAK_GBS, 5), "bytes_per_launch": round(st["bytes"] / max(1, st["launches"]), 1),
                                     "note": "20 N + 340 K_t with the measured K_t (SURVEY 8d's B_nn + B_fdf): counts covariance and Mahalanobis matrices this design never "
                                             "writes or reads, so it is not bounded by the peak; kept for comparison with rounds 1-3"},

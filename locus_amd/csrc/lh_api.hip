@@ -879,12 +879,13 @@ lh_status lh_gicp_debug_sweep_fused(lh_gicp* g, const float T[16], int sweep_ind
     launch_seed(c->descs_dev, sa, g->src->n, c->stream);
     a.job[0].pad = 1;   // the cold sweep: seeds in prev_nn, certificates / records not read
   }
+  a.job[0].pad |= sweep_greedy_flag(sweep_index);
   CostArgs ca;
   ca.njobs = 1; ca.pad = 0; ca.job[0].slot = 0; ca.job[0].out_offset = 0;
   memcpy(ca.job[0].T, a.job[0].T, sizeof(a.job[0].T));
   launch_sweep_fused(c->descs_dev, a, sweep_is_split(&t, sweep_index) ? 1u : 0u, g->src->n, c->mom_partials_dev, c->mom_stride, nullptr, true, c->wmask_dev,
                      c->mask_stride, c->stream);
-  ca.pad = sweep_is_split(&t, sweep_index) ? 0 : 1;   // whose rows the final sum adds: the fused sweep's or k_late's + k_walk's
+  ca.pad = (sweep_is_split(&t, sweep_index) || sweep_coop(true)) ? 0 : 1;   // whose rows the final sum adds: the fused sweep's or k_late's + k_walk's
   launch_moments_final(c->descs_dev, ca, c->mom_partials_dev, c->mom_stride, c->partials_host, nullptr, c->wmask_dev, c->mask_stride, c->stream);
   HIPCHK(hipGetLastError());
   if (tgt_idx) HIPCHK(hipMemcpyAsync(tgt_idx, g->ws.prev_nn, sizeof(int32_t) * (size_t)g->src->n, hipMemcpyDeviceToHost, c->stream));

@@ -1008,6 +1008,382 @@ __global__ void __launch_bounds__(FUSED_WG) __attribute__((amdgpu_waves_per_eu(L
   }
 }
 
+// ===== the all-walk sweeps as a COOPERATIVE search (round 6; cost_mode 1, covariances from normals) ===========================
+// k_sweep_fused walks one query per lane: a wave lives for the LONGEST of its 64 walks and alternates node and leaf steps by vote --
+// 27-35 of 64 lanes busy per vector instruction, 10.7 (warm) to 17.6 (cold) wave steps for 4.6 to 6.7 steps of work per query
+// (tools/model/grid_start_model.cpp).  Here the unit of work is an ITEM (query, subtree), not a lane's whole walk, and the 256 queries
+// of a workgroup share it (tools/model/item_stack_model.cpp prices the variants -- a wave-shared walk of the k-NN block-search kind
+// costs 55-80 full-wave visits per 64 queries, a shared stack without the first descent explodes when the warm bound is loose):
+//   phase 1  every lane: loads, transform, warm candidate / seed, certificate test (sweep_point's first half), then -- in the pair's
+//            first two sweeps, where the candidate is a loose bound -- a GREEDY DESCENT from the query's own start-grid cell to one
+//            leaf and a scan of it: no stack, no sort, no vote, every lane busy; the bound is tight afterwards.  Then the start items
+//            of the exact search: the start cell grid_start chooses for that bound and the neighbour cells the ball still reaches.
+//   phase 2  level-synchronous rounds over the workgroup's item queues in LDS: a LEAF round (every queued leaf is scanned by whichever
+//            lane its position in the queue falls to; the query's (d2, index) slot takes a 64-bit atomic minimum, its certificate
+//            bound a 32-bit one), then a NODE round (four child boxes against the query's bound of the moment; survivors are appended
+//            to the next round's queues with one LDS atomic per wave and kind).  Every step is of ONE kind with (nearly) 64 busy lanes.
+// Exactness: a subtree is dropped only when its box is farther than a real candidate's distance, a leaf is always scanned, and the
+// minimum over (d2 bits << 32 | index) IS the nearest point with the lowest index -- the rule of every other search here, whatever the
+// order of the visits.  The certificate bound is min(d2 of every examined point but the winner, box distance of every dropped subtree):
+// each contribution is an exact value of a set that does not depend on timing (bounds only change in leaf rounds, are only read for
+// pruning in node rounds, and a barrier separates the two), so neighbours, certificates and sums are bitwise reproducible.
+// A queue that overflows (a non-finite query walks the whole tree; a degenerate cloud) sets a flag and the WHOLE workgroup redoes its
+// points with sweep_point's per-lane walk -- the decision depends only on item counts, which are deterministic too.
+// MEASURED (MI355X, 32 x 100 k points, sweeps 0 / 1 / 2; docs/NOTEBOOK_r6.md section 1): 2 699 / 2 108 / 1 610 vector instructions per wave at
+// 44-49 active lanes against k_sweep_fused's 3 072 / 2 614 / 2 093 at 31-35 -- and 453 / 287 / 237 us against 395 / 288 / 222: a quarter
+// fewer instructions buy nothing, because a workgroup's life is its chain of dependent memory round trips (loads, greedy descent, start
+// cells, a node and a leaf round per tree level, the final gather: ~16, each behind a barrier), as long as a lane's walk was.  NOT the
+// default (LH_SWEEP_COOP=1 selects it); it passes the same exact-neighbour and whole-alignment tests (tests/test_gpu_coop.py).
+#ifndef LH_COOP_NCAP
+#define LH_COOP_NCAP 640
+#endif
+#ifndef LH_COOP_LCAP
+#define LH_COOP_LCAP 768
+#endif
+#ifndef LH_COOP_WAVES
+#define LH_COOP_WAVES 5
+#endif
+constexpr int COOP_NCAP = LH_COOP_NCAP, COOP_LCAP = LH_COOP_LCAP;
+// LDS atomics on address-space-3 pointers (ds_add_rtn_u32 / ds_min_u32 / ds_min_rtn_u64; through a generic pointer they would be flat atomics)
+typedef __attribute__((address_space(3))) uint32_t* LdsU32;
+typedef __attribute__((address_space(3))) unsigned long long* LdsU64;
+__device__ __forceinline__ uint32_t lds_add(LdsU32 p, uint32_t v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void lds_min(LdsU32 p, uint32_t v) { (void)__hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ unsigned long long lds_min64(LdsU64 p, unsigned long long v) { return __hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+constexpr int COOP_GREEDY_BIT = 1 << 30;        // SweepJob::pad: the sweep starts with the greedy descent (its candidate is a loose bound)
+constexpr int COOP_MAX_POINTS = 1 << 24;        // a leaf item keeps 24 bits of sorted position beside the 8-bit query slot
+constexpr size_t COOP_OFF_KEY = 0, COOP_OFF_GQ = 2048, COOP_OFF_Q = 6144, COOP_OFF_NQ = 10240, COOP_OFF_LQ = COOP_OFF_NQ + 2 * 8 * (size_t)COOP_NCAP,
+                 COOP_OFF_CTR = COOP_OFF_LQ + 2 * 4 * (size_t)COOP_LCAP, COOP_LDS_BYTES = COOP_OFF_CTR + 32;
+static_assert(COOP_LDS_BYTES >= (size_t)LDS_STACK * 256 * 8, "the fallback's traversal stacks alias the queues");
+static_assert(COOP_LDS_BYTES >= 4 * 32 * GRAM_RS * 8, "the Gram staging rows alias the queues");
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LH_COOP_WAVES))) k_sweep_coop(const PairDesc* __restrict__ descs, SweepArgs a, double* __restrict__ partials,
+                                                                                       int partials_stride, const OuterState* __restrict__ states) {
+  extern __shared__ __attribute__((aligned(16))) uint64_t lds_stack[];
+  typedef __attribute__((address_space(3))) unsigned char* LdsBytes;
+  LdsBytes const lds = (LdsBytes)lds_stack;
+  auto* const skey = (__attribute__((address_space(3))) unsigned long long*)(lds + COOP_OFF_KEY);   // per query: d2 bits << 32 | index
+  typedef uint32_t U32x4 __attribute__((ext_vector_type(4)));   // (HIP's vector classes have no address-space-qualified assignment)
+  typedef float F32x4 __attribute__((ext_vector_type(4)));
+  auto* const sgq = (__attribute__((address_space(3))) U32x4*)(lds + COOP_OFF_GQ);                  // per query: GridQuery
+  auto* const sq = (__attribute__((address_space(3))) F32x4*)(lds + COOP_OFF_Q);                    // per query: x y z, bits of the certificate bound
+  auto lb_of = [&](int q) { return (LdsU32)(lds + COOP_OFF_Q + 16 * (size_t)q + 12); };
+  auto* const nq = (__attribute__((address_space(3))) unsigned long long*)(lds + COOP_OFF_NQ);      // node items [2][NCAP]: (key & ~255 | query) << 32 | node
+  auto* const lq = (__attribute__((address_space(3))) uint32_t*)(lds + COOP_OFF_LQ);                // leaf items [2][LCAP]: query << 24 | sorted position
+  auto* const ctr = (__attribute__((address_space(3))) uint32_t*)(lds + COOP_OFF_CTR);              // [0..1] node counts, [2..3] leaf counts, [4] overflow
+  int jb, blk;
+  if (!xcd_job_map(a.njobs, a.bpj, jb, blk)) return;
+  const SweepJob& job = a.job[jb];
+  const PairDesc d = descs[job.slot];
+  if (blk * 256 >= d.n) return;  // (uniform)
+  float T[12];
+  if (!job_transform(job, states, T)) return;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int i = blk * 256 + tid;
+  const int cold = job.pad & 0xffff;
+  const bool greedy = (job.pad & COOP_GREEDY_BIT) != 0;
+  if (tid < 8) ctr[tid] = 0u;
+  TreeView tv{d.tgt_sorted, d.tgt_nodes, d.tgt_hdr, d.m};
+  TreeHeader h;
+  h.root = gld(&tv.hdr->root);
+  h.org[0] = gld(&tv.hdr->org[0]); h.org[1] = gld(&tv.hdr->org[1]); h.org[2] = gld(&tv.hdr->org[2]);
+  h.inv = gld(&tv.hdr->inv); h.scl2 = gld(&tv.hdr->scl2);
+  const bool grid_on = gld(&tv.hdr->grid_on) != 0;
+  const float scl2 = h.scl2;
+  const float INF = INFINITY;
+  // ---- phase 1a: sweep_point's first half -- the candidate and the certificate test
+  bool need_search = false;
+  int w = -1;
+  float qx = 0.f, qy = 0.f, qz = 0.f;
+  Nn1CertCollector col{INF, 0x7fffffff, INF};
+  if (i < d.n) {
+    const float4 p = gld(d.src + i);
+    w = gld(d.prev_nn + i);
+    int w_alt = -1;
+    float4 t_alt = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (cold > 1 && w >= 0) {
+      const int e = i % cold;
+      if (e > 0) {
+        w_alt = min(d.m - 1, w + e);
+        t_alt = gld(d.tgt_xyz + w_alt);
+      }
+    }
+    float4 cq = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 t = cq;
+    if (!cold) {
+      cq = gld(d.cert + i);
+      t = rec_pos(d, i);
+    } else if (w >= 0)
+      t = gld(d.tgt_xyz + w);
+    xform_pt(T, p.x, p.y, p.z, qx, qy, qz);  // gicp.hpp:469
+    need_search = true;
+    if (w_alt >= 0 && d2f(qx, qy, qz, t_alt.x, t_alt.y, t_alt.z) < d2f(qx, qy, qz, t.x, t.y, t.z)) {
+      w = w_alt;
+      t = t_alt;
+    }
+    if (w >= 0) {
+      col.bd = d2f(qx, qy, qz, t.x, t.y, t.z);
+      col.bi = w;
+      const float e = sqrt_bound(d2f(qx, qy, qz, cq.x, cq.y, cq.z));
+      const float dw = sqrt_bound(col.bd), lo = sqrt_bound(cq.w);
+      if (!cold && dw * (1.0f + a.cert_rel) + e * (1.0f + a.cert_rel) + 1e-12f < lo * (1.0f - a.cert_rel)) need_search = false;
+    }
+  }
+  __syncthreads();   // the counters are zero
+  // ---- phase 1b: greedy descent (loose candidates only), start items
+  if (need_search) {
+    const GridQuery gq = grid_query(h, qx, qy, qz);
+    if (greedy) {
+      int32_t r = h.root;
+      if (grid_on) {   // from the query's own level-5 cell if that holds anything (tree_descend<.., true>)
+        const float ksc = gld(&tv.hdr->key_sc);
+        const int cx = (int)fminf(fmaxf((qx - h.org[0]) * ksc, 0.0f), 1023.0f) >> 5, cy = (int)fminf(fmaxf((qy - h.org[1]) * ksc, 0.0f), 1023.0f) >> 5,
+                  cz = (int)fminf(fmaxf((qz - h.org[2]) * ksc, 0.0f), 1023.0f) >> 5;
+        const int32_t g = gld(tv.grid() + grid_index(5, cx, cy, cz));
+        if (g != GRID_EMPTY) r = g;
+      }
+      while (r >= 0) {
+        const NodeX& nd = tv.nodes[r];
+        const uint4 ba = gload16<uint4>(nd.lo_xy);
+        const uint4 bb = gload16<uint4>(nd.hi_xy);
+        const uint4 bc = gload16<uint4>(nd.z_lohi);
+        const int4 ch = gload16<int4>(nd.child);
+        float d0 = boxd2_q(gq, ba.x, bb.x, bc.x, scl2), d1 = boxd2_q(gq, ba.y, bb.y, bc.y, scl2);
+        float d2 = boxd2_q(gq, ba.z, bb.z, bc.z, scl2), d3 = boxd2_q(gq, ba.w, bb.w, bc.w, scl2);
+        d1 = ch.y == NO_CHILD ? INF : d1;
+        d2 = ch.z == NO_CHILD ? INF : d2;
+        d3 = ch.w == NO_CHILD ? INF : d3;
+        float dm = d0; int32_t rm = ch.x;
+        if (d1 < dm) { dm = d1; rm = ch.y; }
+        if (d2 < dm) { dm = d2; rm = ch.z; }
+        if (d3 < dm) { dm = d3; rm = ch.w; }
+        r = rm;
+      }
+      scan_leaf(tv, r, qx, qy, qz, col);
+    }
+    auto push = [&](uint32_t key, int32_t ref) {   // a start item (one LDS atomic per item: at most eight per query, once)
+      if (ref >= 0) {
+        const uint32_t pos = lds_add(&ctr[0], 1u);
+        if (pos < (uint32_t)COOP_NCAP) nq[pos] = ((unsigned long long)((key & ~255u) | (uint32_t)tid) << 32) | (uint32_t)ref;
+        else ctr[4] = 1u;
+      } else {
+        const uint32_t pos = lds_add(&ctr[2], 1u);
+        if (pos < (uint32_t)COOP_LCAP) lq[pos] = ((uint32_t)tid << 24) | ((uint32_t)~ref >> 4);
+        else ctr[4] = 1u;
+      }
+    };
+    int32_t ref = h.root;
+    if (col.bd < INF && grid_on) {
+      const int32_t g = grid_start(h.org, gld(&tv.hdr->key_sc), gld(&tv.hdr->key_inv), tv.grid(), qx, qy, qz, col, push);
+      if (g != GRID_USE_ROOT) ref = g;
+    }
+    if (ref != GRID_EMPTY) push(0u, ref);
+    skey[tid] = ((unsigned long long)f2u(col.bd) << 32) | (uint32_t)col.bi;
+    sgq[tid] = U32x4{gq.up_xy, gq.dn_xy, gq.z, f2u(gq.e2)};
+    sq[tid] = F32x4{qx, qy, qz, col.lb};
+  }
+  __syncthreads();   // the start items, the queries' slots
+  // ---- phase 2: rounds
+  bool fallback = d.m + LEAF_CAP > COOP_MAX_POINTS;   // (a leaf item could not hold the sorted position: per-lane walks)
+  int par = 0;
+  for (;;) {
+    const uint32_t nN = ctr[par], nL = ctr[2 + par];
+    if (fallback || ctr[4] != 0u) { fallback = true; break; }
+    if (nN == 0u && nL == 0u) break;
+    auto* const lqc = lq + par * COOP_LCAP;
+    for (uint32_t c0 = (uint32_t)wave * 64u; c0 < nL; c0 += 256u) {   // leaf round
+      const uint32_t k = c0 + (uint32_t)lane;
+      if (k < nL) {
+        const uint32_t it = lqc[k];
+        const int qid = (int)(it >> 24);
+        const F32x4 qq = sq[qid];
+        const unsigned long long snap = skey[qid];
+        Nn1CertCollector c{u2f((uint32_t)(snap >> 32)), (int)(uint32_t)snap, INF};
+        const float4* p = tv.pts + (it & 0xffffffu);
+        float4 v[LEAF_CAP];
+#pragma unroll
+        for (int e = 0; e < LEAF_CAP; e++) v[e] = gload16<float4>(p + e);
+#pragma unroll
+        for (int e = 0; e < LEAF_CAP; e++) c.offer(d2f(qq.x, qq.y, qq.z, v[e].x, v[e].y, v[e].z), (int)f2u(v[e].w));
+        const unsigned long long mine = ((unsigned long long)f2u(c.bd) << 32) | (uint32_t)c.bi;
+        float contrib = c.lb;
+        if (mine < snap) {
+          const unsigned long long old = lds_min64(&skey[qid], mine);
+          if (old != mine) contrib = fminf(contrib, u2f((uint32_t)((old > mine ? old : mine) >> 32)));   // the loser of the two is a runner-up
+        }
+        if (contrib < INF) lds_min(lb_of(qid), f2u(contrib));
+      }
+    }
+    __syncthreads();   // the bounds of this round's node tests are final; everybody has read the counts
+    if (tid == 0) { ctr[par] = 0u; ctr[2 + par] = 0u; }   // (pushed to again only after the next barrier but one)
+    auto* const nqc = nq + par * COOP_NCAP;
+    auto* const nqn = nq + (par ^ 1) * COOP_NCAP;
+    auto* const lqn = lq + (par ^ 1) * COOP_LCAP;
+    for (uint32_t c0 = (uint32_t)wave * 64u; c0 < nN; c0 += 256u) {   // node round
+      const uint32_t k = c0 + (uint32_t)lane;
+      bool v0 = false, v1 = false, v2 = false, v3 = false;
+      int4 ch = make_int4(NO_CHILD, NO_CHILD, NO_CHILD, NO_CHILD);
+      float d0 = INF, d1 = INF, d2 = INF, d3 = INF;
+      int qid = 0;
+      if (k < nN) {
+        const unsigned long long it = nqc[k];
+        const uint32_t hi = (uint32_t)(it >> 32);
+        qid = (int)(hi & 255u);
+        const float key = u2f(hi & ~255u);
+        const float bd = u2f((uint32_t)(skey[qid] >> 32));
+        if (key <= bd) {
+          const U32x4 g4 = sgq[qid];
+          const GridQuery gq{g4.x, g4.y, g4.z, u2f(g4.w)};
+          const NodeX& nd = tv.nodes[(int32_t)(uint32_t)it];
+          const uint4 ba = gload16<uint4>(nd.lo_xy);
+          const uint4 bb = gload16<uint4>(nd.hi_xy);
+          const uint4 bc = gload16<uint4>(nd.z_lohi);
+          ch = gload16<int4>(nd.child);
+          d0 = boxd2_q(gq, ba.x, bb.x, bc.x, scl2);
+          d1 = boxd2_q(gq, ba.y, bb.y, bc.y, scl2);
+          d2 = boxd2_q(gq, ba.z, bb.z, bc.z, scl2);
+          d3 = boxd2_q(gq, ba.w, bb.w, bc.w, scl2);
+          d1 = ch.y == NO_CHILD ? INF : d1;
+          d2 = ch.z == NO_CHILD ? INF : d2;
+          d3 = ch.w == NO_CHILD ? INF : d3;
+          v0 = d0 <= bd && d0 < INF; v1 = d1 <= bd && d1 < INF; v2 = d2 <= bd && d2 < INF; v3 = d3 <= bd && d3 < INF;
+          const float sk = fminf(fminf(v0 ? INF : d0, v1 ? INF : d1), fminf(v2 ? INF : d2, v3 ? INF : d3));   // the dropped children (Collector::skip)
+          if (sk < INF) lds_min(lb_of(qid), f2u(sk));
+        } else
+          lds_min(lb_of(qid), f2u(key));   // dropped at the pop
+      }
+      // survivors -> the next round's queues: one atomic per wave and kind, positions by ballot
+      const bool n0 = v0 && ch.x >= 0, n1 = v1 && ch.y >= 0, n2 = v2 && ch.z >= 0, n3 = v3 && ch.w >= 0;
+      const bool l0 = v0 && ch.x < 0, l1 = v1 && ch.y < 0, l2 = v2 && ch.z < 0, l3 = v3 && ch.w < 0;
+      const unsigned long long mn0 = __ballot(n0), mn1 = __ballot(n1), mn2 = __ballot(n2), mn3 = __ballot(n3);
+      const unsigned long long ml0 = __ballot(l0), ml1 = __ballot(l1), ml2 = __ballot(l2), ml3 = __ballot(l3);
+      const uint32_t tn = (uint32_t)(__popcll(mn0) + __popcll(mn1) + __popcll(mn2) + __popcll(mn3));
+      const uint32_t tl = (uint32_t)(__popcll(ml0) + __popcll(ml1) + __popcll(ml2) + __popcll(ml3));
+      uint32_t bn = 0u, bl = 0u;
+      if (lane == 0) {
+        if (tn) bn = lds_add(&ctr[par ^ 1], tn);
+        if (tl) bl = lds_add(&ctr[2 + (par ^ 1)], tl);
+      }
+      bn = (uint32_t)__builtin_amdgcn_readfirstlane((int)bn);
+      bl = (uint32_t)__builtin_amdgcn_readfirstlane((int)bl);
+      if (bn + tn > (uint32_t)COOP_NCAP || bl + tl > (uint32_t)COOP_LCAP) {
+        if (lane == 0) ctr[4] = 1u;
+      } else {
+        auto below = [&](unsigned long long m) { return (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); };
+        auto nitem = [&](float dk, int32_t r) { return ((unsigned long long)((f2u(dk) & ~255u) | (uint32_t)qid) << 32) | (uint32_t)r; };
+        auto litem = [&](int32_t r) { return ((uint32_t)qid << 24) | ((uint32_t)~r >> 4); };
+        if (n0) nqn[bn + below(mn0)] = nitem(d0, ch.x);
+        bn += (uint32_t)__popcll(mn0);
+        if (n1) nqn[bn + below(mn1)] = nitem(d1, ch.y);
+        bn += (uint32_t)__popcll(mn1);
+        if (n2) nqn[bn + below(mn2)] = nitem(d2, ch.z);
+        bn += (uint32_t)__popcll(mn2);
+        if (n3) nqn[bn + below(mn3)] = nitem(d3, ch.w);
+        if (l0) lqn[bl + below(ml0)] = litem(ch.x);
+        bl += (uint32_t)__popcll(ml0);
+        if (l1) lqn[bl + below(ml1)] = litem(ch.y);
+        bl += (uint32_t)__popcll(ml1);
+        if (l2) lqn[bl + below(ml2)] = litem(ch.z);
+        bl += (uint32_t)__popcll(ml2);
+        if (l3) lqn[bl + below(ml3)] = litem(ch.w);
+      }
+    }
+    __syncthreads();   // the next round's items
+    par ^= 1;
+  }
+  // ---- sweep_point's second half: the neighbour, its certificate, the Mahalanobis matrix
+  SweepPoint sp;
+  sp.matched = false;
+  sp.searched = false;
+  sp.nonn = false;
+  sp.p = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (fallback) {
+    __syncthreads();   // (everybody has left the loop: the traversal stacks alias the queues)
+    if (i < d.n) sweep_point<true, 256>(d, T, i, lds_stack + tid, sp, a.cert_rel, cold);
+  } else if (i < d.n) {
+    if (need_search) {
+      const unsigned long long kk = skey[tid];
+      const F32x4 qq = sq[tid];
+      col.bd = u2f((uint32_t)(kk >> 32));
+      col.bi = (int)(uint32_t)kk;
+      col.lb = qq.w;
+      gst(d.cert + i, make_float4(qx, qy, qz, nn_index(col.bi, col.bd) >= 0 ? col.lb : -1.0f));
+      if (d.stats) atomicAdd(&d.stats[0], 1ull);
+    }
+    if (d.stats) atomicAdd(&d.stats[1], 1ull);
+    const int j = nn_index(col.bi, col.bd);
+    sp.searched = need_search;
+    sp.nonn = j < 0;
+    sp.j = j;
+    sp.p = gld(d.src + i);
+    if (j != w || cold) gst(d.prev_nn + i, j);
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f), tn = t, nn = t;
+    if (j >= 0) {
+      nn = gld(d.src_nrm + i);
+      if (need_search) {
+        t = gld(d.tgt_xyz + j);
+        tn = gld(d.tgt_nrm + j);
+        if ((j != w || cold) && d.rec) rec_put(d, i, t, tn);   // the record follows prev_nn
+      } else {
+        t = rec_pos(d, i);
+        tn = rec_nrm(d, i);
+      }
+    }
+    sp.matched = j >= 0 && (double)col.bd < d.corr_dist2;  // gicp.hpp:483
+    if (sp.matched) {   // (sweep_point's kRank1 branch, expression for expression: every sweep kernel must produce the same bits for a point)
+      double R[9];
+      if (d.guess_identity) {
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+          for (int cc = 0; cc < 3; cc++) R[r * 3 + cc] = (double)T[r * 4 + cc];
+      } else {
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+          for (int cc = 0; cc < 3; cc++)
+            R[r * 3 + cc] = (((double)T[r * 4 + 0] * d.guess3[0 * 3 + cc] + (double)T[r * 4 + 1] * d.guess3[1 * 3 + cc]) +
+                             (double)T[r * 4 + 2] * d.guess3[2 * 3 + cc]) + (double)T[r * 4 + 3] * 0.0;
+      }
+      double G[6], M6[6];
+      {
+        int q = 0;
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+          for (int cc = r; cc < 3; cc++) {
+            const double rr = __builtin_fma(R[r * 3 + 2], R[cc * 3 + 2], __builtin_fma(R[r * 3 + 1], R[cc * 3 + 1], R[r * 3 + 0] * R[cc * 3 + 0]));
+            G[q++] = r == cc ? rr + 1.0 : rr;
+          }
+      }
+      maha_rank1(R, 3, G, 1.0 - d.gicp_eps, nn, tn, M6);
+      sp.M[0] = M6[0]; sp.M[1] = M6[1]; sp.M[2] = M6[2];
+      sp.M[3] = M6[1]; sp.M[4] = M6[3]; sp.M[5] = M6[4];
+      sp.M[6] = M6[2]; sp.M[7] = M6[4]; sp.M[8] = M6[5];
+      sp.tgt = t;
+    }
+  }
+  // ---- the 74 moments: k_sweep_fused's tail with four waves per workgroup (one row per 256 points, like k_late's)
+  double M6[6] = {0, 0, 0, 0, 0, 0}, Ma[3] = {0, 0, 0}, pt[4] = {0, 0, 0, 0}, pp[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, aMa = 0.0;
+  if (sp.matched) moments_of_point(T, sp, M6, Ma, aMa, pt, pp);
+  const double live = sp.matched ? 1.0 : (sp.nonn ? NO_NN_MARK : 0.0);
+  const int walks = __popcll(__ballot(sp.searched));
+  double* out = partials + (size_t)job.slot * partials_stride + (size_t)blk * MOM_ROW;
+  {
+    const double av[11] = {M6[0], M6[1], M6[2], M6[3], M6[4], M6[5], Ma[0], Ma[1], Ma[2], aMa, live};
+    GramAcc acc;
+    gram_zero(acc);
+    __syncthreads();  // every lane is done with the queues / its traversal stack
+    double* wl = reinterpret_cast<double*>(lds_stack) + wave * (32 * GRAM_RS);
+    gram_accumulate(wl, av, sp.p, sp.matched, acc, sp.nonn);
+    gram_store(acc, wl, (double)walks);
+    wg_row_sum(reinterpret_cast<double*>(lds_stack), 32 * GRAM_RS, out);
+  }
+  if (a.span > 0) {   // the walk rows of this job stay zero (k_moments_final adds the same rows whichever way the sweep was launched)
+    const int bps = a.span >> 8;
+    if (blk % bps == 0 && tid < MOM_ROW) partials[(size_t)job.slot * partials_stride + ((size_t)((d.n + 255) / 256) + blk / bps) * MOM_ROW + tid] = 0.0;
+  }
+}
+
 // ===== the same sweep in two launches (cost_mode 1, covariances from normals, guess = I) =======================================
 // What bounds k_sweep_fused once most certificates hold (SQ counters, profiles/): a wave that has nothing to search still carries
 // the traversal's costs -- 24 KB of LDS stack per workgroup (6 waves per SIMD), a workgroup barrier in front of the reduction (its
@@ -1313,6 +1689,18 @@ int sweep_walk_span() {
   return span;
 }
 int sweep_fused_wg() { return FUSED_WG; }
+// the all-walk sweeps of cost_mode 1 with covariances from normals: k_sweep_fused, or k_sweep_coop with LH_SWEEP_COOP=1 (measured slower:
+// see the comment above the kernel; kept selectable for A/B runs and held to the same parity tests)
+bool sweep_coop(bool normals_only) {
+  static const bool on = []() { const char* e = getenv("LH_SWEEP_COOP"); return e ? atoi(e) != 0 : false; }();
+  return on && normals_only;
+}
+// a pair's first sweeps start with the greedy descent: their candidate (a seed; a neighbour found before the first, largest step) is a loose bound
+int sweep_coop_greedy_until() {
+  static const int until = []() { const char* e = getenv("LH_COOP_GREEDY"); int v = e ? atoi(e) : 2; return v < 0 ? 0 : v; }();
+  return until;
+}
+int sweep_greedy_flag(int sweep_index) { return sweep_index < sweep_coop_greedy_until() ? COOP_GREEDY_BIT : 0; }
 int sweep_split_from() {
   static const int from = []() { const char* e = getenv("LH_SPLIT_FROM"); int v = e ? atoi(e) : 3; return v < 0 ? 0 : v; }();
   return from;
@@ -1323,8 +1711,11 @@ void launch_sweep_fused(const PairDesc* descs, SweepArgs& a, uint32_t split_mask
   static const int refill = []() { const char* e = getenv("LH_WALK_REFILL"); int v = e ? atoi(e) : 16; return v < 1 ? 1 : (v > 64 ? 64 : v); }();
   a.span = sweep_walk_span();
   a.cert_rel = cert_margin();
-  for (int j = 0; j < a.njobs; j++)
-    if (a.job[j].pad) a.job[j].pad = seed_group_size();   // a cold job: the sweep is told the seed pass's group size (sweep_point)
+  const bool coop = sweep_coop(normals_only);
+  for (int j = 0; j < a.njobs; j++) {
+    const int flags = coop ? (a.job[j].pad & COOP_GREEDY_BIT) : 0;   // (only k_sweep_coop knows the bit)
+    a.job[j].pad = ((a.job[j].pad & 0xffff) ? seed_group_size() : 0) | flags;   // a cold job: the sweep is told the seed pass's group size (sweep_point)
+  }
   static const int exp_lanes = []() { const char* e = getenv("LH_EXP_LANES"); return e ? atoi(e) : 0; }();
   a.pad2 = exp_lanes;
   a.refill = refill;
@@ -1333,9 +1724,14 @@ void launch_sweep_fused(const PairDesc* descs, SweepArgs& a, uint32_t split_mask
   if (f.njobs > 0) {
     size_t lds = stack_lds_bytes(f.max_depth, FUSED_WG);
     if (lds < (FUSED_WG / 64) * 32 * GRAM_RS * sizeof(double)) lds = (FUSED_WG / 64) * 32 * GRAM_RS * sizeof(double);
+    if (coop) {
+      f.bpj = (max_n + 255) / 256;
+      hipLaunchKernelGGL(k_sweep_coop, dim3(xcd_grid(f.njobs, f.bpj)), dim3(256), COOP_LDS_BYTES, s, descs, f, partials_dev, partials_stride, states);
+    } else {
     f.bpj = (max_n + FUSED_WG - 1) / FUSED_WG;
     if (normals_only) hipLaunchKernelGGL(k_sweep_fused<true>, dim3(xcd_grid(f.njobs, f.bpj)), dim3(FUSED_WG), lds, s, descs, f, partials_dev, partials_stride, states);
     else hipLaunchKernelGGL(k_sweep_fused<false>, dim3(xcd_grid(f.njobs, f.bpj)), dim3(FUSED_WG), lds, s, descs, f, partials_dev, partials_stride, states);
+    }
   }
   if (sp.njobs > 0) {
     sp.bpj = (max_n + 255) / 256;

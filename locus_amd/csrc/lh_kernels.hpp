@@ -151,6 +151,8 @@ void launch_sweep_fused(const PairDesc* descs, SweepArgs& a, uint32_t split_mask
                         const OuterState* states, bool normals_only, unsigned long long* wmask, int mask_stride, hipStream_t s);
 int sweep_walk_span();    // source points per walk row (LH_WALK_SPAN, default 512)
 int sweep_split_from();   // first outer iteration (0-based) swept in two launches (LH_SPLIT_FROM)
+bool sweep_coop(bool normals_only);   // the fused jobs of such a launch are swept by k_sweep_coop: one partial row per 256 points (CostArgs::pad bit clear)
+int sweep_greedy_flag(int sweep_index); // SweepJob::pad flag of a pair's sweep_index-th sweep (k_sweep_coop's greedy descent)
 int sweep_fused_wg();      // source points per partial row of the FUSED sweep (its workgroup size: 256, or 64 with one wave per workgroup)
 inline int sweep_rows(int n) { return (n + sweep_fused_wg() - 1) / sweep_fused_wg() + (n + sweep_walk_span() - 1) / sweep_walk_span(); }   // partial rows of one job at most: one per workgroup of the sweep + the walk rows
 void launch_moments_final(const PairDesc* descs, const CostArgs& a, double* partials_dev, int partials_stride, double* out, const OuterState* states,

@@ -232,10 +232,17 @@ static lh_status group_launch(lh_ctx* c, Group& g) {
         Task* t = g.sweeps[o + j];
         if (t->P.recompute_source_cov || t->P.recompute_target_cov) normals_only = false;
         if (sweep_is_split(t, t->sweeps_done)) split_mask |= 1u << j;
+        a.job[j].pad |= sweep_greedy_flag(t->sweeps_done);
         t->sweeps_done++;
       }
-      launch_sweep_fused(c->descs_dev, a, split_mask, max_n, c->mom_partials_dev, c->mom_stride, nullptr, normals_only, c->wmask_dev, c->mask_stride, st);
-      ca.pad = (int)(~split_mask & (a.njobs >= 32 ? 0xffffffffu : ((1u << a.njobs) - 1u)));   // the jobs whose rows the fused sweep left
+      {
+        // (a second, nested scope by KIND of sweep -- every pair of the launch walks / certificate holders + walkers / both -- so that a profile
+        // can put each kind against its own byte count: bench.py roofline.per_kernel)
+        const uint32_t all = a.njobs >= 32 ? 0xffffffffu : ((1u << a.njobs) - 1u);
+        ProfScope pk(c, split_mask == 0u ? "nn_sweep_allwalk" : (split_mask == all ? "nn_sweep_late_walk" : "nn_sweep_mixed"), 0.0, st);
+        launch_sweep_fused(c->descs_dev, a, split_mask, max_n, c->mom_partials_dev, c->mom_stride, nullptr, normals_only, c->wmask_dev, c->mask_stride, st);
+      }
+      ca.pad = sweep_coop(normals_only) ? 0 : (int)(~split_mask & (a.njobs >= 32 ? 0xffffffffu : ((1u << a.njobs) - 1u)));   // the jobs whose rows the fused sweep left (one per 64 points)
       launch_moments_final(c->descs_dev, ca, c->mom_partials_dev, c->mom_stride, c->partials_host, nullptr, c->wmask_dev, c->mask_stride, st);
     } else {
       {
@@ -458,6 +465,7 @@ static lh_status dev_enqueue(lh_ctx* c, DevGroup& g, int rounds) {
           t->first_sweep = false;
         }
         if (sweep_is_split(t, t->enq_iters)) split_mask |= 1u << j;
+        a.job[j].pad |= sweep_greedy_flag(t->enq_iters);
         t->enq_iters++;
       }
       if (seed.njobs > 0) {
@@ -466,8 +474,12 @@ static lh_status dev_enqueue(lh_ctx* c, DevGroup& g, int rounds) {
       }
       {
         ProfScope p(c, "nn_sweep", bytes, st);
-        launch_sweep_fused(c->descs_dev, a, split_mask, max_n, c->mom_partials_dev, c->mom_stride, c->states_dev, normals_only, c->wmask_dev, c->mask_stride, st);
-        ca.pad = (int)(~split_mask & (a.njobs >= 32 ? 0xffffffffu : ((1u << a.njobs) - 1u)));   // the jobs whose rows the fused sweep left
+        {
+          const uint32_t all = a.njobs >= 32 ? 0xffffffffu : ((1u << a.njobs) - 1u);   // (nested scope by kind of sweep: see the host-driven loop)
+          ProfScope pk(c, split_mask == 0u ? "nn_sweep_allwalk" : (split_mask == all ? "nn_sweep_late_walk" : "nn_sweep_mixed"), 0.0, st);
+          launch_sweep_fused(c->descs_dev, a, split_mask, max_n, c->mom_partials_dev, c->mom_stride, c->states_dev, normals_only, c->wmask_dev, c->mask_stride, st);
+        }
+        ca.pad = sweep_coop(normals_only) ? 0 : (int)(~split_mask & (a.njobs >= 32 ? 0xffffffffu : ((1u << a.njobs) - 1u)));   // the jobs whose rows the fused sweep left (one per 64 points)
         launch_moments_final(c->descs_dev, ca, c->mom_partials_dev, c->mom_stride, c->chunks_dev, c->states_dev, c->wmask_dev, c->mask_stride, st);
       }
       if (c->dev_reduce_fn) {   // the source-sharded pair: the chunk sums are summed over the ranks where they lie, on this stream, before k_solve reads them

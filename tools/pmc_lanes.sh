@@ -12,7 +12,7 @@ python - "$f" <<'PY' | tee $R/gpurun_out/pmc/lanes.txt
 import csv, sys, collections
 rows = collections.defaultdict(lambda: collections.defaultdict(float)); tag = {}
 for r in csv.DictReader(open(sys.argv[1])):
-    for p in ("k_sweep_fused", "k_late", "k_walk", "k_seed"):
+    for p in ("k_sweep_coop", "k_sweep_fused", "k_late", "k_walk", "k_seed"):
         if p in r["Kernel_Name"]:
             rows[int(r["Dispatch_Id"])][r["Counter_Name"]] += float(r["Counter_Value"]); tag[int(r["Dispatch_Id"])] = p
 per = collections.defaultdict(list)
@@ -23,4 +23,6 @@ for p, v in per.items():
     print(p, "dispatches (profiled alignment):", len(v))
     print("   active lanes per VALU instruction:", " ".join("%.1f" % (d["SQ_THREAD_CYCLES_VALU"] / max(d["SQ_INSTS_VALU"], 1.0)) for d in v))
     print("   VALU instructions per wave       :", " ".join("%.0f" % (d["SQ_INSTS_VALU"] / max(d["SQ_WAVES"], 1.0)) for d in v))
+    print("   wave cycles (x4) per wave        :", " ".join("%.0f" % (d["SQ_WAVE_CYCLES"] / max(d["SQ_WAVES"], 1.0)) for d in v))
+    print("   VALU-active cycles / busy cycles  :", " ".join("%.2f" % (d["SQ_ACTIVE_INST_VALU"] / max(d["SQ_BUSY_CYCLES"], 1.0)) for d in v))
 PY
