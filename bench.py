@@ -869,6 +869,15 @@ def production_leg(ctx):
         for tag, env in (("gpu_promote", {}), ("gpu_two_uploads", {"LOCUS_HIP_NO_PROMOTE": "1"})):
             o = subprocess.run([exe, path, "3"], capture_output=True, text=True, timeout=120, env=dict(os.environ, **env))
             res[tag] = json.loads(o.stdout.strip().splitlines()[-1]) if o.returncode == 0 and o.stdout.strip() else {"error": (o.stderr or o.stdout)[-300:]}
+        # LOCUS's WHOLE per-scan registration work (Locus.cc:450-520): odometry update + frame transforms + map neighbours + MeasurementUpdate
+        # (GICP against the neighbours, aligned query, correspondences, Ap, covariance) + keyframe insertion, through the same mirrors -- with host
+        # clouds in and out of every call (the drop-in surface) and with everything between the two registrations resident in HBM
+        exe2 = os.path.join(ROOT, "locus_amd", "host", "locus_stream")
+        if os.path.exists(exe2):
+            o = subprocess.run([exe2, path, "3"], capture_output=True, text=True, timeout=180, env=dict(os.environ))
+            res["locus_per_scan"] = json.loads(o.stdout.strip().splitlines()[-1]) if o.stdout.strip().startswith("{") else {"error": (o.stderr or o.stdout)[-300:]}
+            if isinstance(res["locus_per_scan"], dict):
+                res["locus_per_scan"]["exit_code"] = o.returncode   # 6: the device-resident flow did not reproduce the host surface's poses bit for bit
     finally:
         os.unlink(path)
     # the CPU path on the same scans: oracle.gicp_align at 4 OMP threads (LOCUS Husky default), tree build + covariances + 20-iteration loop
@@ -883,6 +892,29 @@ def production_leg(ctx):
         if i > 3:
             times.append(1e3 * (time.perf_counter() - t0))
     res["cpu_4_threads_ms_per_update_median"] = float(np.median(times))
+    if isinstance(res.get("locus_per_scan"), dict) and "host_surface" in res["locus_per_scan"]:
+        # ... and the CPU path's share of MeasurementUpdate beside it: a second registration of the same sizes under the localization parameters
+        # (PointCloudLocalization.cc:234-240: corr_dist 0.2, 50 inner iterations, tf_eps 1e-5; the previous scan stands in for the map's neighbours:
+        # one reference point per query point), the ungated 1-NN pass and Ap + covariance, 4 OMP threads
+        kwl = dict(max_iterations=20, max_inner_iterations=50, corr_dist=0.2, transformation_epsilon=1e-5)
+        tl = []
+        for i in range(4, min(n_scans, 16)):
+            a, b = scans[i], scans[i - 1]
+            s4, sn = O.xyz4(np.stack([a["x"], a["y"], a["z"]], 1)), O.nrm4(np.stack([a["normal_x"], a["normal_y"], a["normal_z"]], 1))
+            t4, tn = O.xyz4(np.stack([b["x"], b["y"], b["z"]], 1)), O.nrm4(np.stack([b["normal_x"], b["normal_y"], b["normal_z"]], 1))
+            t0 = time.perf_counter()
+            r = O.gicp_align(s4, sn, t4, tn, O.default_params(num_threads=4, **kwl), want_trace=False)
+            q4 = O.transform(s4, np.asarray(r["T"], np.float32))
+            io = O.Tree(t4).nn1(q4, threads=4)[0]
+            Ap = O.p2plane_Ap(O.normalize_cloud(s4), tn, io)
+            O.icp_covariance(Ap, 0.01)
+            tl.append(1e3 * (time.perf_counter() - t0))
+        res["locus_per_scan"]["cpu_4_threads_ms_per_scan_median"] = round(res["cpu_4_threads_ms_per_update_median"] + float(np.median(tl)), 3)
+        res["locus_per_scan"]["cpu_what"] = "odometry registration + a second registration of the same sizes under the localization parameters + 1-NN + Ap + covariance (oracle, 4 OMP threads)"
+        for k in ("host_surface", "device_resident"):
+            m = res["locus_per_scan"][k].get("ms_per_scan_median")
+            if m:
+                res["locus_per_scan"][k]["speedup_vs_cpu_4_threads"] = round(res["locus_per_scan"]["cpu_4_threads_ms_per_scan_median"] / m, 2)
     if isinstance(res.get("gpu_promote"), dict) and res["gpu_promote"].get("ms_per_update_median"):
         res["speedup_vs_cpu_4_threads"] = round(res["cpu_4_threads_ms_per_update_median"] / res["gpu_promote"]["ms_per_update_median"], 2)
     return res

@@ -294,6 +294,35 @@ lh_status lh_p2plane_information(lh_ctx* ctx, const lh_cloud* query, const lh_cl
 /* H2: ComputePoint2PlaneICPCovariance conditioning (PointCloudLocalization.cc:487-538); host-side, 6x6 */
 lh_status lh_icp_covariance(const double Ap[36], double icp_max_covariance, double cov[36], double* condition_number);
 
+/* PointCloudLocalization::MeasurementUpdate's device work in ONE call on the handle's source (the query) and target (the reference),
+   both device-resident since setInputSource / setInputTarget (PointCloudLocalization.cc:305-336, 398-421, 469-486, 694-750):
+     icp_->align                                        -> result (lh_gicp_align's statuses; on LH_ETOO_FEW_CORR / LH_ESOLVER / LH_ENO_NN the
+                                                           call goes on with the transform align left, like the reference does)
+     transformPointCloudWithNormals(*query, aligned, T) -> aligned_out (nullable): xyz at off_xyz, normals at off_normal
+                                                           (0xffffffff: no normals) of count * stride bytes
+     nearestKSearch(aligned point, 1) for every point   -> corr (nullable, n int32; -1: a non-finite point has no neighbour)
+     normalizePCloud(query) + ComputeAp_ForPoint2PlaneICP(query_normalized, reference, corr) -> Ap (row-major 6x6), want_information != 0
+     0.05^2 Ap^-1, LDLT clamp, condition number         -> covariance, condition_number (lh_icp_covariance; covariance_ok 0 = its
+                                                           "failed to find eigen values" return)
+   Nothing is uploaded, and the host waits once: for the 21 sums of Ap, the correspondences and the aligned cloud it asked for.
+   The pieces are the parity-tested ones (lh_gicp_align, lh_cloud_transform, lh_nn1, lh_p2plane_information, lh_icp_covariance)
+   and the call returns their bits.  Returns lh_gicp_align's status. */
+typedef struct lh_measurement {
+  lh_gicp_result result;
+  double Ap[36];
+  double covariance[36];
+  double condition_number;
+  int32_t have_information;
+  int32_t covariance_ok;
+} lh_measurement;
+lh_status lh_gicp_measurement_update(lh_gicp* g, const float guess[16], int want_information, double icp_max_covariance, lh_measurement* out,
+                                     int32_t* corr, void* aligned_out, uint32_t stride, uint32_t off_xyz, uint32_t off_normal);
+/* the same with the aligned query left in HBM (*aligned: a new cloud the caller destroys; nullable) -- the device-resident LOCUS flow
+   (Locus.cc:474-489: scan -> fixed frame -> map neighbours -> sensor frame -> MeasurementUpdate -> map insert) then moves one scan up
+   and two 6x6 matrices down per update */
+lh_status lh_gicp_measurement_update_cloud(lh_gicp* g, const float guess[16], int want_information, double icp_max_covariance, lh_measurement* out,
+                                           int32_t* corr, lh_cloud** aligned);
+
 /* K1: CustomVoxelGrid::filter (custom_voxel_grid.cc:76-87): voxel centroid of x,y,z,intensity, pass-through
    limits on one axis (limit_axis -1 none / 0,1,2), output in ascending voxel index.  out = xyzi float[cap][4].
    *out_count is the number of voxels (may exceed cap: then only cap are written).  LH_EINVAL on int32 index overflow. */

@@ -80,6 +80,17 @@ class GicpResult(C.Structure):
     ]
 
 
+class Measurement(C.Structure):   # lh_measurement
+    _fields_ = [
+        ("result", GicpResult),
+        ("Ap", C.c_double * 36),
+        ("covariance", C.c_double * 36),
+        ("condition_number", C.c_double),
+        ("have_information", C.c_int32),
+        ("covariance_ok", C.c_int32),
+    ]
+
+
 class GicpTrace(C.Structure):
     _fields_ = [
         ("n_iters", C.c_int),
@@ -107,7 +118,7 @@ EXPORTS = [
     "lh_gicp_set_source", "lh_gicp_set_target", "lh_gicp_set_source_cloud", "lh_gicp_set_target_cloud",
     "lh_gicp_promote_source_to_target", "lh_gicp_align", "lh_gicp_fitness", "lh_set_allreduce", "lh_set_device_allreduce", "lh_nn1", "lh_nn1_cloud", "lh_knn_cloud",
     "lh_gicp_align_batch", "lh_gicp_align_batch_out", "lh_gicp_align_stream", "lh_device_count", "lh_gicp_align_batch_multi", "lh_gicp_align_batch_multi_views", "lh_cov_knn", "lh_gicp_debug_sweep", "lh_gicp_debug_sweep_fused", "lh_gicp_debug_stats", "lh_debug_traversal_stats", "lh_debug_index_dump", "lh_debug_small_index", "lh_gicp_debug_cost", "lh_p2plane_information",
-    "lh_icp_covariance", "lh_voxel_grid", "lh_cloud_voxel_grid", "lh_cloud_voxel_grid_pointf", "lh_cloud_nearest_neighbors", "lh_cloud_crop_box", "lh_default_ndt_params", "lh_ndt_create", "lh_ndt_destroy", "lh_ndt_set_params",
+    "lh_icp_covariance", "lh_gicp_measurement_update", "lh_gicp_measurement_update_cloud", "lh_voxel_grid", "lh_cloud_voxel_grid", "lh_cloud_voxel_grid_pointf", "lh_cloud_nearest_neighbors", "lh_cloud_crop_box", "lh_default_ndt_params", "lh_ndt_create", "lh_ndt_destroy", "lh_ndt_set_params",
     "lh_ndt_set_source", "lh_ndt_set_target", "lh_ndt_set_source_cloud", "lh_ndt_set_target_cloud", "lh_ndt_align", "lh_ndt_debug_cells",
     "lh_ndt_debug_derivatives", "lh_map_create", "lh_map_destroy", "lh_map_insert", "lh_map_refresh", "lh_map_cloud", "lh_map_size", "lh_normals_knn", "lh_normals_knn_cloud", "lh_normals_knn_batch", "lh_cov_knn_batch",
     "lh_normals_radius", "lh_normals_radius_cloud", "lh_cloud_remove_nan_normals", "lh_profile_enable",
@@ -167,6 +178,8 @@ def lib():
         L.lh_gicp_promote_source_to_target.argtypes = [vp]
         L.lh_gicp_align.argtypes = [vp, vp, C.POINTER(GicpResult), C.POINTER(GicpTrace), vp, u32, u32]
         L.lh_gicp_fitness.argtypes = [vp, C.POINTER(dbl)]
+        L.lh_gicp_measurement_update.argtypes = [vp, vp, C.c_int, dbl, vp, vp, vp, u32, u32, u32]
+        L.lh_gicp_measurement_update_cloud.argtypes = [vp, vp, C.c_int, dbl, vp, vp, C.POINTER(vp)]
         L.lh_nn1.argtypes = [vp, C.POINTER(CloudView), vp, vp]
         L.lh_nn1_cloud.argtypes = [vp, vp, vp, vp]
         L.lh_knn_cloud.argtypes = [vp, vp, i32, vp, vp]
@@ -714,6 +727,7 @@ class Gicp:
         _check(lib().lh_gicp_set_params(self.h, C.byref(params)), "lh_gicp_set_params")
 
     def set_source(self, points):
+        self._n_src = len(points)
         if isinstance(points, Cloud):
             self._src = points
             _check(lib().lh_gicp_set_source_cloud(self.h, points.h), "lh_gicp_set_source_cloud")
@@ -750,6 +764,35 @@ class Gicp:
         f = C.c_double()
         _check(lib().lh_gicp_fitness(self.h, C.byref(f)), "lh_gicp_fitness")
         return f.value
+
+    def measurement_update(self, guess=None, want_information=True, icp_max_covariance=0.01, aligned_out=None, want_corr=True, aligned_cloud=False):
+        """lh_gicp_measurement_update(_cloud): align -> aligned query (points + normals) -> ungated 1-NN -> Ap -> covariance, in one call;
+        aligned_cloud: the aligned query stays on the device (out["aligned"] = a Cloud)"""
+        m = Measurement()
+        g = np.ascontiguousarray(guess, np.float32).reshape(16) if guess is not None else None
+        corr = np.empty(self._n_src, np.int32) if want_corr else None
+        ac = C.c_void_p()
+        if aligned_cloud:
+            st = lib().lh_gicp_measurement_update_cloud(self.h, _ptr(g), 1 if want_information else 0, icp_max_covariance, C.byref(m), _ptr(corr), C.byref(ac))
+        elif aligned_out is not None:
+            f = aligned_out.dtype.fields
+            off_n = f["normal_x"][1] if "normal_x" in f else 0xFFFFFFFF
+            st = lib().lh_gicp_measurement_update(self.h, _ptr(g), 1 if want_information else 0, icp_max_covariance, C.byref(m), _ptr(corr),
+                                                  _ptr(aligned_out), aligned_out.dtype.itemsize, f["x"][1], off_n)
+        else:
+            st = lib().lh_gicp_measurement_update(self.h, _ptr(g), 1 if want_information else 0, icp_max_covariance, C.byref(m), _ptr(corr), None, 0, 0, 0xFFFFFFFF)
+        if st not in (LH_OK, LH_ETOO_FEW_CORR, LH_ESOLVER, LH_ENO_NN):
+            raise LocusHipError(st, "lh_gicp_measurement_update")
+        out = _result_dict(m.result)
+        out["corr"] = corr
+        if aligned_cloud and ac:
+            out["aligned"] = Cloud(self.ctx, None, _handle=ac)
+        if m.have_information:
+            out["Ap"] = np.array(m.Ap, np.float64).reshape(6, 6)
+            out["covariance"] = np.array(m.covariance, np.float64).reshape(6, 6)
+            out["condition_number"] = m.condition_number
+            out["covariance_ok"] = bool(m.covariance_ok)
+        return out
 
     def nn1(self, points):
         v, keep = view_of(points)

@@ -575,6 +575,94 @@ lh_status lh_gicp_fitness(lh_gicp* g, double* fitness) {
   return LH_OK;
 }
 
+static lh_status cloud_like(const lh_cloud* in, lh_cloud** out);
+// PointCloudLocalization::MeasurementUpdate's device work in one call (PointCloudLocalization.cc:305-336, 398-421, 469-486, 694-750): see locus_hip.h
+static lh_status measurement_update_impl(lh_gicp* g, const float guess[16], int want_information, double icp_max_covariance, lh_measurement* out,
+                                         int32_t* corr, void* aligned_out, uint32_t stride, uint32_t off_xyz, uint32_t off_normal, lh_cloud** aligned_cloud) {
+  if (!g || !out) return LH_EINVAL;
+  if (aligned_cloud) *aligned_cloud = nullptr;
+  lh_ctx* c = g->ctx;
+  memset(out, 0, sizeof(*out));
+  if (!g->src || !g->tgt) { out->result.status = LH_EINVAL; return LH_EINVAL; }
+  if (want_information && !g->tgt->nrm) return LH_EINVAL;   // Ap reads the reference's normals
+  lh_status st = lh_gicp_align(g, guess, &out->result, nullptr, nullptr, 0, 0);   // icp_->align (:309)
+  if (st != LH_OK && st != LH_ETOO_FEW_CORR && st != LH_ESOLVER && st != LH_ENO_NN) return st;   // (the reference goes on with whatever transform align left)
+  const lh_status align_status = st;
+  const int n = g->src->n;
+  if (n <= 0) return align_status;
+  HIPCHK(hipSetDevice(c->device));
+  const int nb = sum_blocks(n);
+  DevGuard guard;
+  float4 *d_xyz = nullptr, *d_nrm = nullptr;
+  int32_t* d_idx = nullptr;
+  float* d_d2 = nullptr;
+  double* d_scr = nullptr;
+  if (aligned_cloud) {   // the aligned query stays on the device: a cloud shaped like the source (every other field copied, like PCL's `output = input`)
+    st = cloud_like(g->src, &guard.cloud);
+    if (st) return st;
+    d_xyz = guard.cloud->xyz;
+    d_nrm = guard.cloud->nrm;
+    if (g->src->intensity) HIPCHK(hipMemcpyAsync(guard.cloud->intensity, g->src->intensity, sizeof(float) * (size_t)n, hipMemcpyDeviceToDevice, c->stream));
+  } else {
+    HIPCHK(guard.alloc(&d_xyz, sizeof(float4) * (size_t)n));
+    if (g->src->nrm) HIPCHK(guard.alloc(&d_nrm, sizeof(float4) * (size_t)n));
+  }
+  HIPCHK(guard.alloc(&d_idx, sizeof(int32_t) * (size_t)n));
+  HIPCHK(guard.alloc(&d_d2, sizeof(float) * (size_t)n));
+  HIPCHK(guard.alloc(&d_scr, sizeof(double) * ((size_t)nb * 21 + 4 + 21)));
+  st = ctx_ensure_small(c, 21);
+  if (st) return st;
+  // pcl::transformPointCloudWithNormals(*query, *aligned_query, T) (:325): points and normals, on the device
+  float T12[12];
+  fill_T12(out->result.T, T12);
+  { ProfScope p(c, "transform", 64.0 * n); launch_transform(g->src->xyz, g->src->nrm, n, T12, d_xyz, d_nrm, c->stream); }
+  // the ungated 1-NN of every aligned point in the reference's tree (:327-336); the index is the one align() built
+  if (!g->tgt->has_index) { st = cloud_build_index(g->tgt); if (st) return st; }
+  { ProfScope p(c, "nn1", 24.0 * n); launch_nn1(d_xyz, n, nullptr, g->tgt->view(), d_idx, d_d2, c->stream); }
+  // ComputePoint2PlaneICPCovariance / ComputeIcpObservability: normalizePCloud(query) + ComputeAp_ForPoint2PlaneICP (:469-486, 723-750)
+  double* d_out21 = d_scr + (size_t)nb * 21 + 4;
+  if (want_information) {
+    ProfScope p(c, "p2plane_Ap", 40.0 * n);
+    st = p2plane_information_device(g->src->xyz, n, g->tgt->nrm, d_idx, d_scr, d_out21, c->stream);
+    if (st) return st;
+    HIPCHK(hipMemcpyAsync(c->small_host, d_out21, sizeof(double) * 21, hipMemcpyDeviceToHost, c->stream));
+  }
+  // what the caller asked back: the correspondences, the aligned cloud -- and ONE wait for everything
+  if (corr) HIPCHK(hipMemcpyAsync(corr, d_idx, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+  std::vector<float> hx, hn;
+  if (aligned_out) {
+    hx.resize((size_t)n * 4);
+    HIPCHK(hipMemcpyAsync(hx.data(), d_xyz, sizeof(float) * hx.size(), hipMemcpyDeviceToHost, c->stream));
+    if (d_nrm && off_normal != 0xffffffffu) {
+      hn.resize((size_t)n * 4);
+      HIPCHK(hipMemcpyAsync(hn.data(), d_nrm, sizeof(float) * hn.size(), hipMemcpyDeviceToHost, c->stream));
+    }
+  }
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (aligned_out)
+    for (int i = 0; i < n; i++) {
+      memcpy((char*)aligned_out + (size_t)i * stride + off_xyz, &hx[4 * (size_t)i], 12);
+      if (!hn.empty()) memcpy((char*)aligned_out + (size_t)i * stride + off_normal, &hn[4 * (size_t)i], 12);
+    }
+  if (want_information) {
+    int t = 0;
+    for (int r = 0; r < 6; r++)
+      for (int cc = r; cc < 6; cc++) { out->Ap[r * 6 + cc] = c->small_host[t]; out->Ap[cc * 6 + r] = c->small_host[t]; t++; }
+    out->have_information = 1;
+    out->covariance_ok = lh_icp_covariance(out->Ap, icp_max_covariance, out->covariance, &out->condition_number) == LH_OK ? 1 : 0;
+  }
+  if (aligned_cloud) *aligned_cloud = guard.keep_cloud();
+  return align_status;
+}
+lh_status lh_gicp_measurement_update(lh_gicp* g, const float guess[16], int want_information, double icp_max_covariance, lh_measurement* out,
+                                     int32_t* corr, void* aligned_out, uint32_t stride, uint32_t off_xyz, uint32_t off_normal) {
+  return measurement_update_impl(g, guess, want_information, icp_max_covariance, out, corr, aligned_out, stride, off_xyz, off_normal, nullptr);
+}
+lh_status lh_gicp_measurement_update_cloud(lh_gicp* g, const float guess[16], int want_information, double icp_max_covariance, lh_measurement* out,
+                                           int32_t* corr, lh_cloud** aligned) {
+  return measurement_update_impl(g, guess, want_information, icp_max_covariance, out, corr, nullptr, 0, 0, 0xffffffffu, aligned);
+}
+
 lh_status lh_nn1(lh_gicp* g, const lh_cloud_view* q, int32_t* idx, float* d2) {
   if (!g || !g->tgt || !q) return LH_EINVAL;
   HIPCHK(hipSetDevice(g->ctx->device));

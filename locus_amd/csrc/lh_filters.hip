@@ -2,10 +2,7 @@
 // grids, NDT (registration_method ndt), body filter, local map, profiling.  Runtime types: lh_runtime.hpp.
 #include "lh_runtime.hpp"
 
-#pragma GCC visibility push(default)   // the C ABI is the library's ONLY exported surface (the TUs are compiled -fvisibility=hidden)
-extern "C" {
-
-// ---- K8 / H2 -----------------------------------------------------------------------------------------------
+// ---- K8: normalizePCloud's reductions (utils.cc:106-128) -------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_centroid_partials(const float4* __restrict__ xyz, int n, double* __restrict__ part) {
   // per-block sums of x, y, z over finite points + count (pcl::compute3DCentroid), fixed reduction shape
   double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
@@ -44,6 +41,110 @@ __global__ void __launch_bounds__(256) k_dist_partials(const float4* __restrict_
   if (threadIdx.x == 0) part[blockIdx.x] = ((sm[0] + sm[1]) + sm[2]) + sm[3];
 }
 
+// ---- K8 without the host in the middle (lh_gicp_measurement_update): normalizePCloud's two reductions end ON the device, the information
+// matrix is summed from the un-normalised query with the normalisation applied in flight, the 21 sums leave in one copy.  Every value is
+// formed exactly as lh_p2plane_information forms it (same partial sums, same order of the final sums, same float expressions), so the
+// two entry points return the same bits.
+__global__ void __launch_bounds__(64) k_centroid_final(const double* __restrict__ part, int nb, float* __restrict__ cf) {
+  if (threadIdx.x != 0) return;
+  double sx = 0, sy = 0, sz = 0, cnt = 0;
+  for (int b = 0; b < nb; b++) { sx += part[b * 4]; sy += part[b * 4 + 1]; sz += part[b * 4 + 2]; cnt += part[b * 4 + 3]; }
+  cf[0] = (float)(sx / cnt); cf[1] = (float)(sy / cnt); cf[2] = (float)(sz / cnt);
+}
+__global__ void __launch_bounds__(256) k_dist_partials_dev(const float4* __restrict__ xyz, int n, const float* __restrict__ cf, double* __restrict__ part) {
+  const float cx = cf[0], cy = cf[1], cz = cf[2];
+  double a = 0;
+  int base = blockIdx.x * 1024;
+  for (int r = 0; r < 4; r++) {
+    int i = base + r * 256 + threadIdx.x;
+    if (i < n) {
+      float4 p = xyz[i];
+      float dx = p.x - cx, dy = p.y - cy, dz = p.z - cz;
+      a += (double)sqrtf((dx * dx + dy * dy) + dz * dz);  // utils.cc:118
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off, 64);
+  __shared__ double sm[4];
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = ((sm[0] + sm[1]) + sm[2]) + sm[3];
+}
+__global__ void __launch_bounds__(64) k_factor_final(const double* __restrict__ part, int nb, int n, float* __restrict__ cf) {
+  if (threadIdx.x != 0) return;
+  double dist = 0;
+  for (int b = 0; b < nb; b++) dist += part[b];
+  cf[3] = (float)n / (float)dist;  // utils.cc:120
+}
+// Ap = sum H^T H, H = [a x n, n] (PointCloudLocalization.cc:723-750) with a = factor * (p - centroid) formed in flight (the expression of
+// launch_transform with T12 = {f, 0, 0, -f cx, ...}); corr < 0 (a query without a neighbour: a non-finite point) is skipped like a NaN
+__global__ void __launch_bounds__(256) k_ap_norm(const float4* __restrict__ xyz, int n, const float* __restrict__ cf, const float4* __restrict__ ref_nrm,
+                                                 const int32_t* __restrict__ corr, double* __restrict__ partials) {
+  const float f = cf[3];
+  const float T12[12] = {f, 0, 0, -f * cf[0], 0, f, 0, -f * cf[1], 0, 0, f, -f * cf[2]};
+  double acc[21];
+#pragma unroll
+  for (int k = 0; k < 21; k++) acc[k] = 0.0;
+  int base = blockIdx.x * 1024;
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    int i = base + r * 256 + threadIdx.x;
+    if (i < n) {
+      const int32_t j = corr[i];
+      if (j >= 0) {
+        float4 p = xyz[i];
+        float ax, ay, az;
+        lh::xform_pt(T12, p.x, p.y, p.z, ax, ay, az);
+        float4 n4 = ref_nrm[j];
+        double a0 = ax, a1 = ay, a2 = az, n0 = n4.x, n1 = n4.y, n2 = n4.z;
+        bool bad = (a0 != a0) || (a1 != a1) || (a2 != a2) || (n0 != n0) || (n1 != n1) || (n2 != n2);  // PointCloudLocalization.cc:742
+        if (!bad) {
+          double H[6] = {a1 * n2 - a2 * n1, a2 * n0 - a0 * n2, a0 * n1 - a1 * n0, n0, n1, n2};
+          int t = 0;
+#pragma unroll
+          for (int rr = 0; rr < 6; rr++)
+#pragma unroll
+            for (int cc = rr; cc < 6; cc++) acc[t++] += H[rr] * H[cc];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+    for (int k = 0; k < 21; k++) acc[k] += __shfl_down(acc[k], off, 64);
+  }
+  __shared__ double sm[4][21];
+  int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 21; k++) sm[wave][k] = acc[k];
+  }
+  __syncthreads();
+  if (threadIdx.x < 21) partials[blockIdx.x * 21 + threadIdx.x] = ((sm[0][threadIdx.x] + sm[1][threadIdx.x]) + sm[2][threadIdx.x]) + sm[3][threadIdx.x];
+}
+__global__ void __launch_bounds__(64) k_ap_final(const double* __restrict__ partials, int nb, double* __restrict__ out21) {
+  if (threadIdx.x >= 21) return;
+  double s = 0;
+  for (int b = 0; b < nb; b++) s += partials[(size_t)b * 21 + threadIdx.x];
+  out21[threadIdx.x] = s;
+}
+// The whole chain, enqueued on s: out21 (device) receives the 21 unique entries of Ap.  scratch: (21 nb + 4) doubles of device memory.
+lh_status p2plane_information_device(const float4* qxyz, int n, const float4* ref_nrm, const int32_t* corr, double* scratch, double* out21, hipStream_t s) {
+  const int nb = lh::sum_blocks(n);
+  float* cf = reinterpret_cast<float*>(scratch + (size_t)nb * 21);
+  hipLaunchKernelGGL(k_centroid_partials, dim3(nb), dim3(256), 0, s, qxyz, n, scratch);
+  hipLaunchKernelGGL(k_centroid_final, dim3(1), dim3(64), 0, s, scratch, nb, cf);
+  hipLaunchKernelGGL(k_dist_partials_dev, dim3(nb), dim3(256), 0, s, qxyz, n, cf, scratch);
+  hipLaunchKernelGGL(k_factor_final, dim3(1), dim3(64), 0, s, scratch, nb, n, cf);
+  hipLaunchKernelGGL(k_ap_norm, dim3(nb), dim3(256), 0, s, qxyz, n, cf, ref_nrm, corr, scratch);
+  hipLaunchKernelGGL(k_ap_final, dim3(1), dim3(64), 0, s, scratch, nb, out21);
+  return hipGetLastError() == hipSuccess ? LH_OK : LH_EDEVICE;
+}
+
+#pragma GCC visibility push(default)   // the C ABI is the library's ONLY exported surface (the TUs are compiled -fvisibility=hidden)
+extern "C" {
+
+// ---- K8 / H2 -----------------------------------------------------------------------------------------------
 lh_status lh_p2plane_information(lh_ctx* c, const lh_cloud* query, const lh_cloud* reference, const int64_t* corr, double Ap[36]) {
   if (!c || !query || !reference || !corr || !Ap || !reference->nrm) return LH_EINVAL;
   HIPCHK(hipSetDevice(c->device));

@@ -318,6 +318,9 @@ struct DevGuard {
 void runtime_check_streams(lh_ctx* c, int groups);   // lh_api.hip: one-time report when the runtime serialises the scheduler's streams
 lh_status ctx_ensure_scratch(lh_ctx* c, int n);
 lh_status ctx_ensure_small(lh_ctx* c, size_t doubles);
+// K8 with both reductions ended on the device (lh_filters.hip): enqueues the chain on s; out21 (device) = the 21 unique entries of Ap
+lh_status p2plane_information_device(const float4* qxyz, int n, const float4* ref_nrm, const int32_t* corr, double* scratch /* 21 sum_blocks(n) + 4 doubles */,
+                                     double* out21, hipStream_t s);
 lh_status ctx_ensure_slots(lh_ctx* c, int n_slots, int max_n);
 // K2 (lh_index.hip): the NN indexes of several clouds by the same launches; k-NN covariances of a cloud
 lh_status build_indices(lh_ctx* x, lh_cloud* const* clouds, int n_clouds, hipStream_t s_in = nullptr, int set = 0);   // set: which of lh_ctx::idx_sets the build uses

@@ -5,6 +5,7 @@
 // pcl::Registration instead and forwards to the same calls.
 #pragma once
 #include <cmath>
+#include <cstring>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -93,6 +94,56 @@ public:
     check(lh_nn1(g_, &v, idx.data(), nullptr), "nearestTargetIndices");
     out->resize(q.size());
     for (size_t i = 0; i < idx.size(); i++) (*out)[i] = (size_t)idx[i];
+  }
+  // align + transformPointCloudWithNormals + the 1-NN loop + ComputeAp + the covariance conditioning of MeasurementUpdate
+  // (PointCloudLocalization.cc:305-336, 398-421) without a second upload and with ONE wait (include/locus_hip.h)
+  bool measurementUpdate(PointCloudF* aligned, std::vector<size_t>* correspondences, bool want_information, double icp_max_covariance,
+                         Measurement* m) override {
+    lh_measurement r;
+    std::vector<int32_t> idx(src_->size());
+    if (aligned) {   // PCL copies every field of the input and overwrites the points and normals
+      aligned->points = src_->points;
+      aligned->stamp = src_->stamp;
+    }
+    lh_status st = lh_gicp_measurement_update(g_, nullptr, want_information ? 1 : 0, icp_max_covariance, &r, idx.data(), aligned ? aligned->points.data() : nullptr,
+                                              sizeof(PointF), offsetof(PointF, x), offsetof(PointF, normal_x));
+    if (st != LH_OK && st != LH_ETOO_FEW_CORR && st != LH_ESOLVER && st != LH_ENO_NN) check(st, "measurementUpdate");
+    for (int i = 0; i < 16; i++) final_[i] = r.result.T[i];
+    converged_ = r.result.converged != 0;
+    iterations_ = r.result.iterations;
+    last_status_ = r.result.status;
+    if (correspondences) {
+      correspondences->resize(idx.size());
+      for (size_t i = 0; i < idx.size(); i++) (*correspondences)[i] = (size_t)idx[i];
+    }
+    if (m) {
+      memcpy(m->Ap, r.Ap, sizeof(r.Ap));
+      memcpy(m->covariance, r.covariance, sizeof(r.covariance));
+      m->condition_number = r.condition_number;
+      m->have_information = r.have_information != 0;
+      m->covariance_ok = r.covariance_ok != 0;
+    }
+    return true;
+  }
+  // the device-resident form: source and target are clouds that already live in HBM (the caller keeps ownership), the aligned query stays there
+  void setInputSourceCloud(lh_cloud* c) { src_.reset(); check(lh_gicp_set_source_cloud(g_, c), "setInputSourceCloud"); }
+  void setInputTargetCloud(lh_cloud* c) { tgt_.reset(); check(lh_gicp_set_target_cloud(g_, c), "setInputTargetCloud"); }
+  bool measurementUpdateCloud(lh_cloud** aligned, bool want_information, double icp_max_covariance, Measurement* m) {
+    lh_measurement r;
+    lh_status st = lh_gicp_measurement_update_cloud(g_, nullptr, want_information ? 1 : 0, icp_max_covariance, &r, nullptr, aligned);
+    if (st != LH_OK && st != LH_ETOO_FEW_CORR && st != LH_ESOLVER && st != LH_ENO_NN) check(st, "measurementUpdateCloud");
+    for (int i = 0; i < 16; i++) final_[i] = r.result.T[i];
+    converged_ = r.result.converged != 0;
+    iterations_ = r.result.iterations;
+    last_status_ = r.result.status;
+    if (m) {
+      memcpy(m->Ap, r.Ap, sizeof(r.Ap));
+      memcpy(m->covariance, r.covariance, sizeof(r.covariance));
+      m->condition_number = r.condition_number;
+      m->have_information = r.have_information != 0;
+      m->covariance_ok = r.covariance_ok != 0;
+    }
+    return true;
   }
   lh_gicp* handle() { return g_; }
   lh_ctx* context() { return ctx_; }

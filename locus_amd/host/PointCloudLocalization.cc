@@ -88,19 +88,58 @@ bool PointCloudLocalization::MeasurementUpdate(const PointCloudF::Ptr& query, co
   }
   icp_->setInputSource(query);
   icp_->setInputTarget(reference);
-  PointCloudF icpAlignedPointsLocalization_;
-  icp_->align(icpAlignedPointsLocalization_);
+  // align (:309), transformPointCloudWithNormals (:325), the 1-NN loop (:327-336) and ComputeAp + the covariance conditioning (:398-421) are ONE
+  // call on the two clouds the setters uploaded (lh_gicp_measurement_update): no host point loop, no second upload, one wait.  A registration
+  // object without that entry point (NDT) gets the steps one by one.
+  const bool want_info = params_.compute_icp_observability || (params_.compute_icp_covariance && params_.icp_covariance_method == 1);
+  RegistrationHip::Measurement meas;
+  std::vector<size_t> correspondences;
+  const bool fused = icp_->measurementUpdate(aligned_query, &correspondences, want_info, params_.icp_max_covariance, &meas);
+  if (!fused) {
+    PointCloudF icpAlignedPointsLocalization_;
+    icp_->align(icpAlignedPointsLocalization_);
+  }
   const float* T = icp_->getFinalTransformation();  // column-major
   auto Tm = [&](int r, int c) { return (double)T[c * 4 + r]; };
-  // transformPointCloudWithNormals(*query, *aligned_query, T) (:325)
   gu::Transform3 Tt;
   Tt.translation = gu::Vec3(Tm(0, 3), Tm(1, 3), Tm(2, 3));
   Tt.rotation = gu::Rot3(Tm(0, 0), Tm(0, 1), Tm(0, 2), Tm(1, 0), Tm(1, 1), Tm(1, 2), Tm(2, 0), Tm(2, 1), Tm(2, 2));
-  TransformWithNormals(*query, aligned_query, Tt);
-  // correspondences: ungated 1-NN of every aligned point in the target tree (:327-336) -- one GPU sweep
-  std::vector<size_t> correspondences;
-  icp_->nearestTargetIndices(*aligned_query, &correspondences);
+  if (!fused) {
+    TransformWithNormals(*query, aligned_query, Tt);   // transformPointCloudWithNormals(*query, *aligned_query, T) (:325)
+    icp_->nearestTargetIndices(*aligned_query, &correspondences);   // (:327-336)
+  }
 
+  UpdatePoses();
+  if (params_.compute_icp_observability) {  // :384-396
+    double evec[36], eval[6];
+    if (fused && meas.have_information) {
+      memcpy(observability_matrix_, meas.Ap, sizeof(meas.Ap));
+      EigenDecomp6x6(meas.Ap, evec, eval);
+    } else
+      ComputeIcpObservability(*query, *reference, correspondences, T, evec, eval, observability_matrix_);
+  }
+  {
+    std::lock_guard<std::mutex> lock(icp_covariance_mutex_);  // :398-421
+    memset(icp_covariance_, 0, sizeof(icp_covariance_));
+    if (params_.compute_icp_covariance && params_.icp_covariance_method == 1) {
+      if (fused && meas.have_information) {
+        memcpy(icp_covariance_, meas.covariance, sizeof(meas.covariance));
+        condition_number_ = meas.condition_number;
+      } else
+        ComputePoint2PlaneICPCovariance(*query, *reference, correspondences, T, icp_covariance_);
+    }
+  }
+  is_healthy_ = true;
+  return true;
+}
+
+// the pose chain of MeasurementUpdate (:338-382) from the registration object's final transformation
+void PointCloudLocalization::UpdatePoses() {
+  const float* T = icp_->getFinalTransformation();  // column-major
+  auto Tm = [&](int r, int c) { return (double)T[c * 4 + r]; };
+  gu::Transform3 Tt;
+  Tt.translation = gu::Vec3(Tm(0, 3), Tm(1, 3), Tm(2, 3));
+  Tt.rotation = gu::Rot3(Tm(0, 0), Tm(0, 1), Tm(0, 2), Tm(1, 0), Tm(1, 1), Tm(1, 2), Tm(2, 0), Tm(2, 1), Tm(2, 2));
   gu::Transform3 pose_update;
   if (b_is_flat_ground_assumption_) {  // :340-353
     double yaw = Tt.rotation.Yaw();
@@ -115,15 +154,51 @@ bool PointCloudLocalization::MeasurementUpdate(const PointCloudF::Ptr& query, co
   }
   integrated_estimate_ = gu::PoseUpdate(integrated_estimate_, incremental_estimate_);  // :381-382
 
-  if (params_.compute_icp_observability) {  // :384-396
+}
+
+// ---- the device-resident surface ----------------------------------------------------------------------------------------------------------
+static void Pose16(const gu::Transform3& e, float T16[16]) {   // column-major float 4x4, the cast TransformWithNormals makes
+  for (int i = 0; i < 16; i++) T16[i] = (i % 5 == 0) ? 1.0f : 0.0f;
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++) T16[c * 4 + r] = (float)e.rotation.m[r * 3 + c];
+  T16[12] = (float)e.translation.x; T16[13] = (float)e.translation.y; T16[14] = (float)e.translation.z;
+}
+bool PointCloudLocalization::TransformPointsToFixedFrame(const lh_cloud* points, lh_cloud** out) const {  // :181-200
+  if (!points || !out) return false;
+  float T16[16];
+  Pose16(gu::PoseUpdate(integrated_estimate_, incremental_estimate_), T16);
+  return lh_cloud_transform(points, T16, 1, out) == LH_OK;
+}
+bool PointCloudLocalization::TransformPointsToSensorFrame(const lh_cloud* points, lh_cloud** out) const {  // :202-221
+  if (!points || !out) return false;
+  float T16[16];
+  Pose16(gu::PoseInverse(gu::PoseUpdate(integrated_estimate_, incremental_estimate_)), T16);
+  return lh_cloud_transform(points, T16, 1, out) == LH_OK;
+}
+bool PointCloudLocalization::MeasurementUpdate(lh_cloud* query, lh_cloud* reference, lh_cloud** aligned_query) {  // :291-427
+  MultithreadedGicpHip* gicp = dynamic_cast<MultithreadedGicpHip*>(icp_.get());
+  if (aligned_query == NULL || !gicp || !query || !reference) {
+    is_healthy_ = false;
+    return false;
+  }
+  gicp->setInputSourceCloud(query);
+  gicp->setInputTargetCloud(reference);
+  const bool want_info = params_.compute_icp_observability || (params_.compute_icp_covariance && params_.icp_covariance_method == 1);
+  RegistrationHip::Measurement meas;
+  gicp->measurementUpdateCloud(aligned_query, want_info, params_.icp_max_covariance, &meas);
+  UpdatePoses();
+  if (params_.compute_icp_observability && meas.have_information) {
     double evec[36], eval[6];
-    ComputeIcpObservability(*query, *reference, correspondences, T, evec, eval, observability_matrix_);
+    memcpy(observability_matrix_, meas.Ap, sizeof(meas.Ap));
+    EigenDecomp6x6(meas.Ap, evec, eval);
   }
   {
-    std::lock_guard<std::mutex> lock(icp_covariance_mutex_);  // :398-421
+    std::lock_guard<std::mutex> lock(icp_covariance_mutex_);
     memset(icp_covariance_, 0, sizeof(icp_covariance_));
-    if (params_.compute_icp_covariance && params_.icp_covariance_method == 1)
-      ComputePoint2PlaneICPCovariance(*query, *reference, correspondences, T, icp_covariance_);
+    if (params_.compute_icp_covariance && params_.icp_covariance_method == 1 && meas.have_information) {
+      memcpy(icp_covariance_, meas.covariance, sizeof(meas.covariance));
+      condition_number_ = meas.condition_number;
+    }
   }
   is_healthy_ = true;
   return true;
@@ -157,7 +232,11 @@ void PointCloudLocalization::ComputeIcpObservability(const PointCloudF& query_cl
   double Ap[36];
   if (!ComputeAp(query_cloud, reference_cloud, correspondences, Ap)) return;
   memcpy(A, Ap, sizeof(Ap));
-  // doEigenDecomp6x6 (utils.cc:130-142): cyclic Jacobi, ascending eigenvalues, eigenvectors in columns
+  EigenDecomp6x6(Ap, eigenvectors, eigenvalues);
+}
+
+// doEigenDecomp6x6 (utils.cc:130-142): cyclic Jacobi, ascending eigenvalues, eigenvectors in columns
+void PointCloudLocalization::EigenDecomp6x6(const double Ap[36], double eigenvectors[36], double eigenvalues[6]) {
   const int n = 6;
   double M[36], V[36];
   memcpy(M, Ap, sizeof(M));

@@ -39,6 +39,12 @@ public:
   bool TransformPointsToSensorFrame(const PointCloudF& points, PointCloudF* points_transformed) const;
   bool MotionUpdate(const gu::Transform3& incremental_odom);
   bool MeasurementUpdate(const PointCloudF::Ptr& query, const PointCloudF::Ptr& reference, PointCloudF* aligned_query);
+  // The same three steps on clouds that live in HBM (lh_cloud: the scan uploaded once, the map's neighbours found there): the MI355X-first form
+  // of Locus.cc:474-489.  *out / *aligned_query are new device clouds the caller destroys.  Poses, covariance and observability are the host
+  // surface's bit for bit (tests: host_check `device_flow`).
+  bool TransformPointsToFixedFrame(const lh_cloud* points, lh_cloud** out) const;
+  bool TransformPointsToSensorFrame(const lh_cloud* points, lh_cloud** out) const;
+  bool MeasurementUpdate(lh_cloud* query, lh_cloud* reference, lh_cloud** aligned_query);
   bool ComputePoint2PlaneICPCovariance(const PointCloudF& query_cloud, const PointCloudF& reference_cloud,
                                        const std::vector<size_t>& correspondences, const float* T_colmajor, double covariance[36]);
   void ComputeIcpObservability(const PointCloudF& query_cloud, const PointCloudF& reference_cloud,
@@ -61,6 +67,8 @@ public:
 
 private:
   bool SetupICP();
+  void UpdatePoses();
+  static void EigenDecomp6x6(const double Ap[36], double eigenvectors[36], double eigenvalues[6]);
   bool ComputeAp(const PointCloudF& query_cloud, const PointCloudF& reference_cloud, const std::vector<size_t>& corr, double Ap[36]);
 
   lh_ctx* ctx_;

@@ -72,6 +72,19 @@ public:
     return ok;
   }
 
+  // the same two calls on clouds that already live in HBM (the device-resident LOCUS flow): no upload, no download
+  bool InsertPoints(const lh_cloud* points, uint32_t* added = nullptr) {
+    if (!map_ || !points || lh_cloud_size(points) == 0) return false;
+    uint32_t a = 0;
+    lh_status st = lh_map_insert(map_, points, &a);
+    if (added) *added = a;
+    return st == LH_OK;
+  }
+  bool ApproxNearestNeighbors(const lh_cloud* points, lh_cloud** neighbors) {   // *neighbors: a new device cloud the caller destroys
+    if (!map_ || !neighbors || !points || lh_cloud_size(points) == 0 || lh_map_size(map_) == 0) return false;
+    return lh_cloud_nearest_neighbors(lh_map_cloud(map_), points, neighbors) == LH_OK;
+  }
+
   // Locus.cc:537
   void Refresh(const gu::Transform3& current_pose) {
     if (!map_ || box_filter_size_ <= 0) return;

@@ -32,6 +32,11 @@ public:
   virtual double getFitnessScore() = 0;
   // getSearchMethodTarget()->nearestKSearch(pt, 1, ...) for a whole cloud (PointCloudLocalization.cc:327-336)
   virtual void nearestTargetIndices(const PointCloudF& q, std::vector<size_t>* out) = 0;
+  // PointCloudLocalization::MeasurementUpdate's device work in one call on the clouds setInputSource / setInputTarget uploaded
+  // (lh_gicp_measurement_update: align, aligned query with normals, correspondences, Ap, covariance).  false: this registration
+  // object has no such entry point (NDT) and the caller stitches the steps itself.
+  struct Measurement { double Ap[36]; double covariance[36]; double condition_number; bool have_information, covariance_ok; };
+  virtual bool measurementUpdate(PointCloudF*, std::vector<size_t>*, bool, double, Measurement*) { return false; }
 };
 
 }  // namespace locus_hip

@@ -229,6 +229,49 @@ int main() {
     pcl_.GetLatestDeltaCovariance(dc);
     EXPECT_NEAR(dc[0], 0.01, epsilion);
     EXPECT(pcl_.MotionUpdate(gu::Transform3()));
+
+    // device_flow: the same three calls on clouds that live in HBM give the host surface's results bit for bit -- frame transforms (the
+    // z +- 3 KAT of test_point_cloud_localization.cpp), MeasurementUpdate's aligned query, poses and covariance
+    {
+      PointCloudLocalization ha(ctx), da(ctx);
+      PointCloudLocalization::Config lc;
+      lc.initial_pose.translation = gu::Vec3(0.3, -0.2, 3.0);
+      lc.initial_pose.rotation = gu::Rot3(0.01, -0.02, 0.3);
+      lc.compute_icp_observability = true;
+      EXPECT(ha.Initialize(lc) && da.Initialize(lc));
+      PointCloudF::Ptr scan = GenerateHollowCubic(ctx), ref = GenerateHollowCubic(ctx);
+      for (auto& p : scan->points) { p.x += 0.02f; p.y -= 0.01f; }
+      gu::Transform3 inc;
+      inc.translation = gu::Vec3(0.05, 0.0, -0.01);
+      ha.MotionUpdate(inc); da.MotionUpdate(inc);
+      lh_cloud_view vs = ViewOf(*scan), vr = ViewOf(*ref);
+      lh_cloud *cs = nullptr, *cr = nullptr, *fixed = nullptr, *back = nullptr, *al = nullptr;
+      EXPECT(lh_cloud_create(ctx, &vs, &cs) == LH_OK && lh_cloud_create(ctx, &vr, &cr) == LH_OK);
+      PointCloudF h_fixed, h_back, d_dl;
+      EXPECT(ha.TransformPointsToFixedFrame(*scan, &h_fixed) && da.TransformPointsToFixedFrame(cs, &fixed));
+      auto same_cloud = [&](const lh_cloud* c, const PointCloudF& h) {
+        PointCloudF dl;
+        dl.points.assign(lh_cloud_size(c), PointF());
+        if (dl.size() != h.size()) return false;
+        if (lh_cloud_download(c, dl.points.data(), sizeof(PointF), offsetof(PointF, x), offsetof(PointF, normal_x), offsetof(PointF, intensity), offsetof(PointF, curvature)) != LH_OK) return false;
+        for (size_t i = 0; i < h.size(); i++)
+          if (memcmp(&dl.points[i].x, &h.points[i].x, 12) != 0 || memcmp(&dl.points[i].normal_x, &h.points[i].normal_x, 12) != 0) return false;
+        return true;
+      };
+      EXPECT(same_cloud(fixed, h_fixed));
+      EXPECT(ha.TransformPointsToSensorFrame(h_fixed, &h_back) && da.TransformPointsToSensorFrame(fixed, &back));
+      EXPECT(same_cloud(back, h_back));
+      PointCloudF h_al;
+      EXPECT(ha.MeasurementUpdate(scan, ref, &h_al) && da.MeasurementUpdate(cs, cr, &al));
+      EXPECT(al != nullptr && same_cloud(al, h_al));
+      EXPECT(memcmp(&ha.GetIntegratedEstimate(), &da.GetIntegratedEstimate(), sizeof(gu::Transform3)) == 0);
+      EXPECT(memcmp(&ha.GetIncrementalEstimate(), &da.GetIncrementalEstimate(), sizeof(gu::Transform3)) == 0);
+      double hc[36], dcv[36];
+      ha.GetLatestDeltaCovariance(hc); da.GetLatestDeltaCovariance(dcv);
+      EXPECT(memcmp(hc, dcv, sizeof(hc)) == 0);
+      EXPECT(ha.condition_number() == da.condition_number());
+      lh_cloud_destroy(al); lh_cloud_destroy(back); lh_cloud_destroy(fixed); lh_cloud_destroy(cs); lh_cloud_destroy(cr);
+    }
   }
 
   {  // the same odometry scenario with registration_method "ndt" (SetupICP NDT branch, PointCloudOdometry.cc:182-196): a dense
