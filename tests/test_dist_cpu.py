@@ -67,6 +67,47 @@ def test_two_rank_gather_over_gloo(n_pairs):
     assert np.allclose(traj[-1][:3, :3] @ traj[-1][:3, :3].T, np.eye(3), atol=1e-5)
 
 
+def test_four_rank_gather_with_an_uneven_shard_over_gloo():
+    """world size 4, 10 pairs: blocks of 3 / 3 / 2 / 2 -- the padded all_gather trims every rank's block to its own count, the table is in pair
+    order on every rank, the timing is the slowest rank's"""
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    n_pairs, world = 10, 4
+    assert [ldist.shard_range(n_pairs, r, world) for r in range(world)] == [(0, 3), (3, 6), (6, 8), (8, 10)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_pairs, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    expect = np.stack([_fake_pose(i) for i in range(n_pairs)])
+    assert sorted(r[0] for r in res) == [0, 1, 2, 3]
+    for rank, allposes, t in res:
+        assert np.array_equal(allposes, expect)
+        assert t == 4.0
+
+
+def test_strong_split_of_a_fixed_queue():
+    """bench.py --strong (BASELINE configs[3]: 512 queued pairs over 8 GPUs): --pairs is the TOTAL, every rank takes shard_range's block, the
+    blocks cover the queue exactly once whatever the rank count, and the per-GPU load the line reports is the largest block"""
+    for total, world in ((512, 8), (512, 3), (10, 4), (7, 8)):
+        blocks = [ldist.shard_range(total, r, world) for r in range(world)]
+        assert blocks[0][0] == 0 and blocks[-1][1] == total
+        assert all(blocks[k][1] == blocks[k + 1][0] for k in range(world - 1))
+        sizes = [hi - lo for lo, hi in blocks]
+        assert max(sizes) - min(sizes) <= 1 and sum(sizes) == total
+    assert [hi - lo for lo, hi in (ldist.shard_range(512, r, 8) for r in range(8))] == [64] * 8   # configs[3]'s per-GPU load
+    # the script's own use of it (bench.py main(): pairs_here under --strong)
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")).read()
+    assert "ldist.shard_range(args.pairs" in src and "args.strong" in src
+
+
 def _records_worker(rank, world, port, q):
     import torch.distributed as dist
     from locus_amd import capi

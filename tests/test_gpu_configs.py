@@ -282,6 +282,50 @@ def test_batched_odometry_stream_chain_ate(ctx, capi, oracle):
     assert a1 < max(3.0 * floor, 2e-2)    # different but equally valid rounding: held to the reference's own noise floor
 
 
+def test_config4_full_size_stream_64_pairs_ate_vs_cpu_chain(ctx, capi, oracle):
+    """BASELINE configs[3] at FULL size (bench.py's trajectory leg holds the same bars over 512 pairs): 65 consecutive
+    100 032-point scans, the 64 pairs (i - 1, i) aligned as ONE batch under the forced-20 parameters of the headline, poses chained
+    (PointCloudOdometry.cc:308-309); ATE against ground truth and against the CPU path's chain on the SAME inputs (the device's normals
+    downloaded for it); per pair the pose distance to the CPU path within the headline's quantile bars."""
+    from concurrent.futures import ThreadPoolExecutor
+    from locus_amd import dist as ldist
+    n = 65
+    poses = [synth.pose_matrix(0.26 * i, 0.9 * np.sin(i / 40.0), 0.0, 0, 0, 0.004 * i) for i in range(n)]
+    clouds = []
+    for i in range(n):
+        c = capi.Cloud(ctx, synth.scan(poses[i], 64, 1563, (-25.0, 15.0), 2.0, 0.02, seed=5000 + i))
+        clouds.append(c)
+    assert len(clouds[0]) == 100032
+    capi.normals_knn_batch(clouds[:64], 20)
+    capi.normals_knn_batch(clouds[64:], 20)
+    for c in clouds:
+        c.drop_index()
+    kw = dict(max_iterations=20, max_inner_iterations=20, corr_dist=1.0, transformation_epsilon=1e-12, rotation_epsilon=1e-12)
+    out = capi.align_batch(ctx, capi.default_params(**kw), clouds[1:], clouds[:-1], max_in_flight=64)
+    assert all(o["status"] == 0 for o in out)
+    chain = ldist.chain_poses(np.stack([o["T"] for o in out]))
+    gt = np.stack([np.linalg.inv(poses[0]) @ p for p in poses])
+
+    def ate(a, b):
+        return float(np.sqrt(np.mean(np.sum((a[:, :3, 3] - b[:, :3, 3]) ** 2, axis=1))))
+    assert ate(chain, gt) < 0.15   # 64 chained alignments with 2 cm range noise over 16.6 m
+    dl = [c.download() for c in clouds]
+
+    def cpu(i):
+        a, b = dl[i], dl[i - 1]
+        return oracle.gicp_align(oracle.xyz4(np.stack([a["x"], a["y"], a["z"]], 1)), oracle.nrm4(np.stack([a["normal_x"], a["normal_y"], a["normal_z"]], 1)),
+                                 oracle.xyz4(np.stack([b["x"], b["y"], b["z"]], 1)), oracle.nrm4(np.stack([b["normal_x"], b["normal_y"], b["normal_z"]], 1)),
+                                 oracle.default_params(num_threads=4, **kw), want_trace=False)["T"]
+    import os
+    with ThreadPoolExecutor(max(1, min(16, (os.cpu_count() or 4) // 4))) as ex:   # (the C oracle releases the GIL)
+        cposes = list(ex.map(cpu, range(1, n)))
+    cchain = ldist.chain_poses(np.stack(cposes))
+    dts = [float(np.abs(np.asarray(o["T"], np.float64).reshape(4, 4).T[:3, 3] - np.asarray(p, np.float64).reshape(4, 4).T[:3, 3]).max()) for o, p in zip(out, cposes)]
+    print("ATE vs truth %.4f m, vs the CPU chain %.2e m; per pair |dt| median %.2e p90 %.2e max %.2e" % (ate(chain, gt), ate(chain, cchain), np.median(dts), np.quantile(dts, 0.9), max(dts)))
+    assert np.median(dts) <= 1e-4 and np.quantile(dts, 0.9) <= 2.5e-4 and max(dts) <= 5e-3   # the headline's bars (DESIGN.md section 2)
+    assert ate(chain, cchain) <= 5e-3   # (the CPU chain itself sits 0.1 m from ground truth)
+
+
 def test_local_map_insert_refresh_and_scan_to_map(ctx, capi, oracle):
     # SURVEY 8f-1: the mapper behind Locus.cc:464-465 / 479-483 / 531-538, device resident.  Insert / Refresh are integer
     # (voxel occupancy) work: accepted points, their order and payload must be IDENTICAL to the sequential restatement.

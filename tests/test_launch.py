@@ -67,3 +67,8 @@ def test_plain_command_gpus_2_yields_a_two_rank_line():
     assert line["n_gpus"] == 2 and line["rccl_world"] == 2 and line["self_launched"] is True
     assert line["strong_scaling_same_pairs"]["total_pairs"] == 8 and line["strong_scaling_same_pairs"]["pairs_per_gpu"] == 4
     assert line["value"] > 0
+    # configs[4]'s multi-GPU form rides along at N > 1: the source-sharded dense pair, every rank ending with the same transform
+    sp = line["config5_sharded_pair"]
+    assert "error" not in sp, sp
+    assert sp["status"] == 0 and sp["all_ranks_same_transform_bit_for_bit"] is True and sp["translation_err_vs_truth_m"] < 0.05
+    assert 0 < sp["source_points_this_rank"] < sp["points_after_voxel_grid"]
