@@ -62,6 +62,10 @@ def _farm_init(cpus):
     # the parent's main thread was bound to ONE core by its own OpenMP runtime (OMP_PROC_BIND=close binds the initial thread) and a child
     # inherits that mask: without this every worker of the farm -- and every thread of its team -- shares that core (measured: 383 s for 512 pairs)
     os.environ["LH_BENCH_WORKER"] = "1"
+    # ... and the binding itself must not reach a worker whenever it is started (the pool starts workers lazily, possibly after the parent has put
+    # the variables back): cleared here, before the oracle's OpenMP runtime is loaded in this process
+    os.environ.pop("OMP_PROC_BIND", None)
+    os.environ.pop("OMP_PLACES", None)
     try:
         os.sched_setaffinity(0, cpus)
     except (OSError, AttributeError):
@@ -720,9 +724,11 @@ def cpu_baseline(S, T, host, P):
     # SURVEY 8d's protocol for whatever `value` and `best` quote: 3 warm-up pairs, then the median of >= 10 timed pairs -- the sweep above
     # located the best settings on 2-5 pairs, they are now timed properly
     for serial in (True, False):
-        cand = [r for r in rows if r["cost_functor"].startswith("serial") == serial]
-        top = max(cand, key=lambda r: r["pairs_per_s"])
-        if top["pairs_timed"] < 10:
+        for _ in range(4):   # (a properly timed row may fall behind another 2-pair row: that one is then timed properly as well)
+            cand = [r for r in rows if r["cost_functor"].startswith("serial") == serial]
+            top = max(cand, key=lambda r: r["pairs_per_s"])
+            if top["pairs_timed"] >= 10:
+                break
             rows[rows.index(top)] = run_row(top["threads"], 0 if serial else 1, 3, 10)
     ref_rows = [r for r in rows if r["cost_functor"].startswith("serial")]
     best = max(ref_rows, key=lambda r: r["pairs_per_s"])
@@ -1243,7 +1249,7 @@ def main():
             # the same fraction per KIND of sweep launch (the scheduler's nested profile scopes): an all-walk sweep (k_sweep_coop: a pair's first
             # three), a late sweep (k_late + k_walk: from the fourth on)
             per_kernel = {}
-            for key, label in (("nn_sweep_allwalk", "k_sweep_coop (all-walk sweep)"), ("nn_sweep_late_walk", "k_late + k_walk (late sweep)"), ("nn_sweep_mixed", "mixed launch")):
+            for key, label in (("nn_sweep_allwalk", "%s (all-walk sweep: a pair's first three)" % ("k_sweep_coop" if os.environ.get("LH_SWEEP_COOP", "0") not in ("", "0") else "k_sweep_fused")), ("nn_sweep_late_walk", "k_late + k_walk (late sweep)"), ("nn_sweep_mixed", "mixed launch")):
                 v = stats.get(key)
                 if v and v["launches"] > 0 and v["ms"] > 0:
                     us = 1e3 * v["ms"] / v["launches"]
@@ -1450,7 +1456,15 @@ def main():
                 dt0 = time.perf_counter() - t1
                 result["cost_mode0"] = {"value": round(pairs_here / dt0, 2), "unit": "scan-pairs/s",
                                         "max_abs_pose_diff_vs_mode1": float(max(np.abs(np.asarray(a["T"]) - np.asarray(b["T"])).max()
-                                                                                for a, b in zip(out0, out)))}
+                                                                                for a, b in zip(out0, out))),
+                                        "what": "the STRICT mode under the headline's forced 20 iterations: every per-point operation the reference's (float T p, float residual, "
+                                                "M from the reference's covariance products and cofactor inverse), one cost pass per functor evaluation (~600 per pair); vs the CPU "
+                                                "path |dt| median 0, p90 <= 1e-4 m (tests/test_gpu_align.py). Its cost pass streams 32 B + 48 B per matched point and runs at "
+                                                "~6.8 TB/s (18 500 launches of 32 x 100 k points per 512-pair step): at its own byte roofline -- docs/NOTEBOOK_r6.md section 3"}
+                cbv = result.get("cpu_baseline", {})
+                if cbv.get("best", {}).get("value"):   # the north star's ">= 50x" quoted on the STRICT mode against the fastest CPU configuration sampled
+                    result["cost_mode0"]["speedup_vs_cpu_baseline_best"] = round(result["cost_mode0"]["value"] / cbv["best"]["value"], 1)
+                    result["cost_mode0"]["speedup_vs_cpu_baseline_reference_structured"] = round(result["cost_mode0"]["value"] / cbv["value"], 1)
             _leg("natural convergence")
             if world == 1:
                 # SURVEY 8d "natural convergence" run: the same pairs with the production stopping rule (tf_eps 1e-3, rot_eps 2e-3,

@@ -62,7 +62,7 @@ lh_status upload_view(lh_ctx* c, const lh_cloud_view* v, lh_cloud** out, bool sy
 
 
 // =========================================================================================================
-#pragma GCC visibility push(default)   // the C ABI is the library's ONLY exported surface (the TUs are compiled -fvisibility=hidden)
+// ---- the stream-concurrency probe (hidden: only the C ABI below is exported) ----
 // one wave that stays resident for `ticks` of the 100-MHz wall clock and says when it ran: the probe's unit of work
 __global__ void __launch_bounds__(64) k_probe_spin(unsigned long long ticks, unsigned long long* __restrict__ span) {
   const unsigned long long t0 = wall_clock64();
@@ -70,7 +70,7 @@ __global__ void __launch_bounds__(64) k_probe_spin(unsigned long long ticks, uns
   if (span && threadIdx.x == 0) { span[0] = t0; span[1] = wall_clock64(); }
 }
 static std::mutex g_probe_mu;
-static double g_probe_concurrency[64] = {};   // per device; 0 = not measured yet
+static double g_probe_concurrency[64] = {};   // per device; 0 = not measured yet, < 0 = the probe failed (remembered: a failing probe is not paid for again)
 // How many of sixteen one-wave kernels on the CONTEXT'S OWN sixteen streams are resident at the same instant (their own wall-clock stamps; the
 // largest overlap of the sixteen intervals).  The scheduler's streams, not new ones: the runtime hands hardware queues to streams as they are
 // created, and a process with more streams than queues runs far worse than one with fewer (round 4: 24 groups 3.8 k pairs/s against 12.2 k
@@ -78,18 +78,19 @@ static double g_probe_concurrency[64] = {};   // per device; 0 = not measured ye
 static double probe_stream_concurrency(lh_ctx* c) {
   std::lock_guard<std::mutex> lk(g_probe_mu);
   const int device = c->device;
-  if (device >= 0 && device < 64 && g_probe_concurrency[device] > 0) return g_probe_concurrency[device];
+  if (device >= 0 && device < 64 && g_probe_concurrency[device] != 0) return g_probe_concurrency[device] > 0 ? g_probe_concurrency[device] : 0.0;
+  auto failed = [&]() { if (device >= 0 && device < 64) g_probe_concurrency[device] = -1.0; return 0.0; };
   constexpr int NS = 16;
   hipStream_t* side[lh_ctx::MAX_GROUPS - 1] = {&c->stream2, &c->stream3, &c->stream4};
   for (int k = 0; k < lh_ctx::MAX_GROUPS - 4; k++) side[3 + k] = &c->stream_more[k];
   hipStream_t st[NS];
   st[0] = c->stream;
   for (int k = 1; k < NS; k++) {
-    if (!*side[k - 1] && hipStreamCreateWithFlags(side[k - 1], hipStreamNonBlocking) != hipSuccess) return 0.0;
+    if (!*side[k - 1] && hipStreamCreateWithFlags(side[k - 1], hipStreamNonBlocking) != hipSuccess) return failed();
     st[k] = *side[k - 1];
   }
   unsigned long long* span = nullptr;
-  if (hipMalloc(&span, sizeof(unsigned long long) * 2 * NS) != hipSuccess) return 0.0;
+  if (hipMalloc(&span, sizeof(unsigned long long) * 2 * NS) != hipSuccess) return failed();
   const unsigned long long ticks = 200000ull;   // 2 ms of the 100-MHz clock: sixteen launches are issued in a fraction of that
   bool ok = true;
   for (int k = 0; k < NS; k++) hipLaunchKernelGGL(k_probe_spin, dim3(1), dim3(64), 0, st[k], 100ull, (unsigned long long*)nullptr);   // warm-up: code object, queues
@@ -110,13 +111,17 @@ static double probe_stream_concurrency(lh_ctx* c) {
     }
     conc = (double)best;
   }
-  if (device >= 0 && device < 64) g_probe_concurrency[device] = conc;
+  if (device >= 0 && device < 64) g_probe_concurrency[device] = conc > 0 ? conc : -1.0;
   return conc;
 }
-// called by the scheduler the first time a batch spreads over more than four streams
+// called by the scheduler the first time a batch spreads over more than four streams: ONE measurement per device and process (2-8 ms: sixteen
+// 2-ms kernels and their synchronisation), success or failure; every later batch returns at the flag
 void runtime_check_streams(lh_ctx* c, int groups) {
   static std::atomic<bool> said{false};
+  static std::atomic<unsigned long long> checked{0ull};   // one bit per device
   if (groups <= 4 || said.load()) return;
+  const unsigned long long bit = (c->device >= 0 && c->device < 64) ? (1ull << c->device) : 0ull;
+  if (bit && (checked.fetch_or(bit) & bit)) return;
   const double conc = probe_stream_concurrency(c);
   if (conc > 0 && conc < 0.7 * std::min(groups, 16) && !said.exchange(true)) {
     const char* e = getenv("GPU_MAX_HW_QUEUES");
@@ -126,6 +131,7 @@ void runtime_check_streams(lh_ctx* c, int groups) {
   }
 }
 
+#pragma GCC visibility push(default)   // the C ABI is the library's ONLY exported surface (the TUs are compiled -fvisibility=hidden)
 extern "C" {
 
 

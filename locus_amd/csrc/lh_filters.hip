@@ -1051,7 +1051,7 @@ lh_status lh_map_refresh(lh_map* m, const float center[3], float half_extent) {
 // ---- next-row helper: mapper_->ApproxNearestNeighbors (Locus.cc:479-483) ------------------------------
 // for every query point the nearest map point is copied (xyz, normal, intensity) into a new cloud; the reference uses an
 // approximate octree search, this is the exact search (never farther than the reference's answer)
-__global__ void __launch_bounds__(256) k_gather_cloud(const float4* __restrict__ xyz, const float4* __restrict__ nrm, const float* __restrict__ inten,
+static __global__ void __launch_bounds__(256) k_gather_cloud(const float4* __restrict__ xyz, const float4* __restrict__ nrm, const float* __restrict__ inten,
                                                      const int32_t* __restrict__ idx, int n, float4* __restrict__ oxyz, float4* __restrict__ onrm,
                                                      float* __restrict__ ointen) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;

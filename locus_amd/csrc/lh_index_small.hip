@@ -73,7 +73,7 @@ __global__ void __launch_bounds__(SMALL_THREADS) k_index_small(const IndexDesc* 
   if (n <= 0) return;
   __shared__ uint64_t skey[SMALL_INDEX_MAX_N];        // sort keys (key30 << 32 | index), then (cloud << 32 | key30) of the sorted positions; LATER the radix nodes' children
   __shared__ uint32_t vals[SMALL_INDEX_MAX_N];        // original index of the point at a sorted position; LATER the radix nodes' parents
-  __shared__ uint32_t lid[SMALL_INDEX_MAX_N];         // inclusive scan of the leaf-start flags
+  __shared__ alignas(16) uint32_t lid[SMALL_INDEX_MAX_N];   // inclusive scan of the leaf-start flags (the radix sort reads it as uint4: 16-byte aligned)
   __shared__ uint64_t lkey[SMALL_INDEX_MAX_N + 1];    // key of a leaf's first point (+ sentinel)
   __shared__ uint32_t lstart[SMALL_INDEX_MAX_N + 1];  // first sorted position of a leaf (+ sentinel)
   __shared__ SBoxC b8[SMALL_INDEX_MAX_N / 8], b64[SMALL_INDEX_MAX_N / 64], b512[SMALL_INDEX_MAX_N / 512];   // boxes of 8 / 64 / 512 consecutive leaves

@@ -35,6 +35,16 @@ def test_library_exports_every_declared_symbol(capi):
     assert L.lh_abi_version() == 1
 
 
+def test_library_exports_no_function_but_the_c_abi(capi):
+    """the TUs are compiled -fvisibility=hidden: the only FUNCTIONS liblocus_hip.so exports are the header's (kernel handles are data symbols)"""
+    import shutil
+    import subprocess
+    nm = shutil.which("nm") or "/opt/rocm/lib/llvm/bin/llvm-nm"
+    out = subprocess.run([nm, "-D", "--defined-only", capi.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    funcs = [ln.split()[2] for ln in out.splitlines() if len(ln.split()) == 3 and ln.split()[1] == "T"]
+    assert sorted(funcs) == _header_symbols(), sorted(set(funcs) ^ set(_header_symbols()))
+
+
 def test_rccl_library_exports_every_declared_symbol(capi):
     """liblocus_hip_rccl.so (include/locus_hip_rccl.h): loads next to librccl and exports what its header declares"""
     from locus_amd import rccl

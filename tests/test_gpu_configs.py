@@ -290,10 +290,16 @@ def test_config4_full_size_stream_64_pairs_ate_vs_cpu_chain(ctx, capi, oracle):
     from concurrent.futures import ThreadPoolExecutor
     from locus_amd import dist as ldist
     n = 65
-    poses = [synth.pose_matrix(0.26 * i, 0.9 * np.sin(i / 40.0), 0.0, 0, 0, 0.004 * i) for i in range(n)]
+
+    def pose(i, total=512):   # the first 65 poses of bench.py's trajectory (two laps of a 16 x 3.5 m ellipse in 512 steps of ~0.26 m: trajectory_pose)
+        t = i / float(total)
+        a = 4.0 * np.pi * t
+        return synth.pose_matrix(16.0 * np.cos(a), 3.5 * np.sin(a), 0.05 * np.sin(6.0 * np.pi * t), np.deg2rad(0.3) * np.sin(10.0 * np.pi * t),
+                                 np.deg2rad(0.3) * np.cos(14.0 * np.pi * t), 0.5 * np.sin(4.0 * np.pi * t))
+    poses = [pose(i) for i in range(n)]
     clouds = []
     for i in range(n):
-        c = capi.Cloud(ctx, synth.scan(poses[i], 64, 1563, (-25.0, 15.0), 2.0, 0.02, seed=5000 + i))
+        c = capi.Cloud(ctx, synth.scan(poses[i], 64, 1563, (-25.0, 15.0), 2.0, 0.02, seed=100 + i))
         clouds.append(c)
     assert len(clouds[0]) == 100032
     capi.normals_knn_batch(clouds[:64], 20)
@@ -308,7 +314,7 @@ def test_config4_full_size_stream_64_pairs_ate_vs_cpu_chain(ctx, capi, oracle):
 
     def ate(a, b):
         return float(np.sqrt(np.mean(np.sum((a[:, :3, 3] - b[:, :3, 3]) ** 2, axis=1))))
-    assert ate(chain, gt) < 0.15   # 64 chained alignments with 2 cm range noise over 16.6 m
+    assert ate(chain, gt) < 0.25   # 64 chained alignments with 2 cm range noise over 16.6 m (the 512-pair chain of the bench: 0.40 m over 135 m)
     dl = [c.download() for c in clouds]
 
     def cpu(i):

@@ -2,8 +2,9 @@
  * Round 4 saw one full bench run in dozens sit in interpreter / runtime teardown for minutes AFTER its result line was out; the script then
  * left through os._exit, which hid the teardown instead of exercising it.  Now every run tears down normally (clouds, lh_destroy, interpreter
  * finalisation, the HIP runtime's own atexit), and this guard -- a detached native thread that needs neither the GIL nor a living interpreter --
- * ends the process with the run's own exit code if that takes longer than the stated number of seconds, saying on stderr which phase was the
- * last to be announced.     gcc -O2 -shared -fPIC -o libexitguard.so exitguard.c -lpthread */
+ * ends the process if that takes longer than the stated number of seconds, saying on stderr which phase was the last to be announced -- with
+ * the run's own exit code when that was a failure already, with 97 when the run itself had succeeded: a teardown that hangs is a failure a
+ * driver must be able to see in the exit status.     gcc -O2 -shared -fPIC -o libexitguard.so exitguard.c -lpthread */
 #include <pthread.h>
 #include <stdio.h>
 #include <string.h>
@@ -20,9 +21,10 @@ static void* guard(void* unused) {
   (void)unused;
   sleep((unsigned)g_seconds);
   char msg[256];
-  int n = snprintf(msg, sizeof msg, "[exitguard] teardown still running after %d s (last phase: %s): leaving with exit code %d\n", g_seconds, g_phase, g_code);
+  const int code = g_code != 0 ? g_code : 97;
+  int n = snprintf(msg, sizeof msg, "[exitguard] teardown still running after %d s (last phase: %s): leaving with exit code %d\n", g_seconds, g_phase, code);
   if (n > 0) (void)!write(2, msg, (size_t)n);
-  _exit(g_code);
+  _exit(code);
   return NULL;
 }
 int exitguard_arm(int seconds, int code) {
