@@ -110,7 +110,7 @@ __global__ void __launch_bounds__(256) k_key_b(const IndexDesc* __restrict__ des
 }
 // --- leaves: the largest key-prefix cell around every sorted position with <= LEAF_CAP points --------------------------
 // One workgroup per tile of LEAF_TILE sorted positions.  k_leafcell_b: the leaf-start flags and the tile's number of leaves;
-// (one workgroup then turns the tile counts into offsets: k_tile_offsets); k_leaves_b: the same tile again -- the running leaf
+// (every k_leaves_b workgroup adds the counts of the tiles below its own: no scan launch); k_leaves_b: the same tile again -- the running leaf
 // number of every position (lid = inclusive scan of the flags), the sorted points (x, y, z, original index) gathered through the
 // sorted index, the inverse permutation, and for every flagged position the leaf's record.  (Round 2: flags, a library scan with
 // its own init kernel, gather, leaf records = five launches and two more round trips through the flags.)
@@ -148,26 +148,9 @@ __global__ void __launch_bounds__(256) k_leafcell_b(TreeScratch t) {   // one so
   const uint32_t c = (uint32_t)__popcll(__ballot(f != 0u));
   if ((threadIdx.x & 63) == 0) wcnt[threadIdx.x >> 6] = c;
   __syncthreads();
-  // leaves per tile of LEAF_TILE positions (16 workgroups each): integer adds, order-free.  tsum is zero when a build starts (k_tile_offsets
+  // leaves per tile of LEAF_TILE positions (16 workgroups each): integer adds, order-free.  tsum is zero when a build starts (k_boxes_b
   // of the previous build left it so)
   if (threadIdx.x == 0) atomicAdd(&t.tsum[(blockIdx.x * 256) / LEAF_TILE], wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3]);
-}
-__global__ void __launch_bounds__(256) k_tile_offsets(uint32_t* __restrict__ tsum, uint32_t* __restrict__ toff, int tiles) {   // ONE workgroup: exclusive prefix; the counts are zeroed for the next build
-  __shared__ uint32_t wsum[4];
-  __shared__ uint32_t carry_s;
-  if (threadIdx.x == 0) carry_s = 0;
-  __syncthreads();
-  for (int t0 = 0; t0 < tiles; t0 += 256) {
-    const int tt = t0 + threadIdx.x;
-    const uint32_t v = tt < tiles ? tsum[tt] : 0u;
-    uint32_t tot;
-    const uint32_t ex = block_exclusive_u32(v, wsum, &tot);
-    const uint32_t carry = carry_s;
-    if (tt < tiles) { toff[tt] = carry + ex; tsum[tt] = 0u; }
-    __syncthreads();
-    if (threadIdx.x == 0) carry_s = carry + tot;
-    __syncthreads();
-  }
 }
 __global__ void __launch_bounds__(256) k_leaves_b(const IndexDesc* __restrict__ descs, TreeScratch t, const uint32_t* __restrict__ vals, uint32_t* bbox_next) {
   __shared__ uint32_t cnt[LEAF_PER_THREAD][4];   // leaves per (round, wave) of the tile, then their exclusive prefix in (round, wave) order
@@ -195,7 +178,19 @@ __global__ void __launch_bounds__(256) k_leaves_b(const IndexDesc* __restrict__ 
     (&cnt[0][0])[threadIdx.x] = inc - v;
   }
   __syncthreads();
-  const uint32_t tile_base = t.toff[blockIdx.x];
+  // The tile's first leaf id = the leaves of all earlier tiles: every workgroup adds the (<= total / 4096) counts below its own itself, in
+  // parallel -- a separate one-workgroup scan launch (k_tile_offsets, round 2-5: 5 us + its launch gap on the build's critical path) for
+  // a sum that 256 threads form in a microsecond.  Integer adds: order-free.  The counts are zeroed for the next build by k_boxes_b.
+  __shared__ uint32_t tb_part[4];
+  {
+    uint32_t s = 0;
+    for (int tt = threadIdx.x; tt < (int)blockIdx.x; tt += 256) s += t.tsum[tt];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if (lane == 0) tb_part[wave] = s;
+  }
+  __syncthreads();
+  const uint32_t tile_base = (tb_part[0] + tb_part[1]) + (tb_part[2] + tb_part[3]);
   int cur = -1;
   const float4* xyz = nullptr; float4* sorted = nullptr; int d_off = 0, d_n = 0;
 #pragma unroll 4
@@ -250,49 +245,68 @@ __device__ __forceinline__ void box_store(float4* tab, int idx, const Box6& b) {
   tab[2 * (size_t)idx] = make_float4(b.lx, b.ly, b.lz, 0.f);
   tab[2 * (size_t)idx + 1] = make_float4(b.hx, b.hy, b.hz, 0.f);
 }
-// one thread per leaf: its (<= LEAF_CAP) points in ONE round of loads (the sorted array is padded, the count masks)
-__global__ void __launch_bounds__(256) k_leafbox_b(const IndexDesc* __restrict__ descs, TreeScratch t) {
+// The three box tables in ONE launch (round 6; k_leafbox_b + two k_chunkbox_b launches before): a workgroup takes 1 024 consecutive leaves in
+// four rounds of 256 -- a thread forms a leaf's box from its (<= LEAF_CAP) points in one round of loads (the sorted array is padded, the
+// count masks) -> lbox; 32 consecutive lanes hold 32 consecutive leaves, five shuffle steps give their union -> a1box; the workgroup's 32
+// chunk boxes meet in LDS -> a2box.  min / max are exact and order-free: the tables are the separate launches' byte for byte.
+__global__ void __launch_bounds__(256) k_boxes_b(const IndexDesc* __restrict__ descs, TreeScratch t, int tiles) {
+  __shared__ float cb[32][6];
+  {  // the tile counts of k_leafcell_b have been consumed by k_leaves_b: zero for the next build of this scratch set
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    if (gid < tiles) t.tsum[gid] = 0u;
+  }
   const int n_leaves = (int)t.lid[t.total - 1];
-  int L = blockIdx.x * blockDim.x + threadIdx.x;
-  if (L >= n_leaves) return;
-  const int cloud = (int)(t.lkey[L] >> 32);
-  const IndexDesc d = descs[cloud];
-  const uint32_t s0 = t.lstart[L], s1 = t.lstart[L + 1];
-  const float4* pp = d.sorted + (s0 - (uint32_t)d.offset);
-  float4 q[LEAF_CAP];
+  const int base = blockIdx.x * 1024;
+  if (base >= n_leaves) return;   // (uniform)
+#pragma unroll 1
+  for (int r = 0; r < 4; r++) {
+    const int L = base + r * 256 + (int)threadIdx.x;
+    Box6 b = box_empty();
+    if (L < n_leaves) {
+      const int cloud = (int)(t.lkey[L] >> 32);
+      const IndexDesc d = descs[cloud];
+      const uint32_t s0 = t.lstart[L], s1 = t.lstart[L + 1];
+      const float4* pp = d.sorted + (s0 - (uint32_t)d.offset);
+      float4 q[LEAF_CAP];
 #pragma unroll
-  for (int e = 0; e < LEAF_CAP; e++) q[e] = pp[e];
-  Box6 b = box_empty();
+      for (int e = 0; e < LEAF_CAP; e++) q[e] = pp[e];
 #pragma unroll
-  for (int e = 0; e < LEAF_CAP; e++)
-    if (s0 + (uint32_t)e < s1) {
-      b.lx = fminf(b.lx, q[e].x); b.ly = fminf(b.ly, q[e].y); b.lz = fminf(b.lz, q[e].z);
-      b.hx = fmaxf(b.hx, q[e].x); b.hy = fmaxf(b.hy, q[e].y); b.hz = fmaxf(b.hz, q[e].z);
+      for (int e = 0; e < LEAF_CAP; e++)
+        if (s0 + (uint32_t)e < s1) {
+          b.lx = fminf(b.lx, q[e].x); b.ly = fminf(b.ly, q[e].y); b.lz = fminf(b.lz, q[e].z);
+          b.hx = fmaxf(b.hx, q[e].x); b.hy = fmaxf(b.hy, q[e].y); b.hz = fmaxf(b.hz, q[e].z);
+        }
+      box_store(t.lbox, L, b);
+      const int a_c = (int)t.lid[d.offset] - 1, b_c = (int)t.lid[d.offset + d.n - 1] - 1;
+      if (a_c == b_c) {  // the whole cloud is one leaf: no internal node will write the header
+        d.hdr->root = leaf_ref(0u, d.n);
+        d.hdr->n_leaves = 1;
+      }
     }
-  box_store(t.lbox, L, b);
-  const int a_c = (int)t.lid[d.offset] - 1, b_c = (int)t.lid[d.offset + d.n - 1] - 1;
-  if (a_c == b_c) {  // the whole cloud is one leaf: no internal node will write the header
-    d.hdr->root = leaf_ref(0u, d.n);
-    d.hdr->n_leaves = 1;
-  }
-}
-// chunk tables: dst[c] = union of src[32c .. 32c+31] (entries past n_src are skipped).  32 lanes per chunk, one entry each, five
-// shuffle steps (a thread per chunk read its 64 table words one after the other).
-__global__ void __launch_bounds__(256) k_chunkbox_b(TreeScratch t, int level) {
-  const int n_leaves = (int)t.lid[t.total - 1];
-  const int n_src = level == 1 ? n_leaves : (n_leaves + 31) / 32;
-  const float4* src = level == 1 ? t.lbox : t.a1box;
-  float4* dst = level == 1 ? t.a1box : t.a2box;
-  const int c = (blockIdx.x * blockDim.x + threadIdx.x) >> 5, e = c * 32 + (threadIdx.x & 31);
-  if (c * 32 >= n_src) return;   // (uniform per half wave)
-  Box6 b = box_empty();
-  if (e < n_src) box_merge(b, src, e);
+    // a1: the union of the 32 leaves of a half wave (lanes past the last leaf hold the empty box)
 #pragma unroll
-  for (int off = 16; off > 0; off >>= 1) {
-    b.lx = fminf(b.lx, __shfl_down(b.lx, off, 32)); b.ly = fminf(b.ly, __shfl_down(b.ly, off, 32)); b.lz = fminf(b.lz, __shfl_down(b.lz, off, 32));
-    b.hx = fmaxf(b.hx, __shfl_down(b.hx, off, 32)); b.hy = fmaxf(b.hy, __shfl_down(b.hy, off, 32)); b.hz = fmaxf(b.hz, __shfl_down(b.hz, off, 32));
+    for (int off = 16; off > 0; off >>= 1) {
+      b.lx = fminf(b.lx, __shfl_down(b.lx, off, 32)); b.ly = fminf(b.ly, __shfl_down(b.ly, off, 32)); b.lz = fminf(b.lz, __shfl_down(b.lz, off, 32));
+      b.hx = fmaxf(b.hx, __shfl_down(b.hx, off, 32)); b.hy = fmaxf(b.hy, __shfl_down(b.hy, off, 32)); b.hz = fmaxf(b.hz, __shfl_down(b.hz, off, 32));
+    }
+    if ((threadIdx.x & 31) == 0) {
+      const int c = (base + r * 256 + (int)threadIdx.x) >> 5;   // chunk of 32 leaves
+      if (c * 32 < n_leaves) box_store(t.a1box, c, b);
+      float* w = cb[r * 8 + (threadIdx.x >> 5)];
+      w[0] = b.lx; w[1] = b.ly; w[2] = b.lz; w[3] = b.hx; w[4] = b.hy; w[5] = b.hz;
+    }
   }
-  if ((threadIdx.x & 31) == 0) box_store(dst, c, b);
+  __syncthreads();
+  if (threadIdx.x < 32) {   // a2: the union of the workgroup's 32 chunks (empty boxes where the cloud batch ends)
+    const float* w = cb[threadIdx.x];
+    Box6 b{w[0], w[1], w[2], w[3], w[4], w[5]};
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) {
+      b.lx = fminf(b.lx, __shfl_down(b.lx, off, 32)); b.ly = fminf(b.ly, __shfl_down(b.ly, off, 32)); b.lz = fminf(b.lz, __shfl_down(b.lz, off, 32));
+      b.hx = fmaxf(b.hx, __shfl_down(b.hx, off, 32)); b.hy = fmaxf(b.hy, __shfl_down(b.hy, off, 32)); b.hz = fmaxf(b.hz, __shfl_down(b.hz, off, 32));
+    }
+    if (threadIdx.x == 0) box_store(t.a2box, blockIdx.x, b);
+  }
 }
 // box of the leaves [a, e): entries fetched four at a time, independent loads in flight together, merged afterwards (min / max are
 // exact and order-free, so the boxes do not depend on how they are gathered)
@@ -476,16 +490,15 @@ void launch_index_keys(const IndexDesc* descs, int n_clouds, int max_n, uint32_t
 void launch_index_leaves(const IndexDesc* descs, int n_clouds, const TreeScratch& t, const uint32_t* vals_sorted, uint32_t* bbox, hipStream_t s) {
   const int tiles = (t.total + LEAF_TILE - 1) / LEAF_TILE;
   hipLaunchKernelGGL(k_leafcell_b, dim3((t.total + 255) / 256), dim3(256), 0, s, t);
-  hipLaunchKernelGGL(k_tile_offsets, dim3(1), dim3(256), 0, s, t.tsum, t.toff, tiles);
-  hipLaunchKernelGGL(k_leaves_b, dim3(tiles), dim3(256), 0, s, descs, t, vals_sorted, bbox);
+  hipLaunchKernelGGL(k_leaves_b, dim3(tiles), dim3(256), 0, s, descs, t, vals_sorted, bbox);   // (forms its own tile offset: no scan launch in between)
   (void)n_clouds;
 }
 void launch_index_trees(const IndexDesc* descs, int n_clouds, int max_n, const TreeScratch& t, hipStream_t s, int stage) {
   int blocks = (t.total + 255) / 256;  // upper bound of the leaf count; the kernels read the real one from lid[total-1]
-  if (stage == 0) {        // box tables: per leaf, per 32 leaves, per 1024 leaves
-    hipLaunchKernelGGL(k_leafbox_b, dim3(blocks), dim3(256), 0, s, descs, t);
-    hipLaunchKernelGGL(k_chunkbox_b, dim3(blocks), dim3(256), 0, s, t, 1);                        // 32 lanes per chunk of 32 leaves: leaves <= points
-    hipLaunchKernelGGL(k_chunkbox_b, dim3((blocks + 31) / 32 + 1), dim3(256), 0, s, t, 2);
+  if (stage == 0) {        // box tables: per leaf, per 32 leaves, per 1024 leaves -- one launch, 1 024 leaves per workgroup (leaves <= points)
+    const int tiles = (t.total + LEAF_TILE - 1) / LEAF_TILE;
+    const int nb = (t.total + 1023) / 1024, nz = (tiles + 255) / 256;
+    hipLaunchKernelGGL(k_boxes_b, dim3(nb > nz ? nb : nz), dim3(256), 0, s, descs, t, tiles);
   } else if (stage == 1) { // hierarchy + one box per binary node
     hipLaunchKernelGGL(k_radix_b, dim3(blocks), dim3(256), 0, s, t);
   } else {                 // 4-ary nodes + headers

@@ -16,6 +16,12 @@ bash tools/pmc_lanes.sh > $E/pmc_lanes.txt 2>&1
 bash tools/pmc_solve.sh > $E/pmc_solve.txt 2>&1
 bash tools/trace_sweeps.sh > $E/sweep_kernel_trace.txt 2>&1
 bash tools/trace_index.sh > $E/index_kernel_trace.txt 2>&1
+# round 6: the cooperative all-walk sweep (opt-in) beside the default, same box
+cd $GRAFT_REPO_ROOT; LH_SWEEP_COOP=1 bash tools/pmc_lanes.sh > $E/coop_pmc_lanes.txt 2>&1
+cd $GRAFT_REPO_ROOT; LH_SWEEP_COOP=1 bash tools/trace_sweeps.sh > $E/coop_sweep_kernel_trace.txt 2>&1
+cd $GRAFT_REPO_ROOT; LH_SWEEP_COOP=1 python bench.py --quick > $E/coop_bench_quick.json 2> $E/coop_bench_quick.err
+cd $GRAFT_REPO_ROOT; python bench.py --quick > $E/default_bench_quick.json 2> $E/default_bench_quick.err
+cd $GRAFT_REPO_ROOT
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 2 --same-gpu --dist-backend gloo --quick --pairs 64 --in-flight 64 --steps 2 --warmup 1 > $E/bench_two_ranks_one_gpu.json 2> $E/bench_two_ranks_one_gpu.err
 python bench.py --gpus 2 --same-gpu --dist-backend gloo --quick --pairs 64 --in-flight 64 --steps 2 --warmup 1 > $E/bench_self_launched_two_ranks.json 2> $E/bench_self_launched_two_ranks.err
 python bench.py --gpus 2 --same-gpu --dist-backend gloo --pairs 32 --in-flight 32 --steps 2 --warmup 1 --no-trajectory --no-configs > $E/bench_two_ranks_full_line.json 2> $E/bench_two_ranks_full_line.err
