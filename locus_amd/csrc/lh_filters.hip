@@ -45,16 +45,29 @@ __global__ void __launch_bounds__(256) k_dist_partials(const float4* __restrict_
 // matrix is summed from the un-normalised query with the normalisation applied in flight, the 21 sums leave in one copy.  Every value is
 // formed exactly as lh_p2plane_information forms it (same partial sums, same order of the final sums, same float expressions), so the
 // two entry points return the same bits.
-__global__ void __launch_bounds__(64) k_centroid_final(const double* __restrict__ part, int nb, float* __restrict__ cf) {
-  if (threadIdx.x != 0) return;
-  double sx = 0, sy = 0, sz = 0, cnt = 0;
-  for (int b = 0; b < nb; b++) { sx += part[b * 4]; sy += part[b * 4 + 1]; sz += part[b * 4 + 2]; cnt += part[b * 4 + 3]; }
-  cf[0] = (float)(sx / cnt); cf[1] = (float)(sy / cnt); cf[2] = (float)(sz / cnt);
+// the per-block bodies, shared by the multi-block kernels and by the one-launch form for small clouds (k_p2plane_small): same thread -> point map,
+// same shuffle tree, same order of the four waves -- a block's partial sums are the same bits whichever kernel forms them
+__device__ __forceinline__ void centroid_block(const float4* __restrict__ xyz, int n, int blk, double (*sm)[4], double* __restrict__ out4) {
+  double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+  int base = blk * 1024;
+  for (int r = 0; r < 4; r++) {
+    int i = base + r * 256 + threadIdx.x;
+    if (i < n) {
+      float4 p = xyz[i];
+      if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) { a0 += p.x; a1 += p.y; a2 += p.z; a3 += 1.0; }
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    a0 += __shfl_down(a0, off, 64); a1 += __shfl_down(a1, off, 64); a2 += __shfl_down(a2, off, 64); a3 += __shfl_down(a3, off, 64);
+  }
+  if ((threadIdx.x & 63) == 0) { sm[threadIdx.x >> 6][0] = a0; sm[threadIdx.x >> 6][1] = a1; sm[threadIdx.x >> 6][2] = a2; sm[threadIdx.x >> 6][3] = a3; }
+  __syncthreads();
+  if (threadIdx.x < 4) out4[threadIdx.x] = ((sm[0][threadIdx.x] + sm[1][threadIdx.x]) + sm[2][threadIdx.x]) + sm[3][threadIdx.x];
+  __syncthreads();
 }
-__global__ void __launch_bounds__(256) k_dist_partials_dev(const float4* __restrict__ xyz, int n, const float* __restrict__ cf, double* __restrict__ part) {
-  const float cx = cf[0], cy = cf[1], cz = cf[2];
+__device__ __forceinline__ void dist_block(const float4* __restrict__ xyz, int n, int blk, float cx, float cy, float cz, double* sm4, double* __restrict__ out1) {
   double a = 0;
-  int base = blockIdx.x * 1024;
+  int base = blk * 1024;
   for (int r = 0; r < 4; r++) {
     int i = base + r * 256 + threadIdx.x;
     if (i < n) {
@@ -64,27 +77,21 @@ __global__ void __launch_bounds__(256) k_dist_partials_dev(const float4* __restr
     }
   }
   for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off, 64);
-  __shared__ double sm[4];
-  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = a;
+  if ((threadIdx.x & 63) == 0) sm4[threadIdx.x >> 6] = a;
   __syncthreads();
-  if (threadIdx.x == 0) part[blockIdx.x] = ((sm[0] + sm[1]) + sm[2]) + sm[3];
-}
-__global__ void __launch_bounds__(64) k_factor_final(const double* __restrict__ part, int nb, int n, float* __restrict__ cf) {
-  if (threadIdx.x != 0) return;
-  double dist = 0;
-  for (int b = 0; b < nb; b++) dist += part[b];
-  cf[3] = (float)n / (float)dist;  // utils.cc:120
+  if (threadIdx.x == 0) out1[0] = ((sm4[0] + sm4[1]) + sm4[2]) + sm4[3];
+  __syncthreads();
 }
 // Ap = sum H^T H, H = [a x n, n] (PointCloudLocalization.cc:723-750) with a = factor * (p - centroid) formed in flight (the expression of
 // launch_transform with T12 = {f, 0, 0, -f cx, ...}); corr < 0 (a query without a neighbour: a non-finite point) is skipped like a NaN
-__global__ void __launch_bounds__(256) k_ap_norm(const float4* __restrict__ xyz, int n, const float* __restrict__ cf, const float4* __restrict__ ref_nrm,
-                                                 const int32_t* __restrict__ corr, double* __restrict__ partials) {
+__device__ __forceinline__ void ap_block(const float4* __restrict__ xyz, int n, int blk, const float* cf, const float4* __restrict__ ref_nrm,
+                                         const int32_t* __restrict__ corr, double (*sm)[21], double* __restrict__ out21) {
   const float f = cf[3];
   const float T12[12] = {f, 0, 0, -f * cf[0], 0, f, 0, -f * cf[1], 0, 0, f, -f * cf[2]};
   double acc[21];
 #pragma unroll
   for (int k = 0; k < 21; k++) acc[k] = 0.0;
-  int base = blockIdx.x * 1024;
+  int base = blk * 1024;
 #pragma unroll
   for (int r = 0; r < 4; r++) {
     int i = base + r * 256 + threadIdx.x;
@@ -113,14 +120,39 @@ __global__ void __launch_bounds__(256) k_ap_norm(const float4* __restrict__ xyz,
 #pragma unroll
     for (int k = 0; k < 21; k++) acc[k] += __shfl_down(acc[k], off, 64);
   }
-  __shared__ double sm[4][21];
   int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   if (lane == 0) {
 #pragma unroll
     for (int k = 0; k < 21; k++) sm[wave][k] = acc[k];
   }
   __syncthreads();
-  if (threadIdx.x < 21) partials[blockIdx.x * 21 + threadIdx.x] = ((sm[0][threadIdx.x] + sm[1][threadIdx.x]) + sm[2][threadIdx.x]) + sm[3][threadIdx.x];
+  if (threadIdx.x < 21) out21[threadIdx.x] = ((sm[0][threadIdx.x] + sm[1][threadIdx.x]) + sm[2][threadIdx.x]) + sm[3][threadIdx.x];
+  __syncthreads();
+}
+__global__ void __launch_bounds__(256) k_centroid_partials_dev(const float4* __restrict__ xyz, int n, double* __restrict__ part) {
+  __shared__ double sm[4][4];
+  centroid_block(xyz, n, blockIdx.x, sm, part + blockIdx.x * 4);
+}
+__global__ void __launch_bounds__(64) k_centroid_final(const double* __restrict__ part, int nb, float* __restrict__ cf) {
+  if (threadIdx.x != 0) return;
+  double sx = 0, sy = 0, sz = 0, cnt = 0;
+  for (int b = 0; b < nb; b++) { sx += part[b * 4]; sy += part[b * 4 + 1]; sz += part[b * 4 + 2]; cnt += part[b * 4 + 3]; }
+  cf[0] = (float)(sx / cnt); cf[1] = (float)(sy / cnt); cf[2] = (float)(sz / cnt);
+}
+__global__ void __launch_bounds__(256) k_dist_partials_dev(const float4* __restrict__ xyz, int n, const float* __restrict__ cf, double* __restrict__ part) {
+  __shared__ double sm[4];
+  dist_block(xyz, n, blockIdx.x, cf[0], cf[1], cf[2], sm, part + blockIdx.x);
+}
+__global__ void __launch_bounds__(64) k_factor_final(const double* __restrict__ part, int nb, int n, float* __restrict__ cf) {
+  if (threadIdx.x != 0) return;
+  double dist = 0;
+  for (int b = 0; b < nb; b++) dist += part[b];
+  cf[3] = (float)n / (float)dist;  // utils.cc:120
+}
+__global__ void __launch_bounds__(256) k_ap_norm(const float4* __restrict__ xyz, int n, const float* __restrict__ cf, const float4* __restrict__ ref_nrm,
+                                                 const int32_t* __restrict__ corr, double* __restrict__ partials) {
+  __shared__ double sm[4][21];
+  ap_block(xyz, n, blockIdx.x, cf, ref_nrm, corr, sm, partials + blockIdx.x * 21);
 }
 __global__ void __launch_bounds__(64) k_ap_final(const double* __restrict__ partials, int nb, double* __restrict__ out21) {
   if (threadIdx.x >= 21) return;
@@ -128,11 +160,46 @@ __global__ void __launch_bounds__(64) k_ap_final(const double* __restrict__ part
   for (int b = 0; b < nb; b++) s += partials[(size_t)b * 21 + threadIdx.x];
   out21[threadIdx.x] = s;
 }
+// The whole chain in ONE launch of one workgroup for the clouds LOCUS registers (a few thousand points: six dependent launches of 4-5 us each
+// for microseconds of work): the blocks one after the other through the same per-block bodies, the final sums by one thread in block order.
+constexpr int P2P_SMALL_BLOCKS = 16;   // <= 16 384 points
+__global__ void __launch_bounds__(256) k_p2plane_small(const float4* __restrict__ xyz, int n, const float4* __restrict__ ref_nrm, const int32_t* __restrict__ corr,
+                                                       double* __restrict__ out21) {
+  __shared__ double sm4[4][4], smd[4], sma[4][21];
+  __shared__ double part[P2P_SMALL_BLOCKS * 21];
+  __shared__ float cf[4];
+  const int nb = (n + 1023) / 1024;
+  for (int b = 0; b < nb; b++) centroid_block(xyz, n, b, sm4, part + b * 4);
+  if (threadIdx.x == 0) {
+    double sx = 0, sy = 0, sz = 0, cnt = 0;
+    for (int b = 0; b < nb; b++) { sx += part[b * 4]; sy += part[b * 4 + 1]; sz += part[b * 4 + 2]; cnt += part[b * 4 + 3]; }
+    cf[0] = (float)(sx / cnt); cf[1] = (float)(sy / cnt); cf[2] = (float)(sz / cnt);
+  }
+  __syncthreads();
+  for (int b = 0; b < nb; b++) dist_block(xyz, n, b, cf[0], cf[1], cf[2], smd, part + b);
+  if (threadIdx.x == 0) {
+    double dist = 0;
+    for (int b = 0; b < nb; b++) dist += part[b];
+    cf[3] = (float)n / (float)dist;  // utils.cc:120
+  }
+  __syncthreads();
+  for (int b = 0; b < nb; b++) ap_block(xyz, n, b, cf, ref_nrm, corr, sma, part + b * 21);
+  if (threadIdx.x < 21) {
+    double s = 0;
+    for (int b = 0; b < nb; b++) s += part[b * 21 + threadIdx.x];
+    out21[threadIdx.x] = s;
+  }
+}
 // The whole chain, enqueued on s: out21 (device) receives the 21 unique entries of Ap.  scratch: (21 nb + 4) doubles of device memory.
 lh_status p2plane_information_device(const float4* qxyz, int n, const float4* ref_nrm, const int32_t* corr, double* scratch, double* out21, hipStream_t s) {
   const int nb = lh::sum_blocks(n);
+  static const bool small_on = []() { const char* e = getenv("LH_P2P_SMALL"); return e ? atoi(e) != 0 : true; }();   // (0: the six-launch chain for every size: A/B, tests)
+  if (small_on && nb <= P2P_SMALL_BLOCKS) {
+    hipLaunchKernelGGL(k_p2plane_small, dim3(1), dim3(256), 0, s, qxyz, n, ref_nrm, corr, out21);
+    return hipGetLastError() == hipSuccess ? LH_OK : LH_EDEVICE;
+  }
   float* cf = reinterpret_cast<float*>(scratch + (size_t)nb * 21);
-  hipLaunchKernelGGL(k_centroid_partials, dim3(nb), dim3(256), 0, s, qxyz, n, scratch);
+  hipLaunchKernelGGL(k_centroid_partials_dev, dim3(nb), dim3(256), 0, s, qxyz, n, scratch);
   hipLaunchKernelGGL(k_centroid_final, dim3(1), dim3(64), 0, s, scratch, nb, cf);
   hipLaunchKernelGGL(k_dist_partials_dev, dim3(nb), dim3(256), 0, s, qxyz, n, cf, scratch);
   hipLaunchKernelGGL(k_factor_final, dim3(1), dim3(64), 0, s, scratch, nb, n, cf);
