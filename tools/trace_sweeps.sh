@@ -12,10 +12,10 @@ for r in csv.DictReader(open(sys.argv[1])):
     name = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("lh::", "")
     rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), name))
 rows.sort()
-for pat in ("k_sweep_coop", "k_sweep_fused", "k_seed", "k_late", "k_walk", "k_moments_final"):
-    v = [(s, e) for s, e, n in rows if n.startswith(pat)]
+for pat in ("k_sweep_coop", "k_sweep_fused", "k_seed", "k_late", "k_walk_coop", "k_walk", "k_moments_final"):
+    v = [(s, e) for s, e, n in rows if (n == pat if pat == "k_walk" else n.startswith(pat))]
     v = v[-20:] if pat in ("k_sweep_coop", "k_sweep_fused", "k_moments_final", "k_seed") else v
-    half = v[len(v) // 2:] if pat in ("k_late", "k_walk") else v   # the second (profiled) batch
+    half = v[len(v) // 2:] if pat in ("k_late", "k_walk", "k_walk_coop") else v   # the second (profiled) batch
     print("%-18s n=%3d  us:" % (pat, len(half)), " ".join("%.0f" % ((e - s) / 1e3) for s, e in half))
 # gaps: time from the end of k_late to the start of k_walk, and k_walk end -> final start (last batch)
 late = [(s, e) for s, e, n in rows if n.startswith("k_late")]
