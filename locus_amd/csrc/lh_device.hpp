@@ -55,6 +55,11 @@ __host__ __device__ __forceinline__ V gload16(const void* p) {
 #endif
 }
 
+#ifndef LH_GRID_FINEST
+#define LH_GRID_FINEST 5
+#endif
+#define LH_GRID_FINEST_OR_DEFAULT LH_GRID_FINEST
+
 namespace lh {
 
 constexpr int LEAF_CAP = 8;     // max points per leaf (128 B = one cache line of sorted points)
@@ -63,13 +68,14 @@ constexpr int LEAF_CAP = 8;     // max points per leaf (128 B = one cache line o
 #endif
 constexpr int LDS_STACK = LH_LDS_STACK;   // traversal-stack entries (64-bit) a thread keeps in LDS; deeper entries spill to private memory (-DLH_LDS_STACK: A/B builds)
 constexpr int MAX_POINT_BITS = 27; // a cloud holds at most 2^27 points (leaf references keep 27 bits of sorted position; build_indices checks)
-constexpr int GRID_CELL_ROOTS = 3; // levels of the start grid (a cell root is kept as a child instead of being adopted: one 4-ary level for ONE binary level)
+constexpr int GRID_CELL_ROOTS = LH_GRID_FINEST_OR_DEFAULT - 2; // levels of the start grid (a cell root is kept as a child instead of being adopted: one 4-ary level for ONE binary level)
 // The traversal stack is unchecked.  Its structural bound: the binary radix tree is at most 30 key bits + MAX_POINT_BITS tie-break bits deep
 // (runs of identical keys are split by leaf index); a 4-ary node adopts its grandchildren, so a 4-ary level covers two binary levels except
 // at the (at most three) cell roots on a path => ceil((57 + 3) / 2) = 30 levels; a visit stacks at most 3 siblings and descends into the
 // fourth child => 3 * 30 + 1 = 91 entries for a walk from the root.  A walk that starts in the grid stacks <= 7 neighbour cells and then
 // begins at a level-5 cell root, >= 7 levels down: 7 + 3 * 23 + 1 = 77.  LDS_STACK + SPILL_MAX = 92.
-constexpr int SPILL_MAX = 92 - LDS_STACK;   // (80 with the default LDS_STACK)
+constexpr int STACK_BOUND = 3 * ((30 + MAX_POINT_BITS + GRID_CELL_ROOTS + 1) / 2) + 1;   // 91 with three table levels, 94 with four or five
+constexpr int SPILL_MAX = (STACK_BOUND > 92 ? STACK_BOUND : 92) - LDS_STACK;   // (80 with the default LDS_STACK and three table levels)
 constexpr int MAX_DEPTH = 12;   // (size of the instrumentation histogram; only slot 0 is used by the explicit tree)
 
 // child reference: >= 0 internal node index (cloud-local); < 0 leaf: ~ref = (first sorted position << 4) | (count - 1)

@@ -395,7 +395,7 @@ __global__ void __launch_bounds__(256) k_nodex_b(const IndexDesc* __restrict__ d
       // the key grid can own thousands of cells -- is entered by the whole wave (one thread doing it made a 100 k-point build with three
       // 4-km outliers take 0.52 instead of 0.16 ms)
     int32_t* grid = reinterpret_cast<int32_t*>(d.hdr + 1);
-    const bool offer = valid && grid_on && com_i < 15;
+    const bool offer = valid && grid_on && com_i < 3 * GRID_FINEST;   // (a node inside a cell of the finest table offers nothing)
     const int lane = threadIdx.x & 63;
 #pragma unroll
     for (int side = 0; side < 2; side++) {
@@ -403,7 +403,7 @@ __global__ void __launch_bounds__(256) k_nodex_b(const IndexDesc* __restrict__ d
       uint32_t key = 0; int32_t ref = 0;
       if (offer) { key = (uint32_t)t.lkey[c < 0 ? ~c : t.irange[2 * c]] & 0x3fffffffu; ref = child_ref(c); }
 #pragma unroll
-      for (int l = 5; l >= 3; l--) {
+      for (int l = GRID_FINEST; l >= 3; l--) {
         uint32_t lo3[3] = {0, 0, 0}, hi3[3] = {0, 0, 0};
         const bool app = offer && grid_child_cells(l, com_i, c < 0, side ? com_r : com_l, key, lo3, hi3);
         const uint32_t nx = hi3[0] - lo3[0] + 1, ny = hi3[1] - lo3[1] + 1, nz = hi3[2] - lo3[2] + 1, cnt = nx * ny * nz;
