@@ -93,6 +93,11 @@ typedef struct {
                                     takes anyway, lh_set_allreduce); 0 = (default) device for batches of >= 8 pairs in flight, host for
                                     fewer (lower latency for one pair at a time).  Same code, same arithmetic (lh_math.hpp): the
                                     results are bit-identical either way. */
+  int bfgs_quad_curv;            /* pcl::BFGS is un-vendored in the reference tree (gicp.hpp:249-271 calls it); its line search is restated from the GSL
+                                    algorithm it was ported from.  One reported deviation of the port moves results measurably (1.7-2.5e-4 m on the
+                                    reference's own fixtures, tests/test_second_restatement.py): the quadratic interpolation accepts its stationary
+                                    point if `c > a` instead of GSL's `c > 0`.  0 = (default) GSL's test; 1 = the reported PCL reading -- for a
+                                    maintainer who can compare with a real PCL build.  The CPU oracle has the same switch (lo_set_bfgs_variant). */
 } lh_gicp_params;
 
 typedef struct {

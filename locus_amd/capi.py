@@ -51,6 +51,7 @@ class GicpParams(C.Structure):
         ("enable_timing", C.c_int),
         ("cost_mode", C.c_int),
         ("solver", C.c_int),
+        ("bfgs_quad_curv", C.c_int),
     ]
 
 

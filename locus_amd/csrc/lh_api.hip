@@ -154,6 +154,7 @@ void lh_default_gicp_params(lh_gicp_params* p) {
   if (!p) return;
   p->max_iterations = 200;           // gicp.h:129
   p->max_inner_iterations = 20;      // gicp.h:121
+  p->bfgs_quad_curv = 0;             // GSL's curvature test (see the header)
   p->corr_dist = 5.0;                // gicp.h:131
   p->transformation_epsilon = 5e-4;  // gicp.h:130
   p->rotation_epsilon = 2e-3;        // gicp.h:119

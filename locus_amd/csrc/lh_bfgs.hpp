@@ -305,6 +305,7 @@ struct Bfgs {
   Fn* fn = nullptr;
   double rho = 0.01, sigma = 0.01, tau1 = 9, tau2 = 0.05, tau3 = 0.5, step_size = 1;  // gicp.hpp:253-257
   int order = 3, bracket_iters = 100, section_iters = 100;
+  int quad_curv_gt_a = 0;   // lh_gicp_params::bfgs_quad_curv: 1 = `c > a` instead of GSL's `c > 0` in the quadratic interpolation (pcl::BFGS's reported reading)
   double f = 0, delta_f = 0, fp0 = 0, pnorm = 0, g0norm = 0;
   double x0[6], g0[6], dx0[6], dg0[6], p[6], gradient[6];
   double x_alpha[6], g_alpha[6], f_alpha = 0, df_alpha = 0, f_key = 0, df_key = 0, x_key = 0, g_key = 0;
@@ -359,7 +360,7 @@ struct Bfgs {
 
   LH_FN static double cubic(double c0, double c1, double c2, double c3, double z) { return c0 + z * (c1 + z * (c2 + z * c3)); }
 
-  LH_FN static double interpolate(double a, double fa, double fpa, double b, double fb, double fpb, double xmin, double xmax, int order) {
+  LH_FN static double interpolate(double a, double fa, double fpa, double b, double fb, double fpb, double xmin, double xmax, int order, int c_gt_a) {
     double y, ymin = (xmin - a) / (b - a), ymax = (xmax - a) / (b - a), fmin;
     if (ymin > ymax) { double t = ymin; ymin = ymax; ymax = t; }
     if (order > 2 && !(fpb != fpb) && fpb != INFINITY) {
@@ -390,7 +391,7 @@ struct Bfgs {
       double c = 2 * (fb - fa - fpa);
       y = ymin; fmin = fl;
       if (fh < fmin) { y = ymax; fmin = fh; }
-      if (c > 0) {
+      if (c > (c_gt_a ? a : 0.0)) {
         double z = -fpa / c;
         if (z > ymin && z < ymax) {
           double fz = fa + z * (fpa + z * (fb - fa - fpa));
@@ -423,13 +424,13 @@ struct Bfgs {
         break;
       }
       delta = alpha - alpha_prev;
-      alpha_next = interpolate(alpha_prev, falpha_prev, fpalpha_prev, alpha, falpha, fpalpha, alpha + delta, alpha + tau1 * delta, order);
+      alpha_next = interpolate(alpha_prev, falpha_prev, fpalpha_prev, alpha, falpha, fpalpha, alpha + delta, alpha + tau1 * delta, order, quad_curv_gt_a);
       alpha_prev = alpha; falpha_prev = falpha; fpalpha_prev = fpalpha;
       alpha = alpha_next;
     }
     while (i++ < section_iters) {
       delta = b - a;
-      alpha = interpolate(a, fa, fpa, b, fb, fpb, a + tau2 * delta, b - tau3 * delta, order);
+      alpha = interpolate(a, fa, fpa, b, fb, fpb, a + tau2 * delta, b - tau3 * delta, order, quad_curv_gt_a);
       falpha = apply_f(alpha);
       if ((a - alpha) * fpa <= DBL_EPSILON) return BFGS_NOPROGRESS;
       if (falpha > f0 + rho * alpha * fp0l || falpha >= fa) {
@@ -519,11 +520,12 @@ struct Bfgs {
 // estimateRigidTransformationBFGS (gicp.hpp:218-287).  T16 column-major in/out.
 // returns 0 ok, -4 too few correspondences, -5 solver failure, -6 a source point without a nearest neighbour
 template <class Fn, class M>
-LH_FN int estimate_rigid_bfgs(Fn* fn, int max_inner, float* T16, int* n_inner, double* f_end) {
+LH_FN int estimate_rigid_bfgs(Fn* fn, int max_inner, float* T16, int* n_inner, double* f_end, int bfgs_quad_curv = 0) {
   auto TM = [&](int r, int c) { return (double)T16[c * 4 + r]; };
   double x[6] = {TM(0, 3), TM(1, 3), TM(2, 3), M::atan2_d(TM(2, 1), TM(2, 2)), M::asin_d(-TM(2, 0)), M::atan2_d(TM(1, 0), TM(0, 0))};
   const double gradient_tol = 1e-2;
   Bfgs<Fn> b;
+  b.quad_curv_gt_a = bfgs_quad_curv;
   int inner = 0, result;
   b.init(fn, x);
   if (fn->count() >= NO_NN_MARK) return -6;  // `failure` of the NN loop (gicp.hpp:471-478): computeTransformation returns before the solve (:504-506)
@@ -569,6 +571,7 @@ LH_FN int estimate_rigid_bfgs(Fn* fn, int max_inner, float* T16, int* n_inner, d
 struct OuterParams {
   int max_iterations, max_inner_iterations;
   double rotation_epsilon, transformation_epsilon;
+  int bfgs_quad_curv = 0;   // lh_gicp_params::bfgs_quad_curv
 };
 struct OuterState {
   float T[16];      // transformation_ (column-major): where the next sweep transforms the source to
@@ -613,7 +616,7 @@ LH_FN void outer_step(Fn* fn, const OuterParams& P, OuterState* s) {
   const int before = fn->passes;
   int n_inner = 0;
   double f_end = 0.0;
-  int st = estimate_rigid_bfgs<Fn, M>(fn, P.max_inner_iterations, s->T, &n_inner, &f_end);
+  int st = estimate_rigid_bfgs<Fn, M>(fn, P.max_inner_iterations, s->T, &n_inner, &f_end, P.bfgs_quad_curv);
   s->n_corr_last = st == -6 ? 0 : (int)fn->count();
   s->passes += fn->passes - before;
   s->n_inner = n_inner;

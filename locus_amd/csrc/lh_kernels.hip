@@ -2030,7 +2030,7 @@ __global__ void __launch_bounds__(64) k_solve(const PairDesc* __restrict__ descs
   for (int e = lane; e < 144; e += 64) mom.H12[e] = mom.S[MomentModel::h_index(e / 12, e % 12)];
   __syncthreads();
   const PairDesc* d = descs + slot;
-  OuterParams P{d->max_iterations, d->max_inner_iterations, d->rotation_epsilon, d->transformation_epsilon};
+  OuterParams P{d->max_iterations, d->max_inner_iterations, d->rotation_epsilon, d->transformation_epsilon, d->bfgs_quad_curv};
   OuterState s = *sp;
   typedef MomentPass<PortableMath> Pass;
   typedef CostEval<Pass, PortableMath> Fn;

@@ -44,6 +44,7 @@ struct PairDesc {
   int max_iterations, max_inner_iterations;
   double rotation_epsilon, transformation_epsilon;
   lh_gicp_trace* trace;
+  int bfgs_quad_curv, pad_b;   // lh_gicp_params::bfgs_quad_curv
 };
 
 struct SweepJob {  // dynamic per-launch part

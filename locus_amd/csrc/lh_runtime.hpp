@@ -436,7 +436,7 @@ struct Task {
   void run() {
     outer_state_init(&os);  // pcl::Registration::align resets transformation_ to identity
     if (trace) trace->n_iters = 0;
-    const OuterParams OP{P.max_iterations, P.max_inner_iterations, P.rotation_epsilon, P.transformation_epsilon};
+    const OuterParams OP{P.max_iterations, P.max_inner_iterations, P.rotation_epsilon, P.transformation_epsilon, P.bfgs_quad_curv};
     while (!os.done) {
       T16_to_T12(os.T, req_T12);
       yield(REQ_SWEEP);                                   // gicp.hpp:464-498 (transform_R is formed in the kernel from T and the guess)

@@ -135,6 +135,7 @@ lh_status task_prepare(lh_ctx* c, Task* t, bool rebuild_index, bool upload_desc)
     if (d.guess3[k] != ((k % 4 == 0) ? 1.0 : 0.0)) d.guess_identity = 0;
   d.max_iterations = P.max_iterations;
   d.max_inner_iterations = P.max_inner_iterations;
+  d.bfgs_quad_curv = P.bfgs_quad_curv; d.pad_b = 0;
   d.rotation_epsilon = P.rotation_epsilon;
   d.transformation_epsilon = P.transformation_epsilon;
   d.trace = t->trace_dev;

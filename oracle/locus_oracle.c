@@ -569,6 +569,10 @@ typedef struct {
  * T*p with fused multiply-adds, as a -march=native (FMA) build of the reference would; variant 0 (default) = no FMA. */
 static int g_cost_variant = 0;
 void lo_set_cost_variant(int v) { g_cost_variant = v; }
+/* pcl::BFGS deviation switch (no copy of pcl/registration/bfgs.h exists here; tools/golden.py carries the same switch): 1 = the quadratic
+   interpolation of Fletcher's line search accepts its stationary point if `c > a` (the reported reading of PCL's port) instead of GSL's `c > 0` */
+static int g_bfgs_quad_curv_gt_a = 0;
+void lo_set_bfgs_variant(int quad_curv_gt_a) { g_bfgs_quad_curv_gt_a = quad_curv_gt_a; }
 static inline void xform_pt_cost(const float* T, const float* p, float* o) {
   if (g_cost_variant == 1) {
     for (int r = 0; r < 3; r++) o[r] = fmaf(T[8 + r], p[2], fmaf(T[4 + r], p[1], T[0 + r] * p[0])) + T[12 + r];
@@ -791,7 +795,7 @@ static double bfgs_interpolate(double a, double fa, double fpa, double b, double
     y = ymin;
     fmin = fl;
     if (fh < fmin) { y = ymax; fmin = fh; }
-    if (c > 0) {
+    if (c > (g_bfgs_quad_curv_gt_a ? a : 0.0)) {
       double z = -fpa / c;
       if (z > ymin && z < ymax) {
         double f = fa + z * (fpa + z * (fb - fa - fpa));

@@ -69,6 +69,7 @@ enum { LO_OK = 0, LO_EINVAL = -1, LO_ENOMEM = -2, LO_ETOO_FEW = -4, LO_ESOLVER =
 
 void lo_default_params(lo_params* p);
 void lo_set_cost_variant(int v); /* analysis only: 1 = FMA-contracted float T*p in the cost functor */
+void lo_set_bfgs_variant(int quad_curv_gt_a); /* 1 = pcl::BFGS's reported `c > a` curvature test of the quadratic interpolation (GSL: `c > 0`) */
 
 /* exact nearest-neighbour index (stands in for pcl::search::KdTree -> FLANN KDTreeSingleIndex);
    distances are float ((dx*dx+dy*dy)+dz*dz), ties -> lowest original index. */

@@ -91,6 +91,23 @@ int main() {
     printf("trial %d: status %d/%d inner %d/%d fused passes %d (oracle entry-point passes %d) f_end %.9g/%.9g |t-t*| %.3g same=%d\n", trial, st,
            st_o, n_inner, n_inner_o, fn.passes, passes_o, f_end, f_end_o, err, (int)same);
     if (st != 0 || st_o != 0 || !same || n_inner != n_inner_o || f_end != f_end_o || !(err < 5e-3)) bad++;
+    {  // the same comparison under pcl::BFGS's reported `c > a` curvature test (lh_gicp_params::bfgs_quad_curv / lo_set_bfgs_variant): the two
+       // restatements of the deviation must follow the same trajectory bit for bit as well
+      FnL fv;
+      fv.pass = pass;
+      float Tv[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1}, Tvo[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+      int ni_v = 0, ni_vo = 0, passes_vo = 0;
+      double fe_v = 0, fe_vo = 0;
+      int st_v = lh::estimate_rigid_bfgs<FnL, lh::LibmMath>(&fv, 50, Tv, &ni_v, &fe_v, 1);
+      lo_set_bfgs_variant(1);
+      int st_vo = lo_estimate_rigid_bfgs(src.data(), tgt.data(), idx.data(), idx.data(), n, maha.data(), 50, Tvo, &ni_vo, &fe_vo, &passes_vo);
+      lo_set_bfgs_variant(0);
+      bool same_v = true, differs = false;
+      for (int k = 0; k < 16; k++) { same_v = same_v && (Tv[k] == Tvo[k]); differs = differs || (Tv[k] != Tp[k]); }
+      printf("         `c > a` variant: status %d/%d inner %d/%d f_end %.9g/%.9g same=%d (differs from the GSL reading: %d)\n", st_v, st_vo, ni_v, ni_vo, fe_v, fe_vo,
+             (int)same_v, (int)differs);
+      if (st_v != 0 || st_vo != 0 || !same_v || ni_v != ni_vo || fe_v != fe_vo) bad++;
+    }
     // 2. portable flavour on the same per-point functor: another trajectory (last-bit differences in sin / cos), the same minimum
     typedef lh::CostEval<OracleBackedPass, lh::PortableMath> FnP;
     FnP fnp;

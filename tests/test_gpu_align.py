@@ -83,6 +83,35 @@ def test_scan_pair_from_normals_matches_oracle(ctx, capi, oracle, seed, cost_mod
     assert np.abs(Tm[:3, 3] - delta[:3, 3]).max() < 0.03
 
 
+@pytest.mark.parametrize("cost_mode,solver", [(0, 0), (1, 1), (1, 2)])
+def test_bfgs_curvature_switch_follows_the_oracle(ctx, capi, oracle, cost_mode, solver):
+    """lh_gicp_params::bfgs_quad_curv = 1 (pcl::BFGS's reported `c > a` reading of the quadratic interpolation's curvature test; the reference calls
+    pcl::BFGS at gicp.hpp:249-271 and its source is not in the tree): the product with the switch follows the ORACLE with the same switch
+    (lo_set_bfgs_variant) as closely as it follows it without -- on the host loop, the device loop (k_solve) and in the strict mode."""
+    src, ns, tgt, nt, delta = _pair_with_normals(oracle, 22)
+    kw = dict(max_iterations=20, corr_dist=1.0, transformation_epsilon=1e-12, rotation_epsilon=1e-12)
+    L = oracle.lib()
+    out = {}
+    for variant in (0, 1):
+        g = capi.Gicp(ctx, capi.default_params(cost_mode=cost_mode, solver=solver, bfgs_quad_curv=variant, **kw))
+        g.set_source(capi.make_pointf(src, ns))
+        g.set_target(capi.make_pointf(tgt, nt))
+        res = g.align()
+        L.lo_set_bfgs_variant(variant)
+        try:
+            ro = oracle.gicp_align(oracle.xyz4(src), ns, oracle.xyz4(tgt), nt, oracle.default_params(num_threads=4, **kw))
+        finally:
+            L.lo_set_bfgs_variant(0)
+        dt, dR = _pose_err(res["T"], ro["T"], oracle)
+        assert res["status"] == 0 and dt < 2e-4 and dR < 2e-4, (variant, dt, dR)
+        if cost_mode == 0:   # same arithmetic: the whole trajectory matches, evaluation counts included
+            k = min(len(res["trace"]["n_passes"]), len(ro["trace"]["n_passes"]))
+            assert res["iterations"] == ro["iterations"] and (res["trace"]["n_passes"][:k] == ro["trace"]["n_passes"][:k]).all()
+        out[variant] = (res, ro)
+    # the switch is not a no-op on this pair: the oracle's two readings take different numbers of functor evaluations
+    assert sum(out[0][1]["trace"]["n_passes"]) != sum(out[1][1]["trace"]["n_passes"]) or not np.array_equal(np.asarray(out[0][1]["T"]), np.asarray(out[1][1]["T"]))
+
+
 @pytest.mark.parametrize("cost_mode", [0, 1])
 def test_forced_20_iterations_and_guess(ctx, capi, oracle, cost_mode):
     src, ns, tgt, nt, delta = _pair_with_normals(oracle, 31)

@@ -141,6 +141,17 @@ def test_bfgs_inner_steps_against_the_second_vector_bfgs2(gold, oracle, name, ma
     moved = {str(k): float(np.abs(v[:3] - gx[-1][:3]).max()) for k, v in zip(gold[name + "_bfgs_variants"], gold[name + "_bfgs_variant_x"])}
     assert moved["roots=stable"] <= 1e-12 and moved["dir_zero=flip"] == 0.0 and moved["poly_eval=eigen"] <= 1e-12, moved
     assert 1e-5 < moved["quad_curv=c>a"] < 5e-4, moved
+    # ... and that reading is a SWITCH of the oracle (lo_set_bfgs_variant) and of the product (lh_gicp_params::bfgs_quad_curv) as well: under it the
+    # C oracle's solve ends where golden.py's `c > a` variant ends (two independent codings of the deviation agree), and away from where GSL's ends
+    vx = {str(k): v for k, v in zip(gold[name + "_bfgs_variants"], gold[name + "_bfgs_variant_x"])}["quad_curv=c>a"]
+    L = oracle.lib()
+    L.lo_set_bfgs_variant(1)
+    try:
+        tv = oracle.bfgs_trace(oracle.xyz4(src), oracle.xyz4(tgt), si, nn[si], M, np.zeros(6), max_inner=max_inner)
+    finally:
+        L.lo_set_bfgs_variant(0)
+    assert np.abs(tv["x"][-1] - vx).max() <= 1e-12
+    assert np.abs(tv["x"][-1][:3] - tr["x"][-1][:3]).max() > 1e-5
     # and the oracle's full solve from the same inputs ends where this trace ends (lo_estimate_rigid_bfgs is what lo_gicp_align calls)
     Tq = oracle.apply_state(tr["x"][-1])
     assert np.abs(np.asarray(Tq, np.float64).reshape(4, 4).T[:3, 3] - tr["x"][-1][:3]).max() < 1e-6

@@ -26,5 +26,7 @@ python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.
 python bench.py --gpus 2 --same-gpu --dist-backend gloo --quick --pairs 64 --in-flight 64 --steps 2 --warmup 1 > $E/bench_self_launched_two_ranks.json 2> $E/bench_self_launched_two_ranks.err
 python bench.py --gpus 2 --same-gpu --dist-backend gloo --pairs 32 --in-flight 32 --steps 2 --warmup 1 --no-trajectory --no-configs > $E/bench_two_ranks_full_line.json 2> $E/bench_two_ranks_full_line.err
 bash tools/trace_production.sh > $E/production_update_trace.txt 2>&1
+cd $GRAFT_REPO_ROOT; bash tools/trace_locus_stream.sh > $E/locus_stream_trace.txt 2>&1
+cd $GRAFT_REPO_ROOT
 python tests/perf/bench_ndt.py > $E/ndt.json 2> $E/ndt.err
 ls -la $E
