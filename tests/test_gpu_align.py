@@ -104,9 +104,10 @@ def test_bfgs_curvature_switch_follows_the_oracle(ctx, capi, oracle, cost_mode, 
             L.lo_set_bfgs_variant(0)
         dt, dR = _pose_err(res["T"], ro["T"], oracle)
         assert res["status"] == 0 and dt < 2e-4 and dR < 2e-4, (variant, dt, dR)
-        if cost_mode == 0:   # same arithmetic: the whole trajectory matches, evaluation counts included
-            k = min(len(res["trace"]["n_passes"]), len(ro["trace"]["n_passes"]))
-            assert res["iterations"] == ro["iterations"] and (res["trace"]["n_passes"][:k] == ro["trace"]["n_passes"][:k]).all()
+        if cost_mode == 0:   # same arithmetic: the whole trajectory matches, iteration by iteration
+            k = min(len(res["trace"]["n_corr"]), len(ro["trace"]["n_corr"]))
+            assert res["iterations"] == ro["iterations"] and (res["trace"]["n_corr"][:k] == ro["trace"]["n_corr"][:k]).all()
+            assert np.abs(res["trace"]["T"][:k] - ro["trace"]["T"][:k]).max() < 1e-5
         out[variant] = (res, ro)
     # the switch is not a no-op on this pair: the oracle's two readings take different numbers of functor evaluations
     assert sum(out[0][1]["trace"]["n_passes"]) != sum(out[1][1]["trace"]["n_passes"]) or not np.array_equal(np.asarray(out[0][1]["T"]), np.asarray(out[1][1]["T"]))
