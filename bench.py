@@ -1162,8 +1162,9 @@ def main():
         strong = {"total_pairs": k * world, "pairs_per_gpu": k, "pairs_in_flight_per_gpu": min(args.in_flight, k), "value": round(2 * k * world / el_s, 2), "unit": "scan-pairs/s",
                   "what": "the same pairs as a fixed queue of %d split over the %d GPUs (two timed steps after a warm-up, barrier-bracketed, max over ranks)" % (k * world, world)}
     sharded = None
-    if world > 1:
-        # configs[4]'s multi-GPU form: every rank takes part (the exchange is a collective), so it runs here, before rank 0's own legs
+    if world > 1 and args.quick:
+        # configs[4]'s multi-GPU form: every rank takes part (the exchange is a collective).  In the --quick line it runs here; in the full line
+        # it runs LAST (below), when the headline, its roofline and the CPU baseline are already in the partial line the watchdog would print
         try:
             sharded = sharded_pair_leg(ctx, rank, world, args.dist_backend, ddev, local_rank)
         except Exception as e:   # (the headline must not be lost to an extra leg: the error goes into the line)
@@ -1583,6 +1584,19 @@ def main():
             traceback.print_exc()
             result["extras_error"] = "%s in leg %r: %r" % (type(e).__name__, _BEAT[1], e)
             result["all_ok"] = False
+    if world > 1 and not args.quick:
+        # configs[4]'s multi-GPU form, all ranks (the others have been waiting here while rank 0 ran its own legs): a failure or a hang of this
+        # leg cannot cost the line its headline any more -- an exception goes into the line, a hang ends in the watchdog's partial line
+        if rank == 0:
+            _leg("configs[4] as one source-sharded pair over %d ranks" % world)
+        try:
+            sharded = sharded_pair_leg(ctx, rank, world, args.dist_backend, ddev, local_rank)
+        except Exception as e:
+            import traceback
+            traceback.print_exc()
+            sharded = {"error": repr(e)}
+        if rank == 0 and result is not None:
+            result["config5_sharded_pair"] = sharded
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
