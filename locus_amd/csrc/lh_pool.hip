@@ -8,7 +8,7 @@
 // lhFree parks a block in a per-device free list (no hipFree, no sync), lhMalloc takes the smallest parked block that fits with
 // <= 25 % slack.  Safe because every user allocates, launches and frees on the context's primary stream (a recycled block is
 // only reused by work queued behind the work that used it last); the second scheduler stream only ever touches per-slot
-// workspaces and context scratch, which are allocated once and not pooled.  The cache is trimmed when it exceeds 8 GB.
+// workspaces and context scratch, which are allocated once and not pooled.  The cache is trimmed when it exceeds a quarter of the device's memory.
 namespace {
 struct DevPool {
   std::mutex mu;
@@ -63,7 +63,17 @@ hipError_t lhFree(void* p) {
   P.parked.emplace(it->second, p);
   P.parked_bytes += it->second;
   P.live.erase(it);
-  if (P.parked_bytes > ((size_t)8 << 30)) pool_trim(P);
+  // The cache is trimmed (a device synchronisation + one hipFree per parked block: milliseconds) when it exceeds a QUARTER OF THE DEVICE'S MEMORY
+  // (72 GB on an MI355X; 8 GB until round 6: a bench run that had just closed a 513-scan trajectory crossed it in the middle of a timed
+  // configs[4] frame -- 7.4 ms for a 0.46-ms filter stage, one frame in a dozen runs).  LH_POOL_CAP_GB overrides.
+  static const size_t cap = []() {
+    const char* e = getenv("LH_POOL_CAP_GB");
+    if (e && atof(e) > 0) return (size_t)(atof(e) * (double)((size_t)1 << 30));
+    size_t fr = 0, tot = 0;
+    if (hipMemGetInfo(&fr, &tot) != hipSuccess || tot == 0) return (size_t)8 << 30;
+    return std::max<size_t>((size_t)8 << 30, tot / 4);
+  }();
+  if (P.parked_bytes > cap) pool_trim(P);
   return hipSuccess;
 }
 
