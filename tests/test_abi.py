@@ -263,6 +263,36 @@ def test_start_grid_walks_on_a_scan_pair_host_model(tmp_path):
         assert "mismatches 0, bad certificate bounds 0" in l, l
 
 
+def test_work_item_searches_host_model_is_exact(tmp_path):
+    """tools/model/item_stack_model.cpp (round 6): the four restructurings of the sweeps' exact 1-NN search that were priced before any kernel was
+    written -- the wave-shared walk, item stacks, per-lane walks over a shared stack, the lockstep first descent + items that became k_sweep_coop --
+    each run on the host with the product's own grid_start / boxd2_q / leaf arithmetic over a scan pair at three poses: whatever the ORDER of the
+    visits, every scheme must end with the neighbours of the product's walk (the model's own step counts are only as good as that)."""
+    import numpy as np
+    from scipy.spatial.transform import Rotation as R
+    from locus_amd import synth
+    src, tgt, delta = synth.scan_pair(n_rings=16, n_az=400, scale=2.0, noise=0.02, seed=31)
+    src.astype(np.float32).tofile(tmp_path / "src.f32")
+    tgt.astype(np.float32).tofile(tmp_path / "tgt.f32")
+    D = np.asarray(delta, np.float64)
+    poses = []
+    for fr in (0.0, 0.8, 1.0):
+        T = np.eye(4)
+        T[:3, 3] = fr * D[:3, 3]
+        T[:3, :3] = R.from_rotvec(R.from_matrix(D[:3, :3]).as_rotvec() * fr).as_matrix()
+        poses.append(T[:3, :4])
+    np.stack(poses).astype(np.float32).tofile(tmp_path / "poses.f32")
+    exe = "/tmp/lh_item_stack_model"
+    src_cpp = os.path.join(ROOT, "tools", "model", "item_stack_model.cpp")
+    subprocess.check_call(["hipcc", "-O2", "-std=c++17", "-ffp-contract=off", "--offload-arch=gfx950", "-x", "hip", src_cpp, "-o", exe])
+    out = subprocess.run([exe, str(tmp_path), "128"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = [l for l in out.stdout.splitlines() if l.startswith("sweep ")]
+    assert len(lines) >= 3 * 5, out.stdout   # (A), (B), (C) x 2, (D) per sweep (+ the cold variant of (D) in sweep 0)
+    for l in lines:
+        assert l.rstrip().endswith("mismatches 0"), l
+
+
 def test_ndt_host_algebra_matches_oracle(oracle):
     """lh_ndt_host.hpp (pose <-> matrix, the 6x6 SVD solve of the Newton step) against the oracle's restatement of the same
     pclomp pieces; the `oracle` fixture makes sure oracle/liblocus_oracle.so is built"""
