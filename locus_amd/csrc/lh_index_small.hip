@@ -1,8 +1,8 @@
 // lh_index_small.hip -- K2 for SMALL clouds: the whole index build of one cloud in ONE launch, one workgroup per cloud.
 //
 // LOCUS runs its registration on ~3 000 points per scan (the adaptive voxel filter's target, lo_settings.yaml:84-85), one scan at a time.
-// The general build (lh_kernels.hip: 13 launches -- bounding box, keys, a three-pass segmented radix sort, leaf flags, offsets, leaves,
-// three box tables, radix tree, 4-ary nodes) is laid out for batches of 100 k-point clouds; on one 3 k-point cloud every launch is a few
+// The general build (lh_kernels.hip: 17 launches -- bounding box, keys, a three-pass segmented radix sort (nine), leaf flags, leaves,
+// the box tables, radix tree, 4-ary nodes) is laid out for batches of 100 k-point clouds; on one 3 k-point cloud every launch is a few
 // microseconds of work behind ~9 us of dependent-launch latency: 122 us, half of a whole odometry update.  Here the same steps run as phases
 // of one 1024-thread workgroup with the sort, the keys, the leaf numbering and the leaf records in LDS (112 KB) and the box / node tables in
 // the build's usual global scratch (the workgroup's own L1 keeps them coherent between phases: workgroup-scope barriers only).
